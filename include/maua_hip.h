@@ -1,0 +1,142 @@
+/*
+ * maua_hip.h — C ABI of libmaua_hip.so, the MI355X (gfx950) native library behind the audio-reactive StyleGAN2
+ * inference path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless named h_*;
+ * `stream` is a hipStream_t passed as void*.  Every launcher is asynchronous on `stream`, never
+ * synchronises, never allocates, and returns 0 on success, a hipError_t (> 0) from the launch, or a
+ * negative MAUA_E* code for rejected arguments.  All tensors are contiguous fp32 NCHW unless stated.
+ *
+ * Each entry point names the reference interface (file:line under /root/reference) it replaces.
+ */
+#ifndef MAUA_HIP_H
+#define MAUA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAUA_EINVAL (-22)
+#define MAUA_ENOSYS (-38)
+
+/* ABI version of this header; bumped on any signature change. */
+int maua_abi_version(void);
+/* Number of compute units / name of device 0 (diagnostics for bench.py). */
+int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------------ ops
+ * Replaces pybind `upfirdn2d.upfirdn2d(input[major,in_h,in_w,minor], kernel[kh,kw], up_x, up_y, down_x,
+ * down_y, pad_x0, pad_x1, pad_y0, pad_y1)` — op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369.
+ * y must hold major*out_h*out_w*minor floats, out = (in*up + pad0 + pad1 - k)/down + 1 (floor).
+ * `k` is the un-flipped [kh,kw] tap matrix in DEVICE memory (true convolution, as the reference). */
+int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
+                       int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* Replaces pybind `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)` —
+ * op/fused_bias_act.cpp:11-20, op/fused_bias_act_kernel.cu:18-98.  b == NULL or size_b == 0: no bias;
+ * ref == NULL: no reference tensor.  bias index = (i / step_b) % size_b. In-place (y == x) is allowed. */
+int maua_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y, int64_t size_x,
+                            int size_b, int step_b, int act, int grad, float alpha, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ generator layers
+ * Fused Blur -> NoiseInjection -> FusedLeakyReLU tail of an up-sampling StyledConv
+ * (models/stylegan2.py:238,262-266,338-343; op/fused_act.py:74-83):
+ *   y[b,c] = lrelu_0.2( upfirdn2d(x[b,c], k, pad=(pad0,pad1)) * gain[b,c] + noise_w * noise[b,0] + bias[c] ) * sqrt(2)
+ * x [B,C,in_h,in_w] -> y [B,C,out_h,out_w], up = down = 1. gain (may be NULL = 1) carries the demodulation
+ * factor of the preceding shared-weight convolution. noise [B or 1,1,out_h,out_w] (noise_batch_stride 0 = broadcast). */
+int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch, int channels, int in_h, int in_w,
+                            int kh, int kw, int pad0, int pad1, const float* gain, const float* noise,
+                            int64_t noise_batch_stride, const float* noise_w, const float* bias, void* stream);
+
+/* All style affines of one forward in one launch (EqualLinear, models/stylegan2.py:140-146,207,220):
+ *   s[b, off_l + i] = sum_j mod_w_l[i,j] * (1/sqrt(style_dim)) * latent[b, lat_idx_l, j] + mod_b_l[i]
+ * with the truncation lerp of Generator.forward (:541-543) applied to the latent first when trunc != NULL:
+ *   latent' = trunc_latent + trunc[b] * (latent - trunc_latent).
+ * `table` (device, n_layers entries) describes the layers. */
+typedef struct {
+    const float* mod_w; /* [cin, style_dim] */
+    const float* mod_b; /* [cin] */
+    int cin;
+    int lat_idx;        /* which of the n_latent rows feeds this layer */
+    int out_off;        /* offset of this layer's slice in s (floats, per batch row) */
+    int pad_;
+} maua_style_layer_t;
+int maua_style_affine_f32(const float* latents, int batch, int n_latent, int style_dim, const float* trunc,
+                          const float* trunc_latent, const maua_style_layer_t* table, int n_layers,
+                          float* s, int s_stride, void* stream);
+
+/* Demodulation factors (models/stylegan2.py:223-225) for the shared-weight formulation:
+ *   d[b,o] = rsqrt( scale^2 * sum_i wsq[o,i] * s[b,i]^2 + 1e-8 ),  wsq[o,i] = sum_taps W[o,i,:,:]^2 */
+int maua_demod_f32(const float* wsq, const float* s, int s_stride, float* d, int batch, int cout, int cin,
+                   float scale, void* stream);
+
+/* Sum of squared taps wsq[o,i] and the tap-major repack wp[tap][i][o] of a [cout,cin,k,k] weight (one-off, at load). */
+int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream);
+
+/* ModulatedConv2d 3x3 (models/stylegan2.py:217-254) as input-scale -> shared-weight implicit GEMM on MFMA ->
+ * output-demod, with the StyledConv tail (noise + bias + leaky ReLU, :338-343) fused when `fuse_act`:
+ *   plain   : x[B,cin,H,W] -> y[B,cout,H,W]        (pad 1)
+ *   up != 0 : x[B,cin,H,W] -> y[B,cout,2H+1,2W+1]  (conv_transpose2d stride 2, :229-237) — raw, un-demodulated
+ *             when fuse_act == 0 (the blur kernel applies gain/noise/bias/act).
+ * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
+ * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
+ * floats used for split-K partial sums on small feature maps (may be NULL when that returns 0). */
+int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up);
+int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
+                        float* y, int batch, int cin, int cout, int h, int w, int up, float wscale, int fuse_act,
+                        const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
+                        float* ws, void* stream);
+
+/* ToRGB (models/stylegan2.py:356-365): 1x1 modulated conv without demod + bias + 2x FIR-upsampled skip
+ * (Upsample :34-52, kernel k4 = 4x4 taps in device memory, pad (2,1)).  skip == NULL: no skip.
+ *   y[b,c,Y,X] = sum_i (wscale * w[c,i] * s[b,i]) * x[b,i,Y,X] + bias[c] + up2(skip)[b,c,Y,X] */
+int maua_torgb_f32(const float* x, const float* w, const float* s, int s_stride, const float* bias,
+                   const float* skip, const float* k4, float* y, int batch, int cin, int h, int wdt,
+                   float wscale, void* stream);
+
+/* Frame epilogue of render.py:40-43: [B,3,H,W] fp32 -> [B,H,W,3] uint8 via clamp(-1,1), (x+1)*127.5, truncation. */
+int maua_frames_to_u8(const float* img, uint8_t* out, int batch, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ audio / temporal
+ * Circular Gaussian FIR along time (audioreactive/signal.py:319-368): x [T, F] -> y [T, F], taps[2*radius+1]
+ * already normalised / causal-weighted by the host; circular index when radius <= T, else the reference's
+ * single-wrap-then-zero padding (:350-355). */
+int maua_temporal_fir_f32(const float* x, const float* taps, float* y, int n_frames, int64_t features, int radius,
+                          void* stream);
+
+/* Power spectrogram |STFT|^2 (librosa.stft as called at audioreactive/signal.py:51,93,119): centred, reflect-padded
+ * frames, window[n_fft] in device memory, n_fft a power of two <= 4096.  y[n_samples] -> p[n_bins = n_fft/2+1, n_frames]. */
+int maua_stft_power_f32(const float* y, int64_t n_samples, const float* window, int n_fft, int hop, float* p,
+                        int n_frames, void* stream);
+/* out[M,N] = fb[M,K] @ p[K,N] (mel / chroma filterbank projection), optional 10*log10(max(amin, .)) when to_db. */
+int maua_filterbank_f32(const float* fb, const float* p, float* out, int m, int k, int n, int to_db, float amin,
+                        void* stream);
+
+/* 3-D tileable Perlin noise (audioreactive/latent.py:188-246): grad [r0+1,r1+1,r2+1,3] -> out [n0,n1,n2]. */
+int maua_perlin3d_f32(const float* grad, float* out, int n0, int n1, int n2, int r0, int r1, int r2, void* stream);
+
+/* Network-bending warp (audioreactive/bend.py:52-102): per-frame inverse affine map m[b] = {a00,a01,a02,a10,a11,a12}
+ * (output pixel -> source pixel, in pixels), bilinear sampling of the reflect-padded source, zeros outside the padded
+ * canvas (kornia warp_affine default padding_mode='zeros', align_corners as encoded by the host in m). */
+int maua_affine_reflect_warp_f32(const float* x, const float* m, float* y, int batch, int channels, int h, int w,
+                                 int pad_l, int pad_r, int pad_t, int pad_b, const float* add_noise, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ hipGraph runtime
+ * Capture everything launched on `stream` between begin/end into a hipGraph and replay it (per-frame generator
+ * forward, north_star "hipGraph-captured").  Handles are opaque. */
+int maua_graph_begin_capture(void* stream);
+int maua_graph_end_capture(void* stream, void** graph_exec_out);
+int maua_graph_launch(void* graph_exec, void* stream);
+int maua_graph_destroy(void* graph_exec);
+
+/* HIP-event timing on an arbitrary stream (bench.py roofline leg; torch.cuda.Event only sees torch's stream). */
+int maua_event_create(void** ev);
+int maua_event_record(void* ev, void* stream);
+int maua_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int maua_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAUA_HIP_H */

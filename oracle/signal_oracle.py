@@ -1,0 +1,239 @@
+"""Oracle (test infrastructure, CPU) for the audio-feature / latent / noise stages.
+
+PINNED against the imported reference (tests/golden/audioreactive_torch.npz):
+  gaussian_filter       <- /root/reference/audioreactive/signal.py:319-368
+  percentile / percentile_clip / normalize / compress <- signal.py:243-316
+  chroma_weight_latents <- /root/reference/audioreactive/latent.py:15-26
+  noise_side_lengths    <- /root/reference/generate_audiovisual.py:22-34,147-151
+  wrapping_slice        <- latent.py:110-133
+
+PARITY UNPINNED (stated in DESIGN.md): stft_power / mel_filterbank / onset_strength / chroma_filterbank /
+chroma_stft / hpss restate the *published* librosa algorithms that the reference calls at
+signal.py:49-51,115-119,150 (librosa is an un-pinned, un-vendored dependency, requirements.txt:4, and is not
+installed in this image, so no golden vector can be produced).  They define what the HIP STFT/mel path must
+reproduce; they are NOT claimed to be bit-identical to any librosa release.  perlin_noise restates
+latent.py:188-246, whose reference implementation hard-codes .cuda() and numpy global RNG and therefore
+cannot be run here; the oracle takes the gradient angles as inputs.
+"""
+import math
+
+import numpy as np
+import scipy.signal
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------- pinned stages
+
+
+def gaussian_filter(x, sigma, causal=None, smf=1.0):
+    """Circular Gaussian FIR along dim 0 (signal.py:319-368). ``smf`` is the module-global SMF (:21-23,335)."""
+    nd = x.dim()
+    n = x.shape[0]
+    flat = x.reshape(n, -1).to(torch.float32)  # [T, F]
+    radius = min(int(sigma * 4 * smf), 3 * n)
+    taps = torch.arange(-radius, radius + 1, dtype=torch.float32)
+    taps = torch.exp(-0.5 / sigma ** 2 * taps ** 2)
+    if causal is not None:
+        taps[radius + 1:] *= causal if isinstance(causal, float) else 0
+    taps = taps / taps.sum()
+    seq = flat.t()[:, None, :]  # [F,1,T]
+    if radius > n:  # :350-355 — one circular wrap of n on both sides, then zeros
+        seq = F.pad(seq, (n, n), mode="circular")
+        seq = F.pad(seq, (radius - n, radius - n))
+    else:
+        seq = F.pad(seq, (radius, radius), mode="circular")
+    y = F.conv1d(seq, taps.reshape(1, 1, -1))[:, 0, :].t()
+    if nd < 3:  # the reference lifts to 3-D and .squeeze()s back (:331-332,365-366): size-1 dims vanish
+        return y.reshape(list(x.shape) + [1] * (3 - nd)).squeeze()
+    return y.reshape(x.shape)
+
+
+def percentile(sig, p):
+    k = 1 + round(0.01 * float(p) * (sig.numel() - 1))
+    return sig.reshape(-1).kthvalue(k).values.item()
+
+
+def percentile_clip(sig, p):
+    """signal.py:271-292: percentile taken over strict local maxima only."""
+    n = sig.shape[0]
+    idx = torch.arange(n)
+    nxt = sig[(idx + 1).clamp(0, n - 1)]
+    prv = sig[(idx - 1).clamp(0, n - 1)]
+    peaks = (sig > nxt) & (sig > prv)
+    out = sig.clamp(0, percentile(sig[peaks], p))
+    return out / out.max()
+
+
+def normalize(sig):
+    sig = sig - sig.min()
+    return sig / sig.max()
+
+
+def compress(sig, threshold, ratio, invert=False):
+    sig = sig.clone()
+    mask = sig < threshold if invert else sig > threshold
+    sig[mask] = sig[mask] * ratio
+    return normalize(sig)
+
+
+def chroma_weight_latents(chroma, latents):
+    return torch.einsum("tn,nld->tld", chroma, latents)
+
+
+def noise_side_lengths(out_size, g_res):
+    """Side length 2**int(scale/2) for each StyleGAN2 noise scale (generate_audiovisual.py:22-34,147-151)."""
+    log_max = int(np.log2(out_size))
+    log_min = 2 + (log_max - int(np.log2(g_res)))
+    return [2 ** int(s / 2) for s in range(2 * log_min + 1, 2 * (log_max + 1))]
+
+
+def resample(x, num):
+    """Fourier resampling along axis 0 — scipy.signal.resample is the third-party routine the reference
+    calls (signal.py:68,152) and IS installed here, so it is used directly as the anchor."""
+    return scipy.signal.resample(np.asarray(x, dtype=np.float64), num, axis=0)
+
+
+# --------------------------------------------------------------------------------------------- unpinned stages
+
+
+def hann_periodic(n):
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def stft_power(y, n_fft=2048, hop=512, power=2.0):
+    """|STFT|**power, centred frames with reflect padding, periodic Hann (librosa.stft defaults).
+    Returns [1 + n_fft/2, n_frames] float64 with n_frames = 1 + len(y)//hop."""
+    y = np.asarray(y, dtype=np.float64)
+    ypad = np.pad(y, n_fft // 2, mode="reflect")
+    n_frames = 1 + (len(ypad) - n_fft) // hop
+    win = hann_periodic(n_fft)
+    frames = np.stack([ypad[t * hop: t * hop + n_fft] * win for t in range(n_frames)], axis=1)
+    spec = np.fft.rfft(frames, axis=0)
+    mag2 = spec.real ** 2 + spec.imag ** 2
+    return mag2 if power == 2.0 else mag2 ** (power / 2.0)
+
+
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mel = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mel)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr, n_fft=2048, n_mels=128, fmin=0.0, fmax=None):
+    """Slaney-scale triangular filters with area normalisation (librosa.filters.mel defaults)."""
+    fmax = sr / 2.0 if fmax is None else fmax
+    fft_f = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = _mel_to_hz_slaney(np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2))
+    fb = np.zeros((n_mels, fft_f.size))
+    for m in range(n_mels):
+        lo, ce, hi = mel_f[m], mel_f[m + 1], mel_f[m + 2]
+        up = (fft_f - lo) / (ce - lo)
+        dn = (hi - fft_f) / (hi - ce)
+        fb[m] = np.maximum(0.0, np.minimum(up, dn)) * (2.0 / (hi - lo))
+    return fb
+
+
+def power_to_db(s, amin=1e-10, top_db=80.0):
+    db = 10.0 * np.log10(np.maximum(amin, s))
+    return np.maximum(db, db.max() - top_db)
+
+
+def onset_strength(y, sr, fmin=0.0, fmax=None, n_fft=2048, hop=512, n_mels=128):
+    """Spectral-flux onset envelope (librosa.onset.onset_strength defaults: lag 1, max_size 1, mean
+    aggregate, centre compensation of lag + n_fft//(2*hop) frames).  Returns [n_frames]."""
+    fmax = 11025.0 if fmax is None else fmax
+    mel = mel_filterbank(sr, n_fft, n_mels, fmin, fmax) @ stft_power(y, n_fft, hop)
+    db = power_to_db(mel)
+    flux = np.maximum(0.0, db[:, 1:] - db[:, :-1]).mean(axis=0)
+    pad = 1 + n_fft // (2 * hop)
+    env = np.concatenate([np.zeros(pad), flux])
+    return env[: db.shape[1]]
+
+
+def chroma_filterbank(sr, n_fft=2048, n_chroma=12, ctroct=5.0, octwidth=2.0):
+    """librosa.filters.chroma (tuning 0, L2-normalised columns, Gaussian octave weighting, C-based)."""
+    freqs = np.linspace(0, sr, n_fft, endpoint=False)[1:]
+    bins = n_chroma * np.log2(freqs / (440.0 / 16))
+    bins = np.concatenate([[bins[0] - 1.5 * n_chroma], bins])
+    width = np.concatenate([np.maximum(bins[1:] - bins[:-1], 1.0), [1.0]])
+    d = bins[None, :] - np.arange(n_chroma, dtype=np.float64)[:, None]
+    half = np.round(n_chroma / 2.0)
+    d = np.remainder(d + half + 10 * n_chroma, n_chroma) - half
+    w = np.exp(-0.5 * (2 * d / width[None, :]) ** 2)
+    w /= np.maximum(np.sqrt((w ** 2).sum(axis=0, keepdims=True)), np.finfo(np.float64).tiny)
+    w *= np.exp(-0.5 * ((bins / n_chroma - ctroct) / octwidth) ** 2)[None, :]
+    w = np.roll(w, -3 * (n_chroma // 12), axis=0)
+    return w[:, : 1 + n_fft // 2]
+
+
+def chroma_stft(y, sr, n_fft=2048, hop=512):
+    """Power-spectrogram chroma, each frame normalised by its max (librosa.feature.chroma_stft, tuning 0)."""
+    raw = chroma_filterbank(sr, n_fft) @ stft_power(y, n_fft, hop)
+    peak = raw.max(axis=0, keepdims=True)
+    return raw / np.where(peak > np.finfo(np.float64).tiny, peak, 1.0)
+
+
+def onsets(y, sr, n_frames, fmin=20, fmax=8000, smooth=1, clip=100, power=1, smf=1.0):
+    """signal.py:31-73, type="rosa" branch, WITHOUT the percussive separation at :49."""
+    env = onset_strength(y, sr, fmin=fmin, fmax=fmax)
+    env = np.clip(resample(env, n_frames), env.min(), env.max())
+    env = torch.from_numpy(env).float()
+    env = gaussian_filter(env, smooth, causal=0, smf=smf)
+    env = percentile_clip(env, clip)
+    return env ** power
+
+
+def chroma(y, sr, n_frames, notes=12):
+    """signal.py:136-156 with type="stft" and without the harmonic separation at :150 / nn_filter at :130-131."""
+    ch = chroma_stft(y, sr).T
+    ch = resample(ch, n_frames)
+    keep = np.argsort(np.median(ch, axis=0))[:notes]
+    ch = ch[:, keep]
+    return torch.from_numpy(ch / ch.sum(1)[:, None]).float()
+
+
+def perlin_noise(shape, res, theta, phi, tileable=(True, False, False)):
+    """3-D Perlin noise in [-1,1]*... (latent.py:188-246) with the gradient angles supplied by the caller
+    (``theta``/``phi`` [res0+1,res1+1,res2+1], the two np.random.rand draws at :209-210 times 2*pi)."""
+    d = tuple(shape[i] // res[i] for i in range(3))
+    axes = [np.arange(shape[i], dtype=np.float64) * (res[i] / shape[i]) for i in range(3)]
+    frac = [a % 1 for a in axes]
+    g = np.stack([np.sin(phi) * np.cos(theta), np.sin(phi) * np.sin(theta), np.cos(phi)], axis=3)
+    if tileable[0]:
+        g[-1] = g[0]
+    if tileable[1]:
+        g[:, -1] = g[:, 0]
+    if tileable[2]:
+        g[:, :, -1] = g[:, :, 0]
+    cell = [np.arange(shape[i]) // d[i] for i in range(3)]
+    fx, fy, fz = np.meshgrid(frac[0], frac[1], frac[2], indexing="ij")
+    cx, cy, cz = np.meshgrid(cell[0], cell[1], cell[2], indexing="ij")
+
+    def corner(ox, oy, oz):
+        gv = g[cx + ox, cy + oy, cz + oz]
+        return (fx - ox) * gv[..., 0] + (fy - oy) * gv[..., 1] + (fz - oz) * gv[..., 2]
+
+    def fade(t):
+        return t * t * t * (t * (t * 6 - 15) + 10)
+
+    tx, ty, tz = fade(fx), fade(fy), fade(fz)
+    n00 = corner(0, 0, 0) * (1 - tx) + tx * corner(1, 0, 0)
+    n10 = corner(0, 1, 0) * (1 - tx) + tx * corner(1, 1, 0)
+    n01 = corner(0, 0, 1) * (1 - tx) + tx * corner(1, 0, 1)
+    n11 = corner(0, 1, 1) * (1 - tx) + tx * corner(1, 1, 1)
+    n0 = (1 - ty) * n00 + ty * n10
+    n1 = (1 - ty) * n01 + ty * n11
+    return ((1 - tz) * n0 + tz * n1) * 2 - 1

@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE (run in the build container only).
+
+    python tests/golden/make_golden.py [--full]
+
+Imports /root/reference (read-only) with the nvcc JIT loader stubbed (SURVEY.md §8c recipe) so that the
+reference's own pure-PyTorch CPU fallbacks run (op/upfirdn2d.py:159-200, op/fused_act.py:87-94), feeds them
+seeded inputs, asserts the repo's oracle/ restatement agrees (<= 1e-5 abs), and writes small .npz files
+holding *inputs (or their seeds) and the reference's outputs only*.  Generator weights are never stored:
+they are regenerated from numpy default_rng streams by maua_stylegan2_amd/seeding.py.
+
+The reference cannot travel to the GPU box; these fixtures + this script are what travels.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def import_reference():
+    import torch.utils.cpp_extension as cpp_ext
+
+    cpp_ext.load = lambda name, sources, **kw: types.SimpleNamespace()  # op/*.py call load() at import
+    for name in [
+        "librosa", "librosa.display", "madmom", "kornia", "kornia.augmentation", "kornia.geometry",
+        "kornia.geometry.transform", "ffmpeg", "torchvision", "torchvision.utils",
+    ]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.path.insert(0, REF)
+    import models.stylegan2 as ref_sg2  # noqa
+    import op as ref_op  # noqa
+    import audioreactive.signal as ref_signal_mod  # noqa  (module attr is shadowed by scipy.signal, use sys.modules)
+    import audioreactive.latent as ref_latent  # noqa
+    import generate_audiovisual as ref_gav  # noqa
+
+    return ref_sg2, ref_op, sys.modules["audioreactive.signal"], sys.modules["audioreactive.latent"], ref_gav
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+
+
+def check(name, mine, ref, tol=1e-5):
+    err = float((mine - ref).abs().max()) if mine.numel() else 0.0
+    print(f"  {name:58s} oracle-vs-reference max|err| = {err:.3e}")
+    assert err <= tol, (name, err)
+    return err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also run the 256^2 / 1024^2 generators (minutes on CPU)")
+    args = ap.parse_args()
+
+    ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
+    from maua_stylegan2_amd import seeding
+    from oracle import ops_oracle, signal_oracle, stylegan2_oracle as so
+
+    # ------------------------------------------------------------------ (1) upfirdn2d
+    print("upfirdn2d")
+    cases = []
+    r = rng(100)
+    blur = seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)
+    plain = seeding.fir_kernel_2d((1, 3, 3, 1), 1.0)
+    specs = [
+        # name, shape, kernel, up, down, pad
+        ("blur_after_upconv", (2, 5, 17, 17), blur, 1, 1, (1, 1)),
+        ("blur_rect", (1, 3, 33, 65), blur, 1, 1, (1, 1)),
+        ("skip_upsample", (2, 3, 8, 8), blur, 2, 1, (2, 1)),
+        ("skip_upsample_rect", (1, 3, 5, 12), blur, 2, 1, (2, 1)),
+        ("downsample2", (2, 4, 16, 16), plain, 1, 2, (1, 1)),
+        ("blur_pad22", (1, 2, 9, 9), plain, 1, 1, (2, 2)),
+        ("asym4x4", (2, 3, 11, 13), r.standard_normal((4, 4)).astype(np.float32), 1, 1, (1, 1)),
+        ("asym3x3", (1, 4, 10, 7), r.standard_normal((3, 3)).astype(np.float32), 1, 1, (1, 1)),
+        ("asym3x3_up2", (1, 2, 6, 6), r.standard_normal((3, 3)).astype(np.float32), 2, 1, (1, 1)),
+        ("asym4x4_up2_down2", (1, 2, 7, 9), r.standard_normal((4, 4)).astype(np.float32), 2, 2, (2, 1)),
+        ("negative_pad", (1, 2, 12, 12), r.standard_normal((4, 4)).astype(np.float32), 1, 1, (-1, -2)),
+        ("mixed_pad", (1, 2, 12, 12), r.standard_normal((4, 4)).astype(np.float32), 2, 1, (3, -1)),
+        ("asym2x2", (1, 2, 6, 8), r.standard_normal((2, 2)).astype(np.float32), 2, 1, (1, 0)),
+        ("big5x5_generic", (1, 2, 9, 9), r.standard_normal((5, 5)).astype(np.float32), 1, 1, (2, 2)),
+        ("up3_generic", (1, 2, 5, 5), r.standard_normal((4, 4)).astype(np.float32), 3, 2, (2, 2)),
+    ]
+    out = {}
+    for name, shape, k, up, down, pad in specs:
+        x = r.standard_normal(shape).astype(np.float32)
+        y_ref = ref_op.upfirdn2d(t(x), t(k), up=up, down=down, pad=pad)
+        y_mine = ops_oracle.upfirdn2d(t(x), t(k), up=up, down=down, pad=pad)
+        check(name, y_mine, y_ref)
+        y_loops = ops_oracle.upfirdn2d_loops(x, k, up, down, pad)
+        assert np.abs(y_loops - y_ref.numpy()).max() < 1e-4, name
+        out[f"{name}.x"], out[f"{name}.k"], out[f"{name}.y"] = x, k, y_ref.numpy()
+        out[f"{name}.cfg"] = np.array([up, down, pad[0], pad[1]], dtype=np.int64)
+        cases.append(name)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "ops_upfirdn2d.npz"), **out)
+
+    # ------------------------------------------------------------------ (2) fused_leaky_relu
+    print("fused_leaky_relu")
+    out = {}
+    r = rng(101)
+    for name, shape in [("nchw", (2, 7, 5, 5)), ("nc", (4, 16)), ("nchw_odd", (3, 5, 3, 7)), ("ncl", (2, 6, 10))]:
+        x = r.standard_normal(shape).astype(np.float32)
+        b = r.standard_normal(shape[1]).astype(np.float32)
+        y_ref = ref_op.fused_leaky_relu(t(x), t(b))
+        check(name, ops_oracle.fused_leaky_relu(t(x), t(b)), y_ref)
+        k_sem = ops_oracle.fused_bias_act_kernel_semantics(x, b, None, 3, 0, 0.2, 2 ** 0.5)
+        assert np.abs(k_sem - y_ref.numpy()).max() < 1e-6
+        out[f"{name}.x"], out[f"{name}.b"], out[f"{name}.y"] = x, b, y_ref.numpy()
+    out["cases"] = np.array(["nchw", "nc", "nchw_odd", "ncl"])
+    np.savez_compressed(os.path.join(HERE, "ops_fused_leaky_relu.npz"), **out)
+
+    # ------------------------------------------------------------------ (3,4) layers
+    print("ModulatedConv2d / StyledConv / ToRGB")
+    out = {}
+    r = rng(102)
+    layer_cases = []
+    for name, cin, cout, k, up, demod, hw in [
+        ("plain3x3", 8, 6, 3, False, True, (7, 9)),
+        ("up3x3", 8, 6, 3, True, True, (5, 6)),
+        ("rgb1x1", 8, 3, 1, False, False, (6, 6)),
+        ("plain3x3_wide", 16, 40, 3, False, True, (4, 4)),
+        ("up3x3_wide", 12, 34, 3, True, True, (4, 4)),
+    ]:
+        m = ref_sg2.ModulatedConv2d(cin, cout, k, 32, demodulate=demod, upsample=up)
+        w = r.standard_normal((1, cout, cin, k, k)).astype(np.float32)
+        mw = r.standard_normal((cin, 32)).astype(np.float32)
+        mb = (1 + 0.1 * r.standard_normal(cin)).astype(np.float32)
+        m.weight.copy_(t(w)), m.modulation.weight.copy_(t(mw)), m.modulation.bias.copy_(t(mb))
+        x = r.standard_normal((2, cin) + hw).astype(np.float32)
+        s = r.standard_normal((2, 32)).astype(np.float32)
+        y_ref = m(t(x), t(s))
+        y_mine = so.modulated_conv2d(t(x), t(s), t(w), t(mw), t(mb), demodulate=demod, upsample=up,
+                                     blur_kernel=t(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)))
+        check("modconv." + name, y_mine, y_ref)
+        for key, val in dict(x=x, s=s, w=w, mw=mw, mb=mb, y=y_ref.numpy()).items():
+            out[f"modconv.{name}.{key}"] = val
+        out[f"modconv.{name}.cfg"] = np.array([cin, cout, k, int(up), int(demod)], dtype=np.int64)
+        layer_cases.append(name)
+    out["modconv.cases"] = np.array(layer_cases)
+
+    for name, up in [("styled_plain", False), ("styled_up", True)]:
+        cin, cout = 8, 10
+        m = ref_sg2.StyledConv(cin, cout, 3, 32, upsample=up)
+        sd = {
+            "L.conv.weight": r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32),
+            "L.conv.modulation.weight": r.standard_normal((cin, 32)).astype(np.float32),
+            "L.conv.modulation.bias": (1 + 0.1 * r.standard_normal(cin)).astype(np.float32),
+            "L.noise.weight": np.array([0.37], dtype=np.float32),
+            "L.activate.bias": (0.3 * r.standard_normal(cout)).astype(np.float32),
+        }
+        if up:
+            sd["L.conv.blur.kernel"] = seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)
+        m.load_state_dict({k[2:]: t(v) for k, v in sd.items()}, strict=True)
+        h = 6
+        x = r.standard_normal((2, cin, h, h)).astype(np.float32)
+        s = r.standard_normal((2, 32)).astype(np.float32)
+        oh = 2 * h if up else h
+        nz = r.standard_normal((2, 1, oh, oh)).astype(np.float32)
+        y_ref = m(t(x), t(s), noise=t(nz))
+        y_mine = so.styled_conv({k: t(v) for k, v in sd.items()}, "L", t(x), t(s), t(nz), up)
+        check(name, y_mine, y_ref)
+        for k, v in sd.items():
+            out[f"{name}.sd.{k}"] = v
+        out[f"{name}.x"], out[f"{name}.s"], out[f"{name}.noise"], out[f"{name}.y"] = x, s, nz, y_ref.numpy()
+
+    for name, skip in [("torgb_noskip", False), ("torgb_skip", True)]:
+        cin = 8
+        m = ref_sg2.ToRGB(cin, 32, upsample=True)
+        sd = {
+            "L.bias": (0.3 * r.standard_normal((1, 3, 1, 1))).astype(np.float32),
+            "L.upsample.kernel": seeding.fir_kernel_2d((1, 3, 3, 1), 4.0),
+            "L.conv.weight": r.standard_normal((1, 3, cin, 1, 1)).astype(np.float32),
+            "L.conv.modulation.weight": r.standard_normal((cin, 32)).astype(np.float32),
+            "L.conv.modulation.bias": (1 + 0.1 * r.standard_normal(cin)).astype(np.float32),
+        }
+        m.load_state_dict({k[2:]: t(v) for k, v in sd.items()}, strict=True)
+        x = r.standard_normal((2, cin, 8, 8)).astype(np.float32)
+        s = r.standard_normal((2, 32)).astype(np.float32)
+        sk = r.standard_normal((2, 3, 4, 4)).astype(np.float32) if skip else None
+        y_ref = m(t(x), t(s), t(sk) if skip else None)
+        y_mine = so.to_rgb({k: t(v) for k, v in sd.items()}, "L", t(x), t(s), t(sk) if skip else None)
+        check(name, y_mine, y_ref)
+        for k, v in sd.items():
+            out[f"{name}.sd.{k}"] = v
+        out[f"{name}.x"], out[f"{name}.s"], out[f"{name}.y"] = x, s, y_ref.numpy()
+        if skip:
+            out[f"{name}.skip"] = sk
+    np.savez_compressed(os.path.join(HERE, "layers.npz"), **out)
+
+    # ------------------------------------------------------------------ (5) end-to-end generators
+    print("Generator end-to-end")
+    sizes = [(8, 2, 1), (16, 2, 1), (64, 2, 1)]
+    if args.full:
+        sizes += [(256, 2, 4), (1024, 1, 16)]
+    for size, batch, stride in sizes:
+        path = os.path.join(HERE, f"gen_{size}.npz")
+        sd = seeding.seeded_state_dict(size, seed=0)
+        g = ref_sg2.Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+        g.load_state_dict(sd, strict=True)  # proves key names/shapes equal the reference checkpoint layout
+        g.eval()
+        n_latent = g.n_latent
+        lat = seeding.seeded_latents(batch, n_latent, seed=1)
+        noise = seeding.seeded_noise(batch, size, seed=2)
+        trunc = torch.full((batch,), 0.7)
+        tl = torch.from_numpy(seeding.seeded_array(5, "truncation_latent", (1, 512)))
+        g.truncation_latent = tl
+        img_ref, acts_ref = g(styles=lat, noise=list(noise), truncation=trunc, randomize_noise=False,
+                              input_is_latent=True, return_activation_maps=True)
+        img_mine, acts_mine = so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=tl,
+                                                   return_activations=True)
+        check(f"generator {size} image", img_mine, img_ref, tol=2e-4)
+        for a, bb in zip(acts_mine, acts_ref):
+            assert float((a - bb).abs().max()) < 2e-4
+        # second run: checkpoint noise buffers (noise=None), truncation 1 -> identity lerp
+        g.truncation_latent = torch.zeros(1, 512)
+        img_ref2, _ = g(styles=lat, noise=None, truncation=torch.ones(batch), randomize_noise=False, input_is_latent=True)
+        img_mine2 = so.generator_forward(sd, lat, None)
+        check(f"generator {size} image (buffer noise)", img_mine2, img_ref2, tol=2e-4)
+        fix = {
+            "size": np.int64(size), "batch": np.int64(batch), "stride": np.int64(stride),
+            "seeds": np.array([0, 1, 2, 5], dtype=np.int64), "truncation": np.float32(0.7),
+            "image": img_ref.numpy()[:, :, ::stride, ::stride].copy(),
+            "image_buffer_noise": img_ref2.numpy()[:, :, ::stride, ::stride].copy(),
+            "image_mean_std": np.array([img_ref.mean().item(), img_ref.std().item()], dtype=np.float64),
+            "act_mean_abs": np.array([a.abs().mean().item() for a in acts_ref], dtype=np.float64),
+            "act_sum": np.array([a.double().sum().item() for a in acts_ref], dtype=np.float64),
+        }
+        np.savez_compressed(path, **fix)
+        print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+        del g, sd
+
+    # ------------------------------------------------------------------ (6) audioreactive torch stages
+    print("audioreactive: gaussian_filter / percentile_clip / chroma_weight_latents / get_noise_range")
+    out = {}
+    r = rng(103)
+    gcases = []
+    for name, shape, sigma, causal, smf in [
+        ("env_s5", (200,), 5, 0, 1.0),
+        ("env_s2_c02", (150,), 2, 0.2, 1.0),
+        ("lat_s4", (120, 3, 16), 4, None, 1.0),
+        ("lat_s2_c02_smf2", (90, 2, 8), 2, 0.2, 2.0),
+        ("noise_s5", (64, 1, 4, 6), 5, None, 1.0),
+        ("short_radius_gt_n", (10, 2, 4), 5, None, 1.0),  # radius 20 > n_frames 10 -> :350-355 branch
+        ("causal_int", (80,), 3, 1, 1.0),  # non-float causal -> right half zeroed (:340-341)
+    ]:
+        x = r.standard_normal(shape).astype(np.float32)
+        ref_signal.set_SMF(smf)
+        y_ref = ref_signal.gaussian_filter(t(x), sigma, causal=causal)
+        y_mine = signal_oracle.gaussian_filter(t(x), sigma, causal=causal, smf=smf)
+        check("gaussian_filter." + name, y_mine, y_ref)
+        out[f"gf.{name}.x"], out[f"gf.{name}.y"] = x, y_ref.numpy()
+        out[f"gf.{name}.cfg"] = np.array([sigma, -1.0 if causal is None else float(causal), smf,
+                                          0.0 if causal is None else (2.0 if isinstance(causal, float) else 1.0)])
+        gcases.append(name)
+    ref_signal.set_SMF(1)
+    out["gf.cases"] = np.array(gcases)
+    for name, n, p in [("p97", 300, 97), ("p50", 257, 50), ("p100", 100, 100)]:
+        x = np.abs(r.standard_normal(n)).astype(np.float32)
+        y_ref = ref_signal.percentile_clip(t(x).clone(), p)
+        check("percentile_clip." + name, signal_oracle.percentile_clip(t(x).clone(), p), y_ref)
+        out[f"pc.{name}.x"], out[f"pc.{name}.y"], out[f"pc.{name}.p"] = x, y_ref.numpy(), np.int64(p)
+    out["pc.cases"] = np.array(["p97", "p50", "p100"])
+    x = r.standard_normal(64).astype(np.float32)
+    out["normalize.x"], out["normalize.y"] = x, ref_signal.normalize(t(x).clone()).numpy()
+    check("normalize", signal_oracle.normalize(t(x).clone()), t(out["normalize.y"]))
+    out["compress.x"] = x
+    out["compress.y"] = ref_signal.compress(t(x).clone(), 0.5, 0.25).numpy()
+    check("compress", signal_oracle.compress(t(x).clone(), 0.5, 0.25), t(out["compress.y"]))
+    chroma = np.abs(r.standard_normal((40, 12))).astype(np.float32)
+    chroma /= chroma.sum(1, keepdims=True)
+    lats = r.standard_normal((12, 6, 16)).astype(np.float32)
+    y_ref = ref_latent.chroma_weight_latents(t(chroma), t(lats))
+    check("chroma_weight_latents", signal_oracle.chroma_weight_latents(t(chroma), t(lats)), y_ref)
+    out["cwl.chroma"], out["cwl.latents"], out["cwl.y"] = chroma, lats, y_ref.numpy()
+    rows = []
+    for out_size, g_res in [(1024, 1024), (256, 256), (512, 512), (1920, 1024), (1080, 1024), (512, 256), (1024, 512)]:
+        lo, hi, fn = ref_gav.get_noise_range(out_size, g_res, False)
+        sides = [2 ** fn(s) for s in range(lo, hi)]
+        assert signal_oracle.noise_side_lengths(out_size, g_res) == sides, (out_size, g_res)
+        rows.append([out_size, g_res, lo, hi] + sides + [0] * (20 - len(sides)))
+    out["noise_range"] = np.array(rows, dtype=np.int64)
+    wl = ref_latent.wrapping_slice(torch.arange(10), 7, 6)
+    out["wrapping_slice_10_7_6"] = wl.numpy()
+    sel = r.standard_normal((5, 3, 4)).astype(np.float32)
+    out["spline.sel"] = sel
+    out["spline.y"] = ref_latent.spline_loops(sel, 37, 2).numpy()
+    np.savez_compressed(os.path.join(HERE, "audioreactive_torch.npz"), **out)
+
+    # ------------------------------------------------------------------ (7) uint8 post-process (render.py:40-43)
+    print("frame post-process")
+    edge = np.array([-1.0, 1.0, -1.01, 1.01, 0.0, 0.5, -0.5, 0.999999, -0.999999, 1 / 127.5 - 1, 0.0039, 0.33333334,
+                     -0.00392157, 0.00392157, 0.9921569, 0.9960784], dtype=np.float32)
+    vals = np.concatenate([edge, r.uniform(-1.2, 1.2, 3 * 4 * 8 - edge.size).astype(np.float32)]).reshape(1, 3, 4, 8)
+    imgs = (t(vals).clone().clamp_(-1, 1) + 1) * 127.5
+    u8_ref = imgs.permute(0, 2, 3, 1).numpy().astype(np.uint8)
+    assert (so.frames_to_uint8(t(vals)) == u8_ref).all()
+    np.savez_compressed(os.path.join(HERE, "postprocess.npz"), x=vals, y=u8_ref)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
