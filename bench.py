@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py — synthesized 1024^2 StyleGAN2 frames/s on N MI355X (BASELINE.json metric), with roofline + CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size 1024]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of B synthetic frames on every rank: copy the batch's latents
+(already resident in HBM) into the graph's static inputs, replay the hipGraph-captured generator forward
+(style affines, demod, 17 StyledConv, 9 ToRGB), convert to uint8 NHWC frames (render.py:40-43 epilogue).  Frames
+are independent, so ranks shard them with no data-path collective (weak scaling: B frames per rank per step).
+Weights are random-init (seeded numpy streams) of the real 1024^2 architecture; arithmetic is fp32 end to end.
+
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the frame (largest share of device time, measured
+live with HIP events on the launch stream); `roofline_upfirdn2d` is the standalone upfirdn2d op on the Blur-after-
+up-conv shape that carries 49 % of the path's upfirdn2d bytes, which BASELINE.json's metric names.
+`cpu_baseline` times oracle/ (the CPU restatement pinned to the reference by tests/golden) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+
+
+def conv_flops_per_frame(size):
+    """2*Cin*Cout*k^2*H_in*W_in per modulated conv."""
+    from maua_stylegan2_amd.seeding import channels_for
+
+    ch = channels_for(2)
+    total = 2 * 512 * 512 * 9 * 16 + 2 * 512 * 3 * 16
+    cin, res = 512, 4
+    while res < size:
+        res *= 2
+        cout = ch[res]
+        total += 2 * cin * cout * 9 * (res // 2) ** 2 + 2 * cout * cout * 9 * res * res + 2 * cout * 3 * res * res
+        cin = cout
+    return total
+
+
+def time_calls(fn, iters, stream_ptr):
+    """Average device time (ms) of `fn` over `iters` back-to-back launches, HIP events on the launch stream."""
+    from maua_stylegan2_amd import _lib
+
+    for _ in range(3):
+        fn()
+    e0, e1 = _lib.HipEvent(), _lib.HipEvent()
+    e0.record(stream_ptr)
+    for _ in range(iters):
+        fn()
+    e1.record(stream_ptr)
+    return e0.elapsed_ms(e1) / iters
+
+
+def layer_breakdown(g, batch, static, stream):
+    """Per-kernel-family device time of one forward (eager launches on `stream`, HIP events)."""
+    from maua_stylegan2_amd import _lib
+    from maua_stylegan2_amd.seeding import channels_for
+
+    sp = stream.cuda_stream
+    dev = static["latents"].device
+    rows = []
+    bufs = lambda name, shape: g._buf(batch, "bench." + name, shape)  # noqa: E731
+    info = g._table(batch)
+    s = g._buf(batch, "styles", (batch, info["s_total"]))
+    d = g._buf(batch, "demod", (info["d_total"],))
+    ent = info["entries"]
+
+    def demod_of(e):
+        return d[e["d_off"]: e["d_off"] + batch * e["cout"]].view(batch, e["cout"])
+
+    li = 0
+    x = g._buf(batch, "const", (batch, 512, 4, 4))
+    layers = [("conv1", g.conv1, x, 0)]
+    rows.append(("conv1", "modconv", time_calls(lambda: g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), static["noise"][0], bufs, "c1"), 20, sp),
+                 2 * 512 * 512 * 9 * 16 * batch, 0))
+    out = g._buf(batch, "conv1", (batch, 512, 4, 4))
+    rows.append(("to_rgb1", "torgb", time_calls(lambda: g.to_rgb1.run(out, s, ent[1]["s_off"], None, bufs("rgb1", (batch, 3, 4, 4))), 20, sp),
+                 2 * 512 * 3 * 16 * batch, 4 * batch * (512 + 3) * 16))
+    li = 2
+    image = g._buf(batch, "rgb1", (batch, 3, 4, 4))
+    for n in range(g.log_size - 2):
+        up, plain, rgb = g.convs[2 * n], g.convs[2 * n + 1], g.to_rgbs[n]
+        cin, cout = up.conv.in_channel, up.conv.out_channel
+        h = out.shape[2]
+        e_up, e_pl, e_rgb = ent[li], ent[li + 1], ent[li + 2]
+        nz1, nz2 = static["noise"][2 * n + 1], static["noise"][2 * n + 2]
+        xin = out
+        # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
+        raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
+        n_ws = _lib.load().maua_modconv_ws_floats(batch, cin, cout, h, h, 1)
+        ws = g._buf(batch, "bench.ws", (max(n_ws, 1),)) if n_ws else None
+        t_up = time_calls(lambda: up.conv.run(xin, s, e_up["s_off"], demod_of(e_up), raw, ws), 10, sp)
+        rows.append((f"convs.{2*n}.upconv", "modconv_up", t_up, 2 * cin * cout * 9 * h * h * batch, 0))
+        t_all = time_calls(lambda: up.run(xin, s, e_up["s_off"], demod_of(e_up), nz1, bufs, f"u{n}"), 10, sp)
+        blur_bytes = 4 * batch * cout * ((2 * h + 1) ** 2 + (2 * h) ** 2)
+        rows.append((f"convs.{2*n}.blur+noise+act", "upfirdn2d_tail", max(t_all - t_up, 1e-6), 16 * 2 * batch * cout * (2 * h) ** 2, blur_bytes))
+        mid = g._buf(batch, f"convs.{2*n}", (batch, cout, 2 * h, 2 * h))
+        t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}"), 10, sp)
+        rows.append((f"convs.{2*n+1}", "modconv", t_pl, 2 * cout * cout * 9 * (2 * h) ** 2 * batch, 0))
+        out = g._buf(batch, f"convs.{2*n+1}", (batch, cout, 2 * h, 2 * h))
+        o2, img_in = out, image
+        t_rgb = time_calls(lambda: rgb.run(o2, s, e_rgb["s_off"], img_in, bufs(f"rgb{n}", (batch, 3, 2 * h, 2 * h))), 10, sp)
+        rows.append((f"to_rgbs.{n}", "torgb", t_rgb, 2 * cout * 3 * (2 * h) ** 2 * batch, 4 * batch * (cout + 3 + 1) * (2 * h) ** 2))
+        image = g._buf(batch, f"rgbs.{n}", (batch, 3, 2 * h, 2 * h))
+        li += 3
+    return rows
+
+
+def cpu_baseline(size, max_seconds=25.0):
+    """Oracle (kind "port") on the host cores: bounded sample of 1024^2 frames, batch 1."""
+    from maua_stylegan2_amd import seeding
+    from oracle import stylegan2_oracle as so
+
+    torch.set_grad_enabled(False)
+    sd = seeding.seeded_state_dict(size, seed=0)
+    n_latent = 2 * (size.bit_length() - 1) - 2
+    lat = seeding.seeded_latents(1, n_latent, seed=1)
+    noise = seeding.seeded_noise(1, size, seed=2)
+    so.generator_forward(sd, lat, noise)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < 3 or (time.perf_counter() - t0 < max_seconds and n < 64):
+        so.generator_forward(sd, lat, noise)
+        n += 1
+        if time.perf_counter() - t0 > max_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frames of {size}x{size}, batch 1, oracle/stylegan2_oracle.py (torch CPU fp32)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per rank per step (reference default --batch 8)")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.set_grad_enabled(False)
+
+    from maua_stylegan2_amd import _lib, seeding
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    lib = _lib.load()
+    size, B = args.size, args.batch
+    g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
+    g = g.to(dev).eval()
+    if world > 1:  # weights: rank 0 is the source of truth, one RCCL broadcast per tensor
+        for t in list(g.parameters()) + list(g.buffers()):
+            dist.broadcast(t.data, 0)
+
+    # synthetic inputs resident in HBM: a pool of latents for every step of this rank; noise maps for scales <= 256
+    # are per-frame (audio-reactive in the default plugin), 512/1024 use the checkpoint buffers (get_noise -> None).
+    n_steps = args.steps + args.warmup
+    lat_pool = seeding.seeded_latents(n_steps * B, g.n_latent, seed=100 + rank).to(dev)
+    sizes = seeding.noise_sizes(size)
+    noise_shapes = [(r, r) if r <= 256 else None for r in sizes]
+    noise_pool = [torch.from_numpy(seeding.seeded_array(200 + rank, f"n{i}", (B, 1, r, r))).to(dev) if r <= 256 else None
+                  for i, r in enumerate(sizes)]
+
+    stream = torch.cuda.Stream(dev)
+    frames_u8 = torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev)
+    with torch.cuda.stream(stream):
+        graph, static = g.capture_graph(B, noise_shapes)
+        for dst, src in zip(static["noise"], noise_pool):
+            if src is not None:
+                dst.copy_(src)
+        sp = stream.cuda_stream
+
+        def step(i):
+            static["latents"].copy_(lat_pool[i * B:(i + 1) * B], non_blocking=True)
+            graph.replay(sp)
+            _lib.check(lib.maua_frames_to_u8(static["image"].data_ptr(), frames_u8.data_ptr(), B, size, size, sp), "u8")
+
+        for i in range(args.warmup):
+            step(i)
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_steps):
+            step(i)
+        stream.synchronize()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        checksum = int(frames_u8.sum().item())
+
+        result = None
+        if rank == 0:
+            fps = world * args.steps * B / elapsed
+            ms_per_step = 1000.0 * elapsed / args.steps
+            result = {
+                "metric": "1024^2 frames/sec (whole job)" if size == 1024 else f"{size}^2 frames/sec (whole job)",
+                "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"StyleGAN2-{size} generator (config 3 shape: random-init, channel_multiplier 2), "
+                                       f"{B} frames/step/GPU, hipGraph per batch, per-frame noise <=256^2, uint8 NHWC epilogue",
+                           "frames_per_step_per_gpu": B, "parallelism": f"frame-shard x{world}"},
+                "frames_per_sec_per_gpu": fps / world,
+                "conv_tflops_sustained": conv_flops_per_frame(size) * fps / world / 1e12,
+                "frame_checksum": checksum,
+                "device": _lib.device_info(),
+            }
+            # ---- roofline legs (rank 0, N==1 style measurements on this rank's stream)
+            if not args.no_breakdown:
+                rows = layer_breakdown(g, B, static, stream)
+                total_ms = sum(r[2] for r in rows)
+                fam = {}
+                for name, family, ms, flops, byts in rows:
+                    fam.setdefault(family, [0.0, 0, 0])
+                    fam[family][0] += ms
+                    fam[family][1] += flops
+                    fam[family][2] += byts
+                result["kernel_families"] = {k: {"ms_per_step": v[0], "share": v[0] / total_ms,
+                                                 "tflops": v[1] / v[0] / 1e9, "gbs": v[2] / v[0] / 1e6}
+                                             for k, v in fam.items()}
+                result["layers"] = [{"name": n, "ms": ms, "tflops": fl / ms / 1e9, "gbs": by / ms / 1e6} for n, _, ms, fl, by in rows]
+                # dominant kernel instance = the single launch with the largest time
+                dom = max(rows, key=lambda r: r[2])
+                if dom[1].startswith("modconv"):
+                    ach = dom[3] / dom[2] / 1e9
+                    result["roofline"] = {"kernel": f"modconv_mfma_kernel ({dom[0]})", "bound": "mfma", "achieved": ach,
+                                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                                          "traffic": None, "launch_ms": dom[2]}
+                else:
+                    ach = dom[4] / dom[2] / 1e6
+                    result["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": dom[2]}
+            # standalone upfirdn2d on the 1024-res Blur shape (the op BASELINE.json's metric names)
+            from maua_stylegan2_amd.op import upfirdn2d
+
+            r_out = size
+            xin = torch.randn(B, 32 if size == 1024 else 64, r_out + 1, r_out + 1, device=dev)
+            kern = torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)).to(dev)
+            yout = torch.empty(xin.shape[0] * xin.shape[1], r_out, r_out, 1, device=dev)
+            major = xin.shape[0] * xin.shape[1]
+
+            def launch_fir():
+                lib.maua_upfirdn2d_f32(xin.data_ptr(), kern.data_ptr(), yout.data_ptr(), major, r_out + 1, r_out + 1, 1,
+                                       4, 4, 1, 1, 1, 1, 1, 1, 1, 1, sp)
+
+            ms = time_calls(launch_fir, 20, sp)
+            byts = 4 * major * ((r_out + 1) ** 2 + r_out ** 2)
+            ach = byts / ms / 1e6
+            result["roofline_upfirdn2d"] = {"kernel": "fir_tile_kernel<4,4,4,false>", "bound": "hbm", "achieved": ach,
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                            "traffic": None, "launch_ms": ms, "algorithmic_bytes": byts,
+                                            "shape": f"[{xin.shape[0]},{xin.shape[1]},{r_out+1},{r_out+1}] -> {r_out}^2"}
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(size)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

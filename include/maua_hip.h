@@ -49,27 +49,30 @@ int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch,
                             int kh, int kw, int pad0, int pad1, const float* gain, const float* noise,
                             int64_t noise_batch_stride, const float* noise_w, const float* bias, void* stream);
 
-/* All style affines of one forward in one launch (EqualLinear, models/stylegan2.py:140-146,207,220):
- *   s[b, off_l + i] = sum_j mod_w_l[i,j] * (1/sqrt(style_dim)) * latent[b, lat_idx_l, j] + mod_b_l[i]
- * with the truncation lerp of Generator.forward (:541-543) applied to the latent first when trunc != NULL:
- *   latent' = trunc_latent + trunc[b] * (latent - trunc_latent).
- * `table` (device, n_layers entries) describes the layers. */
+/* All style affines and demodulation factors of one forward, two launches in total, table-driven.
+ *  affine (EqualLinear, models/stylegan2.py:140-146,207,220), with the truncation lerp of Generator.forward
+ *  (:541-543) applied to the latent first when trunc != NULL (latent' = trunc_latent + trunc[b]*(latent - trunc_latent)):
+ *      s[b*s_stride + s_off_l + i] = (1/sqrt(style_dim)) * sum_j mod_w_l[i,j] * latent'[b, lat_idx_l, j] + mod_b_l[i]
+ *  demod (:223-225) in the shared-weight formulation, for layers with wsq != NULL:
+ *      d[d_off_l + b*cout_l + o] = rsqrt( wscale_l^2 * sum_i wsq_l[o,i] * s[b, s_off_l + i]^2 + 1e-8 )
+ *  `table` lives in DEVICE memory (n_layers entries). batch <= 64 per call. */
 typedef struct {
     const float* mod_w; /* [cin, style_dim] */
     const float* mod_b; /* [cin] */
+    const float* wsq;   /* [cout, cin] sum over taps of W^2 (maua_pack_weight_f32), NULL = no demodulation */
     int cin;
+    int cout;
     int lat_idx;        /* which of the n_latent rows feeds this layer */
-    int out_off;        /* offset of this layer's slice in s (floats, per batch row) */
+    int s_off;          /* offset of this layer's slice inside one batch row of s */
+    int64_t d_off;      /* offset of this layer's [batch, cout] block inside d */
+    float wscale;       /* 1/sqrt(cin * k * k) */
     int pad_;
 } maua_style_layer_t;
 int maua_style_affine_f32(const float* latents, int batch, int n_latent, int style_dim, const float* trunc,
-                          const float* trunc_latent, const maua_style_layer_t* table, int n_layers,
+                          const float* trunc_latent, const maua_style_layer_t* table, int n_layers, int max_cin,
                           float* s, int s_stride, void* stream);
-
-/* Demodulation factors (models/stylegan2.py:223-225) for the shared-weight formulation:
- *   d[b,o] = rsqrt( scale^2 * sum_i wsq[o,i] * s[b,i]^2 + 1e-8 ),  wsq[o,i] = sum_taps W[o,i,:,:]^2 */
-int maua_demod_f32(const float* wsq, const float* s, int s_stride, float* d, int batch, int cout, int cin,
-                   float scale, void* stream);
+int maua_demod_f32(const maua_style_layer_t* table, int n_layers, int max_cout, const float* s, int s_stride, float* d,
+                   int batch, void* stream);
 
 /* Sum of squared taps wsq[o,i] and the tap-major repack wp[tap][i][o] of a [cout,cin,k,k] weight (one-off, at load). */
 int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream);

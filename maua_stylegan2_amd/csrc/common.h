@@ -1,0 +1,28 @@
+// Shared helpers for libmaua_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/maua_hip.h"
+
+#define MAUA_LAUNCH_CHECK()                       \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bijective XCD-aware remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective"): block b runs on
+// XCD b % 8; give every XCD one contiguous chunk of the logical tile range so that neighbouring tiles
+// (which share halos / weight panels) hit the same 4 MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int NX = 8;
+    int q = nblocks / NX, r = nblocks % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float lrelu_gain(float v) { return (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f; }

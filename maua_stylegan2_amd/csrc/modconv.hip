@@ -1,0 +1,434 @@
+// ModulatedConv2d 3x3 on the gfx950 matrix cores (fp32-in / fp32-accumulate MFMA, exact fp32).
+//
+// Behavioural contract: /root/reference/models/stylegan2.py:217-254 (+ StyledConv tail :338-343).
+// The reference materialises per-sample weights [B,Cout,Cin,3,3] and runs a grouped cuDNN conv.  Here:
+//
+//     y[b,o] = d[b,o] * sum_{i,tap} (wscale * W[o,i,tap]) * (s[b,i] * x[b,i, . + tap])
+//
+// i.e. input-scale -> SHARED-weight implicit GEMM -> output-demod, so one weight panel
+// serves the whole batch of frames and stays L2-resident across pixel tiles.
+//
+// Implicit GEMM on v_mfma_f32_32x32x2_f32:  M = Cout, N = pixels, K = Cin x taps.
+//   A (weights)  : tap-major repack wp[tap][cin][cout_pad] (maua_pack_weight_f32) -> LDS As[tap][c][BM], lanes read
+//                  consecutive cout -> conflict-free ds_read_b32 with immediate offsets.
+//   B (features) : the workgroup stages ONE halo patch per 8-channel chunk (scaled by s[b,i] on the way in);
+//                  the 9 taps are 9 shifted views of the same patch — no im2col replication, in HBM or in LDS.
+//   C            : 64 accumulator VGPRs per wave; epilogue applies demod, noise, bias, leaky-ReLU*sqrt2 in-register
+//                  and stores 128-byte row segments (lane = pixel column).
+// Transposed (stride-2) convolution (:229-237) is evaluated polyphase: the 9 taps split into output parities
+// (4/2/2/1 taps), every workgroup owns a tile of input positions and accumulates all four parities from the same
+// staged patch — 9 MACs per input pixel per channel pair, exactly the reference's FLOPs, no zero-stuffing.
+// Small feature maps (4^2..32^2) are weight-streaming bound: K is split across workgroups (deterministic two-pass
+// split-K through a caller-owned workspace, reduced by reduce_tail_kernel together with the tail).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CC = 8;  // channels per K chunk
+
+struct ConvGeom {
+    int B, Cin, Cout, CoutPad, H, W;  // input feature map
+    int GH, GW;                       // per-image grid of tile positions (plain: H,W   up: H+1,W+1)
+    int OH, OW;                       // output plane
+    int lsw, lsh;                     // log2 sub-tile (one MFMA N=32 group) width / height, 2^(lsw+lsh) = 32
+    int lnsx, lnsy;                   // log2 sub-tiles per tile along x / y
+    int lni;                          // log2 images per tile
+    int tiles_x, tiles_y, img_groups;
+    int PH, PW, PSTRIDE;              // staged patch: rows, cols, floats per channel (all images of the tile)
+    int m_tiles, n_tiles;
+    int splits, chunks_per_split, n_chunks;
+    int s_stride;
+    float wscale;
+    int fuse_act;
+    int64_t noise_batch_stride;
+    int64_t ws_slab;  // floats per split slab
+};
+
+struct ConvPtrs {
+    const float* x;
+    const float* wp;
+    const float* s;
+    const float* d;
+    const float* noise;
+    const float* noise_w;
+    const float* bias;
+    float* y;
+    float* ws;
+};
+
+// UP = false : plain 3x3, pad 1.           per wave: TM x TN MFMA tiles.
+// UP = true  : stride-2 transposed 3x3.    per wave: TM x (TN position groups x 4 output parities).
+template <int BM, int BN, int WM, bool UP>
+__global__ __launch_bounds__(256) void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
+    constexpr int WN = 4 / WM;
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int NPH = UP ? 4 : 1;
+    constexpr int A_FLOATS = 9 * CC * BM;
+    constexpr int A_VEC_ITERS = (A_FLOATS / 4 + 255) / 256;
+    constexpr int MAX_POS = 3;  // patch positions per thread (PSTRIDE <= 768)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;
+    float* Ps = lds + A_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+
+    // ---- which tile
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt_id = t % g.n_tiles;
+    t /= g.n_tiles;
+    const int mt_id = t % g.m_tiles;
+    const int split = t / g.m_tiles;
+    int r = nt_id;
+    const int tile_x = r % g.tiles_x;
+    r /= g.tiles_x;
+    const int tile_y = r % g.tiles_y;
+    const int img_group = r / g.tiles_y;
+
+    const int SW = 1 << g.lsw, SH = 1 << g.lsh;
+    const int TWd = SW << g.lnsx, THt = SH << g.lnsy;
+    const int NI = 1 << g.lni;
+    const int ty0 = tile_y * THt, tx0 = tile_x * TWd, b0 = img_group * NI;
+    const int m0 = mt_id * BM;
+    const size_t plane_in = (size_t)g.H * g.W;
+
+    // ---- per-thread patch positions (decoded once)
+    int src_off[MAX_POS];  // offset of (b, ch 0, y, x) in x, or -1
+    int sb_off[MAX_POS];   // b * s_stride
+#pragma unroll
+    for (int i = 0; i < MAX_POS; ++i) {
+        const int pp = tid + i * 256;
+        src_off[i] = -1;
+        sb_off[i] = 0;
+        if (pp < g.PSTRIDE) {
+            const int per_img = g.PH * g.PW;
+            const int img = pp / per_img;
+            const int rem = pp - img * per_img;
+            const int pr = rem / g.PW, pc = rem - pr * g.PW;
+            const int b = b0 + img, yy = ty0 + pr - 1, xx = tx0 + pc - 1;
+            if (img < NI && b < g.B && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
+                src_off[i] = (int)(((size_t)b * g.Cin * g.H + yy) * g.W + xx);
+                sb_off[i] = b * g.s_stride;
+            }
+        }
+    }
+
+    // ---- per-lane B-fragment base offsets (top-left of the 3x3 window of this lane's pixel, channel parity hi)
+    int boff[TN];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int sub = wn * TN + n;
+        const int jx = l31 & (SW - 1), jy = l31 >> g.lsw;
+        const int sx = sub & ((1 << g.lnsx) - 1);
+        const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
+        const int img = sub >> (g.lnsx + g.lnsy);
+        const int tyy = sy * SH + jy, txx = sx * SW + jx;
+        boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PW + txx;
+    }
+    const int aoff = hi * BM + wm * (TM * 32) + l31;
+
+    f32x16 acc[TM][TN * NPH];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int n = 0; n < TN * NPH; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][n][e] = 0.f;
+
+    const int chunk_begin = split * g.chunks_per_split;
+    int chunk_end = chunk_begin + g.chunks_per_split;
+    if (chunk_end > g.n_chunks) chunk_end = g.n_chunks;
+
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+        const int c0 = chunk * CC;
+        // -- global -> registers
+        float4 av[A_VEC_ITERS];
+#pragma unroll
+        for (int it = 0; it < A_VEC_ITERS; ++it) {
+            const int f = tid + it * 256;  // float4 index in As
+            const int row = f / (BM / 4);  // tap*CC + c
+            const int col = (f - row * (BM / 4)) * 4;
+            const int tap = row / CC, c = row - tap * CC;
+            const int ch = c0 + c, o = m0 + col;
+            av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < A_FLOATS / 4 && ch < g.Cin && o < g.CoutPad)
+                av[it] = *reinterpret_cast<const float4*>(p.wp + ((size_t)tap * g.Cin + ch) * g.CoutPad + o);
+        }
+        float pv[MAX_POS][CC];
+#pragma unroll
+        for (int i = 0; i < MAX_POS; ++i)
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const int ch = c0 + c;
+                float v = 0.f;
+                if (src_off[i] >= 0 && ch < g.Cin) v = p.x[(size_t)src_off[i] + ch * plane_in] * p.s[sb_off[i] + ch];
+                pv[i][c] = v;
+            }
+        // -- registers -> LDS
+#pragma unroll
+        for (int it = 0; it < A_VEC_ITERS; ++it) {
+            const int f = tid + it * 256;
+            if (f < A_FLOATS / 4) reinterpret_cast<float4*>(As)[f] = av[it];
+        }
+#pragma unroll
+        for (int i = 0; i < MAX_POS; ++i) {
+            const int pp = tid + i * 256;
+            if (pp < g.PSTRIDE) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = pv[i][c];
+            }
+        }
+        __syncthreads();
+
+        // -- MFMA
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            // plain: window rows ky, cols kx.  up: output parity (ky&1, kx&1); tap 2 reads the previous row/col.
+            const int dy = UP ? (ky == 2 ? 0 : 1) : ky;
+            const int dx = UP ? (kx == 2 ? 0 : 1) : kx;
+            const int ph = UP ? ((ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0)) : 0;
+            const int tapoff = dy * g.PW + dx;
+#pragma unroll
+            for (int q = 0; q < CC / 2; ++q) {
+                float a[TM], bv[TN];
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) a[mt] = As[(tap * CC + 2 * q) * BM + mt * 32 + aoff];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) bv[n] = Ps[2 * q * g.PSTRIDE + boff[n] + tapoff];
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[mt][n * NPH + ph] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bv[n], acc[mt][n * NPH + ph], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const bool to_ws = g.splits > 1;
+    float* outp = to_ws ? (p.ws + (size_t)split * g.ws_slab) : p.y;
+    const float nw = (!to_ws && g.fuse_act && p.noise) ? p.noise_w[0] : 0.f;
+    const size_t plane_out = (size_t)g.OH * g.OW;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int sub = wn * TN + n;
+        const int jx = l31 & (SW - 1), jy = l31 >> g.lsw;
+        const int sx = sub & ((1 << g.lnsx) - 1);
+        const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
+        const int img = sub >> (g.lnsx + g.lnsy);
+        const int b = b0 + img;
+        const int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
+        const bool pos_ok = (b < g.B) && (gy < g.GH) && (gx < g.GW);
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            const int oy = UP ? 2 * gy + (ph >> 1) : gy;
+            const int ox = UP ? 2 * gx + (ph & 1) : gx;
+            const bool ok = pos_ok && oy < g.OH && ox < g.OW;
+            float nzv = 0.f;
+            if (ok && nw != 0.f) nzv = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox];
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int o = m0 + wm * (TM * 32) + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    if (ok && o < g.Cout) {
+                        float v = acc[mt][n * NPH + ph][e] * g.wscale;
+                        if (!to_ws) {
+                            if (p.d) v *= p.d[b * g.Cout + o];
+                            if (g.fuse_act) v = lrelu_gain(v + nzv + (p.bias ? p.bias[o] : 0.f));
+                        }
+                        outp[((size_t)b * g.Cout + o) * plane_out + (size_t)oy * g.OW + ox] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Sum split-K slabs and apply the same tail as the fused epilogue.
+__global__ __launch_bounds__(256) void reduce_tail_kernel(const float* __restrict__ ws, int splits, int64_t slab,
+                                                          float* __restrict__ y, const float* __restrict__ d,
+                                                          const float* __restrict__ noise, int64_t noise_batch_stride,
+                                                          const float* __restrict__ noise_w,
+                                                          const float* __restrict__ bias, int fuse_act, int cout,
+                                                          int64_t plane, int64_t total) {
+    const float nw = (fuse_act && noise) ? noise_w[0] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += ws[(size_t)s * slab + i];
+        const int64_t bc = i / plane;
+        const int64_t pix = i - bc * plane;
+        const int b = (int)(bc / cout), o = (int)(bc - (int64_t)b * cout);
+        if (d) v *= d[bc];
+        if (fuse_act) {
+            float nz = 0.f;
+            if (nw != 0.f) nz = nw * noise[(size_t)b * noise_batch_stride + pix];
+            v = lrelu_gain(v + nz + (bias ? bias[o] : 0.f));
+        }
+        y[i] = v;
+    }
+}
+
+// wp[tap][i][o_pad] = w[o][i][tap], wsq[o][i] = sum_tap w^2.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                          float* __restrict__ wsq, int cout, int cout_pad, int cin,
+                                                          int ktaps) {
+    const int64_t total = (int64_t)cout_pad * cin;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int o = (int)(idx % cout_pad);
+        const int i = (int)(idx / cout_pad);
+        float ss = 0.f;
+        for (int tp = 0; tp < ktaps; ++tp) {
+            const float v = (o < cout) ? w[((size_t)o * cin + i) * ktaps + tp] : 0.f;
+            if (wp) wp[((size_t)tp * cin + i) * cout_pad + o] = v;
+            ss = fmaf(v, v, ss);
+        }
+        if (wsq && o < cout) wsq[(size_t)o * cin + i] = ss;
+    }
+}
+
+inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+inline int pow2_ceil(int v) { return 1 << ilog2(v); }
+
+struct Plan {
+    int bm, bn, wm;
+    ConvGeom g;
+    size_t lds_bytes;
+    int64_t blocks;
+};
+
+int pad32(int c) { return (c + 31) / 32 * 32; }
+
+// Tile-shape selection (host).  BM follows Cout; the pixel tile is a stack of 32-pixel MFMA groups.
+Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
+    Plan pl{};
+    ConvGeom& g = pl.g;
+    g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = pad32(cout), g.H = h, g.W = w;
+    if (up) {
+        g.GH = h + 1, g.GW = w + 1, g.OH = 2 * h + 1, g.OW = 2 * w + 1;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 128;
+        else pl.bm = 64, pl.wm = 2, pl.bn = 64;
+    } else {
+        g.GH = h, g.GW = w, g.OH = h, g.OW = w;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 512;
+        else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 256;
+        else pl.bm = 128, pl.wm = 2, pl.bn = 128;
+    }
+    auto shape = [&](int bn) {
+        const int nsub = bn / 32;
+        int sw = up ? 8 : 32;
+        if (sw > pow2_ceil(g.GW)) sw = pow2_ceil(g.GW);
+        const int sh = 32 / sw;
+        int nsx = pow2_ceil(ceil_div(g.GW, sw));
+        if (nsx > nsub) nsx = nsub;
+        if (!up && nsx > 1) nsx = 1;  // plain: keep 32-wide row segments, stack rows instead
+        int nsy = pow2_ceil(ceil_div(g.GH, sh));
+        if (nsy > nsub / nsx) nsy = nsub / nsx;
+        const int ni = nsub / (nsx * nsy);
+        g.lsw = ilog2(sw), g.lsh = ilog2(sh), g.lnsx = ilog2(nsx), g.lnsy = ilog2(nsy), g.lni = ilog2(ni);
+        const int tw = sw * nsx, th = sh * nsy;
+        g.tiles_x = ceil_div(g.GW, tw), g.tiles_y = ceil_div(g.GH, th), g.img_groups = ceil_div(batch, ni);
+        g.PH = th + 2, g.PW = tw + 2, g.PSTRIDE = ni * g.PH * g.PW;
+    };
+    shape(pl.bn);
+    if (g.PSTRIDE > 768) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
+        if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
+        else pl.bm = 128, pl.wm = 2, pl.bn = 128;
+        shape(pl.bn);
+    }
+    g.m_tiles = ceil_div(g.CoutPad, pl.bm);
+    g.n_tiles = g.tiles_x * g.tiles_y * g.img_groups;
+    g.n_chunks = ceil_div(cin, CC);
+    // split-K until the grid covers the chip ~2x (256 CUs), never below 2 chunks per split
+    const int64_t base_blocks = (int64_t)g.m_tiles * g.n_tiles;
+    int splits = 1;
+    while (base_blocks * splits < 512 && g.n_chunks / (splits * 2) >= 2) splits *= 2;
+    g.splits = splits;
+    g.chunks_per_split = ceil_div(g.n_chunks, splits);
+    g.splits = ceil_div(g.n_chunks, g.chunks_per_split);
+    g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
+    pl.blocks = base_blocks * g.splits;
+    pl.lds_bytes = ((size_t)9 * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
+    return pl;
+}
+
+template <int BM, int BN, int WM, bool UP>
+int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
+    auto kern = modconv_mfma_kernel<BM, BN, WM, UP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(256), pl.lds_bytes, st, pl.g, ptrs);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream) {
+    if (!w || cout <= 0 || cin <= 0 || ktaps <= 0) return MAUA_EINVAL;
+    const int cout_pad = pad32(cout);
+    const int64_t total = (int64_t)cout_pad * cin;
+    const int64_t blocks = ceil_div64(total, 256);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, w, wp, wsq, cout, cout_pad, cin, ktaps);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
+    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    Plan pl = make_plan(batch, cin, cout, h, w, up);
+    return pl.g.splits > 1 ? pl.g.ws_slab * pl.g.splits : 0;
+}
+
+extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
+                                   float* y, int batch, int cin, int cout, int h, int w, int up, float wscale,
+                                   int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                   const float* bias, float* ws, void* stream) {
+    if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
+    if (noise && !noise_w) return MAUA_EINVAL;
+    if ((int64_t)batch * cin * h * w > 0x7fffffffLL) return MAUA_EINVAL;  // 32-bit patch offsets
+    Plan pl = make_plan(batch, cin, cout, h, w, up);
+    if (pl.g.PSTRIDE > 768) return MAUA_EINVAL;
+    if (pl.g.splits > 1 && !ws) return MAUA_EINVAL;
+    pl.g.s_stride = s_stride;
+    pl.g.wscale = wscale;
+    pl.g.fuse_act = fuse_act;
+    pl.g.noise_batch_stride = noise_batch_stride;
+    ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws};
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (up) {
+        if (pl.bm == 32) rc = launch_conv<32, 128, 1, true>(pl, ptrs, st);
+        else rc = launch_conv<64, 64, 2, true>(pl, ptrs, st);
+    } else {
+        if (pl.bm == 32) rc = launch_conv<32, 512, 1, false>(pl, ptrs, st);
+        else if (pl.bm == 64) rc = launch_conv<64, 256, 1, false>(pl, ptrs, st);
+        else rc = launch_conv<128, 128, 2, false>(pl, ptrs, st);
+    }
+    if (rc) return rc;
+    if (pl.g.splits > 1) {
+        const int64_t total = pl.g.ws_slab;
+        const int64_t blocks = ceil_div64(total, 256);
+        hipLaunchKernelGGL(reduce_tail_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, ws,
+                           pl.g.splits, pl.g.ws_slab, y, d, noise, noise_batch_stride, noise_w, bias, fuse_act, cout,
+                           (int64_t)pl.g.OH * pl.g.OW, total);
+        MAUA_LAUNCH_CHECK();
+    }
+    return 0;
+}

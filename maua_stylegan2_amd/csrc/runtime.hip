@@ -1,0 +1,126 @@
+// Runtime glue of libmaua_hip.so: ABI version, device query, hipGraph capture/replay, HIP-event timing and the
+// uint8 frame epilogue (render.py:40-43).
+#include "common.h"
+
+#include <string.h>
+
+extern "C" int maua_abi_version(void) { return 1; }
+
+extern "C" int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return (int)e;
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ hipGraph
+extern "C" int maua_graph_begin_capture(void* stream) {
+    return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+}
+
+extern "C" int maua_graph_end_capture(void* stream, void** graph_exec_out) {
+    if (!graph_exec_out) return MAUA_EINVAL;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return (int)e;
+    *graph_exec_out = (void*)exec;
+    return 0;
+}
+
+extern "C" int maua_graph_launch(void* graph_exec, void* stream) {
+    if (!graph_exec) return MAUA_EINVAL;
+    return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+}
+
+extern "C" int maua_graph_destroy(void* graph_exec) {
+    if (!graph_exec) return 0;
+    return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+
+// ------------------------------------------------------------------------------------------------ events
+extern "C" int maua_event_create(void** ev) {
+    if (!ev) return MAUA_EINVAL;
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return (int)r;
+    *ev = (void*)e;
+    return 0;
+}
+extern "C" int maua_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+extern "C" int maua_event_elapsed_ms(void* a, void* b, float* ms) {
+    hipError_t r = hipEventSynchronize((hipEvent_t)b);
+    if (r != hipSuccess) return (int)r;
+    return (int)hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b);
+}
+extern "C" int maua_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+
+// ------------------------------------------------------------------------------------------------ frame epilogue
+namespace {
+// [B,3,H,W] fp32 -> [B,H,W,3] uint8.  Each thread converts 4 consecutive pixels of one row: three 16-byte loads
+// (one per colour plane) and one 12-byte (3 x dword) store — 1 read + 0.25 write bytes per input byte, HBM-bound.
+__global__ __launch_bounds__(256) void frames_to_u8_kernel(const float* __restrict__ img, uint8_t* __restrict__ out,
+                                                           int64_t quads_per_frame, int64_t plane, int64_t total) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t b = q / quads_per_frame;
+        const int64_t p = (q - b * quads_per_frame) * 4;
+        const float* base = img + b * 3 * plane + p;
+        const float4 r = *reinterpret_cast<const float4*>(base);
+        const float4 g = *reinterpret_cast<const float4*>(base + plane);
+        const float4 bl = *reinterpret_cast<const float4*>(base + 2 * plane);
+        auto cv = [](float v) -> uint32_t {
+            v = fminf(fmaxf(v, -1.f), 1.f);
+            return (uint32_t)((v + 1.f) * 127.5f);  // truncating cast, as numpy astype(uint8) on [0,255]
+        };
+        const uint32_t w0 = cv(r.x) | (cv(g.x) << 8) | (cv(bl.x) << 16) | (cv(r.y) << 24);
+        const uint32_t w1 = cv(g.y) | (cv(bl.y) << 8) | (cv(r.z) << 16) | (cv(g.z) << 24);
+        const uint32_t w2 = cv(bl.z) | (cv(r.w) << 8) | (cv(g.w) << 16) | (cv(bl.w) << 24);
+        uint32_t* o = reinterpret_cast<uint32_t*>(out + (b * plane + p) * 3);
+        o[0] = w0;
+        o[1] = w1;
+        o[2] = w2;
+    }
+}
+
+__global__ __launch_bounds__(256) void frames_to_u8_scalar_kernel(const float* __restrict__ img, uint8_t* __restrict__ out,
+                                                                  int64_t plane, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t c = i % 3;
+        const int64_t p = (i / 3) % plane;
+        const int64_t b = i / (3 * plane);
+        float v = img[(b * 3 + c) * plane + p];
+        v = fminf(fmaxf(v, -1.f), 1.f);
+        out[i] = (uint8_t)((v + 1.f) * 127.5f);
+    }
+}
+}  // namespace
+
+extern "C" int maua_frames_to_u8(const float* img, uint8_t* out, int batch, int h, int w, void* stream) {
+    if (!img || !out || batch <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
+    const int64_t plane = (int64_t)h * w;
+    hipStream_t st = (hipStream_t)stream;
+    if (plane % 4 == 0 && (((uintptr_t)img) & 15) == 0 && (((uintptr_t)out) & 3) == 0) {
+        const int64_t total = (int64_t)batch * plane / 4;
+        const int64_t blocks = ceil_div64(total, 256);
+        hipLaunchKernelGGL(frames_to_u8_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, img,
+                           out, plane / 4, plane, total);
+    } else {
+        const int64_t total = (int64_t)batch * plane * 3;
+        const int64_t blocks = ceil_div64(total, 256);
+        hipLaunchKernelGGL(frames_to_u8_scalar_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st,
+                           img, out, plane, total);
+    }
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,251 @@
+// Audio-feature and temporal kernels for gfx950 (the device side of audioreactive/).
+//
+//   temporal_fir   <- /root/reference/audioreactive/signal.py:319-368 gaussian_filter (circular FIR along time)
+//   stft_power     <- librosa.stft + |.|^2 as called at signal.py:51,93,119 (centred, reflect-padded, Hann)
+//   filterbank     <- mel / chroma filterbank projection (+ power_to_db), signal.py:51,119
+//   perlin3d       <- /root/reference/audioreactive/latent.py:188-246
+//   affine warp    <- /root/reference/audioreactive/bend.py:52-102 (ReflectionPad2d -> kornia affine -> CenterCrop)
+//
+// None of these is near a roofline that matters for the frames/s metric; they exist so that latents / noise are
+// produced on-device (north_star) instead of round-tripping through host numpy.  The temporal FIR is the one heavy
+// pre-processing stage (sigma = 128 on [n_frames,1,256,256] noise = 121 GMAC at 1800 frames): it is
+// register-tiled 16 outputs deep along time so each staged sample feeds 16 FMAs, lanes run along the contiguous
+// feature axis (dense 256-byte loads), taps are broadcast from LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int FIR_TT = 16;
+
+__global__ __launch_bounds__(256) void temporal_fir_kernel(const float* __restrict__ x, const float* __restrict__ taps,
+                                                           float* __restrict__ y, int T, int64_t F, int radius) {
+    extern __shared__ __attribute__((aligned(16))) float tp[];  // [2*radius+1]
+    const int ntaps = 2 * radius + 1;
+    for (int i = threadIdx.x; i < ntaps; i += 256) tp[i] = taps[i];
+    __syncthreads();
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * FIR_TT;
+    if (f >= F) return;
+    float acc[FIR_TT];
+#pragma unroll
+    for (int u = 0; u < FIR_TT; ++u) acc[u] = 0.f;
+    // y[t] = sum_k taps[k] * xpad[t + k], xpad[i] = x[(i - radius) mod T] inside one wrap, 0 beyond (radius > T branch)
+    for (int j = 0; j < ntaps + FIR_TT - 1; ++j) {
+        const int i = t0 + j - radius;  // un-wrapped source time
+        float v = 0.f;
+        if (i >= -T && i < 2 * T) {
+            int w = i;
+            if (w < 0) w += T;
+            if (w >= T) w -= T;
+            v = x[(int64_t)w * F + f];
+        }
+#pragma unroll
+        for (int u = 0; u < FIR_TT; ++u) {
+            const int k = j - u;
+            if (k >= 0 && k < ntaps) acc[u] = fmaf(tp[k], v, acc[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < FIR_TT; ++u)
+        if (t0 + u < T) y[(int64_t)(t0 + u) * F + f] = acc[u];
+}
+
+// One workgroup = one STFT frame: radix-2 DIT FFT of n_fft (<= 4096) complex points in LDS, twiddles from a table
+// built once per workgroup with sincospif.
+__global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict__ y, int64_t n, const float* __restrict__ win,
+                                                         int n_fft, int log2n, int hop, float* __restrict__ p,
+                                                         int n_frames) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* re = sm;
+    float* im = sm + n_fft;
+    float* twc = sm + 2 * n_fft;  // cos(-2 pi k / n), k < n/2
+    float* tws = twc + n_fft / 2;
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t start = (int64_t)frame * hop - n_fft / 2;
+    for (int i = tid; i < n_fft; i += 256) {
+        int64_t src = start + i;  // reflect padding (numpy 'reflect': no edge repeat)
+        if (n > 1) {
+            const int64_t period = 2 * (n - 1);
+            src %= period;
+            if (src < 0) src += period;
+            if (src >= n) src = period - src;
+        } else {
+            src = 0;
+        }
+        const int rev = (int)(__brev((unsigned)i) >> (32 - log2n));
+        re[rev] = y[src] * win[i];
+        im[rev] = 0.f;
+    }
+    for (int k = tid; k < n_fft / 2; k += 256) {
+        float s_, c_;
+        sincospif(-2.0f * (float)k / (float)n_fft, &s_, &c_);
+        twc[k] = c_;
+        tws[k] = s_;
+    }
+    __syncthreads();
+    for (int st = 1; st <= log2n; ++st) {
+        const int half = 1 << (st - 1);
+        const int tw_stride = n_fft >> st;
+        for (int bfly = tid; bfly < n_fft / 2; bfly += 256) {
+            const int grp = bfly / half, k = bfly - grp * half;
+            const int a = grp * 2 * half + k, b = a + half;
+            const float c_ = twc[k * tw_stride], s_ = tws[k * tw_stride];
+            const float br = re[b] * c_ - im[b] * s_;
+            const float bi = re[b] * s_ + im[b] * c_;
+            const float ar = re[a], ai = im[a];
+            re[a] = ar + br, im[a] = ai + bi;
+            re[b] = ar - br, im[b] = ai - bi;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k <= n_fft / 2; k += 256) p[(int64_t)k * n_frames + frame] = re[k] * re[k] + im[k] * im[k];
+}
+
+__global__ __launch_bounds__(256) void filterbank_kernel(const float* __restrict__ fb, const float* __restrict__ p,
+                                                         float* __restrict__ out, int m, int k, int n, int to_db,
+                                                         float amin) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int row = blockIdx.y;
+    if (col >= n) return;
+    float acc = 0.f;
+    const float* fr = fb + (size_t)row * k;
+    for (int kk = 0; kk < k; ++kk) acc = fmaf(fr[kk], p[(size_t)kk * n + col], acc);
+    if (to_db) acc = 10.0f * log10f(fmaxf(amin, acc));
+    out[(size_t)row * n + col] = acc;
+}
+
+__device__ __forceinline__ float fade5(float t) { return t * t * t * (t * (t * 6.f - 15.f) + 10.f); }
+
+__global__ __launch_bounds__(256) void perlin3d_kernel(const float* __restrict__ grad, float* __restrict__ out, int n0,
+                                                       int n1, int n2, int r0, int r1, int r2) {
+    const int64_t total = (int64_t)n0 * n1 * n2;
+    const int d0 = n0 / r0, d1 = n1 / r1, d2 = n2 / r2;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int i2 = (int)(idx % n2);
+        const int i1 = (int)((idx / n2) % n1);
+        const int i0 = (int)(idx / ((int64_t)n1 * n2));
+        const int c0 = i0 / d0, c1 = i1 / d1, c2 = i2 / d2;
+        const float f0 = (float)(i0 - c0 * d0) / (float)d0;
+        const float f1 = (float)(i1 - c1 * d1) / (float)d1;
+        const float f2 = (float)(i2 - c2 * d2) / (float)d2;
+        float nv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int o0 = c & 1, o1 = (c >> 1) & 1, o2 = (c >> 2) & 1;
+            const float* gv = grad + ((((size_t)(c0 + o0) * (r1 + 1)) + (c1 + o1)) * (r2 + 1) + (c2 + o2)) * 3;
+            nv[c] = (f0 - o0) * gv[0] + (f1 - o1) * gv[1] + (f2 - o2) * gv[2];
+        }
+        const float t0 = fade5(f0), t1 = fade5(f1), t2 = fade5(f2);
+        const float n00 = nv[0] * (1 - t0) + t0 * nv[1];
+        const float n10 = nv[2] * (1 - t0) + t0 * nv[3];
+        const float n01 = nv[4] * (1 - t0) + t0 * nv[5];
+        const float n11 = nv[6] * (1 - t0) + t0 * nv[7];
+        const float m0 = (1 - t1) * n00 + t1 * n10;
+        const float m1 = (1 - t1) * n01 + t1 * n11;
+        out[idx] = ((1 - t2) * m0 + t2 * m1) * 2.f - 1.f;
+    }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // ReflectionPad2d semantics (no edge repeat), |i| < 2n
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+// Output pixel (oy, ox) of the h x w centre crop -> padded-canvas coords via the per-frame inverse affine map m
+// (canvas pixel units), bilinear taps, zeros outside the canvas; canvas pixel -> reflected source pixel.
+__global__ __launch_bounds__(256) void affine_reflect_warp_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                                  float* __restrict__ y, int channels, int h, int w,
+                                                                  int pad_l, int pad_r, int pad_t, int pad_b,
+                                                                  const float* __restrict__ add_noise) {
+    const int b = blockIdx.z;
+    const int ch = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= h * w) return;
+    const int oy = pix / w, ox = pix - oy * w;
+    const int ch_h = h + pad_t + pad_b, cw = w + pad_l + pad_r;
+    // centre crop origin inside the canvas (kornia CenterCrop: floor((canvas - out) / 2))
+    const float cy = (float)(oy + (ch_h - h) / 2), cx = (float)(ox + (cw - w) / 2);
+    const float* a = m + (size_t)b * 6;
+    const float sx = a[0] * cx + a[1] * cy + a[2];
+    const float sy = a[3] * cx + a[4] * cy + a[5];
+    const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+    const float fx = sx - x0, fy = sy - y0;
+    const float* xp = x + ((size_t)b * channels + ch) * h * w;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int yy = y0 + dy, xx = x0 + dx;
+            if (yy < 0 || yy >= ch_h || xx < 0 || xx >= cw) continue;
+            const float wgt = (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
+            float v = xp[reflect_idx(yy - pad_t, h) * w + reflect_idx(xx - pad_l, w)];
+            if (add_noise) v += add_noise[(size_t)yy * cw + xx];
+            acc = fmaf(wgt, v, acc);
+        }
+    y[((size_t)b * channels + ch) * h * w + pix] = acc;
+}
+
+}  // namespace
+
+extern "C" int maua_temporal_fir_f32(const float* x, const float* taps, float* y, int n_frames, int64_t features,
+                                     int radius, void* stream) {
+    if (!x || !taps || !y || n_frames <= 0 || features <= 0 || radius < 0) return MAUA_EINVAL;
+    const size_t lds = (size_t)(2 * radius + 1) * sizeof(float);
+    if (lds > 64 * 1024) return MAUA_EINVAL;
+    const int64_t bx = ceil_div64(features, 256);
+    if (bx > 0x7fffffff) return MAUA_EINVAL;
+    hipLaunchKernelGGL(temporal_fir_kernel, dim3((unsigned)bx, ceil_div(n_frames, FIR_TT)), dim3(256), lds,
+                       (hipStream_t)stream, x, taps, y, n_frames, features, radius);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_stft_power_f32(const float* y, int64_t n_samples, const float* window, int n_fft, int hop, float* p,
+                                   int n_frames, void* stream) {
+    if (!y || !window || !p || n_samples <= 0 || hop <= 0 || n_frames <= 0) return MAUA_EINVAL;
+    int log2n = 0;
+    while ((1 << log2n) < n_fft) ++log2n;
+    if ((1 << log2n) != n_fft || n_fft < 64 || n_fft > 4096) return MAUA_EINVAL;
+    const size_t lds = (size_t)3 * n_fft * sizeof(float);
+    hipLaunchKernelGGL(stft_power_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, y, n_samples, window,
+                       n_fft, log2n, hop, p, n_frames);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_filterbank_f32(const float* fb, const float* p, float* out, int m, int k, int n, int to_db,
+                                   float amin, void* stream) {
+    if (!fb || !p || !out || m <= 0 || k <= 0 || n <= 0) return MAUA_EINVAL;
+    hipLaunchKernelGGL(filterbank_kernel, dim3(ceil_div(n, 256), m), dim3(256), 0, (hipStream_t)stream, fb, p, out, m, k,
+                       n, to_db, amin);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_perlin3d_f32(const float* grad, float* out, int n0, int n1, int n2, int r0, int r1, int r2,
+                                 void* stream) {
+    if (!grad || !out || n0 <= 0 || n1 <= 0 || n2 <= 0 || r0 <= 0 || r1 <= 0 || r2 <= 0) return MAUA_EINVAL;
+    if (n0 % r0 || n1 % r1 || n2 % r2) return MAUA_EINVAL;
+    const int64_t total = (int64_t)n0 * n1 * n2;
+    const int64_t blocks = ceil_div64(total, 256);
+    hipLaunchKernelGGL(perlin3d_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, grad, out, n0, n1, n2, r0, r1, r2);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_affine_reflect_warp_f32(const float* x, const float* m, float* y, int batch, int channels, int h,
+                                            int w, int pad_l, int pad_r, int pad_t, int pad_b, const float* add_noise,
+                                            void* stream) {
+    if (!x || !m || !y || batch <= 0 || channels <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
+    if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || channels > 65535 || batch > 65535) return MAUA_EINVAL;
+    hipLaunchKernelGGL(affine_reflect_warp_kernel, dim3(ceil_div(h * w, 256), channels, batch), dim3(256), 0,
+                       (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,132 @@
+// Style affines + demodulation factors for every layer of one generator forward: two table-driven launches.
+//
+// Behavioural contract: /root/reference/models/stylegan2.py:140-146 (EqualLinear), :207,220 (modulation, bias_init 1),
+// :223-225 (demodulation), :541-543 (truncation lerp).  The reference runs 26 F.linear + 17 pow/sum/rsqrt launches
+// per forward at 1024^2; these are GEMV-sized (<= 512 x 512 per layer), so the only goal here is to not pay 43
+// launch boundaries: a workgroup owns 64 output rows of one layer, keeps the (truncated) latent rows / squared styles
+// of up to 16 frames in LDS, holds each weight row in registers and reduces with wave64 butterfly shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int BCHUNK = 16;   // frames staged in LDS per pass
+constexpr int MAX_PER_LANE = 16;  // style_dim, cin <= 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void style_affine_kernel(const float* __restrict__ latents, int batch, int n_latent,
+                                                           int style_dim, const float* __restrict__ trunc,
+                                                           const float* __restrict__ trunc_latent,
+                                                           const maua_style_layer_t* __restrict__ table,
+                                                           float* __restrict__ s, int s_stride) {
+    extern __shared__ __attribute__((aligned(16))) float lat[];  // [BCHUNK][style_dim]
+    const maua_style_layer_t L = table[blockIdx.x];
+    const int row0 = blockIdx.y * 64;
+    if (row0 >= L.cin) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float inv = 1.0f / sqrtf((float)style_dim);
+    const int per_lane = style_dim / 64;
+
+    for (int bc = 0; bc < batch; bc += BCHUNK) {
+        const int nb = min(BCHUNK, batch - bc);
+        __syncthreads();
+        for (int e = tid; e < nb * style_dim; e += 256) {
+            const int b = e / style_dim, j = e - b * style_dim;
+            float v = latents[((size_t)(bc + b) * n_latent + L.lat_idx) * style_dim + j];
+            if (trunc) {
+                const float tl = trunc_latent ? trunc_latent[j] : 0.f;
+                v = tl + trunc[bc + b] * (v - tl);
+            }
+            lat[e] = v;
+        }
+        __syncthreads();
+        for (int rr = wave; rr < 64; rr += 4) {
+            const int i = row0 + rr;
+            if (i >= L.cin) break;
+            float w[MAX_PER_LANE];
+#pragma unroll
+            for (int q = 0; q < MAX_PER_LANE; ++q) w[q] = (q < per_lane) ? L.mod_w[(size_t)i * style_dim + q * 64 + lane] : 0.f;
+            const float bias = L.mod_b[i];
+            for (int b = 0; b < nb; ++b) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < MAX_PER_LANE; ++q)
+                    if (q < per_lane) acc = fmaf(w[q], lat[b * style_dim + q * 64 + lane], acc);
+                acc = wave_sum(acc);
+                if (lane == 0) s[(size_t)(bc + b) * s_stride + L.s_off + i] = acc * inv + bias;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void demod_kernel(const maua_style_layer_t* __restrict__ table,
+                                                    const float* __restrict__ s, int s_stride, float* __restrict__ d,
+                                                    int batch) {
+    extern __shared__ __attribute__((aligned(16))) float s2[];  // [BCHUNK][cin]
+    const maua_style_layer_t L = table[blockIdx.x];
+    if (!L.wsq) return;
+    const int row0 = blockIdx.y * 64;
+    if (row0 >= L.cout) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_lane = (L.cin + 63) / 64;
+    const float ws2 = L.wscale * L.wscale;
+
+    for (int bc = 0; bc < batch; bc += BCHUNK) {
+        const int nb = min(BCHUNK, batch - bc);
+        __syncthreads();
+        for (int e = tid; e < nb * L.cin; e += 256) {
+            const int b = e / L.cin, i = e - b * L.cin;
+            const float v = s[(size_t)(bc + b) * s_stride + L.s_off + i];
+            s2[e] = v * v;
+        }
+        __syncthreads();
+        for (int rr = wave; rr < 64; rr += 4) {
+            const int o = row0 + rr;
+            if (o >= L.cout) break;
+            float w[MAX_PER_LANE];
+#pragma unroll
+            for (int q = 0; q < MAX_PER_LANE; ++q) {
+                const int i = q * 64 + lane;
+                w[q] = (q < per_lane && i < L.cin) ? L.wsq[(size_t)o * L.cin + i] : 0.f;
+            }
+            for (int b = 0; b < nb; ++b) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < MAX_PER_LANE; ++q) {
+                    const int i = q * 64 + lane;
+                    if (q < per_lane && i < L.cin) acc = fmaf(w[q], s2[b * L.cin + i], acc);
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) d[L.d_off + (size_t)(bc + b) * L.cout + o] = rsqrtf(acc * ws2 + 1e-8f);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int maua_style_affine_f32(const float* latents, int batch, int n_latent, int style_dim, const float* trunc,
+                                     const float* trunc_latent, const maua_style_layer_t* table, int n_layers,
+                                     int max_cin, float* s, int s_stride, void* stream) {
+    if (!latents || !table || !s || batch <= 0 || n_layers <= 0 || max_cin <= 0) return MAUA_EINVAL;
+    if (style_dim <= 0 || style_dim % 64 || style_dim > 64 * MAX_PER_LANE) return MAUA_EINVAL;
+    const size_t lds = (size_t)BCHUNK * style_dim * sizeof(float);
+    hipLaunchKernelGGL(style_affine_kernel, dim3(n_layers, ceil_div(max_cin, 64)), dim3(256), lds, (hipStream_t)stream,
+                       latents, batch, n_latent, style_dim, trunc, trunc_latent, table, s, s_stride);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_demod_f32(const maua_style_layer_t* table, int n_layers, int max_cout, const float* s, int s_stride,
+                              float* d, int batch, void* stream) {
+    if (!table || !s || !d || batch <= 0 || n_layers <= 0 || max_cout <= 0) return MAUA_EINVAL;
+    const size_t lds = (size_t)BCHUNK * 64 * MAX_PER_LANE * sizeof(float);
+    hipLaunchKernelGGL(demod_kernel, dim3(n_layers, ceil_div(max_cout, 64)), dim3(256), lds, (hipStream_t)stream, table,
+                       s, s_stride, d, batch);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}

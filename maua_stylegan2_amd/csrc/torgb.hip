@@ -1,0 +1,144 @@
+// ToRGB for gfx950: 1x1 modulated conv (no demod) + bias + FIR-upsampled skip, one HBM-bound launch.
+//
+// Behavioural contract: /root/reference/models/stylegan2.py:346-365 (ToRGB), :34-52 (Upsample = upfirdn2d up 2,
+// pad (2,1)), :353 demodulate=False.  The reference runs linear, mul, grouped conv, add, upfirdn2d, add (6 launches
+// and 4 extra passes over [B,3,H,W]); here the feature map is read exactly once with 16-byte loads, the three
+// modulated weight rows live in LDS, and the 2x2 polyphase taps of the skip are gathered on the fly (the skip is
+// 3 channels at quarter area — it stays in L2).  Small planes split the channel loop across threads (KS slices)
+// and combine through LDS so a 4x4x512 layer is not a 512-deep serial dependency chain.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ s, int s_stride,
+                                                    const float* __restrict__ bias, const float* __restrict__ skip,
+                                                    const float* __restrict__ k4, float* __restrict__ y, int cin, int h,
+                                                    int wdt, float wscale, int ks_log2, int quads_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // wm[3][cin] then partial[KS][QPB][12]
+    float* wm = lds;
+    float* part = lds + ((3 * cin + 3) & ~3);
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int plane = h * wdt;
+    const int quads = plane >> 2;
+    for (int e = tid; e < 3 * cin; e += 256) {
+        const int i = e % cin;
+        wm[e] = wscale * w[e] * s[(size_t)b * s_stride + i];
+    }
+    __syncthreads();
+
+    const int ks = 1 << ks_log2;
+    const int qi = tid & (quads_per_block - 1);
+    const int slice = tid / quads_per_block;
+    const int q = blockIdx.x * quads_per_block + qi;
+    const bool active = q < quads;
+    float4 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        const int per = (cin + ks - 1) / ks;
+        const int i0 = slice * per;
+        const int i1 = min(cin, i0 + per);
+        const float* xp = x + ((size_t)b * cin) * plane + (size_t)q * 4;
+        int i = i0;
+        for (; i + 8 <= i1; i += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (size_t)(i + u) * plane);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float wv = wm[c * cin + i + u];
+                    acc[c].x = fmaf(wv, v[u].x, acc[c].x);
+                    acc[c].y = fmaf(wv, v[u].y, acc[c].y);
+                    acc[c].z = fmaf(wv, v[u].z, acc[c].z);
+                    acc[c].w = fmaf(wv, v[u].w, acc[c].w);
+                }
+        }
+        for (; i < i1; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)i * plane);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float wv = wm[c * cin + i];
+                acc[c].x = fmaf(wv, v.x, acc[c].x);
+                acc[c].y = fmaf(wv, v.y, acc[c].y);
+                acc[c].z = fmaf(wv, v.z, acc[c].z);
+                acc[c].w = fmaf(wv, v.w, acc[c].w);
+            }
+        }
+    }
+    if (ks > 1) {
+        float* mine = part + ((size_t)slice * quads_per_block + qi) * 12;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(mine + c * 4) = acc[c];
+        __syncthreads();
+        if (slice == 0) {
+            for (int sl = 1; sl < ks; ++sl) {
+                const float* o = part + ((size_t)sl * quads_per_block + qi) * 12;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(o + c * 4);
+                    acc[c].x += v.x, acc[c].y += v.y, acc[c].z += v.z, acc[c].w += v.w;
+                }
+            }
+        }
+    }
+    if (!active || slice != 0) return;
+
+    const int pix = q * 4;
+    const int Y = pix / wdt, X0 = pix - Y * wdt;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float out[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
+        const float bc = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] += bc;
+        if (skip) {
+            const int sh = h >> 1, sw = wdt >> 1;
+            const float* sp = skip + ((size_t)b * 3 + c) * sh * sw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int X = X0 + e;
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cy = Y + i - 2;  // zero-stuffed canvas row (pad0 = 2)
+                    if (cy < 0 || (cy & 1)) continue;
+                    const int iy = cy >> 1;
+                    if (iy >= sh) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cx = X + j - 2;
+                        if (cx < 0 || (cx & 1)) continue;
+                        const int ix = cx >> 1;
+                        if (ix >= sw) continue;
+                        a = fmaf(k4[(3 - i) * 4 + (3 - j)], sp[iy * sw + ix], a);
+                    }
+                }
+                out[e] += a;
+            }
+        }
+        *reinterpret_cast<float4*>(y + ((size_t)b * 3 + c) * plane + pix) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int maua_torgb_f32(const float* x, const float* w, const float* s, int s_stride, const float* bias,
+                              const float* skip, const float* k4, float* y, int batch, int cin, int h, int wdt,
+                              float wscale, void* stream) {
+    if (!x || !w || !s || !y || batch <= 0 || cin <= 0 || h <= 0 || wdt <= 0) return MAUA_EINVAL;
+    if (wdt % 4) return MAUA_EINVAL;            // a 4-pixel group must stay inside one row
+    if (skip && (!k4 || (h & 1) || (wdt & 1))) return MAUA_EINVAL;
+    const int quads = h * wdt / 4;
+    int qpb = 256, ks_log2 = 0;
+    while (qpb > 4 && qpb / 2 >= quads) qpb >>= 1, ++ks_log2;
+    const int ks = 1 << ks_log2;
+    const size_t lds = ((size_t)((3 * cin + 3) & ~3) + (ks > 1 ? (size_t)ks * qpb * 12 : 0)) * sizeof(float);
+    hipLaunchKernelGGL(torgb_kernel, dim3(ceil_div(quads, qpb), batch), dim3(256), lds, (hipStream_t)stream, x, w, s,
+                       s_stride, bias, skip, k4, y, cin, h, wdt, wscale, ks_log2, qpb);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,242 @@
+// upfirdn2d for gfx950 — up-sample / FIR / down-sample of NCHW planes.
+//
+// Behavioural contract: /root/reference/op/upfirdn2d.py:145-200 and op/upfirdn2d_kernel.cu (semantics only:
+// zero-stuff by `up`, pad (negative pad crops), TRUE convolution with the tap matrix, decimate by `down`).
+// This is a new design for CDNA4, not a translation of the reference kernel:
+//
+//  * fir_tile_kernel (up = down = 1, the Blur-after-up-conv hot case, 96 % of the path's upfirdn2d bytes —
+//    BASELINE.md §3.2): HBM-bound streaming.  One 256-thread workgroup owns a (WY*32) x (WX*64) output tile of one
+//    plane.  The input tile (+ KH-1 / KW-1 halo) is fetched with dense, lane-consecutive dword loads — rows of the
+//    (2H+1)-wide up-conv output are only 4-byte aligned, so 16-byte vector loads are not available — ALL issued
+//    before the first LDS write (~36 loads/thread, ~36 KB in flight per workgroup, 4 workgroups per CU).  After
+//    one barrier each wave walks down its 64 columns: lane = column, KW conflict-free ds_read_b32 per input row,
+//    KH rotating accumulators, one dense 256-byte store per wave per output row.  Optional fused tail
+//    (demod gain, noise, bias, leaky-ReLU*sqrt2) = the rest of StyledConv.forward.
+//    Logical tile order is (plane, tile_x, tile_y) with tile_y fastest and an XCD-aware remap so that vertically
+//    adjacent tiles (which share KH-1 halo rows) are served by the same L2.
+//  * fir_generic_kernel: any up/down/pad/minor, one thread per output, polyphase tap skipping.
+#include "common.h"
+
+namespace {
+
+struct FirTail {
+    const float* gain;    // [planes] or null
+    const float* noise;   // [B or 1, out_h, out_w] or null
+    const float* noise_w; // [1]
+    const float* bias;    // [channels]
+    int64_t noise_batch_stride;
+    int channels;
+};
+
+constexpr int TILE_ROWS_PER_WAVE = 32;
+
+template <int KH, int KW, int WX, bool TAIL>
+__global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                       float* __restrict__ y, int planes, int in_h, int in_w,
+                                                       int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
+                                                       int tiles_y, FirTail tail) {
+    constexpr int WY = 4 / WX;
+    constexpr int TH = TILE_ROWS_PER_WAVE;
+    constexpr int TW = 64 * WX;
+    constexpr int RH = WY * TH + KH - 1;  // staged rows
+    constexpr int RW = TW + KW - 1;       // staged cols
+    constexpr int NIT = (RH * RW + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int nblocks = gridDim.x;
+    int t = xcd_remap(blockIdx.x, nblocks);
+    const int tiles_per_plane = tiles_x * tiles_y;
+    const int plane = t / tiles_per_plane;
+    t -= plane * tiles_per_plane;
+    const int tile_x = t / tiles_y;
+    const int tile_y = t - tile_x * tiles_y;
+    const int oy0 = tile_y * (WY * TH);
+    const int ox0 = tile_x * TW;
+
+    // flipped taps -> SGPRs (uniform loads)
+    float kf[KH][KW];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
+
+    const float* xp = x + (size_t)plane * in_h * in_w;
+    const int iy0 = oy0 - pad_y0;
+    const int ix0 = ox0 - pad_x0;
+
+    // ---- stage: issue every global load first, then write LDS
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int rr = idx / RW;
+        const int cc = idx - rr * RW;
+        const int iy = iy0 + rr;
+        const int ix = ix0 + cc;
+        const bool ok = (idx < RH * RW) && (iy >= 0) && (iy < in_h) && (ix >= 0) && (ix < in_w);
+        v[it] = ok ? xp[(size_t)iy * in_w + ix] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < RH * RW) lds[idx] = v[it];
+    }
+    __syncthreads();
+
+    // ---- compute: wave (wx, wy), lane = column
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wx = wave % WX, wy = wave / WX;
+    const int col = wx * 64 + lane;
+    const int ox = ox0 + col;
+    const int row0 = wy * TH;
+    const bool col_ok = ox < out_w;
+
+    float g = 1.f, nw = 0.f, bs = 0.f;
+    const float* nz = nullptr;
+    if (TAIL) {
+        const int b = plane / tail.channels;
+        const int c = plane - b * tail.channels;
+        if (tail.gain) g = tail.gain[plane];
+        if (tail.noise) {
+            nw = tail.noise_w[0];
+            nz = tail.noise + (size_t)b * tail.noise_batch_stride;
+        }
+        bs = tail.bias ? tail.bias[c] : 0.f;
+    }
+    float* yp = y + (size_t)plane * out_h * out_w;
+
+    float acc[KH];
+#pragma unroll
+    for (int i = 0; i < KH; ++i) acc[i] = 0.f;
+    const float* lrow = lds + row0 * RW + col;
+#pragma unroll
+    for (int r = 0; r < TH + KH - 1; ++r) {
+        float in[KW];
+#pragma unroll
+        for (int j = 0; j < KW; ++j) in[j] = lrow[r * RW + j];
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+            const int o = r - i;  // output row (within the wave's strip) this input row feeds through tap row i
+            if (o >= 0 && o < TH) {
+#pragma unroll
+                for (int j = 0; j < KW; ++j) acc[o % KH] = fmaf(kf[i][j], in[j], acc[o % KH]);
+            }
+        }
+        const int o_done = r - (KH - 1);
+        if (o_done >= 0) {
+            const int oy = oy0 + row0 + o_done;
+            float val = acc[o_done % KH];
+            acc[o_done % KH] = 0.f;
+            if (col_ok && oy < out_h) {
+                if (TAIL) {
+                    val *= g;
+                    if (nz) val = fmaf(nw, nz[(size_t)oy * out_w + ox], val);
+                    val = lrelu_gain(val + bs);
+                }
+                yp[(size_t)oy * out_w + ox] = val;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                          float* __restrict__ y, int major, int in_h, int in_w,
+                                                          int minor, int kh, int kw, int up_x, int up_y, int down_x,
+                                                          int down_y, int pad_x0, int pad_y0, int out_h, int out_w,
+                                                          int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t rest = idx;
+        const int mi = (int)(rest % minor);
+        rest /= minor;
+        const int ox = (int)(rest % out_w);
+        rest /= out_w;
+        const int oy = (int)(rest % out_h);
+        const int64_t m = rest / out_h;
+        float acc = 0.f;
+        for (int i = 0; i < kh; ++i) {
+            const int cy = oy * down_y + i - pad_y0;  // row in the zero-stuffed (unpadded) canvas
+            if (cy < 0 || cy % up_y) continue;
+            const int iy = cy / up_y;
+            if (iy >= in_h) continue;
+            for (int j = 0; j < kw; ++j) {
+                const int cx = ox * down_x + j - pad_x0;
+                if (cx < 0 || cx % up_x) continue;
+                const int ix = cx / up_x;
+                if (ix >= in_w) continue;
+                acc = fmaf(k[(kh - 1 - i) * kw + (kw - 1 - j)], x[((m * in_h + iy) * in_w + ix) * minor + mi], acc);
+            }
+        }
+        y[idx] = acc;
+    }
+}
+
+template <int KH, int KW, bool TAIL>
+int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
+                    int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
+    auto go = [&](auto wx_tag) -> int {
+        constexpr int WX = decltype(wx_tag)::value;
+        constexpr int WY = 4 / WX;
+        constexpr int RH = WY * TILE_ROWS_PER_WAVE + KH - 1, RW = 64 * WX + KW - 1;
+        const int tiles_x = ceil_div(out_w, 64 * WX), tiles_y = ceil_div(out_h, WY * TILE_ROWS_PER_WAVE);
+        const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
+        if (nblocks <= 0) return 0;
+        if (nblocks > 0x7fffffff) return MAUA_EINVAL;
+        const size_t lds_bytes = (size_t)RH * RW * sizeof(float);
+        hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k,
+                           y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
+        MAUA_LAUNCH_CHECK();
+        return 0;
+    };
+    if (out_w <= 64) return go(std::integral_constant<int, 1>{});
+    if (out_w <= 128) return go(std::integral_constant<int, 2>{});
+    return go(std::integral_constant<int, 4>{});
+}
+
+template <bool TAIL>
+int dispatch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
+                      int kh, int kw, int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
+    if (kh == 4 && kw == 4) return launch_fir_tile<4, 4, TAIL>(x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tail, st);
+    if (kh == 3 && kw == 3) return launch_fir_tile<3, 3, TAIL>(x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tail, st);
+    if (kh == 2 && kw == 2) return launch_fir_tile<2, 2, TAIL>(x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tail, st);
+    return MAUA_ENOSYS;
+}
+
+}  // namespace
+
+extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
+                                  int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                                  int pad_y0, int pad_y1, void* stream) {
+    if (!x || !k || !y || major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 || up_x <= 0 ||
+        up_y <= 0 || down_x <= 0 || down_y <= 0)
+        return MAUA_EINVAL;
+    const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
+    const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+    if (out_h <= 0 || out_w <= 0) return MAUA_EINVAL;
+    if (major == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == kw && kh >= 2 && kh <= 4) {
+        FirTail none{};
+        return dispatch_fir_tile<false>(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, none, st);
+    }
+    const int64_t total = (int64_t)major * out_h * out_w * minor;
+    const int64_t blocks = ceil_div64(total, 256);
+    const unsigned grid = (unsigned)(blocks < 256 * 32 ? blocks : 256 * 32);
+    hipLaunchKernelGGL(fir_generic_kernel, dim3(grid), dim3(256), 0, st, x, k, y, major, in_h, in_w, minor, kh, kw,
+                       up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w, total);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch, int channels, int in_h,
+                                       int in_w, int kh, int kw, int pad0, int pad1, const float* gain,
+                                       const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                       const float* bias, void* stream) {
+    if (!x || !k || !y || batch <= 0 || channels <= 0 || in_h <= 0 || in_w <= 0) return MAUA_EINVAL;
+    if (noise && !noise_w) return MAUA_EINVAL;
+    const int out_h = in_h + pad0 + pad1 - kh + 1, out_w = in_w + pad0 + pad1 - kw + 1;
+    if (out_h <= 0 || out_w <= 0) return MAUA_EINVAL;
+    FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels};
+    return dispatch_fir_tile<true>(x, k, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, pad0, pad0, tail,
+                                   (hipStream_t)stream);
+}

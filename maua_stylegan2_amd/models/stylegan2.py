@@ -1,0 +1,613 @@
+"""StyleGAN2 generator (inference) for MI355X — host-side mirror of /root/reference/models/stylegan2.py:1-576.
+
+Same class names, constructor arguments, ``forward`` signatures and state-dict keys as the reference (so
+``th.load(ckpt)["g_ema"]`` drops in, models/stylegan2.py:458-459), but the forward is a different program:
+
+  reference (per StyledConv)                          here
+  ------------------------------------------------    ---------------------------------------------------------
+  F.linear, mul, pow/sum/rsqrt, mul  (per layer)      2 launches for ALL layers: maua_style_affine_f32, maua_demod_f32
+  grouped conv with per-sample weights (cuDNN)        shared-weight implicit GEMM on fp32 MFMA, input-scale/output-demod
+  add noise, fused_bias_act                           fused into the conv epilogue (plain) / the blur kernel (upsample)
+  conv_transpose2d + upfirdn2d (Blur)                 polyphase MFMA transposed conv + fir_tile_kernel with fused tail
+  ToRGB: linear, mul, conv, add, upfirdn2d, add       1 launch (maua_torgb_f32)
+
+All activations live in a per-batch-size cache of static device buffers, so a forward performs no allocation after
+its first call and can be captured into a hipGraph (``capture_graph``).  There is no CPU path: CPU tensors raise.
+"""
+import ctypes
+import math
+
+import torch as th
+from torch import nn
+from torch.nn import functional as F
+
+from .. import _lib
+from ..op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d
+
+
+class PixelNorm(nn.Module):
+    def forward(self, inputs):
+        return inputs * th.rsqrt(th.mean(inputs ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def make_kernel(k):
+    k = th.tensor(k, dtype=th.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    k /= k.sum()
+    return k
+
+
+class Upsample(nn.Module):
+    """reference :34-52 — upfirdn2d(up=factor, pad=(pad0, pad1)) with kernel * factor**2."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, inputs):
+        return upfirdn2d(inputs, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Blur(nn.Module):
+    """reference :76-92."""
+
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer("kernel", kernel)
+        self.pad = pad
+
+    def forward(self, inputs):
+        return upfirdn2d(inputs, self.kernel, pad=self.pad)
+
+
+class EqualLinear(nn.Module):
+    """reference :123-146 (mapping network / standalone use; the per-layer modulations inside the generator forward
+    go through the table-driven style kernel instead)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(th.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(th.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, inputs):
+        if self.activation:
+            out = F.linear(inputs, self.weight * self.scale)
+            return fused_leaky_relu(out, self.bias * self.lr_mul)
+        return F.linear(inputs, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+
+def _style_table(entries, device):
+    """entries: list of dict(mod_w, mod_b, wsq|None, cin, cout, lat_idx, s_off, d_off, wscale) -> device byte tensor."""
+    arr = (_lib.StyleLayer * len(entries))()
+    for i, e in enumerate(entries):
+        arr[i].mod_w = e["mod_w"].data_ptr()
+        arr[i].mod_b = e["mod_b"].data_ptr()
+        arr[i].wsq = e["wsq"].data_ptr() if e["wsq"] is not None else None
+        arr[i].cin, arr[i].cout, arr[i].lat_idx = e["cin"], e["cout"], e["lat_idx"]
+        arr[i].s_off, arr[i].d_off, arr[i].wscale = e["s_off"], e["d_off"], e["wscale"]
+    raw = th.frombuffer(bytearray(bytes(arr)), dtype=th.uint8).clone()
+    return raw.to(device)
+
+
+class ModulatedConv2d(nn.Module):
+    """reference :164-254.  ``forward(inputs, style)`` keeps the reference contract; the generator calls
+    ``run(...)`` with styles / demod factors already computed for all layers."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError("downsample=True is discriminator-only (SURVEY.md §2 row 4: out of scope)")
+        if kernel_size not in (1, 3):
+            raise NotImplementedError("the generator only uses 3x3 and 1x1 modulated convolutions")
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(th.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self._packed = None  # (key, wp, wsq)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
+                f"upsample={self.upsample}, downsample={self.downsample})")
+
+    def packed(self):
+        """Tap-major repack + per-(o,i) squared-tap sums of the shared weight; rebuilt when the parameter changes
+        (model rewriting, render.py:160-167, swaps the Parameter object)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if self._packed is None or self._packed[0] != key:
+            wd = _lib.require_cuda(w.detach(), "weight")
+            k2 = self.kernel_size ** 2
+            cpad = (self.out_channel + 31) // 32 * 32
+            wp = th.empty((k2, self.in_channel, cpad), dtype=th.float32, device=w.device) if k2 == 9 else None
+            wsq = th.empty((self.out_channel, self.in_channel), dtype=th.float32, device=w.device)
+            with th.cuda.device(w.device):
+                rc = _lib.load().maua_pack_weight_f32(wd.data_ptr(), _lib.ptr(wp), wsq.data_ptr(), self.out_channel,
+                                                      self.in_channel, k2, _lib.stream_ptr(w.device))
+            _lib.check(rc, "maua_pack_weight_f32")
+            self._packed = (key, wp, wsq)
+        return self._packed[1], self._packed[2]
+
+    def table_entry(self, lat_idx, s_off, d_off):
+        wp, wsq = self.packed()
+        return dict(mod_w=self.modulation.weight, mod_b=self.modulation.bias, wsq=wsq if self.demodulate else None,
+                    cin=self.in_channel, cout=self.out_channel, lat_idx=lat_idx, s_off=s_off, d_off=d_off,
+                    wscale=self.scale)
+
+    def run(self, x, s, s_off, d, out, ws, fuse_act=False, noise=None, noise_w=None, bias=None):
+        """3x3 only. x [B,Cin,H,W]; s [B,S] (this layer's slice at s_off); d [B,Cout] or None.
+        Writes ``out`` ([B,Cout,H,W] or [B,Cout,2H+1,2W+1] when upsample)."""
+        lib = _lib.load()
+        wp, _ = self.packed()
+        b, cin, h, w = x.shape
+        nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
+        rc = lib.maua_modconv3x3_f32(
+            x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b, cin,
+            self.out_channel, h, w, int(self.upsample), float(self.scale), int(fuse_act), _lib.ptr(noise), nstride,
+            _lib.ptr(noise_w), _lib.ptr(bias), _lib.ptr(ws), _lib.stream_ptr(x.device),
+        )
+        _lib.check(rc, "maua_modconv3x3_f32")
+        return out
+
+    def forward(self, inputs, style):
+        x = _lib.require_cuda(inputs, "inputs")
+        style = _lib.require_cuda(style, "style")
+        b, cin, h, w = x.shape
+        dev = x.device
+        lib = _lib.load()
+        with th.cuda.device(dev):
+            s = th.empty((b, cin), dtype=th.float32, device=dev)
+            d = th.empty((b, self.out_channel), dtype=th.float32, device=dev) if self.demodulate else None
+            table = _style_table([self.table_entry(0, 0, 0)], dev)
+            lat = style.reshape(b, 1, -1)
+            st = _lib.stream_ptr(dev)
+            _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 1, lat.shape[-1], None, None, table.data_ptr(), 1,
+                                                 cin, s.data_ptr(), cin, st), "maua_style_affine_f32")
+            if d is not None:
+                _lib.check(lib.maua_demod_f32(table.data_ptr(), 1, self.out_channel, s.data_ptr(), cin, d.data_ptr(), b,
+                                              st), "maua_demod_f32")
+            if self.kernel_size == 1:
+                if self.out_channel != 3 or self.demodulate:
+                    raise NotImplementedError("1x1 modulated conv is only built for ToRGB (3 channels, no demodulation)")
+                out = th.empty((b, 3, h, w), dtype=th.float32, device=dev)
+                _lib.check(lib.maua_torgb_f32(x.data_ptr(), self.weight.data_ptr(), s.data_ptr(), cin, None, None, None,
+                                              out.data_ptr(), b, cin, h, w, float(self.scale), st), "maua_torgb_f32")
+                return out
+            oh, ow = (2 * h + 1, 2 * w + 1) if self.upsample else (h, w)
+            out = th.empty((b, self.out_channel, oh, ow), dtype=th.float32, device=dev)
+            n_ws = lib.maua_modconv_ws_floats(b, cin, self.out_channel, h, w, int(self.upsample))
+            ws = th.empty(n_ws, dtype=th.float32, device=dev) if n_ws else None
+            self.run(x, s, 0, d, out, ws)
+            if self.upsample:
+                out = self.blur(out)
+        return out
+
+
+class NoiseInjection(nn.Module):
+    """reference :257-266 (standalone; inside StyledConv the add is fused into the conv / blur epilogue)."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(th.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            batch, _, height, width = image.shape
+            noise = image.new_empty(batch, 1, height, width).normal_()
+        return image + self.weight * noise.to(image.device)
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(th.randn(1, channel, size, size))
+
+    def forward(self, inputs):
+        return self.input.repeat(inputs.shape[0], 1, 1, 1)
+
+
+class ManipulationLayer(nn.Module):
+    """reference :297-307 — applies every transform whose "layer" id matches."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.layer = layer
+
+    def forward(self, input, tranforms_dict_list):
+        out = input
+        for transform_dict in tranforms_dict_list:
+            if transform_dict["layer"] == self.layer:
+                out = transform_dict["transform"].to(out.device)(out)
+        return out
+
+
+class StyledConv(nn.Module):
+    """reference :310-343: ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU -> ManipulationLayer."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True, layerID=-1):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+        self.manipulation = ManipulationLayer(layerID)
+
+    def run(self, x, s, s_off, d, noise, bufs, tag):
+        """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers."""
+        lib = _lib.load()
+        conv = self.conv
+        b, cin, h, w = x.shape
+        n_ws = lib.maua_modconv_ws_floats(b, cin, conv.out_channel, h, w, int(conv.upsample))
+        ws = bufs("ws", (n_ws,)) if n_ws else None
+        if noise is not None:
+            noise = _lib.require_cuda(noise, "noise")
+        if not conv.upsample:
+            out = bufs(tag, (b, conv.out_channel, h, w))
+            return conv.run(x, s, s_off, d, out, ws, fuse_act=True, noise=noise, noise_w=self.noise.weight,
+                            bias=self.activate.bias)
+        raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
+        conv.run(x, s, s_off, d, raw, ws)
+        k = conv.blur.kernel
+        pad0, pad1 = conv.blur.pad
+        oh, ow = raw.shape[2] + pad0 + pad1 - k.shape[0] + 1, raw.shape[3] + pad0 + pad1 - k.shape[1] + 1
+        out = bufs(tag, (b, conv.out_channel, oh, ow))
+        if noise is not None and tuple(noise.shape[-2:]) != (oh, ow):
+            raise RuntimeError(f"noise {tuple(noise.shape)} does not match feature map {oh}x{ow}")
+        nstride = 0 if noise is None or noise.shape[0] == 1 else oh * ow
+        rc = lib.maua_blur_noise_act_f32(raw.data_ptr(), k.data_ptr(), out.data_ptr(), b, conv.out_channel, raw.shape[2],
+                                         raw.shape[3], k.shape[0], k.shape[1], pad0, pad1, None, _lib.ptr(noise), nstride,
+                                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(),
+                                         _lib.stream_ptr(x.device))
+        _lib.check(rc, "maua_blur_noise_act_f32")
+        return out
+
+    def forward(self, inputs, style, noise=None, transform_dict_list=[]):
+        x = _lib.require_cuda(inputs, "inputs")
+        style = _lib.require_cuda(style, "style")
+        b, cin = x.shape[:2]
+        dev = x.device
+        lib = _lib.load()
+        with th.cuda.device(dev):
+            s = th.empty((b, cin), dtype=th.float32, device=dev)
+            d = th.empty((b, self.conv.out_channel), dtype=th.float32, device=dev)
+            table = _style_table([self.conv.table_entry(0, 0, 0)], dev)
+            lat = style.reshape(b, 1, -1)
+            st = _lib.stream_ptr(dev)
+            _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 1, lat.shape[-1], None, None, table.data_ptr(), 1,
+                                                 cin, s.data_ptr(), cin, st), "maua_style_affine_f32")
+            _lib.check(lib.maua_demod_f32(table.data_ptr(), 1, self.conv.out_channel, s.data_ptr(), cin, d.data_ptr(), b,
+                                          st), "maua_demod_f32")
+            if noise is None:
+                up = 2 if self.conv.upsample else 1
+                noise = th.randn(b, 1, x.shape[2] * up, x.shape[3] * up, device=dev)
+            out = self.run(x, s, 0, d if self.conv.demodulate else None, noise,
+                           lambda name, shape: th.empty(shape, dtype=th.float32, device=dev), "out")
+        return self.manipulation(out, transform_dict_list)
+
+
+class ToRGB(nn.Module):
+    """reference :346-365."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(th.zeros(1, 3, 1, 1))
+
+    def run(self, x, s, s_off, skip, out):
+        lib = _lib.load()
+        b, cin, h, w = x.shape
+        k4 = None
+        if skip is not None:
+            k4 = self.upsample.kernel
+            if tuple(k4.shape) != (4, 4) or self.upsample.factor != 2:
+                raise NotImplementedError("fused ToRGB skip path is built for the 4-tap / factor-2 Upsample")
+            if skip.shape[2] * 2 != h or skip.shape[3] * 2 != w:
+                raise RuntimeError(f"skip {tuple(skip.shape)} is not half of {h}x{w}")
+        rc = lib.maua_torgb_f32(x.data_ptr(), self.conv.weight.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1],
+                                self.bias.data_ptr(), _lib.ptr(skip), _lib.ptr(k4), out.data_ptr(), b, cin, h, w,
+                                float(self.conv.scale), _lib.stream_ptr(x.device))
+        _lib.check(rc, "maua_torgb_f32")
+        return out
+
+    def forward(self, inputs, style, skip=None):
+        x = _lib.require_cuda(inputs, "inputs")
+        style = _lib.require_cuda(style, "style")
+        b, cin, h, w = x.shape
+        dev = x.device
+        lib = _lib.load()
+        with th.cuda.device(dev):
+            s = th.empty((b, cin), dtype=th.float32, device=dev)
+            table = _style_table([self.conv.table_entry(0, 0, 0)], dev)
+            lat = style.reshape(b, 1, -1)
+            _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 1, lat.shape[-1], None, None, table.data_ptr(), 1,
+                                                 cin, s.data_ptr(), cin, _lib.stream_ptr(dev)), "maua_style_affine_f32")
+            out = th.empty((b, 3, h, w), dtype=th.float32, device=dev)
+            if skip is not None:
+                skip = _lib.require_cuda(skip, "skip")
+            return self.run(x, s, 0, skip, out)
+
+
+class Generator(nn.Module):
+    """reference :368-576 (ConstantInput generators only — load_generator passes constant_input=not noconst,
+    generate_audiovisual.py:49; the LatentInput variant is outside the hot path)."""
+
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01,
+                 constant_input=False, checkpoint=None, output_size=None, min_rgb_size=4, base_res_factor=1):
+        super().__init__()
+        if not constant_input:
+            raise NotImplementedError("only constant_input=True generators are built (the default of the "
+                                      "generate_audiovisual path); pass constant_input=True")
+        self.size = size
+        self.style_dim = style_dim
+        layers = [PixelNorm()]
+        for _ in range(n_mlp):
+            layers.append(EqualLinear(style_dim, style_dim, lr_mul=lr_mlp, activation="fused_lrelu"))
+        self.style = nn.Sequential(*layers)
+        self.channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+                         256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.n_latent = self.log_size * 2 - 2
+        self.min_rgb_size = min_rgb_size
+        self.input = ConstantInput(self.channels[4])
+        self.const_manipulation = ManipulationLayer(0)
+        layerID = 1
+        self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel, layerID=layerID)
+        self.to_rgb1 = ToRGB(self.channels[4], style_dim, upsample=False)
+        self.convs = nn.ModuleList()
+        self.upsamples = nn.ModuleList()
+        self.to_rgbs = nn.ModuleList()
+        self.noises = nn.Module()
+        in_channel = self.channels[4]
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f"noise_{layer_idx}", th.randn(1, 1, 2 ** res, 2 ** res))
+        for i in range(3, self.log_size + 1):
+            out_channel = self.channels[2 ** i]
+            layerID += 1
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True, blur_kernel=blur_kernel,
+                                         layerID=layerID))
+            layerID += 1
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel, layerID=layerID))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim))
+            in_channel = out_channel
+        self.truncation_latent = None
+        if checkpoint is not None:
+            self.load_state_dict(th.load(checkpoint)["g_ema"])
+        if size != output_size or base_res_factor != 1:  # reference :461-470 (resizes only the noise buffers)
+            for layer_idx in range(self.num_layers):
+                res = (layer_idx + 5) // 2
+                shape = [1, 1, int(base_res_factor * 2 ** res * (2 if output_size == 1080 else 1)),
+                         int(base_res_factor * 2 ** res * (2 if output_size == 1920 else 1))]
+                setattr(self.noises, f"noise_{layer_idx}", th.randn(*shape))
+        self._bufs = {}
+        self._tables = {}
+
+    # ------------------------------------------------------------------ helpers shared with the reference API
+    def make_noise(self):
+        device = self.input.input.device
+        noises = [th.randn(1, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            for _ in range(2):
+                noises.append(th.randn(1, 1, 2 ** i, 2 ** i, device=device))
+        return noises
+
+    def mean_latent(self, n_latent):
+        latent_in = th.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(latent_in).mean(0, keepdim=True)
+
+    def get_latent(self, inputs):
+        return self.style(inputs)
+
+    # ------------------------------------------------------------------ static buffers / tables
+    def _buf(self, batch, name, shape, dtype=th.float32):
+        key = (batch, name)
+        t = self._bufs.get(key)
+        shape = tuple(int(v) for v in shape)
+        if t is None or tuple(t.shape) != shape or t.device != self.input.input.device:
+            t = th.empty(shape, dtype=dtype, device=self.input.input.device)
+            self._bufs[key] = t
+        return t
+
+    def _style_layers(self):
+        """(module ModulatedConv2d, latent index) in forward order: conv1, to_rgb1, then per resolution
+        conv_up, conv, to_rgb with latent indices i, i+1, i+2 (reference :549-569)."""
+        seq = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
+        i = 1
+        for n in range(self.log_size - 2):
+            seq += [(self.convs[2 * n].conv, i), (self.convs[2 * n + 1].conv, i + 1), (self.to_rgbs[n].conv, i + 2)]
+            i += 2
+        return seq
+
+    def _table(self, batch):
+        seq = self._style_layers()
+        key = (batch,) + tuple((m.weight.data_ptr(), m.weight._version, m.modulation.weight.data_ptr()) for m, _ in seq)
+        cached = self._tables.get(batch)
+        if cached is not None and cached["key"] == key:
+            return cached
+        entries, s_off, d_off = [], 0, 0
+        for m, lat_idx in seq:
+            entries.append(m.table_entry(lat_idx, s_off, d_off))
+            s_off += m.in_channel
+            d_off += batch * m.out_channel if m.demodulate else 0
+        info = dict(key=key, table=_style_table(entries, self.input.input.device), entries=entries, s_total=s_off,
+                    d_total=max(d_off, 1), max_cin=max(e["cin"] for e in entries),
+                    max_cout=max(e["cout"] for e in entries))
+        self._tables[batch] = info
+        return info
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, styles, return_latents=False, return_activation_maps=False, inject_index=None, truncation=1.0,
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True, transform_dict_list=[],
+                map_latents=False):
+        dev = self.input.input.device
+        if dev.type != "cuda":
+            raise RuntimeError("Generator must live on a HIP device (.cuda()); the MI355X path has no CPU fallback")
+        if map_latents:
+            # evident intent of the reference branch (:506-509), whose literal code normalises over a singleton dim
+            # (SURVEY.md §8a quirks): map z [N,512] through the mapping network and repeat to n_latent.
+            return self.style(styles)[:, None, :].repeat(1, self.n_latent, 1)
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+            if len(styles) < 2:
+                inject_index = self.n_latent
+                latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1) if styles[0].ndim < 3 else styles[0]
+            else:
+                if inject_index is None:
+                    import random
+                    inject_index = random.randint(1, self.n_latent - 1)
+                latent = th.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+        else:
+            latent = styles
+            if latent.dim() == 2:
+                latent = latent[:, None, :].repeat(1, self.n_latent, 1)
+        latent = _lib.require_cuda(latent.to(dev), "styles")
+        batch = latent.shape[0]
+
+        noise = list(noise) if noise is not None else [None] * self.num_layers
+        for ns in range(self.num_layers):
+            if noise[ns] is None and not randomize_noise:
+                noise[ns] = getattr(self.noises, f"noise_{ns}")
+        # truncation (:537-543).  A float 1.0 is an exact identity and skips the lazy random mean_latent.
+        trunc = None
+        if not (isinstance(truncation, float) and truncation == 1.0 and truncation_latent is None
+                and self.truncation_latent is None):
+            if isinstance(truncation, float):
+                truncation = th.full((1,), truncation, device=dev)
+            if self.truncation_latent is None:
+                self.truncation_latent = truncation_latent if truncation_latent is not None else self.mean_latent(2 ** 14)
+            trunc = _lib.require_cuda(truncation.to(dev).float().reshape(-1), "truncation")
+            if trunc.numel() == 1 and batch > 1:
+                trunc = trunc.expand(batch).contiguous()
+            if trunc.numel() != batch:
+                raise RuntimeError(f"truncation has {trunc.numel()} entries for a batch of {batch}")
+        tl = _lib.require_cuda(self.truncation_latent.to(dev).reshape(-1), "truncation_latent") if trunc is not None else None
+
+        with th.cuda.device(dev):
+            image, acts, lat_out = self._forward_device(latent, noise, trunc, tl, transform_dict_list,
+                                                        return_activation_maps, return_latents)
+        if return_activation_maps:
+            return image, acts
+        if return_latents:
+            return image, lat_out
+        return image, None
+
+    def _forward_device(self, latent, noise, trunc, tl, bends, want_acts=False, want_latents=False):
+        lib = _lib.load()
+        dev = latent.device
+        batch = latent.shape[0]
+        st = _lib.stream_ptr(dev)
+        info = self._table(batch)
+        bufs = lambda name, shape: self._buf(batch, name, shape)  # noqa: E731
+        s = bufs("styles", (batch, info["s_total"]))
+        d = bufs("demod", (info["d_total"],))
+        _lib.check(lib.maua_style_affine_f32(latent.data_ptr(), batch, latent.shape[1], latent.shape[2], _lib.ptr(trunc),
+                                             _lib.ptr(tl), info["table"].data_ptr(), len(info["entries"]),
+                                             info["max_cin"], s.data_ptr(), info["s_total"], st), "maua_style_affine_f32")
+        _lib.check(lib.maua_demod_f32(info["table"].data_ptr(), len(info["entries"]), info["max_cout"], s.data_ptr(),
+                                      info["s_total"], d.data_ptr(), batch, st), "maua_demod_f32")
+        ent = info["entries"]
+
+        def demod_of(e):
+            if e["wsq"] is None:
+                return None
+            return d[e["d_off"]: e["d_off"] + batch * e["cout"]].view(batch, e["cout"])
+
+        def noise_for(i, h, w):
+            nz = noise[i]
+            if nz is None:  # randomize_noise=True: fresh N(0,1) per call (:262-265)
+                nz = bufs(f"rand_noise_{i}", (batch, 1, h, w)).normal_()
+            return nz.to(dev)
+
+        acts = []
+        x = bufs("const", (batch,) + tuple(self.input.input.shape[1:]))
+        x.copy_(self.input.input.expand(batch, -1, -1, -1))
+        x = self.const_manipulation(x, bends)
+        li = 0
+        out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1")
+        out = self.conv1.manipulation(out, bends)
+        acts.append(out)
+        li += 1
+        image = self.to_rgb1.run(out, s, ent[li]["s_off"], None, bufs("rgb1", (batch, 3) + tuple(out.shape[2:])))
+        li += 1
+        for n in range(self.log_size - 2):
+            up, plain, rgb = self.convs[2 * n], self.convs[2 * n + 1], self.to_rgbs[n]
+            out = up.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 1, out.shape[2] * 2, out.shape[3] * 2),
+                         bufs, f"convs.{2 * n}")
+            out = up.manipulation(out, bends)
+            acts.append(out)
+            li += 1
+            out = plain.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 2, out.shape[2], out.shape[3]),
+                            bufs, f"convs.{2 * n + 1}")
+            out = plain.manipulation(out, bends)
+            acts.append(out)
+            li += 1
+            image = rgb.run(out, s, ent[li]["s_off"], image, bufs(f"rgbs.{n}", (batch, 3) + tuple(out.shape[2:])))
+            li += 1
+        lat_out = None
+        if want_latents:
+            lat_out = latent if trunc is None else tl[None, None, :] + trunc[:, None, None] * (latent - tl[None, None, :])
+        return image, acts, lat_out
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture_graph(self, batch, noise_static, truncated=False):
+        """Capture one forward of ``batch`` frames into a hipGraph.  Returns (graph, static) where static holds the
+        input buffers to overwrite before each ``graph.replay()`` (latents, truncation, per-layer noise or None for
+        checkpoint noise buffers) and ``static["image"]`` is the output buffer.  Bends are not capturable."""
+        dev = self.input.input.device
+        with th.cuda.device(dev):
+            static = {
+                "latents": self._buf(batch, "g.latents", (batch, self.n_latent, self.style_dim)),
+                "trunc": self._buf(batch, "g.trunc", (batch,)) if truncated else None,
+                "noise": [],
+            }
+            static["latents"].zero_()
+            if truncated:
+                static["trunc"].fill_(1.0)
+            for i in range(self.num_layers):
+                nz = noise_static[i]
+                if nz is None:
+                    static["noise"].append(getattr(self.noises, f"noise_{i}"))
+                else:
+                    b = self._buf(batch, f"g.noise_{i}", (batch, 1) + tuple(nz))
+                    b.zero_()
+                    static["noise"].append(b)
+            tl = None
+            if truncated:
+                if self.truncation_latent is None:
+                    self.truncation_latent = self.mean_latent(2 ** 14)
+                tl = self.truncation_latent.to(dev).reshape(-1).contiguous()
+            static["trunc_latent"] = tl
+            # warm-up (allocates every static buffer, packs weights), then capture
+            self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [])
+            th.cuda.synchronize(dev)
+            graph = _lib.HipGraph()
+            with graph:
+                image, _, _ = self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [])
+            static["image"] = image
+        return graph, static

