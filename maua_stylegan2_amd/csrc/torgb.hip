@@ -10,6 +10,13 @@
 
 namespace {
 
+template <int V>
+__device__ __forceinline__ float4 load_px(const float* p) {
+    if (V == 4) return *reinterpret_cast<const float4*>(p);
+    return make_float4(p[0], 0.f, 0.f, 0.f);
+}
+
+template <int V>
 __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ s, int s_stride,
                                                     const float* __restrict__ bias, const float* __restrict__ skip,
@@ -21,7 +28,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int plane = h * wdt;
-    const int quads = plane >> 2;
+    const int quads = plane / V;
     for (int e = tid; e < 3 * cin; e += 256) {
         const int i = e % cin;
         wm[e] = wscale * w[e] * s[(size_t)b * s_stride + i];
@@ -40,12 +47,12 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
         const int per = (cin + ks - 1) / ks;
         const int i0 = slice * per;
         const int i1 = min(cin, i0 + per);
-        const float* xp = x + ((size_t)b * cin) * plane + (size_t)q * 4;
+        const float* xp = x + ((size_t)b * cin) * plane + (size_t)q * V;
         int i = i0;
         for (; i + 8 <= i1; i += 8) {
             float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (size_t)(i + u) * plane);
+            for (int u = 0; u < 8; ++u) v[u] = load_px<V>(xp + (size_t)(i + u) * plane);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
                 }
         }
         for (; i < i1; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(xp + (size_t)i * plane);
+            const float4 v = load_px<V>(xp + (size_t)i * plane);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float wv = wm[c * cin + i];
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
     }
     if (!active || slice != 0) return;
 
-    const int pix = q * 4;
+    const int pix = q * V;
     const int Y = pix / wdt, X0 = pix - Y * wdt;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
             const int sh = h >> 1, sw = wdt >> 1;
             const float* sp = skip + ((size_t)b * 3 + c) * sh * sw;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < V; ++e) {
                 const int X = X0 + e;
                 float a = 0.f;
 #pragma unroll
@@ -120,7 +127,9 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
                 out[e] += a;
             }
         }
-        *reinterpret_cast<float4*>(y + ((size_t)b * 3 + c) * plane + pix) = make_float4(out[0], out[1], out[2], out[3]);
+        float* yp = y + ((size_t)b * 3 + c) * plane + pix;
+        if (V == 4) *reinterpret_cast<float4*>(yp) = make_float4(out[0], out[1], out[2], out[3]);
+        else yp[0] = out[0];
     }
 }
 
@@ -130,15 +139,19 @@ extern "C" int maua_torgb_f32(const float* x, const float* w, const float* s, in
                               const float* skip, const float* k4, float* y, int batch, int cin, int h, int wdt,
                               float wscale, void* stream) {
     if (!x || !w || !s || !y || batch <= 0 || cin <= 0 || h <= 0 || wdt <= 0) return MAUA_EINVAL;
-    if (wdt % 4) return MAUA_EINVAL;            // a 4-pixel group must stay inside one row
+    const int vec = (wdt % 4 == 0) ? 4 : 1;      // a 4-pixel group must stay inside one row
     if (skip && (!k4 || (h & 1) || (wdt & 1))) return MAUA_EINVAL;
-    const int quads = h * wdt / 4;
+    const int quads = h * wdt / vec;
     int qpb = 256, ks_log2 = 0;
     while (qpb > 4 && qpb / 2 >= quads) qpb >>= 1, ++ks_log2;
     const int ks = 1 << ks_log2;
     const size_t lds = ((size_t)((3 * cin + 3) & ~3) + (ks > 1 ? (size_t)ks * qpb * 12 : 0)) * sizeof(float);
-    hipLaunchKernelGGL(torgb_kernel, dim3(ceil_div(quads, qpb), batch), dim3(256), lds, (hipStream_t)stream, x, w, s,
-                       s_stride, bias, skip, k4, y, cin, h, wdt, wscale, ks_log2, qpb);
+    if (vec == 4)
+        hipLaunchKernelGGL(torgb_kernel<4>, dim3(ceil_div(quads, qpb), batch), dim3(256), lds, (hipStream_t)stream, x, w,
+                           s, s_stride, bias, skip, k4, y, cin, h, wdt, wscale, ks_log2, qpb);
+    else
+        hipLaunchKernelGGL(torgb_kernel<1>, dim3(ceil_div(quads, qpb), batch), dim3(256), lds, (hipStream_t)stream, x, w,
+                           s, s_stride, bias, skip, k4, y, cin, h, wdt, wscale, ks_log2, qpb);
     MAUA_LAUNCH_CHECK();
     return 0;
 }
