@@ -1,0 +1,7 @@
+"""Drop-in for the reference's ``audioreactive`` package: everything star-exported as ``ar.*``
+(/root/reference/audioreactive/__init__.py:1-5)."""
+from . import signal as _signal_module
+from .bend import *  # noqa: F401,F403
+from .latent import *  # noqa: F401,F403
+from .signal import *  # noqa: F401,F403
+from .signal import set_SMF  # noqa: F401

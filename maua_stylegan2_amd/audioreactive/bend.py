@@ -1,0 +1,134 @@
+"""Network bending with the reference's ``audioreactive.bend`` surface, on one HIP warp kernel instead of kornia.
+
+Mirrors /root/reference/audioreactive/bend.py: NetworkBend :12-26 · AddNoise :29-41 · Print :44-49 · Translate :52-72 ·
+Zoom :75-87 · Rotate :90-102.  The reference composes ReflectionPad2d -> kornia Translate/Scale/Rotate -> kornia
+CenterCrop (three full-size intermediates); here the composition is evaluated per OUTPUT pixel by
+maua_affine_reflect_warp_f32: inverse affine map into the padded canvas, bilinear taps, reflection folded into the
+index.  kornia is an un-pinned, un-vendored dependency (requirements.txt:8) -> "parity unpinned" (DESIGN.md); the
+conventions implemented are kornia's documented ones: pixel-unit translation, transforms about the canvas centre
+((W-1)/2, (H-1)/2), bilinear, zeros outside the canvas, anticlockwise-positive angles in degrees.
+"""
+import math
+
+import torch as th
+
+from .. import _lib
+
+
+class NetworkBend(th.nn.Module):
+    def __init__(self, sequential_fn, modulation):
+        super().__init__()
+        self.sequential = sequential_fn(modulation)
+
+    def forward(self, x):
+        return self.sequential(x)
+
+
+class AddNoise(th.nn.Module):
+    def __init__(self, noise):
+        super().__init__()
+        self.noise = noise
+
+    def forward(self, x):
+        return x + self.noise.to(x.device)
+
+
+class Print(th.nn.Module):
+    def forward(self, x):
+        print(x.shape, [x.min().item(), x.mean().item(), x.max().item()], th.std(x).item())
+        return x
+
+
+class AffineReflectWarp(th.nn.Module):
+    """y = CenterCrop(h, w)( Affine( ReflectionPad(x) [+ noise] ) ) with a per-sample inverse map ``m`` [B, 6]."""
+
+    def __init__(self, inv_maps, pads, noise=None):
+        super().__init__()
+        self.inv_maps = inv_maps
+        self.pads = pads  # (left, right, top, bottom)
+        self.noise = noise
+
+    def forward(self, x):
+        lib = _lib.load()
+        x = _lib.require_cuda(x, "x")
+        b, c, h, w = x.shape
+        m = self.inv_maps.to(x.device, th.float32).contiguous()
+        if m.shape[0] == 1 and b > 1:
+            m = m.expand(b, 6).contiguous()
+        if m.shape != (b, 6):
+            raise RuntimeError(f"expected {b} inverse affine maps, got {tuple(m.shape)}")
+        nz = None
+        if self.noise is not None:
+            nz = _lib.require_cuda(self.noise.to(x.device).float(), "noise")
+            pl, pr, pt, pb = self.pads
+            if nz.numel() != (h + pt + pb) * (w + pl + pr):
+                raise RuntimeError("bend noise must have the size of one padded canvas plane")
+        y = th.empty_like(x)
+        with th.cuda.device(x.device):
+            _lib.check(lib.maua_affine_reflect_warp_f32(x.data_ptr(), m.data_ptr(), y.data_ptr(), b, c, h, w, self.pads[0],
+                                                        self.pads[1], self.pads[2], self.pads[3], _lib.ptr(nz),
+                                                        _lib.stream_ptr(x.device)), "maua_affine_reflect_warp_f32")
+        return y
+
+
+def _inverse_maps_translate(t):
+    """dst = src + t  ->  src = dst - t (pixels)."""
+    t = t.reshape(-1, 2).float()
+    m = th.zeros(t.shape[0], 6)
+    m[:, 0] = 1.0
+    m[:, 4] = 1.0
+    m[:, 2] = -t[:, 0].cpu()
+    m[:, 5] = -t[:, 1].cpu()
+    return m
+
+
+def _inverse_maps_scale(s, cw, ch):
+    s = s.float().cpu()
+    if s.dim() == 1:
+        s = s[:, None].expand(-1, 2)
+    cx, cy = (cw - 1) / 2.0, (ch - 1) / 2.0
+    m = th.zeros(s.shape[0], 6)
+    m[:, 0] = 1.0 / s[:, 0]
+    m[:, 4] = 1.0 / s[:, 1]
+    m[:, 2] = cx - cx / s[:, 0]
+    m[:, 5] = cy - cy / s[:, 1]
+    return m
+
+
+def _inverse_maps_rotate(angle_deg, cw, ch):
+    a = th.deg2rad(angle_deg.float().cpu().reshape(-1))
+    cx, cy = (cw - 1) / 2.0, (ch - 1) / 2.0
+    cos, sin = th.cos(a), th.sin(a)
+    # forward (OpenCV/kornia get_rotation_matrix2d): dst = R(src - c) + c with R = [[cos, sin], [-sin, cos]];
+    # inverse: src = R^T (dst - c) + c
+    m = th.zeros(a.shape[0], 6)
+    m[:, 0], m[:, 1] = cos, -sin
+    m[:, 3], m[:, 4] = sin, cos
+    m[:, 2] = cx - cos * cx + sin * cy
+    m[:, 5] = cy - sin * cx - cos * cy
+    return m
+
+
+class Translate(NetworkBend):
+    """Horizontal scrolling (reference :52-72): reflect-pad 2.5 w left / 1.5 w right, add noise, translate, crop."""
+
+    def __init__(self, modulation, h, w, noise):
+        pads = (int(w / 2) + w + w, int(w / 2) + w, 0, 0)
+        sequential_fn = lambda b: AffineReflectWarp(_inverse_maps_translate(b), pads, noise)  # noqa: E731
+        super().__init__(sequential_fn, modulation)
+
+
+class Zoom(NetworkBend):
+    def __init__(self, modulation, h, w):
+        padding = int(max(h, w)) - 1
+        pads = (padding,) * 4
+        sequential_fn = lambda b: AffineReflectWarp(_inverse_maps_scale(b, w + 2 * padding, h + 2 * padding), pads)  # noqa: E731
+        super().__init__(sequential_fn, modulation)
+
+
+class Rotate(NetworkBend):
+    def __init__(self, modulation, h, w):
+        padding = int(max(h, w) * (1 - math.sqrt(2) / 2))
+        pads = (padding,) * 4
+        sequential_fn = lambda b: AffineReflectWarp(_inverse_maps_rotate(b, w + 2 * padding, h + 2 * padding), pads)  # noqa: E731
+        super().__init__(sequential_fn, modulation)

@@ -1,0 +1,309 @@
+"""Audio-feature library with the reference's ``audioreactive.signal`` surface, computed on the MI355X.
+
+Mirrors /root/reference/audioreactive/signal.py (names, arguments, return shapes):
+  set_SMF :21-23 · onsets :31-73 · rms :76-99 · raw_chroma :102-133 · chroma :136-156 · normalize :243-254 ·
+  percentile :257-268 · percentile_clip :271-292 · compress/expand :295-316 · gaussian_filter :319-368 ·
+  load_audio :371-405.
+
+What runs where: the STFT (LDS radix-2 FFT), the mel / chroma / rms filterbank projections, and the temporal Gaussian
+FIR are HIP kernels (csrc/signal.hip) behind the C ABI; the O(n_frames) envelope post-processing (resample, clip,
+percentile, power) is a handful of torch ops on the same device.  Inputs may be numpy arrays or tensors on any device;
+results come back on the device the reference would have produced them on (envelopes: CPU tensors) unless
+``device=`` says otherwise, so existing plugins keep working while the heavy tensors can stay in HBM.
+
+Divergences from the reference, all stated in DESIGN.md ("parity unpinned" rows): librosa / madmom are not
+dependencies here.  ``onsets`` implements the spectral-flux definition of the type="rosa" branch for both ``type``
+values and skips the percussive separation (``margin`` is accepted and ignored); ``chroma`` implements the
+type="stft" filterbank for every ``type`` and skips harmonic separation / nn_filter.
+"""
+import math
+import os
+import warnings
+from pathlib import Path
+
+import numpy as np
+import scipy.signal
+import torch as th
+
+from .. import _lib
+
+SMF = 1  # smoothing factor, set by generate() from the rendering fps (reference :18-23)
+
+
+def set_SMF(smf):
+    global SMF
+    SMF = smf
+
+
+def _dev():
+    return th.device("cuda", th.cuda.current_device())
+
+
+def _to_dev(x, dtype=th.float32):
+    if isinstance(x, np.ndarray):
+        x = th.from_numpy(np.ascontiguousarray(x))
+    return x.to(device=_dev(), dtype=dtype).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ filterbanks (host, once)
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    lin = f / (200.0 / 3)
+    log = 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) / (np.log(6.4) / 27.0)
+    return np.where(f >= 1000.0, log, lin)
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3))
+
+
+def mel_filterbank(sr, n_fft=2048, n_mels=128, fmin=0.0, fmax=None):
+    """Slaney mel scale, triangular, area-normalised — [n_mels, n_fft/2+1] float32."""
+    fmax = sr / 2.0 if fmax is None else float(fmax)
+    freqs = np.arange(1 + n_fft // 2) * (sr / n_fft)
+    edges = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    width = np.diff(edges)
+    ramps = edges[:, None] - freqs[None, :]
+    lower = -ramps[:-2] / width[:-1, None]
+    upper = ramps[2:] / width[1:, None]
+    fb = np.maximum(0.0, np.minimum(lower, upper))
+    fb *= (2.0 / (edges[2:] - edges[:-2]))[:, None]
+    return fb.astype(np.float32)
+
+
+def chroma_filterbank(sr, n_fft=2048, n_chroma=12, ctroct=5.0, octwidth=2.0):
+    """STFT-bin -> pitch-class weights (tuning 0, C-based) — [12, n_fft/2+1] float32."""
+    f = np.arange(1, n_fft) * (sr / n_fft)
+    pos = n_chroma * np.log2(f / 27.5)
+    pos = np.concatenate([[pos[0] - 1.5 * n_chroma], pos])
+    bw = np.concatenate([np.maximum(np.diff(pos), 1.0), [1.0]])
+    dist = pos[None, :] - np.arange(n_chroma)[:, None]
+    half = round(n_chroma / 2)
+    dist = np.remainder(dist + half + 10 * n_chroma, n_chroma) - half
+    w = np.exp(-0.5 * (2.0 * dist / bw[None, :]) ** 2)
+    w /= np.maximum(np.linalg.norm(w, axis=0, keepdims=True), np.finfo(float).tiny)
+    w *= np.exp(-0.5 * ((pos / n_chroma - ctroct) / octwidth) ** 2)[None, :]
+    w = np.roll(w, -3 * (n_chroma // 12), axis=0)
+    return np.ascontiguousarray(w[:, : 1 + n_fft // 2]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ device primitives
+def stft_power(audio, n_fft=2048, hop=512):
+    """|STFT|^2 on device: [n_fft/2+1, 1 + len/hop] float32 (centred, reflect-padded, periodic Hann)."""
+    lib = _lib.load()
+    y = _to_dev(audio)
+    n = y.numel()
+    n_frames = 1 + n // hop
+    win = th.from_numpy((0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32)).to(y.device)
+    p = th.empty((n_fft // 2 + 1, n_frames), dtype=th.float32, device=y.device)
+    with th.cuda.device(y.device):
+        _lib.check(lib.maua_stft_power_f32(y.data_ptr(), n, win.data_ptr(), n_fft, hop, p.data_ptr(), n_frames,
+                                           _lib.stream_ptr(y.device)), "maua_stft_power_f32")
+    return p
+
+
+def project(fb, p, to_db=False, amin=1e-10):
+    """fb [M,K] (numpy or tensor) @ p [K,N] on device, optional 10*log10(max(amin, .))."""
+    lib = _lib.load()
+    fbt = _to_dev(fb)
+    m, k = fbt.shape
+    n = p.shape[1]
+    out = th.empty((m, n), dtype=th.float32, device=p.device)
+    with th.cuda.device(p.device):
+        _lib.check(lib.maua_filterbank_f32(fbt.data_ptr(), p.data_ptr(), out.data_ptr(), m, k, n, int(to_db), float(amin),
+                                           _lib.stream_ptr(p.device)), "maua_filterbank_f32")
+    return out
+
+
+def resample(x, num):
+    """Fourier-method resampling along dim 0 (what scipy.signal.resample does at reference :68,152), on device."""
+    n = x.shape[0]
+    spec = th.fft.rfft(x.to(th.float64), dim=0)
+    m = min(n, num)
+    out = th.zeros((num // 2 + 1,) + tuple(x.shape[1:]), dtype=spec.dtype, device=x.device)
+    keep = m // 2 + 1
+    out[:keep] = spec[:keep]
+    if m % 2 == 0:  # the shared Nyquist bin of the shorter grid
+        if num < n:
+            out[m // 2] = out[m // 2] * 2.0  # fold +/- Nyquist of the source into the single real bin
+            out[m // 2] = out[m // 2].real.to(out.dtype)
+        elif num > n:
+            out[m // 2] = out[m // 2] * 0.5
+    return th.fft.irfft(out, n=num, dim=0) * (float(num) / float(n))
+
+
+def gaussian_filter(x, sigma, causal=None):
+    """Circular Gaussian smoothing along time (dim 0), HIP FIR kernel; same tap construction as reference :335-343."""
+    lib = _lib.load()
+    src_device = x.device if isinstance(x, th.Tensor) else th.device("cpu")
+    xd = _to_dev(x)
+    dim = xd.dim()
+    n_frames = xd.shape[0]
+    lifted = xd
+    while lifted.dim() < 3:
+        lifted = lifted[:, None]
+    radius = min(int(sigma * 4 * SMF), 3 * len(lifted))
+    taps = th.arange(-radius, radius + 1, dtype=th.float32)
+    taps = th.exp(-0.5 / sigma ** 2 * taps ** 2)
+    if causal is not None:
+        taps[radius + 1:] *= 0 if not isinstance(causal, float) else causal
+    taps = (taps / taps.sum()).to(xd.device)
+    if radius > n_frames:
+        print(f"WARNING: Gaussian filter radius ({int(sigma * 4 * SMF)}) is larger than number of frames ({n_frames}).\n"
+              f"\t Filter size has been lowered to ({radius}). You might want to consider lowering sigma ({sigma}).")
+    feats = xd.numel() // max(n_frames, 1)
+    y = th.empty_like(xd)
+    with th.cuda.device(xd.device):
+        _lib.check(lib.maua_temporal_fir_f32(xd.data_ptr(), taps.data_ptr(), y.data_ptr(), n_frames, feats, radius,
+                                             _lib.stream_ptr(xd.device)), "maua_temporal_fir_f32")
+    if dim < 3:
+        y = y.reshape(list(xd.shape) + [1] * (3 - dim)).squeeze()
+    return y.to(src_device)
+
+
+# ------------------------------------------------------------------------------------------------ envelope post-processing
+def normalize(signal):
+    signal -= signal.min()
+    signal /= signal.max()
+    return signal
+
+
+def percentile(signal, p):
+    k = 1 + round(0.01 * float(p) * (signal.numel() - 1))
+    return signal.view(-1).kthvalue(k).values.item()
+
+
+def percentile_clip(signal, p):
+    locs = th.arange(0, signal.shape[0], device=signal.device)
+    plus = signal.take((locs + 1).clamp(0, signal.shape[0] - 1))
+    minus = signal.take((locs - 1).clamp(0, signal.shape[0] - 1))
+    peaks = th.gt(signal, plus) & th.gt(signal, minus)
+    signal = signal.clamp(0, percentile(signal[peaks], p))
+    signal /= signal.max()
+    return signal
+
+
+def compress(signal, threshold, ratio, invert=False):
+    if invert:
+        signal[signal < threshold] *= ratio
+    else:
+        signal[signal > threshold] *= ratio
+    return normalize(signal)
+
+
+def expand(signal, threshold, ratio, invert=False):
+    return compress(signal, threshold, ratio, invert)
+
+
+# ------------------------------------------------------------------------------------------------ features
+def onset_strength(audio, sr, fmin=0.0, fmax=None, n_fft=2048, hop=512, n_mels=128):
+    """Spectral-flux onset envelope on device (mel power -> dB -> positive first difference -> mean over bands,
+    shifted by lag + n_fft//(2*hop) frames)."""
+    fmax = sr / 2.0 if fmax is None else fmax
+    p = stft_power(audio, n_fft, hop)
+    db = project(mel_filterbank(sr, n_fft, n_mels, fmin, fmax), p, to_db=True)
+    db = th.maximum(db, db.max() - 80.0)
+    flux = th.clamp(db[:, 1:] - db[:, :-1], min=0).mean(0)
+    pad = 1 + n_fft // (2 * hop)
+    env = th.cat([th.zeros(pad, device=flux.device), flux])
+    return env[: db.shape[1]]
+
+
+def onsets(audio, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, type="mm", device=None):
+    env = onset_strength(audio, sr, fmin=fmin, fmax=fmax)
+    onset = resample(env, n_frames).clamp(float(env.min()), float(env.max())).float()
+    onset = gaussian_filter(onset, smooth, causal=0)
+    onset = percentile_clip(onset, clip)
+    onset = onset ** power
+    return onset.to(device if device is not None else "cpu")
+
+
+def rms(y, sr, n_frames, fmin=20, fmax=8000, smooth=180, clip=50, power=6, device=None):
+    y_filt = scipy.signal.sosfilt(scipy.signal.butter(12, [fmin, fmax], "bp", fs=sr, output="sos"), np.asarray(y))
+    n_fft = 2048
+    p = stft_power(y_filt.astype(np.float32), n_fft, 512)
+    wts = np.ones((1, n_fft // 2 + 1), np.float32)
+    wts[0, 0] = wts[0, -1] = 0.5
+    env = th.sqrt(project(wts * (2.0 / n_fft ** 2), p))[0]
+    env = resample(env, n_frames).clamp(float(env.min()), float(env.max())).float()
+    env = gaussian_filter(env, smooth, causal=0.05)
+    env = percentile_clip(env, clip)
+    env = env ** power
+    return env.to(device if device is not None else "cpu")
+
+
+def raw_chroma(audio, sr, type="cens", nearest_neighbor=True):
+    """[12, n_stft_frames] numpy chromagram (STFT filterbank, per-frame max normalisation)."""
+    if type not in ("stft",):
+        warnings.warn(f"chroma type {type!r}: only the STFT filterbank chroma is built on this path; using it", stacklevel=2)
+    raw = project(chroma_filterbank(sr), stft_power(audio))
+    peak = raw.max(dim=0, keepdim=True).values
+    return (raw / th.where(peak > 0, peak, th.ones_like(peak))).cpu().numpy()
+
+
+def chroma(audio, sr, n_frames, margin=16, type="cens", notes=12, device=None):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ch = th.from_numpy(raw_chroma(audio, sr, type=type)).to(_dev()).t()
+    ch = resample(ch, n_frames)
+    keep = th.argsort(th.quantile(ch, 0.5, dim=0))[:notes]  # np.median semantics (mean of the two middle values)
+    ch = ch[:, keep]
+    ch = (ch / ch.sum(1)[:, None]).float()
+    return ch.to(device if device is not None else "cpu")
+
+
+def laplacian_segmentation(signal, sr, k=5, plot=False):
+    raise NotImplementedError("laplacian_segmentation is outside the hot path (SURVEY.md §2 row 7: only kelp.py uses it)")
+
+
+# ------------------------------------------------------------------------------------------------ audio loading
+def _read_audio_file(audio_file, target_sr=22050):
+    """WAV (PCM / float) via scipy; anything else needs ffmpeg on PATH.  Returns mono float32 at ``target_sr``."""
+    import scipy.io.wavfile
+
+    path = str(audio_file)
+    if not path.lower().endswith(".wav"):
+        import shutil
+        import subprocess
+
+        if shutil.which("ffmpeg") is None:
+            raise RuntimeError(f"cannot decode {path}: only .wav is readable without an ffmpeg binary on PATH")
+        raw = subprocess.run(["ffmpeg", "-v", "error", "-i", path, "-f", "f32le", "-ac", "1", "-ar", str(target_sr), "-"],
+                             check=True, capture_output=True).stdout
+        return np.frombuffer(raw, dtype=np.float32).copy(), target_sr
+    sr, data = scipy.io.wavfile.read(path)
+    if data.dtype.kind == "i":
+        data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
+    elif data.dtype.kind == "u":
+        data = (data.astype(np.float32) - 128.0) / 128.0
+    data = data.astype(np.float32)
+    if data.ndim == 2:
+        data = data.mean(axis=1)
+    if sr != target_sr:
+        g = math.gcd(int(sr), int(target_sr))
+        data = scipy.signal.resample_poly(data, target_sr // g, sr // g).astype(np.float32)
+    return data, target_sr
+
+
+def load_audio(audio_file, offset=0, duration=-1, cache=True):
+    """Reference :371-405: (audio float32 mono @22050 Hz, sr, duration); cached under workspace/<stem>*.npy."""
+    full, sr = None, 22050
+    cache_file = None
+    audio, sr = _read_audio_file(audio_file, 22050)
+    audio_dur = len(audio) / sr
+    if duration == -1 or audio_dur < duration:
+        duration = audio_dur
+        if offset != 0:
+            duration -= offset
+    if cache:
+        cache_file = (f"workspace/{Path(audio_file).stem}" + ("" if duration == -1 else f"_length{duration}")
+                      + ("" if offset == 0 else f"_start{offset}") + ".npy")
+        if os.path.exists(cache_file):
+            return np.load(cache_file), sr, duration
+    start = int(round(offset * sr))
+    audio = audio[start: start + int(round(duration * sr))]
+    if cache_file is not None:
+        os.makedirs("workspace", exist_ok=True)
+        np.save(cache_file, audio)
+    return audio, sr, duration

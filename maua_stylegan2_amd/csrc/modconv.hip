@@ -60,15 +60,15 @@ struct ConvPtrs {
 
 // UP = false : plain 3x3, pad 1.           per wave: TM x TN MFMA tiles.
 // UP = true  : stride-2 transposed 3x3.    per wave: TM x (TN position groups x 4 output parities).
-template <int BM, int BN, int WM, bool UP>
-__global__ __launch_bounds__(256) void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
+template <int BM, int BN, int WM, bool UP, bool MULTI>
+__global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int NPH = UP ? 4 : 1;
     constexpr int A_FLOATS = 9 * CC * BM;
     constexpr int A_VEC_ITERS = (A_FLOATS / 4 + 255) / 256;
-    constexpr int MAX_POS = 3;  // patch positions per thread (PSTRIDE <= 768)
+    constexpr int MAX_POS = BN > 256 ? 3 : 2;  // patch positions per thread (PSTRIDE <= 256 * MAX_POS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Ps = lds + A_FLOATS;
@@ -144,10 +144,14 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ConvGeom g, ConvPtrs 
     int chunk_end = chunk_begin + g.chunks_per_split;
     if (chunk_end > g.n_chunks) chunk_end = g.n_chunks;
 
-    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+    // Software pipeline (issue-early / write-late): the global loads of chunk c+1 are issued right after the barrier
+    // that publishes chunk c and stay in flight underneath chunk c's 36*TM*TN*NPH' MFMAs; they are only waited for
+    // when their registers are written to LDS at the top of the next iteration.
+    float4 av[A_VEC_ITERS];
+    float pv[MAX_POS][CC];
+    constexpr bool one_image = !MULTI;  // every patch position belongs to image b0: styles are block-uniform
+    auto issue_loads = [&](int chunk) {
         const int c0 = chunk * CC;
-        // -- global -> registers
-        float4 av[A_VEC_ITERS];
 #pragma unroll
         for (int it = 0; it < A_VEC_ITERS; ++it) {
             const int f = tid + it * 256;  // float4 index in As
@@ -159,17 +163,25 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ConvGeom g, ConvPtrs 
             if (f < A_FLOATS / 4 && ch < g.Cin && o < g.CoutPad)
                 av[it] = *reinterpret_cast<const float4*>(p.wp + ((size_t)tap * g.Cin + ch) * g.CoutPad + o);
         }
-        float pv[MAX_POS][CC];
 #pragma unroll
         for (int i = 0; i < MAX_POS; ++i)
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
                 const int ch = c0 + c;
                 float v = 0.f;
-                if (src_off[i] >= 0 && ch < g.Cin) v = p.x[(size_t)src_off[i] + ch * plane_in] * p.s[sb_off[i] + ch];
+                if (src_off[i] >= 0 && ch < g.Cin) {
+                    v = p.x[(size_t)src_off[i] + ch * plane_in];
+                    if (!one_image) v *= p.s[sb_off[i] + ch];
+                }
                 pv[i][c] = v;
             }
-        // -- registers -> LDS
+    };
+    auto write_lds = [&](int chunk) {
+        const int c0 = chunk * CC;
+        float sc[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c)  // uniform address -> scalar loads
+            sc[c] = (one_image && c0 + c < g.Cin && b0 < g.B) ? p.s[b0 * g.s_stride + c0 + c] : 1.f;
 #pragma unroll
         for (int it = 0; it < A_VEC_ITERS; ++it) {
             const int f = tid + it * 256;
@@ -180,10 +192,16 @@ __global__ __launch_bounds__(256) void modconv_mfma_kernel(ConvGeom g, ConvPtrs 
             const int pp = tid + i * 256;
             if (pp < g.PSTRIDE) {
 #pragma unroll
-                for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = pv[i][c];
+                for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = pv[i][c] * sc[c];
             }
         }
+    };
+
+    if (chunk_begin < chunk_end) issue_loads(chunk_begin);
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+        write_lds(chunk);
         __syncthreads();
+        if (chunk + 1 < chunk_end) issue_loads(chunk + 1);
 
         // -- MFMA
 #pragma unroll
@@ -322,7 +340,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         else pl.bm = 64, pl.wm = 2, pl.bn = 64;
     } else {
         g.GH = h, g.GW = w, g.OH = h, g.OW = w;
-        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 512;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 256;
         else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 256;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
     }
@@ -343,7 +361,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         g.PH = th + 2, g.PW = tw + 2, g.PSTRIDE = ni * g.PH * g.PW;
     };
     shape(pl.bn);
-    if (g.PSTRIDE > 768) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
+    if (g.PSTRIDE > (pl.bn > 256 ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
         shape(pl.bn);
@@ -364,9 +382,9 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     return pl;
 }
 
-template <int BM, int BN, int WM, bool UP>
-int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
-    auto kern = modconv_mfma_kernel<BM, BN, WM, UP>;
+template <int BM, int BN, int WM, bool UP, bool MULTI>
+int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
+    auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -375,6 +393,13 @@ int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(256), pl.lds_bytes, st, pl.g, ptrs);
     MAUA_LAUNCH_CHECK();
     return 0;
+}
+
+template <int BM, int BN, int WM, bool UP>
+int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
+    if (pl.g.PSTRIDE > 256 * (BN > 256 ? 3 : 2)) return MAUA_EINVAL;
+    if (pl.g.lni > 0) return launch_conv_impl<BM, BN, WM, UP, true>(pl, ptrs, st);
+    return launch_conv_impl<BM, BN, WM, UP, false>(pl, ptrs, st);
 }
 
 }  // namespace
@@ -404,7 +429,6 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
     if (noise && !noise_w) return MAUA_EINVAL;
     if ((int64_t)batch * cin * h * w > 0x7fffffffLL) return MAUA_EINVAL;  // 32-bit patch offsets
     Plan pl = make_plan(batch, cin, cout, h, w, up);
-    if (pl.g.PSTRIDE > 768) return MAUA_EINVAL;
     if (pl.g.splits > 1 && !ws) return MAUA_EINVAL;
     pl.g.s_stride = s_stride;
     pl.g.wscale = wscale;
@@ -417,7 +441,7 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
         if (pl.bm == 32) rc = launch_conv<32, 128, 1, true>(pl, ptrs, st);
         else rc = launch_conv<64, 64, 2, true>(pl, ptrs, st);
     } else {
-        if (pl.bm == 32) rc = launch_conv<32, 512, 1, false>(pl, ptrs, st);
+        if (pl.bm == 32) rc = launch_conv<32, 256, 1, false>(pl, ptrs, st);
         else if (pl.bm == 64) rc = launch_conv<64, 256, 1, false>(pl, ptrs, st);
         else rc = launch_conv<128, 128, 2, false>(pl, ptrs, st);
     }

@@ -140,6 +140,161 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fir_vec4_kernel: the wide-plane fast path (out_w >= 256, out_w % 4 == 0).  Same tiling idea as fir_tile_kernel
+// (32 x 256 output tile, one barrier), but every HBM access is 16 bytes per lane:
+//   * loads : float4 at 16-byte ALIGNED absolute addresses.  Rows of the (2H+1)-wide plane start at arbitrary 4-byte
+//             phases, so the aligned quad sequence of row r is shifted by sh_r = (row start) mod 4 floats against the
+//             tile's logical columns; the shift is undone while scattering the quad into LDS (4 ds_write_b32).
+//   * stores: lane = 4 consecutive output columns -> one float4 per lane per row, 1 KiB per wave instruction.
+//   * LDS   : two ds_read_b128 per lane per input row feed 4 x KH x KW FMAs.
+// Measured on MI355X: dword-per-lane streaming peaks at ~3.5 TB/s, 16-byte-per-lane at ~5.1 TB/s (tools/microbench.py).
+template <int KH, int KW, bool TAIL>
+__global__ __launch_bounds__(256) void fir_vec4_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                       float* __restrict__ y, int planes, int in_h, int in_w,
+                                                       int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
+                                                       int tiles_y, int64_t total_in, FirTail tail) {
+    constexpr int TW = 256, WR = 8, TH = 4 * WR;
+    constexpr int RH = TH + KH - 1;
+    constexpr int RW = TW + KW - 1;
+    constexpr int LW = TW + 8;                 // LDS row stride (floats), multiple of 4
+    constexpr int NJ = (RW + 3 + 3) / 4;       // aligned quads that can overlap one staged row
+    constexpr int NIT = (RH * NJ + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    int plane, tile_x, tile_y;
+    if (TAIL) {  // channel fastest: the 32..512 planes that share one noise tile run back-to-back on one XCD
+        const int c = t % tail.channels;
+        t /= tail.channels;
+        tile_y = t % tiles_y;
+        t /= tiles_y;
+        tile_x = t % tiles_x;
+        plane = (t / tiles_x) * tail.channels + c;
+    } else {
+        const int tiles_per_plane = tiles_x * tiles_y;
+        plane = t / tiles_per_plane;
+        t -= plane * tiles_per_plane;
+        tile_x = t / tiles_y;
+        tile_y = t - tile_x * tiles_y;
+    }
+    const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+
+    float kf[KH][KW];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
+
+    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+    const int64_t plane_base = (int64_t)plane * in_h * in_w;
+
+    // ---- stage (all global loads first)
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = tid + it * 256;
+        const int r = item / NJ, j = item - r * NJ;
+        const int iy = iy0 + r;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (item < RH * NJ && iy >= 0 && iy < in_h) {
+            const int64_t g0 = plane_base + (int64_t)iy * in_w + ix0;  // absolute index of logical column 0
+            const int64_t a = (g0 & ~(int64_t)3) + 4 * j;
+            if (a >= 0 && a + 3 < total_in) {
+                v[it] = *reinterpret_cast<const float4*>(x + a);
+            } else {  // first / last quad of the whole tensor
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = (a + q >= 0 && a + q < total_in) ? x[a + q] : 0.f;
+                v[it] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+    // noise quads of this lane's 8 output rows (TAIL): in flight together with the input tile
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ox = ox0 + 4 * lane;
+    const bool col_ok = ox < out_w;
+    float4 nzq[WR];
+    float g = 1.f, nw = 0.f, bs = 0.f;
+    if (TAIL) {
+        const int b = plane / tail.channels;
+        const int c = plane - b * tail.channels;
+        if (tail.gain) g = tail.gain[plane];
+        bs = tail.bias ? tail.bias[c] : 0.f;
+#pragma unroll
+        for (int o = 0; o < WR; ++o) nzq[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tail.noise) {
+            nw = tail.noise_w[0];
+            const float* nz = tail.noise + (size_t)b * tail.noise_batch_stride;
+#pragma unroll
+            for (int o = 0; o < WR; ++o) {
+                const int oy = oy0 + wave * WR + o;
+                if (col_ok && oy < out_h) nzq[o] = *reinterpret_cast<const float4*>(nz + (size_t)oy * out_w + ox);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int item = tid + it * 256;
+        const int r = item / NJ, j = item - r * NJ;
+        if (item < RH * NJ) {
+            const int64_t g0 = plane_base + (int64_t)(iy0 + r) * in_w + ix0;
+            const int sh = (int)(g0 & 3);
+            const float e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 4 * j + q - sh;  // logical tile column of this element
+                const int ix = ix0 + c;
+                if (c >= 0 && c < RW) lds[r * LW + c] = (ix >= 0 && ix < in_w) ? e[q] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- compute: wave = 8 output rows, lane = 4 output columns
+    float* yp = y + (size_t)plane * out_h * out_w;
+    float acc[KH][4];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = 0.f;
+    const float* lrow = lds + (wave * WR) * LW + 4 * lane;
+#pragma unroll
+    for (int r = 0; r < WR + KH - 1; ++r) {
+        const float4 lo = *reinterpret_cast<const float4*>(lrow + r * LW);
+        const float4 hi4 = *reinterpret_cast<const float4*>(lrow + r * LW + 4);
+        const float in[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+            const int o = r - i;
+            if (o >= 0 && o < WR) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < KW; ++j) acc[o % KH][q] = fmaf(kf[i][j], in[q + j], acc[o % KH][q]);
+            }
+        }
+        const int o_done = r - (KH - 1);
+        if (o_done >= 0) {
+            const int oy = oy0 + wave * WR + o_done;
+            float out4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                out4[q] = acc[o_done % KH][q];
+                acc[o_done % KH][q] = 0.f;
+            }
+            if (TAIL) {
+                const float nzv[4] = {nzq[o_done].x, nzq[o_done].y, nzq[o_done].z, nzq[o_done].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out4[q] = lrelu_gain(fmaf(nw, nzv[q], out4[q] * g) + bs);
+            }
+            if (col_ok && oy < out_h)
+                *reinterpret_cast<float4*>(yp + (size_t)oy * out_w + ox) = make_float4(out4[0], out4[1], out4[2], out4[3]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                           float* __restrict__ y, int major, int in_h, int in_w,
                                                           int minor, int kh, int kw, int up_x, int up_y, int down_x,
@@ -174,6 +329,19 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restric
 template <int KH, int KW, bool TAIL>
 int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
                     int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
+    const bool aligned = ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) &&
+                         (!TAIL || !tail.noise || ((((uintptr_t)tail.noise) & 15) == 0 && tail.noise_batch_stride % 4 == 0));
+    if (out_w >= 256 && out_w % 4 == 0 && aligned) {
+        constexpr int TH = 32, TW = 256, RH = TH + KH - 1, LW = TW + 8;
+        const int tiles_x = ceil_div(out_w, TW), tiles_y = ceil_div(out_h, TH);
+        const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
+        if (nblocks > 0x7fffffff) return MAUA_EINVAL;
+        hipLaunchKernelGGL((fir_vec4_kernel<KH, KW, TAIL>), dim3((unsigned)nblocks), dim3(256),
+                           (size_t)RH * LW * sizeof(float), st, x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0,
+                           tiles_x, tiles_y, (int64_t)planes * in_h * in_w, tail);
+        MAUA_LAUNCH_CHECK();
+        return 0;
+    }
     auto go = [&](auto wx_tag) -> int {
         constexpr int WX = decltype(wx_tag)::value;
         constexpr int WY = 4 / WX;

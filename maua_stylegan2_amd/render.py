@@ -1,0 +1,225 @@
+"""Frame rendering loop — mirror of /root/reference/render.py:14-192 ``render(...)`` for MI355X.
+
+Same signature and batch semantics (slice latents / noise / bend modulation / truncation on dim 0, call the generator
+with ``input_is_latent=True``), different machinery:
+
+  reference                                             here
+  --------------------------------------------------    ------------------------------------------------------------
+  pin + H2D of latents and up to 17 noise maps / batch    inputs are uploaded ONCE and stay resident in HBM (288 GB)
+  eager generator call, ~200 launches per batch           hipGraph replay per batch (eager only when bends / rewrites /
+                                                          randomize_noise make the batch non-capturable, or a tail batch)
+  clamp/scale/permute on device, per-FRAME .cpu()         one fused fp32->uint8 NHWC kernel, one async D2H per BATCH into
+  .numpy().astype(uint8), two Python threads + queues     pinned double buffers on a copy stream, ordered sink
+  DataParallel replicate/scatter/gather per forward       one process per GPU, contiguous frame shards, RCCL gather of
+                                                          uint8 frames to rank 0 (maua_stylegan2_amd/sharding.py)
+
+Sinks: ffmpeg rawvideo pipe (same pixel format / codec arguments as render.py:58-91) when an ``ffmpeg`` binary exists,
+otherwise raw rgb24 bytes to ``output_file`` (+ ".rgb24"), or a null sink for benchmarking (``output_file=None``).
+"""
+import shutil
+import subprocess
+
+import numpy as np
+import torch as th
+
+from . import _lib, sharding
+
+th.set_grad_enabled(False)
+
+
+def _output_dims(out_size):
+    if out_size == 512:
+        return 512, 512
+    if out_size == 1024:
+        return 1024, 1024
+    if out_size == 1920:
+        return 1920, 1080
+    if out_size == 1080:
+        return 1080, 1920
+    raise Exception("The only output sizes currently supported are: 512, 1024, 1080, or 1920")
+
+
+class FrameSink:
+    """Ordered consumer of uint8 [H, W, 3] frames."""
+
+    def __init__(self, output_file, width, height, framerate, audio_file=None, offset=0, duration=None,
+                 ffmpeg_preset="slow"):
+        self.w, self.h = width, height
+        self.proc = None
+        self.file = None
+        self.count = 0
+        if output_file is None:
+            return
+        if shutil.which("ffmpeg") is not None:
+            cmd = ["ffmpeg", "-hide_banner", "-y", "-v", "warning", "-f", "rawvideo", "-pix_fmt", "rgb24", "-framerate",
+                   f"{framerate}", "-s", f"{width}x{height}", "-i", "pipe:"]
+            if audio_file is not None:
+                cmd += ["-ss", f"{offset}", "-t", f"{duration}", "-guess_layout_max", "0", "-i", audio_file]
+            cmd += ["-r", f"{framerate}", "-vcodec", "libx264", "-pix_fmt", "yuv420p", "-preset", ffmpeg_preset]
+            if audio_file is not None:
+                cmd += ["-b:a", "320K", "-ac", "2"]
+            cmd += [output_file]
+            self.proc = subprocess.Popen(cmd, stdin=subprocess.PIPE)
+        else:
+            path = output_file if output_file.endswith(".rgb24") else output_file + ".rgb24"
+            print(f"ffmpeg binary not found: writing raw rgb24 frames ({width}x{height}) to {path}")
+            self.file = open(path, "wb")
+
+    def write(self, frame):
+        """frame: numpy uint8 [H, W, 3]; wide 2048-px outputs are cropped + resized as render.py:98-105."""
+        if frame.shape[1] == 2048 or frame.shape[0] == 2048:
+            import PIL.Image
+
+            if frame.shape[1] == 2048:
+                frame = np.array(PIL.Image.fromarray(frame[:, 112:-112, :]).resize((1920, 1080), PIL.Image.BILINEAR))
+            else:
+                frame = np.array(PIL.Image.fromarray(frame[112:-112, :, :]).resize((1080, 1920), PIL.Image.BILINEAR))
+        assert frame.shape[1] == self.w and frame.shape[0] == self.h, (
+            f"generator's output image size does not match specified output size: \n"
+            f"got: {frame.shape[1]}x{frame.shape[0]}\t\tshould be {self.w}x{self.h}")
+        if self.proc is not None:
+            self.proc.stdin.write(frame.tobytes())
+        elif self.file is not None:
+            self.file.write(frame.tobytes())
+        self.count += 1
+
+    def close(self):
+        if self.proc is not None:
+            self.proc.stdin.close()
+            self.proc.wait()
+        if self.file is not None:
+            self.file.close()
+
+
+def frames_to_uint8(images, out=None):
+    """[B,3,H,W] fp32 device tensor -> [B,H,W,3] uint8 device tensor (render.py:40-43) via the HIP epilogue."""
+    lib = _lib.load()
+    images = _lib.require_cuda(images, "images")
+    b, c, h, w = images.shape
+    if c != 3:
+        raise RuntimeError("frames must have 3 channels")
+    if out is None:
+        out = th.empty((b, h, w, 3), dtype=th.uint8, device=images.device)
+    with th.cuda.device(images.device):
+        _lib.check(lib.maua_frames_to_u8(images.data_ptr(), out.data_ptr(), b, h, w, _lib.stream_ptr(images.device)),
+                   "maua_frames_to_u8")
+    return out
+
+
+def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), rewrites=None, randomize_noise=False,
+               use_graph=True, frame_range=None):
+    """Generator -> uint8 frames for ``frame_range`` (default: all) of the sequence.  Yields (first_frame_index,
+    uint8 device tensor [b, H, W, 3]) per batch; the tensor is only valid until the next iteration."""
+    dev = generator.input.input.device
+    n_total = len(latents)
+    lo, hi = frame_range if frame_range is not None else (0, n_total)
+    latents = latents.to(dev, th.float32).contiguous()  # resident in HBM for the whole render
+    noise = [None if nz is None else nz.to(dev, th.float32).contiguous() for nz in noise]
+    trunc_t = None if isinstance(truncation, float) else truncation.to(dev, th.float32).contiguous()
+    bends = list(bends or [])
+    for bend in bends:
+        if "modulation" in bend:
+            bend["modulation"] = bend["modulation"].to(dev, th.float32).contiguous()
+    rewrites = rewrites or {}
+    if rewrites:
+        raise NotImplementedError("get_rewrites: the reference's path is dead code (Tensor.copy() at render.py:131, "
+                                  "SURVEY.md §8a quirks) and is a 'next' row (§8f rank 4)")
+    capturable = use_graph and not bends and not randomize_noise and hasattr(generator, "capture_graph")
+    graph = static = None
+    u8 = None
+    stream = th.cuda.Stream(dev)
+    stream.wait_stream(th.cuda.current_stream(dev))
+    with th.cuda.stream(stream):
+        for n in range(lo, hi, batch_size):
+            m = min(n + batch_size, hi)
+            b = m - n
+            if capturable and b == batch_size:
+                if graph is None:
+                    shapes = [None if nz is None else tuple(nz.shape[-2:]) for nz in noise]
+                    graph, static = generator.capture_graph(batch_size, shapes, truncated=trunc_t is not None)
+                static["latents"].copy_(latents[n:m])
+                for dst, src in zip(static["noise"], noise):
+                    if src is not None:
+                        dst.copy_(src[n:m])
+                if trunc_t is not None:
+                    static["trunc"].copy_(trunc_t[n:m])
+                graph.replay()
+                images = static["image"]
+            else:
+                noise_batch = [None if nz is None else nz[n:m] for nz in noise]
+                bend_batch = []
+                for bend in bends:
+                    if "modulation" in bend:
+                        bend_batch.append({"layer": bend["layer"], "transform": bend["transform"](bend["modulation"][n:m])})
+                    else:
+                        bend_batch.append({"layer": bend["layer"], "transform": bend["transform"]})
+                images, _ = generator(styles=latents[n:m], noise=noise_batch,
+                                      truncation=truncation if trunc_t is None else trunc_t[n:m],
+                                      transform_dict_list=bend_batch, randomize_noise=randomize_noise, input_is_latent=True)
+            if u8 is None or u8.shape[0] != b or u8.shape[1:3] != images.shape[2:]:
+                u8 = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
+            frames_to_uint8(images, u8)
+            yield n, u8
+    th.cuda.current_stream(dev).wait_stream(stream)
+
+
+def render(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file=None,
+           truncation=1.0, bends=[], rewrites={}, randomize_noise=False, ffmpeg_preset="slow"):
+    """Drop-in for reference render.render (render.py:14-29).  With torch.distributed initialised (one process per
+    GPU) every rank renders a contiguous shard of the frames and rank 0 receives them in order over RCCL."""
+    width, height = _output_dims(out_size)
+    n_frames = len(latents)
+    rank, world = sharding.rank_world()
+    lo, hi = sharding.shard_bounds(n_frames, rank, world)
+    dev = generator.input.input.device
+    sink = None
+    if rank == 0:
+        sink = FrameSink(output_file, width, height, n_frames / duration, audio_file, offset, duration, ffmpeg_preset)
+
+    if world == 1:
+        # double-buffered pinned staging: D2H of batch k overlaps the graph replay of batch k+1
+        copy_stream = th.cuda.Stream(dev)
+        pinned, events, pending = [None, None], [None, None], []
+
+        def drain(slot_first):
+            slot, first, count = slot_first
+            events[slot].synchronize()
+            host = pinned[slot].numpy()
+            for i in range(count):
+                sink.write(host[i])
+
+        k = 0
+        for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites, randomize_noise):
+            slot = k % 2
+            if len(pending) == 2:
+                drain(pending.pop(0))
+            if pinned[slot] is None or pinned[slot].shape != u8.shape:
+                pinned[slot] = th.empty(u8.shape, dtype=th.uint8).pin_memory()
+            produced = th.cuda.Event()
+            produced.record(th.cuda.current_stream(dev))
+            with th.cuda.stream(copy_stream):
+                copy_stream.wait_event(produced)
+                pinned[slot].copy_(u8, non_blocking=True)
+                events[slot] = th.cuda.Event()
+                events[slot].record(copy_stream)
+            # the producer must not overwrite u8 before the copy has read it
+            th.cuda.current_stream(dev).wait_event(events[slot])
+            pending.append((slot, first, u8.shape[0]))
+            k += 1
+        for p in pending:
+            drain(p)
+    else:
+        shard = None
+        for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites, randomize_noise,
+                                    frame_range=(lo, hi)):
+            if shard is None:
+                shard = th.empty((sharding.max_shard(n_frames, world),) + tuple(u8.shape[1:]), dtype=th.uint8, device=dev)
+            shard[first - lo: first - lo + u8.shape[0]].copy_(u8)
+        th.cuda.synchronize(dev)
+        gathered = sharding.gather_frames(shard, n_frames)
+        if rank == 0:
+            for frame in gathered:
+                sink.write(frame.numpy() if isinstance(frame, th.Tensor) else frame)
+    if sink is not None:
+        sink.close()
+    return sink.count if sink is not None else 0

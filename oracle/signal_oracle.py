@@ -237,3 +237,32 @@ def perlin_noise(shape, res, theta, phi, tileable=(True, False, False)):
     n0 = (1 - ty) * n00 + ty * n10
     n1 = (1 - ty) * n01 + ty * n11
     return ((1 - tz) * n0 + tz * n1) * 2 - 1
+
+
+def affine_reflect_warp(x, inv_maps, pads, add_noise=None):
+    """CenterCrop(h,w)(Affine(ReflectionPad2d(pads)(x) [+ noise])) evaluated per output pixel — restates the
+    composition at /root/reference/audioreactive/bend.py:60-68,84,101 with kornia's documented conventions
+    (bilinear, zeros outside the canvas, pixel-unit maps).  x [B,C,h,w] numpy, inv_maps [B,6], pads (l,r,t,b)."""
+    x = np.asarray(x, dtype=np.float64)
+    b, c, h, w = x.shape
+    pl, pr, pt, pb = pads
+    canvas = np.pad(x, ((0, 0), (0, 0), (pt, pb), (pl, pr)), mode="reflect")
+    if add_noise is not None:
+        canvas = canvas + np.asarray(add_noise, dtype=np.float64).reshape(1, 1, h + pt + pb, w + pl + pr)
+    ch, cw = canvas.shape[-2:]
+    oy, ox = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    cy, cx = oy + (ch - h) // 2, ox + (cw - w) // 2
+    out = np.zeros_like(x)
+    for i in range(b):
+        a = np.asarray(inv_maps[i], dtype=np.float64)
+        sx = a[0] * cx + a[1] * cy + a[2]
+        sy = a[3] * cx + a[4] * cy + a[5]
+        x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+        fx, fy = sx - x0, sy - y0
+        for dy in (0, 1):
+            for dx in (0, 1):
+                yy, xx = y0 + dy, x0 + dx
+                ok = (yy >= 0) & (yy < ch) & (xx >= 0) & (xx < cw)
+                wgt = np.where(dy, fy, 1 - fy) * np.where(dx, fx, 1 - fx) * ok
+                out[i] += wgt[None] * canvas[i][:, np.clip(yy, 0, ch - 1), np.clip(xx, 0, cw - 1)]
+    return out

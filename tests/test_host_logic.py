@@ -1,0 +1,184 @@
+"""CPU: host-side logic of the drop-in surface (no GPU calls)."""
+import argparse
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import signal_oracle
+
+
+def test_generate_signature_matches_reference_contract(built_lib):
+    """generate(...) keyword contract and defaults (reference generate_audiovisual.py:59-91)."""
+    from maua_stylegan2_amd.generate_audiovisual import generate
+
+    sig = inspect.signature(generate)
+    expected = dict(initialize=None, get_latents=None, get_noise=None, get_bends=None, get_rewrites=None,
+                    get_truncation=None, output_dir="./output", audioreactive_file="audioreactive/examples/default.py",
+                    offset=0, duration=-1, latent_file=None, shuffle_latents=False, G_res=1024, out_size=1024, fps=30,
+                    latent_count=12, batch=8, dataparallel=False, truncation=1.0, stylegan1=False, noconst=False,
+                    latent_dim=512, n_mlp=8, channel_multiplier=2, randomize_noise=False, ffmpeg_preset="slow",
+                    base_res_factor=1, output_file=None, args=None)
+    names = list(sig.parameters)
+    assert names[:2] == ["ckpt", "audio_file"]
+    for k, v in expected.items():
+        assert sig.parameters[k].default == v, k
+    assert names[2:] == list(expected)
+
+
+def test_render_signature(built_lib):
+    from maua_stylegan2_amd.render import render
+
+    names = list(inspect.signature(render).parameters)
+    assert names == ["generator", "latents", "noise", "offset", "duration", "batch_size", "out_size", "output_file",
+                     "audio_file", "truncation", "bends", "rewrites", "randomize_noise", "ffmpeg_preset"]
+
+
+def test_noise_range_matches_reference_golden(built_lib, golden):
+    from maua_stylegan2_amd.generate_audiovisual import get_noise_range
+
+    g = golden("audioreactive_torch.npz")
+    for row in g["noise_range"]:
+        out_size, g_res, lo, hi = (int(v) for v in row[:4])
+        rmin, rmax, fn = get_noise_range(out_size, g_res, False)
+        assert (rmin, rmax) == (lo, hi)
+        assert [2 ** fn(s) for s in range(rmin, rmax)] == [int(v) for v in row[4:] if v]
+
+
+def test_plugin_loader_and_override(tmp_path, built_lib):
+    from maua_stylegan2_amd.generate_audiovisual import load_plugin
+
+    f = tmp_path / "plug.py"
+    f.write_text("OVERRIDE = dict(fps=24, batch=4)\n\ndef initialize(args):\n    args.hello = 1\n    return args\n\n"
+                 "def get_noise(height, width, scale, num_scales, args):\n    return None\n")
+    funcs, override = load_plugin(str(f))
+    assert override == {"fps": 24, "batch": 4}
+    assert funcs["initialize"](argparse.Namespace()).hello == 1
+    assert funcs["get_latents"] is None and funcs["get_bends"] is None and callable(funcs["get_noise"])
+
+
+def test_reference_module_aliases(built_lib):
+    import sys
+
+    import maua_stylegan2_amd.generate_audiovisual  # noqa: F401
+
+    import audioreactive as ar
+    from models.stylegan2 import Generator  # noqa: F401
+    from op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d  # noqa: F401
+
+    for name in ["onsets", "chroma", "rms", "gaussian_filter", "percentile_clip", "normalize", "compress", "expand",
+                 "load_audio", "set_SMF", "chroma_weight_latents", "slerp", "slerp_loops", "spline_loops", "wrapping_slice",
+                 "generate_latents", "save_latents", "load_latents", "perlin_noise", "NetworkBend", "AddNoise", "Print",
+                 "Translate", "Zoom", "Rotate"]:
+        assert hasattr(ar, name), name
+    assert "render" in sys.modules
+
+
+def test_state_dict_keys_equal_seeded_layout(built_lib):
+    """The mirror Generator exposes exactly the reference checkpoint keys (pinned by load_state_dict(strict) in
+    tests/golden/make_golden.py against the real reference class)."""
+    from maua_stylegan2_amd import seeding
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    for size in (32, 256):
+        g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+        want = seeding.generator_tensor_shapes(size)
+        got = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+        assert got == {k: tuple(v) for k, v in want.items()}
+        g.load_state_dict(seeding.seeded_state_dict(size), strict=True)
+        assert (g.n_latent, g.num_layers) == (2 * int(np.log2(size)) - 2, 2 * (int(np.log2(size)) - 2) + 1)
+
+
+def test_filterbanks_match_oracle(built_lib):
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    for fmin, fmax in [(0.0, None), (20, 8000), (0, 150), (500, 8000)]:
+        np.testing.assert_allclose(sig.mel_filterbank(22050, fmin=fmin, fmax=fmax),
+                                   signal_oracle.mel_filterbank(22050, fmin=fmin, fmax=fmax), atol=1e-6)
+    np.testing.assert_allclose(sig.chroma_filterbank(22050), signal_oracle.chroma_filterbank(22050), atol=1e-6)
+
+
+def test_envelope_postprocessing_matches_golden(built_lib, golden):
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    g = golden("audioreactive_torch.npz")
+    for name in g["pc.cases"]:
+        y = sig.percentile_clip(torch.from_numpy(g[f"pc.{name}.x"]).clone(), int(g[f"pc.{name}.p"]))
+        np.testing.assert_allclose(y.numpy(), g[f"pc.{name}.y"], atol=1e-6)
+    np.testing.assert_allclose(sig.normalize(torch.from_numpy(g["normalize.x"]).clone()).numpy(), g["normalize.y"], atol=1e-6)
+    np.testing.assert_allclose(sig.compress(torch.from_numpy(g["compress.x"]).clone(), 0.5, 0.25).numpy(), g["compress.y"], atol=1e-6)
+
+
+def test_latent_helpers_match_golden(built_lib, golden):
+    from maua_stylegan2_amd.audioreactive import latent
+
+    g = golden("audioreactive_torch.npz")
+    y = latent.chroma_weight_latents(torch.from_numpy(g["cwl.chroma"]), torch.from_numpy(g["cwl.latents"]))
+    np.testing.assert_allclose(y.numpy(), g["cwl.y"], atol=1e-5)
+    assert (latent.wrapping_slice(torch.arange(10), 7, 6).numpy() == g["wrapping_slice_10_7_6"]).all()
+    np.testing.assert_allclose(latent.spline_loops(g["spline.sel"], 37, 2).numpy(), g["spline.y"], atol=1e-9)
+
+
+def test_resample_matches_scipy_on_cpu(built_lib):
+    from maua_stylegan2_amd.audioreactive.signal import resample
+
+    r = np.random.default_rng(0)
+    for n, num in [(431, 300), (300, 431), (128, 64), (64, 128), (87, 87), (100, 51), (51, 100)]:
+        x = r.standard_normal((n, 3))
+        np.testing.assert_allclose(resample(torch.from_numpy(x), num).numpy(), signal_oracle.resample(x, num), atol=1e-9)
+
+
+def test_wav_loading_and_cache(tmp_path, built_lib, monkeypatch):
+    import scipy.io.wavfile
+
+    from maua_stylegan2_amd import seeding
+    from maua_stylegan2_amd.audioreactive.signal import load_audio
+
+    y = seeding.synthetic_audio(2.0, sr=44100)
+    path = tmp_path / "clip.wav"
+    scipy.io.wavfile.write(str(path), 44100, (y * 32767).astype(np.int16))
+    monkeypatch.chdir(tmp_path)
+    audio, sr, dur = load_audio(str(path), 0, -1)
+    assert sr == 22050 and abs(dur - 2.0) < 1e-3 and audio.dtype == np.float32 and abs(len(audio) - 44100) <= 1
+    assert os.path.exists(tmp_path / "workspace")
+    audio2, _, _ = load_audio(str(path), 0, -1)
+    assert np.array_equal(audio, audio2)
+    a3, _, d3 = load_audio(str(path), 0.5, 1.0)
+    assert abs(len(a3) - 22050) <= 1 and d3 == 1.0
+
+
+def test_frame_sink_raw_file(tmp_path, built_lib, monkeypatch):
+    from maua_stylegan2_amd import render
+
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)
+    sink = render.FrameSink(str(tmp_path / "out.mp4"), 512, 512, 30)
+    frame = np.arange(512 * 512 * 3, dtype=np.uint8).reshape(512, 512, 3)
+    sink.write(frame), sink.write(frame[::-1].copy())
+    sink.close()
+    raw = np.fromfile(tmp_path / "out.mp4.rgb24", dtype=np.uint8)
+    assert raw.size == 2 * 512 * 512 * 3 and np.array_equal(raw[: frame.size].reshape(frame.shape), frame)
+    with pytest.raises(AssertionError, match="does not match"):
+        render.FrameSink(None, 512, 512, 30).write(np.zeros((256, 256, 3), np.uint8))
+    with pytest.raises(Exception, match="output sizes"):
+        render._output_dims(777)
+
+
+def test_bend_inverse_maps_are_inverses(built_lib):
+    """Rotate / Zoom inverse maps composed with the forward (kornia-convention) matrices give identity."""
+    from maua_stylegan2_amd.audioreactive import bend
+
+    ang = torch.tensor([30.0, -75.0])
+    cw, ch = 40, 28
+    m = bend._inverse_maps_rotate(ang, cw, ch).numpy()
+    cx, cy = (cw - 1) / 2, (ch - 1) / 2
+    for i, a in enumerate(np.deg2rad(ang.numpy())):
+        alpha, beta = np.cos(a), np.sin(a)
+        fwd = np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy], [0, 0, 1]])
+        inv = np.vstack([m[i].reshape(2, 3), [0, 0, 1]])
+        np.testing.assert_allclose(inv @ fwd, np.eye(3), atol=1e-5)
+    s = torch.tensor([[2.0, 0.5]])
+    mz = bend._inverse_maps_scale(s, cw, ch).numpy()[0].reshape(2, 3)
+    fwd = np.array([[2.0, 0, (1 - 2.0) * cx], [0, 0.5, (1 - 0.5) * cy], [0, 0, 1]])
+    np.testing.assert_allclose(np.vstack([mz, [0, 0, 1]]) @ fwd, np.eye(3), atol=1e-6)

@@ -77,7 +77,7 @@ def test_to_rgb_golden(gpu, golden, name):
 @pytest.mark.parametrize("cin,cout,hw,up,batch", [
     (512, 512, 4, False, 3), (512, 512, 8, True, 2), (512, 512, 16, False, 1), (512, 256, 32, True, 1),
     (128, 128, 64, False, 2), (128, 64, 64, True, 1), (64, 64, 128, False, 1), (64, 32, 96, True, 1),
-    (32, 32, 160, False, 2), (40, 24, 20, False, 1), (24, 72, 12, True, 2),
+    (32, 32, 160, False, 2), (40, 24, 20, False, 1), (24, 72, 12, True, 2), (16, 8, 128, True, 2), (8, 40, 130, True, 1),
 ])
 def test_modconv_shapes_vs_oracle(gpu, cin, cout, hw, up, batch):
     """Every tile configuration (BM 32/64/128, split-K, polyphase) against the oracle's reference formulation."""
@@ -98,3 +98,30 @@ def test_modconv_shapes_vs_oracle(gpu, cin, cout, hw, up, batch):
     got = m(t(x, gpu), t(s, gpu)).cpu().numpy()
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-4)
+
+
+def test_styled_conv_up_wide_vs_oracle(gpu):
+    """Up-sampling StyledConv at 256 / 264-wide outputs: the 16-byte blur + noise + bias + act tail (fir_vec4_kernel),
+    per-frame noise and broadcast (checkpoint buffer) noise."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(21)
+    for cin, cout, h, w, bcast in [(8, 6, 128, 128, False), (16, 4, 33, 132, True)]:
+        m = StyledConv(cin, cout, 3, 512, upsample=True)
+        sd = {
+            "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+            "L.conv.blur.kernel": m.conv.blur.kernel.clone(),
+            "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+            "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+            "L.noise.weight": torch.tensor([0.41]),
+            "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+        }
+        m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+        m = m.to(gpu)
+        x = torch.from_numpy(r.standard_normal((2, cin, h, w)).astype(np.float32))
+        s = torch.from_numpy(r.standard_normal((2, 512)).astype(np.float32))
+        nz = torch.from_numpy(r.standard_normal((1 if bcast else 2, 1, 2 * h, 2 * w)).astype(np.float32))
+        want = so.styled_conv(sd, "L", x, s, nz, True).numpy()
+        got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-4)

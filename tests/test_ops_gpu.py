@@ -28,6 +28,9 @@ def test_upfirdn2d_golden(gpu, golden):
     ((1, 2, 65, 65), 4, (1, 1)), ((2, 3, 129, 129), 4, (1, 1)), ((1, 4, 257, 300), 4, (1, 1)),
     ((1, 2, 100, 37), 3, (1, 1)), ((1, 1, 70, 513), 2, (1, 0)), ((3, 1, 33, 33), 4, (2, 2)),
     ((1, 2, 40, 40), 4, (-1, 0)), ((1, 1, 1025, 1025), 4, (1, 1)),
+    # 16-byte path (out_w >= 256, out_w % 4 == 0) with every row phase / partial tiles / odd plane sizes
+    ((3, 3, 70, 517), 4, (1, 1)), ((2, 2, 45, 512), 3, (1, 1)), ((1, 5, 33, 260), 2, (1, 0)), ((2, 1, 259, 263), 4, (2, 2)),
+    ((1, 3, 257, 257), 4, (1, 1)), ((1, 2, 64, 1028), 4, (0, 3)),
 ])
 def test_upfirdn2d_tiled_path_vs_oracle(gpu, shape, k, pad):
     """Blur-style calls (up = down = 1) across tile-boundary sizes, incl. the 1025^2 -> 1024^2 headline shape."""

@@ -1,0 +1,95 @@
+"""GPU: the render loop / generate() surface end to end on small generators (raw rgb24 sink, no ffmpeg needed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from maua_stylegan2_amd import seeding
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def build(size, dev, seed=0):
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(size, seed=seed), strict=True)
+    return g.to(dev).eval()
+
+
+def test_synthesize_graph_equals_eager_and_oracle(gpu):
+    """10 frames, batch 4 (2 graph batches + eager tail of 2): uint8 frames equal the eager path bit for bit and the
+    oracle's frames to within one grey level."""
+    from maua_stylegan2_amd import render
+    from oracle import stylegan2_oracle as so
+
+    size, n = 32, 10
+    sd = seeding.seeded_state_dict(size, seed=4)
+    g = build(size, gpu, 4)
+    lat = seeding.seeded_latents(n, g.n_latent, seed=6)
+    noise = seeding.seeded_noise(n, size, seed=7)
+    noise[-1] = None  # checkpoint buffer for the last scale, like get_noise -> None
+    trunc = torch.linspace(0.5, 1.0, n)
+    g.truncation_latent = torch.from_numpy(seeding.seeded_array(5, "tl", (1, 512))).to(gpu)
+
+    def run(use_graph):
+        frames = np.zeros((n, size, size, 3), np.uint8)
+        for first, u8 in render.synthesize(g, lat, noise, 4, truncation=trunc, use_graph=use_graph):
+            frames[first: first + u8.shape[0]] = u8.cpu().numpy()
+        return frames
+
+    graphed, eager = run(True), run(False)
+    assert np.array_equal(graphed, eager)
+    want = so.frames_to_uint8(so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=g.truncation_latent.cpu()))
+    diff = np.abs(graphed.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+
+
+def test_render_writes_ordered_frames(gpu, tmp_path, monkeypatch):
+    from maua_stylegan2_amd import render
+
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)  # force the raw sink even if ffmpeg exists
+    g = build(512, gpu, 1)  # smallest size render() accepts (reference render.py:47-56)
+    n = 5
+    lat = seeding.seeded_latents(n, g.n_latent, seed=2)
+    noise = [None] * g.num_layers
+    out = str(tmp_path / "clip.mp4")
+    written = render.render(generator=g, latents=lat, noise=noise, offset=0, duration=n / 30, batch_size=2, out_size=512,
+                            output_file=out)
+    assert written == n
+    raw = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(n, 512, 512, 3)
+    for i in range(n):
+        img, _ = g(styles=lat[i: i + 1].to(gpu), noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+        want = render.frames_to_uint8(img).cpu().numpy()[0]
+        # batch-2 graph vs batch-1 eager: split-K depth depends on the batch, so sums may differ in the last ulp
+        diff = np.abs(raw[i].astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, i
+    with pytest.raises(Exception, match="output sizes"):
+        render.render(g, lat, noise, 0, 1.0, 2, 300, None)
+
+
+def test_generate_end_to_end_default_plugin(gpu, tmp_path, monkeypatch):
+    """generate() with the default plugin semantics (onsets + chroma latents + reactive noise) on a 4 s synthetic WAV,
+    random-init 512^2... kept small: G_res 512 is the smallest the reference's render() accepts."""
+    import scipy.io.wavfile
+
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.audioreactive.examples import default as plugin
+
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)
+    sr = 22050
+    y = seeding.synthetic_audio(2.0, sr)
+    scipy.io.wavfile.write("track.wav", sr, (y * 32767).astype(np.int16))
+    np.save("lat.npy", seeding.seeded_latents(12, 16, seed=3).numpy())
+    out = gav.generate(ckpt=None, audio_file="track.wav", initialize=plugin.initialize, get_latents=plugin.get_latents,
+                       get_noise=plugin.get_noise, latent_file="lat.npy", G_res=512, out_size=512, fps=12, batch=4,
+                       output_file=str(tmp_path / "o.mp4"))
+    raw = np.fromfile(out + ".rgb24", dtype=np.uint8)
+    assert raw.size == 24 * 512 * 512 * 3
+    frames = raw.reshape(24, 512, 512, 3)
+    assert frames.std() > 5 and not np.array_equal(frames[0], frames[12])
+    assert os.path.exists("workspace/last-latents.npy")

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks for profiling runs (rocprofv3 --kernel-trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE).
+
+    python tools/microbench.py [fir] [copy] [conv] [--batch 8] [--iters 5]
+
+`copy` launches the fused_bias_act kernel on buffers of KNOWN size through its 16-byte/lane and its dword/lane paths:
+the PMC byte counters of these two launches calibrate FETCH_SIZE / WRITE_SIZE for the access widths used by the other
+kernels (MI355X_MICROARCH.md §HBM: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maua_stylegan2_amd import _lib, seeding  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="*", default=["fir", "copy"])
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(dev)
+    sp = stream.cuda_stream
+    out = {}
+    with torch.cuda.stream(stream):
+        if "copy" in args.what:
+            n = 1 << 28  # 1 GiB read + 1 GiB write per launch
+            x = torch.randn(n, device=dev)
+            y = torch.empty_like(x)
+            b = torch.zeros(16, device=dev)
+            for name, shape_step in [("copy_vec16B", 4096), ("copy_dword", 4097)]:
+                nn = (n // shape_step) * shape_step
+                e0, e1 = _lib.HipEvent(), _lib.HipEvent()
+                lib.maua_fused_bias_act_f32(x.data_ptr(), b.data_ptr(), None, y.data_ptr(), nn, 16, shape_step, 3, 0, 0.2, 1.0, sp)
+                e0.record(sp)
+                for _ in range(args.iters):
+                    lib.maua_fused_bias_act_f32(x.data_ptr(), b.data_ptr(), None, y.data_ptr(), nn, 16, shape_step, 3, 0, 0.2, 1.0, sp)
+                e1.record(sp)
+                ms = e0.elapsed_ms(e1) / args.iters
+                out[name] = {"ms": ms, "bytes_read": 4 * nn, "bytes_written": 4 * nn, "gbs": 8 * nn / ms / 1e6}
+        if "fir" in args.what:
+            B, C, r = args.batch, 32, 1024
+            x = torch.randn(B, C, r + 1, r + 1, device=dev)
+            k = torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)).to(dev)
+            y = torch.empty(B * C, r, r, 1, device=dev)
+            call = lambda: lib.maua_upfirdn2d_f32(x.data_ptr(), k.data_ptr(), y.data_ptr(), B * C, r + 1, r + 1, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, sp)  # noqa: E731
+            call()
+            e0, e1 = _lib.HipEvent(), _lib.HipEvent()
+            e0.record(sp)
+            for _ in range(args.iters):
+                call()
+            e1.record(sp)
+            ms = e0.elapsed_ms(e1) / args.iters
+            byts = 4 * B * C * ((r + 1) ** 2 + r ** 2)
+            out["fir_1024"] = {"ms": ms, "bytes_read": 4 * B * C * (r + 1) ** 2, "bytes_written": 4 * B * C * r * r,
+                               "gbs": byts / ms / 1e6}
+            nz = torch.randn(1, 1, r, r, device=dev)
+            nw = torch.full((1,), 0.1, device=dev)
+            bias = torch.randn(C, device=dev)
+            y2 = torch.empty(B, C, r, r, device=dev)
+            call2 = lambda: lib.maua_blur_noise_act_f32(x.data_ptr(), k.data_ptr(), y2.data_ptr(), B, C, r + 1, r + 1, 4, 4, 1, 1, None, nz.data_ptr(), 0, nw.data_ptr(), bias.data_ptr(), sp)  # noqa: E731
+            call2()
+            e0.record(sp)
+            for _ in range(args.iters):
+                call2()
+            e1.record(sp)
+            ms = e0.elapsed_ms(e1) / args.iters
+            out["fir_tail_1024"] = {"ms": ms, "gbs": byts / ms / 1e6}
+        stream.synchronize()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
