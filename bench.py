@@ -275,7 +275,7 @@ def main():
             ms = time_calls(launch_fir, 20, sp)
             byts = 4 * major * ((r_out + 1) ** 2 + r_out ** 2)
             ach = byts / ms / 1e6
-            result["roofline_upfirdn2d"] = {"kernel": "fir_tile_kernel<4,4,4,false>", "bound": "hbm", "achieved": ach,
+            result["roofline_upfirdn2d"] = {"kernel": "fir_tile_kernel<4,4,4,false,false>", "bound": "hbm", "achieved": ach,
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                             "traffic": None, "launch_ms": ms, "algorithmic_bytes": byts,
                                             "shape": f"[{xin.shape[0]},{xin.shape[1]},{r_out+1},{r_out+1}] -> {r_out}^2"}

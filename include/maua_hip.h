@@ -24,6 +24,9 @@ int maua_abi_version(void);
 /* Number of compute units / name of device 0 (diagnostics for bench.py). */
 int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
 
+/* Kernel-selection override for profiling / A-B runs (key 0: upfirdn2d path, 0 = automatic). Not needed in production. */
+int maua_tuning_set(int key, int value);
+
 /* ------------------------------------------------------------------------------------------------ ops
  * Replaces pybind `upfirdn2d.upfirdn2d(input[major,in_h,in_w,minor], kernel[kh,kw], up_x, up_y, down_x,
  * down_y, pad_x0, pad_x1, pad_y0, pad_y1)` — op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369.

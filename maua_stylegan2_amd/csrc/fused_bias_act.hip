@@ -32,33 +32,17 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* x, const flo
     if (VEC) {
         const int64_t n4 = n >> 2;
         const int step4 = step_b >> 2;
-        // 4 independent 16-byte loads in flight per lane per trip
-        for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
-            float4 v[4], r[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t i = i0 + u * stride;
-                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < n4) {
-                    v[u] = reinterpret_cast<const float4*>(x)[i];
-                    if (ref) r[u] = reinterpret_cast<const float4*>(ref)[i];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t i = i0 + u * stride;
-                if (i < n4) {
-                    float bb = 0.f;
-                    if (b) bb = b[(i / step4) % size_b];
-                    float4 o;
-                    o.x = act_apply(v[u].x + bb, r[u].x, code, alpha) * scale;
-                    o.y = act_apply(v[u].y + bb, r[u].y, code, alpha) * scale;
-                    o.z = act_apply(v[u].z + bb, r[u].z, code, alpha) * scale;
-                    o.w = act_apply(v[u].w + bb, r[u].w, code, alpha) * scale;
-                    reinterpret_cast<float4*>(y)[i] = o;
-                }
-            }
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ref) r = reinterpret_cast<const float4*>(ref)[i];
+            float bb = 0.f;
+            if (b) bb = b[(i / step4) % size_b];
+            v.x = act_apply(v.x + bb, r.x, code, alpha) * scale;
+            v.y = act_apply(v.y + bb, r.y, code, alpha) * scale;
+            v.z = act_apply(v.z + bb, r.z, code, alpha) * scale;
+            v.w = act_apply(v.w + bb, r.w, code, alpha) * scale;
+            reinterpret_cast<float4*>(y)[i] = v;
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {

@@ -29,8 +29,9 @@ struct FirTail {
 };
 
 constexpr int TILE_ROWS_PER_WAVE = 32;
+int g_fir_path = 0;  // tuning switch (maua_tuning_set): 0 auto (= dword tile), 2 vec4, 3 wave tile, 4 wave tile + nt, 5 dword tile + nt
 
-template <int KH, int KW, int WX, bool TAIL>
+template <int KH, int KW, int WX, bool TAIL, bool NT>
 __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                        float* __restrict__ y, int planes, int in_h, int in_w,
                                                        int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
@@ -46,11 +47,21 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int nblocks = gridDim.x;
     int t = xcd_remap(blockIdx.x, nblocks);
-    const int tiles_per_plane = tiles_x * tiles_y;
-    const int plane = t / tiles_per_plane;
-    t -= plane * tiles_per_plane;
-    const int tile_x = t / tiles_y;
-    const int tile_y = t - tile_x * tiles_y;
+    int plane, tile_x, tile_y;
+    if (TAIL) {  // channel fastest: the planes that share one noise tile run back-to-back on one XCD (L2 hits)
+        const int c = t % tail.channels;
+        t /= tail.channels;
+        tile_y = t % tiles_y;
+        t /= tiles_y;
+        tile_x = t % tiles_x;
+        plane = (t / tiles_x) * tail.channels + c;
+    } else {
+        const int tiles_per_plane = tiles_x * tiles_y;
+        plane = t / tiles_per_plane;
+        t -= plane * tiles_per_plane;
+        tile_x = t / tiles_y;
+        tile_y = t - tile_x * tiles_y;
+    }
     const int oy0 = tile_y * (WY * TH);
     const int ox0 = tile_x * TW;
 
@@ -75,7 +86,34 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
         const int iy = iy0 + rr;
         const int ix = ix0 + cc;
         const bool ok = (idx < RH * RW) && (iy >= 0) && (iy < in_h) && (ix >= 0) && (ix < in_w);
-        v[it] = ok ? xp[(size_t)iy * in_w + ix] : 0.f;
+        v[it] = 0.f;
+        if (ok) v[it] = NT ? __builtin_nontemporal_load(xp + (size_t)iy * in_w + ix) : xp[(size_t)iy * in_w + ix];
+    }
+    // wave (wx, wy), lane = column
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wx = wave % WX, wy = wave / WX;
+    const int col = wx * 64 + lane;
+    const int ox = ox0 + col;
+    const int row0 = wy * TH;
+    const bool col_ok = ox < out_w;
+
+    // tail operands: this lane's 32 noise values are fetched now, in flight together with the input tile
+    float g = 1.f, nw = 0.f, bs = 0.f;
+    float nzv[TAIL ? TH : 1];
+    if (TAIL) {
+        const int b = plane / tail.channels;
+        const int c = plane - b * tail.channels;
+        if (tail.gain) g = tail.gain[plane];
+        bs = tail.bias ? tail.bias[c] : 0.f;
+#pragma unroll
+        for (int o = 0; o < TH; ++o) nzv[o] = 0.f;
+        if (tail.noise) {
+            nw = tail.noise_w[0];
+            const float* nz = tail.noise + (size_t)b * tail.noise_batch_stride;
+#pragma unroll
+            for (int o = 0; o < TH; ++o)
+                if (col_ok && oy0 + row0 + o < out_h) nzv[o] = nz[(size_t)(oy0 + row0 + o) * out_w + ox];
+        }
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -84,26 +122,6 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     }
     __syncthreads();
 
-    // ---- compute: wave (wx, wy), lane = column
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wx = wave % WX, wy = wave / WX;
-    const int col = wx * 64 + lane;
-    const int ox = ox0 + col;
-    const int row0 = wy * TH;
-    const bool col_ok = ox < out_w;
-
-    float g = 1.f, nw = 0.f, bs = 0.f;
-    const float* nz = nullptr;
-    if (TAIL) {
-        const int b = plane / tail.channels;
-        const int c = plane - b * tail.channels;
-        if (tail.gain) g = tail.gain[plane];
-        if (tail.noise) {
-            nw = tail.noise_w[0];
-            nz = tail.noise + (size_t)b * tail.noise_batch_stride;
-        }
-        bs = tail.bias ? tail.bias[c] : 0.f;
-    }
     float* yp = y + (size_t)plane * out_h * out_w;
 
     float acc[KH];
@@ -128,13 +146,120 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
             const int oy = oy0 + row0 + o_done;
             float val = acc[o_done % KH];
             acc[o_done % KH] = 0.f;
+            if (TAIL) val = lrelu_gain(fmaf(nw, nzv[TAIL ? o_done : 0], val * g) + bs);
             if (col_ok && oy < out_h) {
-                if (TAIL) {
-                    val *= g;
-                    if (nz) val = fmaf(nw, nz[(size_t)oy * out_w + ox], val);
-                    val = lrelu_gain(val + bs);
-                }
-                yp[(size_t)oy * out_w + ox] = val;
+                if (NT) __builtin_nontemporal_store(val, yp + (size_t)oy * out_w + ox);
+                else yp[(size_t)oy * out_w + ox] = val;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fir_wave_kernel: one WAVE per workgroup, 32 x 64 output tile, no cross-wave barrier.  The stream probe
+// (tools/stream_probe.hip) shows that on MI355X the copy shapes that approach the HBM ceiling (6.3-6.7 TB/s) are the
+// ones made of very many tiny independent workgroups; phase-locked 256-thread tiles top out ~25 % lower.  Here every
+// wave stages its own 35 x 67 halo tile (37 dword loads in flight per lane, 9.4 KB LDS -> 16 resident waves per CU),
+// then walks down its 64 columns exactly like fir_tile_kernel.  NT selects non-temporal loads/stores for the
+// streamed planes (read once / written once per launch).
+template <int KH, int KW, bool TAIL, bool NT>
+__global__ __launch_bounds__(64) void fir_wave_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                      float* __restrict__ y, int planes, int in_h, int in_w, int out_h,
+                                                      int out_w, int pad_x0, int pad_y0, int tiles_x, int tiles_y,
+                                                      FirTail tail) {
+    constexpr int TH = 32, TW = 64;
+    constexpr int RH = TH + KH - 1, RW = TW + KW - 1;
+    constexpr int NIT = (RH * RW + 63) / 64;
+    __shared__ float lds[RH * RW];
+    const int lane = threadIdx.x;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    int plane, tile_x, tile_y;
+    if (TAIL) {
+        const int c = t % tail.channels;
+        t /= tail.channels;
+        tile_y = t % tiles_y;
+        t /= tiles_y;
+        tile_x = t % tiles_x;
+        plane = (t / tiles_x) * tail.channels + c;
+    } else {
+        const int tiles_per_plane = tiles_x * tiles_y;
+        plane = t / tiles_per_plane;
+        t -= plane * tiles_per_plane;
+        tile_x = t / tiles_y;
+        tile_y = t - tile_x * tiles_y;
+    }
+    const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+    float kf[KH][KW];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
+    const float* xp = x + (size_t)plane * in_h * in_w;
+    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = lane + it * 64;
+        const int rr = idx / RW, cc = idx - rr * RW;
+        const int iy = iy0 + rr, ix = ix0 + cc;
+        const bool ok = (idx < RH * RW) && (iy >= 0) && (iy < in_h) && (ix >= 0) && (ix < in_w);
+        v[it] = 0.f;
+        if (ok) v[it] = NT ? __builtin_nontemporal_load(xp + (size_t)iy * in_w + ix) : xp[(size_t)iy * in_w + ix];
+    }
+    const int ox = ox0 + lane;
+    const bool col_ok = ox < out_w;
+    float g = 1.f, nw = 0.f, bs = 0.f;
+    float nzv[TAIL ? TH : 1];
+    if (TAIL) {
+        const int b = plane / tail.channels;
+        const int c = plane - b * tail.channels;
+        if (tail.gain) g = tail.gain[plane];
+        bs = tail.bias ? tail.bias[c] : 0.f;
+#pragma unroll
+        for (int o = 0; o < TH; ++o) nzv[o] = 0.f;
+        if (tail.noise) {
+            nw = tail.noise_w[0];
+            const float* nz = tail.noise + (size_t)b * tail.noise_batch_stride;
+#pragma unroll
+            for (int o = 0; o < TH; ++o)
+                if (col_ok && oy0 + o < out_h) nzv[o] = nz[(size_t)(oy0 + o) * out_w + ox];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = lane + it * 64;
+        if (idx < RH * RW) lds[idx] = v[it];
+    }
+    __syncthreads();  // single wave: lgkmcnt wait only
+
+    float* yp = y + (size_t)plane * out_h * out_w;
+    float acc[KH];
+#pragma unroll
+    for (int i = 0; i < KH; ++i) acc[i] = 0.f;
+    const float* lrow = lds + lane;
+#pragma unroll
+    for (int r = 0; r < TH + KH - 1; ++r) {
+        float in[KW];
+#pragma unroll
+        for (int j = 0; j < KW; ++j) in[j] = lrow[r * RW + j];
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+            const int o = r - i;
+            if (o >= 0 && o < TH) {
+#pragma unroll
+                for (int j = 0; j < KW; ++j) acc[o % KH] = fmaf(kf[i][j], in[j], acc[o % KH]);
+            }
+        }
+        const int o_done = r - (KH - 1);
+        if (o_done >= 0) {
+            const int oy = oy0 + o_done;
+            float val = acc[o_done % KH];
+            acc[o_done % KH] = 0.f;
+            if (TAIL) val = lrelu_gain(fmaf(nw, nzv[TAIL ? o_done : 0], val * g) + bs);
+            if (col_ok && oy < out_h) {
+                if (NT) __builtin_nontemporal_store(val, yp + (size_t)oy * out_w + ox);
+                else yp[(size_t)oy * out_w + ox] = val;
             }
         }
     }
@@ -329,7 +454,20 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restric
 template <int KH, int KW, bool TAIL>
 int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
                     int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
-    const bool aligned = ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) &&
+    if (g_fir_path >= 3 && out_w >= 64) {  // 3 = wave tiles, 4 = wave tiles + non-temporal
+        const int tiles_x = ceil_div(out_w, 64), tiles_y = ceil_div(out_h, 32);
+        const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
+        if (nblocks > 0x7fffffff) return MAUA_EINVAL;
+        if (g_fir_path == 4)
+            hipLaunchKernelGGL((fir_wave_kernel<KH, KW, TAIL, true>), dim3((unsigned)nblocks), dim3(64), 0, st, x, k, y,
+                               planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
+        else
+            hipLaunchKernelGGL((fir_wave_kernel<KH, KW, TAIL, false>), dim3((unsigned)nblocks), dim3(64), 0, st, x, k, y,
+                               planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
+        MAUA_LAUNCH_CHECK();
+        return 0;
+    }
+    const bool aligned = g_fir_path == 2 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) &&
                          (!TAIL || !tail.noise || ((((uintptr_t)tail.noise) & 15) == 0 && tail.noise_batch_stride % 4 == 0));
     if (out_w >= 256 && out_w % 4 == 0 && aligned) {
         constexpr int TH = 32, TW = 256, RH = TH + KH - 1, LW = TW + 8;
@@ -351,8 +489,12 @@ int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in
         if (nblocks <= 0) return 0;
         if (nblocks > 0x7fffffff) return MAUA_EINVAL;
         const size_t lds_bytes = (size_t)RH * RW * sizeof(float);
-        hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k,
-                           y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
+        if (g_fir_path == 5)
+            hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL, true>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st,
+                               x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
+        else
+            hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL, false>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st,
+                               x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
         MAUA_LAUNCH_CHECK();
         return 0;
     };
@@ -371,6 +513,11 @@ int dispatch_fir_tile(const float* x, const float* k, float* y, int planes, int 
 }
 
 }  // namespace
+
+extern "C" int maua_tuning_set(int key, int value) {
+    if (key == 0) { g_fir_path = value; return 0; }
+    return MAUA_EINVAL;
+}
 
 extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
                                   int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
