@@ -25,6 +25,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CC = 8;  // channels per K chunk
 
@@ -36,7 +37,7 @@ struct ConvGeom {
     int lnsx, lnsy;                   // log2 sub-tiles per tile along x / y
     int lni;                          // log2 images per tile
     int tiles_x, tiles_y, img_groups;
-    int PH, PW, PSTRIDE;              // staged patch: rows, cols, floats per channel (all images of the tile)
+    int PH, PW, PWS, PSTRIDE;         // staged patch: rows, valid cols, LDS row stride, floats per channel (all images)
     int m_tiles, n_tiles;
     int splits, chunks_per_split, n_chunks;
     int s_stride;
@@ -60,8 +61,12 @@ struct ConvPtrs {
 
 // UP = false : plain 3x3, pad 1.           per wave: TM x TN MFMA tiles.
 // UP = true  : stride-2 transposed 3x3.    per wave: TM x (TN position groups x 4 output parities).
-template <int BM, int BN, int WM, bool UP, bool MULTI>
-__global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
+// FAST (Cin % 8 == 0 and the padded weight covers whole BM tiles — every layer of a real generator): loads are
+// unconditional (masked by multiplication at LDS-write time) and addressed as uniform base + 32-bit lane offset,
+// which removes the exec-mask / 64-bit-address scalar work that dominated the short-K (32/64-channel) layers.
+template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST>
+__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (UP ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
+void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -98,21 +103,24 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
     const size_t plane_in = (size_t)g.H * g.W;
 
     // ---- per-thread patch positions (decoded once)
-    int src_off[MAX_POS];  // offset of (b, ch 0, y, x) in x, or -1
-    int sb_off[MAX_POS];   // b * s_stride
+    int src_off[MAX_POS];    // offset of (b, ch 0, y, x) in x; -1 (slow path) / 0 (FAST) when outside the image
+    float src_mask[MAX_POS]; // 1 inside the image, 0 outside (FAST path multiplies instead of branching)
+    int sb_off[MAX_POS];     // b * s_stride
 #pragma unroll
     for (int i = 0; i < MAX_POS; ++i) {
         const int pp = tid + i * 256;
-        src_off[i] = -1;
+        src_off[i] = FAST ? 0 : -1;
+        src_mask[i] = 0.f;
         sb_off[i] = 0;
         if (pp < g.PSTRIDE) {
-            const int per_img = g.PH * g.PW;
+            const int per_img = g.PH * g.PWS;
             const int img = pp / per_img;
             const int rem = pp - img * per_img;
-            const int pr = rem / g.PW, pc = rem - pr * g.PW;
+            const int pr = rem / g.PWS, pc = rem - pr * g.PWS;
             const int b = b0 + img, yy = ty0 + pr - 1, xx = tx0 + pc - 1;
-            if (img < NI && b < g.B && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
+            if (pc < g.PW && img < NI && b < g.B && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
                 src_off[i] = (int)(((size_t)b * g.Cin * g.H + yy) * g.W + xx);
+                src_mask[i] = 1.f;
                 sb_off[i] = b * g.s_stride;
             }
         }
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
         const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
         const int img = sub >> (g.lnsx + g.lnsy);
         const int tyy = sy * SH + jy, txx = sx * SW + jx;
-        boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PW + txx;
+        boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PWS + txx;
     }
     const int aoff = hi * BM + wm * (TM * 32) + l31;
 
@@ -147,11 +155,39 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
     // Software pipeline (issue-early / write-late): the global loads of chunk c+1 are issued right after the barrier
     // that publishes chunk c and stay in flight underneath chunk c's 36*TM*TN*NPH' MFMAs; they are only waited for
     // when their registers are written to LDS at the top of the next iteration.
-    float4 av[A_VEC_ITERS];
+    f32x4 av[A_VEC_ITERS];
     float pv[MAX_POS][CC];
     constexpr bool one_image = !MULTI;  // every patch position belongs to image b0: styles are block-uniform
+    // per-thread constant part of the weight-tile addresses (FAST): (tap*Cin + c)*CoutPad + col
+    int a_off[A_VEC_ITERS];
+#pragma unroll
+    for (int it = 0; it < A_VEC_ITERS; ++it) {
+        const int f = tid + it * 256;
+        const int row = f / (BM / 4);
+        const int col = (f - row * (BM / 4)) * 4;
+        const int tap = row / CC, c = row - tap * CC;
+        a_off[it] = (f < A_FLOATS / 4) ? (tap * g.Cin + c) * g.CoutPad + col : 0;
+    }
     auto issue_loads = [&](int chunk) {
         const int c0 = chunk * CC;
+        if (FAST) {
+            const float* __restrict__ wbase = p.wp + (size_t)c0 * g.CoutPad + m0;  // uniform
+#pragma unroll
+            for (int it = 0; it < A_VEC_ITERS; ++it)
+                av[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)a_off[it]);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float* __restrict__ xbase = p.x + (size_t)(c0 + c) * plane_in;  // uniform
+#pragma unroll
+                for (int i = 0; i < MAX_POS; ++i) pv[i][c] = xbase[(unsigned)src_off[i]];
+            }
+            if (MULTI) {
+#pragma unroll
+                for (int i = 0; i < MAX_POS; ++i)
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) pv[i][c] *= p.s[sb_off[i] + c0 + c];
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < A_VEC_ITERS; ++it) {
             const int f = tid + it * 256;  // float4 index in As
@@ -159,9 +195,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
             const int col = (f - row * (BM / 4)) * 4;
             const int tap = row / CC, c = row - tap * CC;
             const int ch = c0 + c, o = m0 + col;
-            av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            av[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (f < A_FLOATS / 4 && ch < g.Cin && o < g.CoutPad)
-                av[it] = *reinterpret_cast<const float4*>(p.wp + ((size_t)tap * g.Cin + ch) * g.CoutPad + o);
+                av[it] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)tap * g.Cin + ch) * g.CoutPad + o);
         }
 #pragma unroll
         for (int i = 0; i < MAX_POS; ++i)
@@ -175,6 +211,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
                 }
                 pv[i][c] = v;
             }
+        }
     };
     auto write_lds = [&](int chunk) {
         const int c0 = chunk * CC;
@@ -185,14 +222,14 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
 #pragma unroll
         for (int it = 0; it < A_VEC_ITERS; ++it) {
             const int f = tid + it * 256;
-            if (f < A_FLOATS / 4) reinterpret_cast<float4*>(As)[f] = av[it];
+            if (f < A_FLOATS / 4) reinterpret_cast<f32x4*>(As)[f] = av[it];
         }
 #pragma unroll
         for (int i = 0; i < MAX_POS; ++i) {
             const int pp = tid + i * 256;
             if (pp < g.PSTRIDE) {
 #pragma unroll
-                for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = pv[i][c] * sc[c];
+                for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = pv[i][c] * (FAST ? sc[c] * src_mask[i] : sc[c]);
             }
         }
     };
@@ -211,7 +248,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
             const int dy = UP ? (ky == 2 ? 0 : 1) : ky;
             const int dx = UP ? (kx == 2 ? 0 : 1) : kx;
             const int ph = UP ? ((ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0)) : 0;
-            const int tapoff = dy * g.PW + dx;
+            const int tapoff = dy * g.PWS + dx;
 #pragma unroll
             for (int q = 0; q < CC / 2; ++q) {
                 float a[TM], bv[TN];
@@ -231,10 +268,28 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
     }
 
     // ---- epilogue
+    // Per-channel epilogue operands (wscale * demod, bias) go through LDS: fetched once per workgroup with all loads in
+    // flight together.  (Loading them per accumulator element from global memory serialises ~64 dependent L2 round
+    // trips behind the stores — that was ~45 % of the lifetime of a 32-channel 1024^2 workgroup.)
     const bool to_ws = g.splits > 1;
     float* outp = to_ws ? (p.ws + (size_t)split * g.ws_slab) : p.y;
     const float nw = (!to_ws && g.fuse_act && p.noise) ? p.noise_w[0] : 0.f;
     const size_t plane_out = (size_t)g.OH * g.OW;
+    float* Eg = lds;        // [BM] gain
+    float* Eb = lds + BM;   // [BM] bias
+    if (!MULTI) {
+        for (int i = tid; i < BM; i += 256) {
+            const int o = m0 + i;
+            float gain = g.wscale, bias = 0.f;
+            if (!to_ws && o < g.Cout && b0 < g.B) {
+                if (p.d) gain *= p.d[b0 * g.Cout + o];
+                if (g.fuse_act && p.bias) bias = p.bias[o];
+            }
+            Eg[i] = gain;
+            Eb[i] = bias;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
         const int sub = wn * TN + n;
@@ -252,19 +307,26 @@ __global__ __launch_bounds__(256, (BM * BN <= 8192 ? 3 : 2)) void modconv_mfma_k
             const bool ok = pos_ok && oy < g.OH && ox < g.OW;
             float nzv = 0.f;
             if (ok && nw != 0.f) nzv = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox];
+            float* obase = outp + (size_t)b * g.Cout * plane_out + (size_t)oy * g.OW + ox;
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int o = m0 + wm * (TM * 32) + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    if (ok && o < g.Cout) {
-                        float v = acc[mt][n * NPH + ph][e] * g.wscale;
-                        if (!to_ws) {
-                            if (p.d) v *= p.d[b * g.Cout + o];
-                            if (g.fuse_act) v = lrelu_gain(v + nzv + (p.bias ? p.bias[o] : 0.f));
+                    const int ol = wm * (TM * 32) + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    const int o = m0 + ol;
+                    float gain, bias;
+                    if (MULTI) {
+                        gain = g.wscale, bias = 0.f;
+                        if (!to_ws && ok && o < g.Cout) {
+                            if (p.d) gain *= p.d[b * g.Cout + o];
+                            if (g.fuse_act && p.bias) bias = p.bias[o];
                         }
-                        outp[((size_t)b * g.Cout + o) * plane_out + (size_t)oy * g.OW + ox] = v;
+                    } else {
+                        gain = Eg[ol], bias = Eb[ol];
                     }
+                    float v = acc[mt][n * NPH + ph][e] * gain;
+                    if (!to_ws && g.fuse_act) v = lrelu_gain(v + nzv + bias);
+                    if (ok && o < g.Cout) obase[(size_t)o * plane_out] = v;
                 }
             }
         }
@@ -322,6 +384,7 @@ inline int pow2_ceil(int v) { return 1 << ilog2(v); }
 
 struct Plan {
     int bm, bn, wm;
+    bool fallback = false;
     ConvGeom g;
     size_t lds_bytes;
     int64_t blocks;
@@ -358,13 +421,21 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         g.lsw = ilog2(sw), g.lsh = ilog2(sh), g.lnsx = ilog2(nsx), g.lnsy = ilog2(nsy), g.lni = ilog2(ni);
         const int tw = sw * nsx, th = sh * nsy;
         g.tiles_x = ceil_div(g.GW, tw), g.tiles_y = ceil_div(g.GH, th), g.img_groups = ceil_div(batch, ni);
-        g.PH = th + 2, g.PW = tw + 2, g.PSTRIDE = ni * g.PH * g.PW;
+        g.PH = th + 2, g.PW = tw + 2;
+        // LDS row stride: with sub-tiles narrower than 32 pixels the 32 lanes of one MFMA group read SH rows at once;
+        // a stride of SW * odd puts the rows on disjoint bank groups (conflict-free ds_read_b32)
+        g.PWS = g.PW;
+        if (sw < 32) {
+            while (g.PWS % (2 * sw) != sw) ++g.PWS;
+        }
+        g.PSTRIDE = ni * g.PH * g.PWS;
     };
     shape(pl.bn);
     if (g.PSTRIDE > (pl.bn > 256 ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
         shape(pl.bn);
+        pl.fallback = true;
     }
     g.m_tiles = ceil_div(g.CoutPad, pl.bm);
     g.n_tiles = g.tiles_x * g.tiles_y * g.img_groups;
@@ -382,9 +453,9 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     return pl;
 }
 
-template <int BM, int BN, int WM, bool UP, bool MULTI>
+template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST>
 int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
-    auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI>;
+    auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI, FAST>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -398,8 +469,11 @@ int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 template <int BM, int BN, int WM, bool UP>
 int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     if (pl.g.PSTRIDE > 256 * (BN > 256 ? 3 : 2)) return MAUA_EINVAL;
-    if (pl.g.lni > 0) return launch_conv_impl<BM, BN, WM, UP, true>(pl, ptrs, st);
-    return launch_conv_impl<BM, BN, WM, UP, false>(pl, ptrs, st);
+    const bool fast = (pl.g.Cin % CC == 0) && (pl.g.CoutPad % BM == 0);
+    if (pl.g.lni > 0) return fast ? launch_conv_impl<BM, BN, WM, UP, true, true>(pl, ptrs, st)
+                                  : launch_conv_impl<BM, BN, WM, UP, true, false>(pl, ptrs, st);
+    return fast ? launch_conv_impl<BM, BN, WM, UP, false, true>(pl, ptrs, st)
+                : launch_conv_impl<BM, BN, WM, UP, false, false>(pl, ptrs, st);
 }
 
 }  // namespace
@@ -438,7 +512,8 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (up) {
-        if (pl.bm == 32) rc = launch_conv<32, 128, 1, true>(pl, ptrs, st);
+        if (pl.fallback) rc = launch_conv<64, 64, 2, true>(pl, ptrs, st);
+        else if (pl.bm == 32) rc = launch_conv<32, 128, 1, true>(pl, ptrs, st);
         else rc = launch_conv<64, 64, 2, true>(pl, ptrs, st);
     } else {
         if (pl.bm == 32) rc = launch_conv<32, 256, 1, false>(pl, ptrs, st);

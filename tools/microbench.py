@@ -74,6 +74,36 @@ def main():
             e1.record(sp)
             ms = e0.elapsed_ms(e1) / args.iters
             out["fir_tail_1024"] = {"ms": ms, "gbs": byts / ms / 1e6}
+        if "conv" in args.what:
+            import math
+            from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+
+            B = args.batch
+            for name, cin, cout, h, up in [("plain32@1024", 32, 32, 1024, 0), ("plain64@512", 64, 64, 512, 0),
+                                           ("plain128@256", 128, 128, 256, 0), ("plain256@128", 256, 256, 128, 0),
+                                           ("plain512@64", 512, 512, 64, 0), ("up64-32@512", 64, 32, 512, 1),
+                                           ("up128-64@256", 128, 64, 256, 1), ("up512-256@64", 512, 256, 64, 1)]:
+                m = ModulatedConv2d(cin, cout, 3, 512, upsample=bool(up)).to(dev)
+                x = torch.randn(B, cin, h, h, device=dev)
+                s = torch.randn(B, cin, device=dev)
+                d = torch.rand(B, cout, device=dev)
+                oh = 2 * h + 1 if up else h
+                yv = torch.empty(B, cout, oh, oh, device=dev)
+                nz = torch.randn(B, 1, oh, oh, device=dev)
+                nw = torch.full((1,), 0.1, device=dev)
+                bias = torch.randn(cout, device=dev)
+                nws = lib.maua_modconv_ws_floats(B, cin, cout, h, h, up)
+                ws = torch.empty(max(nws, 1), device=dev)
+                run = lambda: m.run(x, s, 0, d, yv, ws if nws else None, fuse_act=not up, noise=None if up else nz, noise_w=nw, bias=bias)  # noqa: E731
+                run()
+                e0, e1 = _lib.HipEvent(), _lib.HipEvent()
+                e0.record(sp)
+                for _ in range(args.iters):
+                    run()
+                e1.record(sp)
+                ms = e0.elapsed_ms(e1) / args.iters
+                fl = 2.0 * cin * cout * 9 * h * h * B
+                out[name] = {"ms": ms, "tflops": fl / ms / 1e9}
         stream.synchronize()
     print(json.dumps(out))
 
