@@ -156,7 +156,8 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -171,7 +172,7 @@ def main():
     g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
     g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
     g = g.to(dev).eval()
-    if world > 1:  # weights: rank 0 is the source of truth, one RCCL broadcast per tensor
+    if use_dist:  # weights: rank 0 is the source of truth, one RCCL broadcast per tensor
         for t in list(g.parameters()) + list(g.buffers()):
             dist.broadcast(t.data, 0)
 
@@ -201,7 +202,7 @@ def main():
         for i in range(args.warmup):
             step(i)
         stream.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -210,7 +211,7 @@ def main():
         stream.synchronize()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             dist.barrier()
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -275,15 +276,18 @@ def main():
             ms = time_calls(launch_fir, 20, sp)
             byts = 4 * major * ((r_out + 1) ** 2 + r_out ** 2)
             ach = byts / ms / 1e6
+            # HBM bytes per launch from the PMC passes of profiles/r01_pmc_upfirdn2d.md (FETCH_SIZE x2 correction,
+            # WRITE_SIZE exact), scaled to this launch's plane count; measured at 256 planes.
+            traffic = (2 * 537346.9 + 1048576.0) * 1024.0 * major / 256.0 if size == 1024 else None
             result["roofline_upfirdn2d"] = {"kernel": "fir_tile_kernel<4,4,4,false,false>", "bound": "hbm", "achieved": ach,
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                            "traffic": None, "launch_ms": ms, "algorithmic_bytes": byts,
+                                            "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_upfirdn2d.md", "launch_ms": ms, "algorithmic_bytes": byts,
                                             "shape": f"[{xin.shape[0]},{xin.shape[1]},{r_out+1},{r_out+1}] -> {r_out}^2"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(size)
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

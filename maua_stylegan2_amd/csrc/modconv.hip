@@ -27,7 +27,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CC = 8;  // channels per K chunk
+constexpr int CC_PLAIN = 8;   // channels per K chunk (plain conv)
+constexpr int CC_UP = 8;      // transposed conv: 36 MFMAs per 2 channels and tile -> deeper chunks amortise the barriers
 
 struct ConvGeom {
     int B, Cin, Cout, CoutPad, H, W;  // input feature map
@@ -64,16 +65,17 @@ struct ConvPtrs {
 // FAST (Cin % 8 == 0 and the padded weight covers whole BM tiles — every layer of a real generator): loads are
 // unconditional (masked by multiplication at LDS-write time) and addressed as uniform base + 32-bit lane offset,
 // which removes the exec-mask / 64-bit-address scalar work that dominated the short-K (32/64-channel) layers.
-template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST>
-__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (UP ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
+template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST, int MAXP>
+__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (UP ? 4 : 1) >= 8 || BM * BN > 8192 || (UP && CC_UP > 8) ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
+    constexpr int CC = UP ? CC_UP : CC_PLAIN;
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int NPH = UP ? 4 : 1;
     constexpr int A_FLOATS = 9 * CC * BM;
     constexpr int A_VEC_ITERS = (A_FLOATS / 4 + 255) / 256;
-    constexpr int MAX_POS = BN > 256 ? 3 : 2;  // patch positions per thread (PSTRIDE <= 256 * MAX_POS)
+    constexpr int MAX_POS = MAXP;  // patch positions per thread (PSTRIDE <= 256 * MAX_POS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;
     float* Ps = lds + A_FLOATS;
@@ -431,7 +433,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         g.PSTRIDE = ni * g.PH * g.PWS;
     };
     shape(pl.bn);
-    if (g.PSTRIDE > (pl.bn > 256 ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
+    if (g.PSTRIDE > 512) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
         shape(pl.bn);
@@ -439,6 +441,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     }
     g.m_tiles = ceil_div(g.CoutPad, pl.bm);
     g.n_tiles = g.tiles_x * g.tiles_y * g.img_groups;
+    const int CC = up ? CC_UP : CC_PLAIN;
     g.n_chunks = ceil_div(cin, CC);
     // split-K until the grid covers the chip ~2x (256 CUs), never below 2 chunks per split
     const int64_t base_blocks = (int64_t)g.m_tiles * g.n_tiles;
@@ -450,12 +453,13 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
     pl.blocks = base_blocks * g.splits;
     pl.lds_bytes = ((size_t)9 * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
+    if (pl.lds_bytes < (size_t)2 * pl.bm * sizeof(float)) pl.lds_bytes = (size_t)2 * pl.bm * sizeof(float);
     return pl;
 }
 
-template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST>
-int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
-    auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI, FAST>;
+template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST, int MAXP>
+int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
+    auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI, FAST, MAXP>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -466,9 +470,16 @@ int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     return 0;
 }
 
+template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST>
+int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
+    if (pl.g.PSTRIDE <= 256) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 1>(pl, ptrs, st);
+    return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
+}
+
 template <int BM, int BN, int WM, bool UP>
 int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
-    if (pl.g.PSTRIDE > 256 * (BN > 256 ? 3 : 2)) return MAUA_EINVAL;
+    constexpr int CC = UP ? CC_UP : CC_PLAIN;
+    if (pl.g.PSTRIDE > 512) return MAUA_EINVAL;
     const bool fast = (pl.g.Cin % CC == 0) && (pl.g.CoutPad % BM == 0);
     if (pl.g.lni > 0) return fast ? launch_conv_impl<BM, BN, WM, UP, true, true>(pl, ptrs, st)
                                   : launch_conv_impl<BM, BN, WM, UP, true, false>(pl, ptrs, st);
