@@ -26,9 +26,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 f32x2u __attribute__((aligned(4)));
 
-constexpr int CC_PLAIN = 8;   // channels per K chunk (plain conv)
-constexpr int CC_UP = 8;      // transposed conv: 36 MFMAs per 2 channels and tile -> deeper chunks amortise the barriers
+// channels per K chunk: the weight tile As[9][CC][BM] is kept at <= 18 KB so that two of them (double buffer) fit 3x per CU
+constexpr int chunk_channels(int bm) { return bm >= 128 ? 4 : 8; }
 
 struct ConvGeom {
     int B, Cin, Cout, CoutPad, H, W;  // input feature map
@@ -46,6 +48,7 @@ struct ConvGeom {
     int fuse_act;
     int64_t noise_batch_stride;
     int64_t ws_slab;  // floats per split slab
+    int debug;        // ablation switches (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads
 };
 
 struct ConvPtrs {
@@ -66,9 +69,9 @@ struct ConvPtrs {
 // unconditional (masked by multiplication at LDS-write time) and addressed as uniform base + 32-bit lane offset,
 // which removes the exec-mask / 64-bit-address scalar work that dominated the short-K (32/64-channel) layers.
 template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST, int MAXP>
-__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (UP ? 4 : 1) >= 8 || BM * BN > 8192 || (UP && CC_UP > 8) ? 2 : 3))
+__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (UP ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
-    constexpr int CC = UP ? CC_UP : CC_PLAIN;
+    constexpr int CC = chunk_channels(BM);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -77,8 +80,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     constexpr int A_VEC_ITERS = (A_FLOATS / 4 + 255) / 256;
     constexpr int MAX_POS = MAXP;  // patch positions per thread (PSTRIDE <= 256 * MAX_POS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: As[2][A_FLOATS] | Ps[2][CC * PSTRIDE]   (the generic path only uses buffer 0 of each)
     float* As = lds;
-    float* Ps = lds + A_FLOATS;
+    float* Ps = lds + 2 * A_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -236,13 +240,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         }
     };
 
-    if (chunk_begin < chunk_end) issue_loads(chunk_begin);
-    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
-        write_lds(chunk);
-        __syncthreads();
-        if (chunk + 1 < chunk_end) issue_loads(chunk + 1);
-
-        // -- MFMA
+    // ---- MFMA phase over one staged chunk
+    auto mfma_chunk = [&](const float* __restrict__ Ac, const float* __restrict__ Pc) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -255,9 +254,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             for (int q = 0; q < CC / 2; ++q) {
                 float a[TM], bv[TN];
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) a[mt] = As[(tap * CC + 2 * q) * BM + mt * 32 + aoff];
+                for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[(tap * CC + 2 * q) * BM + mt * 32 + aoff];
 #pragma unroll
-                for (int n = 0; n < TN; ++n) bv[n] = Ps[2 * q * g.PSTRIDE + boff[n] + tapoff];
+                for (int n = 0; n < TN; ++n) bv[n] = Pc[2 * q * g.PSTRIDE + boff[n] + tapoff];
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -266,7 +265,97 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                             __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bv[n], acc[mt][n * NPH + ph], 0, 0, 0);
             }
         }
+    };
+
+    if (FAST) {
+        // Double-buffered pipeline, ONE barrier per chunk.  The weight tile goes HBM/L2 -> LDS by DMA
+        // (global_load_lds, 1 KiB per wave instruction, no staging registers, no ds_write); the feature patch goes
+        // through registers because it is scaled by the style and masked at the image border on the way in.
+        constexpr int RPI = 256 / BM;              // weight rows (BM floats) per 1-KiB DMA instruction
+        constexpr int LPR = 64 / RPI;              // lanes per row
+        constexpr int A_INSTR = 9 * CC / RPI;      // DMA instructions per tile
+        constexpr int A_PER_WAVE = (A_INSTR + 3) / 4;
+        static_assert((9 * CC) % RPI == 0, "weight tile must be a whole number of DMA instructions");
+        int a_goff[A_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < A_PER_WAVE; ++k) {
+            const int row = (wave + 4 * k) * RPI + lane / LPR;
+            const int col = (lane % LPR) * 4;
+            const int tap = row / CC, c = row - tap * CC;
+            a_goff[k] = (tap * g.Cin + c) * g.CoutPad + col;
+        }
+        auto issue_dma = [&](int chunk, int buf) {
+            const float* __restrict__ wbase = p.wp + (size_t)chunk * CC * g.CoutPad + m0;  // uniform
+            float* dst = As + buf * A_FLOATS;
+#pragma unroll
+            for (int k = 0; k < A_PER_WAVE; ++k) {
+                const int i = wave + 4 * k;
+                if (i < A_INSTR)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(wbase + (unsigned)a_goff[k]),
+                        (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+            }
+        };
+        auto load_patch = [&](int chunk) {
+            const int c0 = chunk * CC;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float* __restrict__ xbase = p.x + (size_t)(c0 + c) * plane_in;  // uniform
+#pragma unroll
+                for (int i = 0; i < MAX_POS; ++i) pv[i][c] = xbase[(unsigned)src_off[i]];
+            }
+            if (MULTI) {
+#pragma unroll
+                for (int i = 0; i < MAX_POS; ++i)
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) pv[i][c] *= p.s[sb_off[i] + c0 + c];
+            }
+        };
+        auto write_patch = [&](int chunk, int buf) {
+            const int c0 = chunk * CC;
+            float* Pd = Ps + buf * (CC * g.PSTRIDE);
+            float sc[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) sc[c] = (one_image && b0 < g.B) ? p.s[b0 * g.s_stride + c0 + c] : 1.f;
+#pragma unroll
+            for (int i = 0; i < MAX_POS; ++i) {
+                const int pp = tid + i * 256;
+                if (pp < g.PSTRIDE) {
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) Pd[c * g.PSTRIDE + pp] = pv[i][c] * (sc[c] * src_mask[i]);
+                }
+            }
+        };
+        int cur = 0;
+        if (chunk_begin < chunk_end) {
+            issue_dma(chunk_begin, 0);
+            load_patch(chunk_begin);
+            write_patch(chunk_begin, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+            const bool more = chunk + 1 < chunk_end;
+            if (more && !(g.debug & 4)) {
+                issue_dma(chunk + 1, cur ^ 1);
+                load_patch(chunk + 1);
+            }
+            if (!(g.debug & 2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * (CC * g.PSTRIDE));
+            if (more && !(g.debug & 4)) write_patch(chunk + 1, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+    if (chunk_begin < chunk_end) issue_loads(chunk_begin);
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+        write_lds(chunk);
+        __syncthreads();
+        if (chunk + 1 < chunk_end) issue_loads(chunk + 1);
+
+        mfma_chunk(As, Ps);
+        __syncthreads();
+    }
     }
 
     // ---- epilogue
@@ -302,13 +391,22 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const int b = b0 + img;
         const int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
         const bool pos_ok = (b < g.B) && (gy < g.GH) && (gx < g.GW);
+        // transposed conv: the two x-parities of a position are adjacent in memory -> one 8-byte store per lane
+        // (rows of the (2W+1)-wide plane are only 4-byte aligned: f32x2u is an align-4 vector type)
+        constexpr int PXN = UP ? 2 : 1;
 #pragma unroll
-        for (int ph = 0; ph < NPH; ++ph) {
-            const int oy = UP ? 2 * gy + (ph >> 1) : gy;
-            const int ox = UP ? 2 * gx + (ph & 1) : gx;
-            const bool ok = pos_ok && oy < g.OH && ox < g.OW;
-            float nzv = 0.f;
-            if (ok && nw != 0.f) nzv = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox];
+        for (int py = 0; py < (UP ? 2 : 1); ++py) {
+            const int oy = UP ? 2 * gy + py : gy;
+            const int ox = UP ? 2 * gx : gx;
+            const bool ok0 = pos_ok && oy < g.OH && ox < g.OW;
+            const bool ok1 = UP && ok0 && (ox + 1 < g.OW);
+            float nzv[PXN];
+#pragma unroll
+            for (int px = 0; px < PXN; ++px) {
+                nzv[px] = 0.f;
+                if ((px ? ok1 : ok0) && nw != 0.f)
+                    nzv[px] = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox + px];
+            }
             float* obase = outp + (size_t)b * g.Cout * plane_out + (size_t)oy * g.OW + ox;
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
@@ -319,16 +417,27 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                     float gain, bias;
                     if (MULTI) {
                         gain = g.wscale, bias = 0.f;
-                        if (!to_ws && ok && o < g.Cout) {
+                        if (!to_ws && ok0 && o < g.Cout) {
                             if (p.d) gain *= p.d[b * g.Cout + o];
                             if (g.fuse_act && p.bias) bias = p.bias[o];
                         }
                     } else {
                         gain = Eg[ol], bias = Eb[ol];
                     }
-                    float v = acc[mt][n * NPH + ph][e] * gain;
-                    if (!to_ws && g.fuse_act) v = lrelu_gain(v + nzv + bias);
-                    if (ok && o < g.Cout) obase[(size_t)o * plane_out] = v;
+                    float v[PXN];
+#pragma unroll
+                    for (int px = 0; px < PXN; ++px) {
+                        v[px] = acc[mt][n * NPH + (UP ? py * 2 + px : 0)][e] * gain;
+                        if (!to_ws && g.fuse_act) v[px] = lrelu_gain(v[px] + nzv[px] + bias);
+                    }
+                    if ((g.debug & 1) && v[0] != 123.456f) continue;
+                    float* dst = obase + (size_t)o * plane_out;
+                    if (UP) {
+                        if (ok1 && o < g.Cout) *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
+                        else if (ok0 && o < g.Cout) dst[0] = v[0];
+                    } else if (ok0 && o < g.Cout) {
+                        dst[0] = v[0];
+                    }
                 }
             }
         }
@@ -393,6 +502,7 @@ struct Plan {
 };
 
 int pad32(int c) { return (c + 31) / 32 * 32; }
+int g_conv_debug = 0;
 
 // Tile-shape selection (host).  BM follows Cout; the pixel tile is a stack of 32-pixel MFMA groups.
 Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
@@ -439,10 +549,10 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         shape(pl.bn);
         pl.fallback = true;
     }
+    const int CC = chunk_channels(pl.bm);
+    g.n_chunks = ceil_div(cin, CC);
     g.m_tiles = ceil_div(g.CoutPad, pl.bm);
     g.n_tiles = g.tiles_x * g.tiles_y * g.img_groups;
-    const int CC = up ? CC_UP : CC_PLAIN;
-    g.n_chunks = ceil_div(cin, CC);
     // split-K until the grid covers the chip ~2x (256 CUs), never below 2 chunks per split
     const int64_t base_blocks = (int64_t)g.m_tiles * g.n_tiles;
     int splits = 1;
@@ -452,7 +562,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     g.splits = ceil_div(g.n_chunks, g.chunks_per_split);
     g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
     pl.blocks = base_blocks * g.splits;
-    pl.lds_bytes = ((size_t)9 * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
+    pl.lds_bytes = 2 * ((size_t)9 * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
     if (pl.lds_bytes < (size_t)2 * pl.bm * sizeof(float)) pl.lds_bytes = (size_t)2 * pl.bm * sizeof(float);
     return pl;
 }
@@ -478,7 +588,7 @@ int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 
 template <int BM, int BN, int WM, bool UP>
 int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
-    constexpr int CC = UP ? CC_UP : CC_PLAIN;
+    constexpr int CC = chunk_channels(BM);
     if (pl.g.PSTRIDE > 512) return MAUA_EINVAL;
     const bool fast = (pl.g.Cin % CC == 0) && (pl.g.CoutPad % BM == 0);
     if (pl.g.lni > 0) return fast ? launch_conv_impl<BM, BN, WM, UP, true, true>(pl, ptrs, st)
@@ -488,6 +598,8 @@ int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 }
 
 }  // namespace
+
+int maua_conv_debug_set(int v) { g_conv_debug = v; return 0; }
 
 extern "C" int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream) {
     if (!w || cout <= 0 || cin <= 0 || ktaps <= 0) return MAUA_EINVAL;
@@ -519,6 +631,7 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
     pl.g.wscale = wscale;
     pl.g.fuse_act = fuse_act;
     pl.g.noise_batch_stride = noise_batch_stride;
+    pl.g.debug = g_conv_debug;
     ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws};
     hipStream_t st = (hipStream_t)stream;
     int rc;
