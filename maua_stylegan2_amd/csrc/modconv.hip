@@ -539,6 +539,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         g.PWS = g.PW;
         if (sw < 32) {
             while (g.PWS % (2 * sw) != sw) ++g.PWS;
+            if (ni * g.PH * g.PWS > 512) g.PWS = g.PW;  // tiny maps, many images per tile: take the conflicts
         }
         g.PSTRIDE = ni * g.PH * g.PWS;
     };

@@ -120,11 +120,18 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
     for bend in bends:
         if "modulation" in bend:
             bend["modulation"] = bend["modulation"].to(dev, th.float32).contiguous()
-    rewrites = rewrites or {}
-    if rewrites:
-        raise NotImplementedError("get_rewrites: the reference's path is dead code (Tensor.copy() at render.py:131, "
-                                  "SURVEY.md §8a quirks) and is a 'next' row (§8f rank 4)")
-    capturable = use_graph and not bends and not randomize_noise and hasattr(generator, "capture_graph")
+    # model rewriting (reference render.py:127-131,160-167, whose `.copy()` typo makes it unreachable there): per batch
+    # the named parameter is replaced by transform(original weight), transform = rewrite(modulation[batch]).
+    rewrites = dict(rewrites or {})
+    param_dict = dict(generator.named_parameters())
+    original_weights = {}
+    for name, (rewrite, modulation) in rewrites.items():
+        if name not in param_dict:
+            raise KeyError(f"get_rewrites: generator has no parameter {name!r}")
+        rewrites[name] = [rewrite, modulation.to(dev, th.float32).contiguous()]
+        original_weights[name] = param_dict[name].detach().clone()
+    capturable = (use_graph and not bends and not rewrites and not randomize_noise
+                  and hasattr(generator, "capture_graph"))
     graph = static = None
     u8 = None
     stream = th.cuda.Stream(dev)
@@ -153,6 +160,13 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
                         bend_batch.append({"layer": bend["layer"], "transform": bend["transform"](bend["modulation"][n:m])})
                     else:
                         bend_batch.append({"layer": bend["layer"], "transform": bend["transform"]})
+                for name, (rewrite, modulation) in rewrites.items():
+                    new_weight = rewrite(modulation[n:m])(original_weights[name]).to(dev, th.float32).contiguous()
+                    module = generator
+                    *path, leaf = name.split(".")
+                    for attr in path:
+                        module = getattr(module, attr)
+                    setattr(module, leaf, th.nn.Parameter(new_weight, requires_grad=False))
                 images, _ = generator(styles=latents[n:m], noise=noise_batch,
                                       truncation=truncation if trunc_t is None else trunc_t[n:m],
                                       transform_dict_list=bend_batch, randomize_noise=randomize_noise, input_is_latent=True)
@@ -160,6 +174,12 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
                 u8 = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
             frames_to_uint8(images, u8)
             yield n, u8
+    for name, w in original_weights.items():  # leave the generator as it was found
+        module = generator
+        *path, leaf = name.split(".")
+        for attr in path:
+            module = getattr(module, attr)
+        setattr(module, leaf, th.nn.Parameter(w, requires_grad=False))
     th.cuda.current_stream(dev).wait_stream(stream)
 
 

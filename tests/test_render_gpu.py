@@ -93,3 +93,85 @@ def test_generate_end_to_end_default_plugin(gpu, tmp_path, monkeypatch):
     frames = raw.reshape(24, 512, 512, 3)
     assert frames.std() > 5 and not np.array_equal(frames[0], frames[12])
     assert os.path.exists("workspace/last-latents.npy")
+
+
+def test_generator_with_bends_and_wide_output_vs_oracle(gpu):
+    """Config-5 style network bending through the whole generator: a layer-0 bend that widens the constant (the
+    reference's route to 2:1 output, tauceti.py:97-100) plus a per-frame modulated Translate at layer 4 and a Zoom at
+    layer 5; the oracle applies the same transforms (oracle warp = restated kornia composition) at the same layer ids."""
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.audioreactive import bend
+    from oracle import signal_oracle
+    from oracle import stylegan2_oracle as so
+
+    size, n = 64, 4
+    sd = seeding.seeded_state_dict(size, seed=8)
+    g = build(size, gpu, 8)
+    lat = seeding.seeded_latents(n, g.n_latent, seed=9)
+    sizes = seeding.noise_sizes(size)
+    noise = [torch.from_numpy(seeding.seeded_array(10, f"wn{i}", (n, 1, r, 2 * r))) for i, r in enumerate(sizes)]
+    h, w = 16, 32  # layer-4 feature size once the constant is 4 x 8
+    shift = torch.tensor([[0.0, 0.0], [2.5, 0.0], [-4.0, 0.0], [7.75, 0.0]])
+    zoom = torch.tensor([1.0, 1.3, 0.8, 1.1])
+    bnoise = torch.from_numpy(seeding.seeded_array(11, "bend_noise", (1, 1, h, 5 * w))) * 0.05
+    bends = [
+        {"layer": 0, "transform": torch.nn.ReplicationPad2d((2, 2, 0, 0))},
+        {"layer": 4, "modulation": shift, "transform": lambda b: bend.Translate(b, h, w, bnoise)},
+        {"layer": 5, "modulation": zoom, "transform": lambda b: bend.Zoom(b, h, w)},
+    ]
+    frames = np.zeros((n, size, 2 * size, 3), np.uint8)
+    for first, u8 in render.synthesize(g, lat, noise, 2, bends=bends):
+        frames[first: first + u8.shape[0]] = u8.cpu().numpy()
+
+    def o_translate(t):
+        pads = (int(w / 2) + 2 * w, int(w / 2) + w, 0, 0)
+        m = bend._inverse_maps_translate(shift).numpy()
+        return torch.from_numpy(signal_oracle.affine_reflect_warp(t.numpy(), m, pads, bnoise.numpy())).float()
+
+    def o_zoom(t):
+        pad = max(h, w) - 1
+        m = bend._inverse_maps_scale(zoom, w + 2 * pad, h + 2 * pad).numpy()
+        return torch.from_numpy(signal_oracle.affine_reflect_warp(t.numpy(), m, (pad,) * 4)).float()
+
+    want = so.generator_forward(sd, lat, noise, bends={0: torch.nn.ReplicationPad2d((2, 2, 0, 0)), 4: o_translate, 5: o_zoom})
+    assert want.shape == (n, 3, size, 2 * size)
+    want_u8 = so.frames_to_uint8(want)
+    diff = np.abs(frames.astype(np.int16) - want_u8.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 5e-3
+
+
+def test_rewrites_vs_oracle(gpu):
+    """Model rewriting (get_rewrites): a per-batch modulated scaling of one conv weight and of one ToRGB bias; the oracle
+    runs each batch with the correspondingly rewritten state dict."""
+    from maua_stylegan2_amd import render
+    from oracle import stylegan2_oracle as so
+
+    size, n, bs = 32, 4, 2
+    sd = seeding.seeded_state_dict(size, seed=12)
+    g = build(size, gpu, 12)
+    lat = seeding.seeded_latents(n, g.n_latent, seed=13)
+    noise = seeding.seeded_noise(n, size, seed=14)
+    mod = torch.tensor([1.0, 1.5, 0.25, 2.0])
+
+    class Scale(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = float(m.mean())
+
+        def forward(self, w):
+            return w * self.m
+
+    rewrites = {"convs.2.conv.weight": [lambda m: Scale(m), mod], "to_rgbs.1.bias": [lambda m: Scale(m), mod]}
+    frames = np.zeros((n, size, size, 3), np.uint8)
+    for first, u8 in render.synthesize(g, lat, noise, bs, rewrites=rewrites):
+        frames[first: first + u8.shape[0]] = u8.cpu().numpy()
+    for b0 in range(0, n, bs):
+        sd2 = dict(sd)
+        k = float(mod[b0: b0 + bs].mean())
+        sd2["convs.2.conv.weight"] = sd["convs.2.conv.weight"] * k
+        sd2["to_rgbs.1.bias"] = sd["to_rgbs.1.bias"] * k
+        want = so.frames_to_uint8(so.generator_forward(sd2, lat[b0: b0 + bs], [x[b0: b0 + bs] for x in noise]))
+        diff = np.abs(frames[b0: b0 + bs].astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 5e-3
+    # the generator is restored afterwards
+    assert torch.equal(g.convs[2].conv.weight.cpu(), sd["convs.2.conv.weight"])
