@@ -279,7 +279,7 @@ def main():
             # HBM bytes per launch from the PMC passes of profiles/r01_pmc_upfirdn2d.md (FETCH_SIZE x2 correction,
             # WRITE_SIZE exact), scaled to this launch's plane count; measured at 256 planes.
             traffic = (2 * 537346.9 + 1048576.0) * 1024.0 * major / 256.0 if size == 1024 else None
-            result["roofline_upfirdn2d"] = {"kernel": "fir_tile_kernel<4,4,4,false,false>", "bound": "hbm", "achieved": ach,
+            result["roofline_upfirdn2d"] = {"kernel": "fir_strip_kernel<4,4,4,false,false>", "bound": "hbm", "achieved": ach,
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                             "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_upfirdn2d.md", "launch_ms": ms, "algorithmic_bytes": byts,
                                             "shape": f"[{xin.shape[0]},{xin.shape[1]},{r_out+1},{r_out+1}] -> {r_out}^2"}

@@ -14,6 +14,11 @@
 //    (demod gain, noise, bias, leaky-ReLU*sqrt2) = the rest of StyledConv.forward.
 //    Logical tile order is (plane, tile_x, tile_y) with tile_y fastest and an XCD-aware remap so that vertically
 //    adjacent tiles (which share KH-1 halo rows) are served by the same L2.
+//  * fir_strip_kernel: the same tile, staged row-wise (thread = one column of the tile, uniform row base + lane offset:
+//    64 VGPRs, 8 waves/SIMD) — the default for the plain op: 5.56 TB/s on [8,32,1025,1025] (69 % of 8 TB/s, 88 % of the
+//    6.3 TB/s copy ceiling of tools/stream_probe.hip); its software-pipelined strip mode (loads of tile t+1 under the
+//    filtering of tile t) measured no better.  The fused-tail variant keeps fir_tile_kernel (4.6 TB/s): its 32 prefetched
+//    noise values per lane cost occupancy in the strip form.
 //  * fir_generic_kernel: any up/down/pad/minor, one thread per output, polyphase tap skipping.
 #include "common.h"
 
@@ -29,7 +34,8 @@ struct FirTail {
 };
 
 constexpr int TILE_ROWS_PER_WAVE = 32;
-int g_fir_path = 0;  // tuning switch (maua_tuning_set): 0 auto (= dword tile), 2 vec4, 3 wave tile, 4 wave tile + nt, 5 dword tile + nt
+int g_fir_path = 0;  // tuning switch (maua_tuning_set): 0 auto (= fir_strip_kernel, strip length 1), 1 fir_tile_kernel, 2 vec4, 3 wave tile, 4 wave tile + nt,
+                     // 5 dword tile + nt, 6.. pipelined strips of (value - 5) tiles
 
 template <int KH, int KW, int WX, bool TAIL, bool NT>
 __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
@@ -41,7 +47,6 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     constexpr int TW = 64 * WX;
     constexpr int RH = WY * TH + KH - 1;  // staged rows
     constexpr int RW = TW + KW - 1;       // staged cols
-    constexpr int NIT = (RH * RW + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -76,18 +81,30 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     const int iy0 = oy0 - pad_y0;
     const int ix0 = ox0 - pad_x0;
 
-    // ---- stage: issue every global load first, then write LDS
-    float v[NIT];
+    // ---- stage: issue every global load first, then write LDS.  Thread (ty, tx) owns column tx of rows ty, ty+WY, ...:
+    // a wave instruction reads 64 consecutive floats of one row (uniform row base + lane offset: no per-element decode,
+    // no 64-bit address registers -> 64 VGPRs, 8 waves/SIMD); the KW-1 halo columns go to the first (KW-1)*RH threads.
+    constexpr int NR = (RH + WY - 1) / WY;
+    constexpr int NH = ((KW - 1) * RH + 255) / 256;
+    const int tx = tid % TW, ty = tid / TW;
+    const int ixm = ix0 + tx;
+    const bool okx = ixm >= 0 && ixm < in_w;
+    float v[NR], vh[NH];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        const int rr = idx / RW;
-        const int cc = idx - rr * RW;
+    for (int i = 0; i < NR; ++i) {
+        const int rr = ty + i * WY;
         const int iy = iy0 + rr;
-        const int ix = ix0 + cc;
-        const bool ok = (idx < RH * RW) && (iy >= 0) && (iy < in_h) && (ix >= 0) && (ix < in_w);
-        v[it] = 0.f;
-        if (ok) v[it] = NT ? __builtin_nontemporal_load(xp + (size_t)iy * in_w + ix) : xp[(size_t)iy * in_w + ix];
+        v[i] = 0.f;
+        if (rr < RH && okx && iy >= 0 && iy < in_h)
+            v[i] = NT ? __builtin_nontemporal_load(xp + (size_t)iy * in_w + ixm) : xp[(size_t)iy * in_w + ixm];
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int e = tid + h * 256;
+        const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
+        const int iy = iy0 + hr, ix = ix0 + hc;
+        vh[h] = 0.f;
+        if (e < (KW - 1) * RH && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) vh[h] = xp[(size_t)iy * in_w + ix];
     }
     // wave (wx, wy), lane = column
     const int wave = tid >> 6, lane = tid & 63;
@@ -116,9 +133,15 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
         }
     }
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < RH * RW) lds[idx] = v[it];
+    for (int i = 0; i < NR; ++i) {
+        const int rr = ty + i * WY;
+        if (rr < RH) lds[rr * RW + tx] = v[i];
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int e = tid + h * 256;
+        const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
+        if (e < (KW - 1) * RH) lds[hr * RW + hc] = vh[h];
     }
     __syncthreads();
 
@@ -152,6 +175,164 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
                 else yp[(size_t)oy * out_w + ox] = val;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fir_strip_kernel: fir_tile_kernel with a software pipeline.  A workgroup walks DOWN a strip of `strip_len` vertically
+// adjacent tiles of one plane: the ~36 dword loads (and, with TAIL, the 32 noise values) of tile t+1 are issued right
+// after the barrier that publishes tile t in LDS and stay in flight while tile t is filtered and stored, so every CU
+// keeps HBM requests outstanding during its compute/store phases instead of alternating load-only / compute-only.
+template <int KH, int KW, int WX, bool TAIL, bool PIPE>
+__global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                        float* __restrict__ y, int planes, int in_h, int in_w,
+                                                        int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
+                                                        int tiles_y, int strip_len, FirTail tail) {
+    constexpr int WY = 4 / WX;
+    constexpr int TH = TILE_ROWS_PER_WAVE;
+    constexpr int TW = 64 * WX;
+    constexpr int RH = WY * TH + KH - 1;
+    constexpr int RW = TW + KW - 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int strips_y = (tiles_y + strip_len - 1) / strip_len;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    int plane, tile_x, strip;
+    if (TAIL) {  // channel fastest: planes sharing one noise strip run back-to-back on one XCD
+        const int c = t % tail.channels;
+        t /= tail.channels;
+        strip = t % strips_y;
+        t /= strips_y;
+        tile_x = t % tiles_x;
+        plane = (t / tiles_x) * tail.channels + c;
+    } else {
+        const int per_plane = tiles_x * strips_y;
+        plane = t / per_plane;
+        t -= plane * per_plane;
+        tile_x = t / strips_y;
+        strip = t - tile_x * strips_y;
+    }
+    const int ty_begin = strip * strip_len;
+    const int ty_end = min(tiles_y, ty_begin + strip_len);
+    const int ox0 = tile_x * TW;
+
+    float kf[KH][KW];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
+
+    const float* xp = x + (size_t)plane * in_h * in_w;
+    float* yp = y + (size_t)plane * out_h * out_w;
+    const int ix0 = ox0 - pad_x0;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wx = wave % WX, wy = wave / WX;
+    const int col = wx * 64 + lane;
+    const int ox = ox0 + col;
+    const int row0 = wy * TH;
+    const bool col_ok = ox < out_w;
+
+    float g = 1.f, nw = 0.f, bs = 0.f;
+    const float* nz = nullptr;
+    if (TAIL) {
+        const int b = plane / tail.channels;
+        const int c = plane - b * tail.channels;
+        if (tail.gain) g = tail.gain[plane];
+        bs = tail.bias ? tail.bias[c] : 0.f;
+        if (tail.noise) {
+            nw = tail.noise_w[0];
+            nz = tail.noise + (size_t)b * tail.noise_batch_stride;
+        }
+    }
+
+    // Staging map: thread (ty, tx) owns column tx of rows ty, ty+WY, ... (a wave instruction = 64 consecutive floats of
+    // one row, address = uniform row base + lane offset -> no per-element decode, no 64-bit address registers); the
+    // KW-1 halo columns are spread over the first (KW-1)*RH threads.
+    constexpr int NR = (RH + WY - 1) / WY;
+    constexpr int NH = ((KW - 1) * RH + 255) / 256;
+    const int tx = tid % TW, ty = tid / TW;
+    const int ixm = ix0 + tx;
+    const bool okx = ixm >= 0 && ixm < in_w;
+    float v[NR], vh[NH];
+    float nzn[TAIL ? TH : 1];  // noise of the tile being fetched (PIPE: a second copy, nzv, holds the tile being filtered)
+    auto issue = [&](int tile_y) {
+        const int iy0 = tile_y * (WY * TH) - pad_y0;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int rr = ty + i * WY;
+            const int iy = iy0 + rr;
+            v[i] = 0.f;
+            if (rr < RH && okx && iy >= 0 && iy < in_h) v[i] = xp[(size_t)iy * in_w + ixm];
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int e = tid + h * 256;
+            const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
+            const int iy = iy0 + hr, ix = ix0 + hc;
+            vh[h] = 0.f;
+            if (e < (KW - 1) * RH && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) vh[h] = xp[(size_t)iy * in_w + ix];
+        }
+        if (TAIL) {
+            const int oyb = tile_y * (WY * TH) + row0;
+#pragma unroll
+            for (int o = 0; o < TH; ++o) {
+                nzn[o] = 0.f;
+                if (nz && col_ok && oyb + o < out_h) nzn[o] = nz[(size_t)(oyb + o) * out_w + ox];
+            }
+        }
+    };
+
+    issue(ty_begin);
+    for (int tile_y = ty_begin; tile_y < ty_end; ++tile_y) {
+        float nzv[(TAIL && PIPE) ? TH : 1];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int rr = ty + i * WY;
+            if (rr < RH) lds[rr * RW + tx] = v[i];
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int e = tid + h * 256;
+            const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
+            if (e < (KW - 1) * RH) lds[hr * RW + hc] = vh[h];
+        }
+        if (TAIL && PIPE) {
+#pragma unroll
+            for (int o = 0; o < TH; ++o) nzv[o] = nzn[o];
+        }
+        __syncthreads();
+        if (PIPE && tile_y + 1 < ty_end) issue(tile_y + 1);
+
+        const int oy0 = tile_y * (WY * TH);
+        float acc[KH];
+#pragma unroll
+        for (int i = 0; i < KH; ++i) acc[i] = 0.f;
+        const float* lrow = lds + row0 * RW + col;
+#pragma unroll
+        for (int r = 0; r < TH + KH - 1; ++r) {
+            float in[KW];
+#pragma unroll
+            for (int j = 0; j < KW; ++j) in[j] = lrow[r * RW + j];
+#pragma unroll
+            for (int i = 0; i < KH; ++i) {
+                const int o = r - i;
+                if (o >= 0 && o < TH) {
+#pragma unroll
+                    for (int j = 0; j < KW; ++j) acc[o % KH] = fmaf(kf[i][j], in[j], acc[o % KH]);
+                }
+            }
+            const int o_done = r - (KH - 1);
+            if (o_done >= 0) {
+                const int oy = oy0 + row0 + o_done;
+                float val = acc[o_done % KH];
+                acc[o_done % KH] = 0.f;
+                if (TAIL) val = lrelu_gain(fmaf(nw, PIPE ? nzv[(TAIL && PIPE) ? o_done : 0] : nzn[TAIL ? o_done : 0], val * g) + bs);
+                if (col_ok && oy < out_h) yp[(size_t)oy * out_w + ox] = val;
+            }
+        }
+        __syncthreads();  // every wave is done reading this tile before the next one overwrites LDS
+        if (!PIPE && tile_y + 1 < ty_end) issue(tile_y + 1);
     }
 }
 
@@ -454,7 +635,7 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restric
 template <int KH, int KW, bool TAIL>
 int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
                     int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
-    if (g_fir_path >= 3 && out_w >= 64) {  // 3 = wave tiles, 4 = wave tiles + non-temporal
+    if ((g_fir_path == 3 || g_fir_path == 4) && out_w >= 64) {  // 3 = wave tiles, 4 = wave tiles + non-temporal
         const int tiles_x = ceil_div(out_w, 64), tiles_y = ceil_div(out_h, 32);
         const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
         if (nblocks > 0x7fffffff) return MAUA_EINVAL;
@@ -489,7 +670,18 @@ int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in
         if (nblocks <= 0) return 0;
         if (nblocks > 0x7fffffff) return MAUA_EINVAL;
         const size_t lds_bytes = (size_t)RH * RW * sizeof(float);
-        if (g_fir_path == 5)
+        if ((g_fir_path == 0 && !TAIL) || g_fir_path >= 6) {  // plain op: fir_strip_kernel with strip length 1; 6.. = pipelined strips
+            int strip_len = g_fir_path >= 6 ? g_fir_path - 5 : 1;
+            if (strip_len > tiles_y) strip_len = tiles_y;
+            while (strip_len > 1 && (int64_t)planes * tiles_x * ceil_div(tiles_y, strip_len) < 1024) strip_len >>= 1;
+            const int64_t nb = (int64_t)planes * tiles_x * ceil_div(tiles_y, strip_len);
+            if (strip_len > 1)
+                hipLaunchKernelGGL((fir_strip_kernel<KH, KW, WX, TAIL, true>), dim3((unsigned)nb), dim3(256), lds_bytes, st,
+                                   x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, strip_len, tail);
+            else
+                hipLaunchKernelGGL((fir_strip_kernel<KH, KW, WX, TAIL, false>), dim3((unsigned)nb), dim3(256), lds_bytes, st,
+                                   x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, strip_len, tail);
+        } else if (g_fir_path == 5)
             hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL, true>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st,
                                x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
         else

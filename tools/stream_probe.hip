@@ -102,14 +102,14 @@ int main() {
     CK(hipMemcpy(fk, hk, 64, hipMemcpyHostToDevice));
     CK(hipMemsetAsync(fx, 0, (size_t)planes * (r + 1) * (r + 1) * 4, st));
     const double fb = 4.0 * planes * ((double)(r + 1) * (r + 1) + (double)r * r);
-    for (int path = 1; path <= 5; ++path) {
+    for (int path : {1, 2, 6, 7, 9, 13, 21, 0}) {
         maua_tuning_set(0, path);
-        char nm[64]; snprintf(nm, 64, "fir path %d (1 tile,2 vec4,3 wave,4 wave+nt,5 tile+nt)", path);
+        char nm[64]; snprintf(nm, 64, "fir path %d (1 tile, 2 vec4, 6+n strips of n+1... , 0 auto)", path);
         rep(nm, time_ms([&] { maua_upfirdn2d_f32(fx, fk, fy, planes, r + 1, r + 1, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, st); }, st), fb);
     }
     float *nzb, *nwb, *bsb; CK(hipMalloc(&nzb, (size_t)r * r * 4)); CK(hipMalloc(&nwb, 4)); CK(hipMalloc(&bsb, 32 * 4));
     CK(hipMemsetAsync(nzb, 0, (size_t)r * r * 4, st)); CK(hipMemsetAsync(nwb, 0, 4, st)); CK(hipMemsetAsync(bsb, 0, 128, st));
-    for (int path : {1, 2, 5}) {
+    for (int path : {1, 7, 9, 0}) {
         maua_tuning_set(0, path);
         char nm[64]; snprintf(nm, 64, "fir+noise+act tail path %d", path);
         rep(nm, time_ms([&] { maua_blur_noise_act_f32(fx, fk, fy, 8, 32, r + 1, r + 1, 4, 4, 1, 1, nullptr, nzb, 0, nwb, bsb, st); }, st), fb);
