@@ -195,7 +195,11 @@ def main():
         sp = stream.cuda_stream
 
         def step(i):
+            # refresh the graph's static inputs from the HBM-resident sequence, exactly as render.synthesize does
             static["latents"].copy_(lat_pool[i * B:(i + 1) * B], non_blocking=True)
+            for dst, src in zip(static["noise"], noise_pool):
+                if src is not None:
+                    dst.copy_(src, non_blocking=True)
             graph.replay(sp)
             _lib.check(lib.maua_frames_to_u8(static["image"].data_ptr(), frames_u8.data_ptr(), B, size, size, sp), "u8")
 

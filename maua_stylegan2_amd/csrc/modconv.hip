@@ -30,7 +30,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x2 f32x2u __attribute__((aligned(4)));
 
 // channels per K chunk: the weight tile As[9][CC][BM] is kept at <= 18 KB so that two of them (double buffer) fit 3x per CU
-constexpr int chunk_channels(int bm) { return bm >= 128 ? 4 : 8; }
+constexpr int chunk_channels(int bm, int bn = 0) { return (bm >= 128 || bn >= 512) ? 4 : 8; }
 
 struct ConvGeom {
     int B, Cin, Cout, CoutPad, H, W;  // input feature map
@@ -71,7 +71,7 @@ struct ConvPtrs {
 template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST, int MAXP>
 __global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (UP ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
-    constexpr int CC = chunk_channels(BM);
+    constexpr int CC = chunk_channels(BM, BN);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -273,16 +273,15 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         // through registers because it is scaled by the style and masked at the image border on the way in.
         constexpr int RPI = 256 / BM;              // weight rows (BM floats) per 1-KiB DMA instruction
         constexpr int LPR = 64 / RPI;              // lanes per row
-        constexpr int A_INSTR = 9 * CC / RPI;      // DMA instructions per tile
+        constexpr int A_INSTR = (9 * CC + RPI - 1) / RPI;  // DMA instructions per tile (the last one may be partial)
         constexpr int A_PER_WAVE = (A_INSTR + 3) / 4;
-        static_assert((9 * CC) % RPI == 0, "weight tile must be a whole number of DMA instructions");
         int a_goff[A_PER_WAVE];
 #pragma unroll
         for (int k = 0; k < A_PER_WAVE; ++k) {
             const int row = (wave + 4 * k) * RPI + lane / LPR;
             const int col = (lane % LPR) * 4;
             const int tap = row / CC, c = row - tap * CC;
-            a_goff[k] = (tap * g.Cin + c) * g.CoutPad + col;
+            a_goff[k] = row < 9 * CC ? (tap * g.Cin + c) * g.CoutPad + col : -1;  // -1: lane past the tile, masked off
         }
         auto issue_dma = [&](int chunk, int buf) {
             const float* __restrict__ wbase = p.wp + (size_t)chunk * CC * g.CoutPad + m0;  // uniform
@@ -290,7 +289,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
             for (int k = 0; k < A_PER_WAVE; ++k) {
                 const int i = wave + 4 * k;
-                if (i < A_INSTR)
+                if (i < A_INSTR && a_goff[k] >= 0)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(wbase + (unsigned)a_goff[k]),
                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
@@ -503,6 +502,7 @@ struct Plan {
 
 int pad32(int c) { return (c + 31) / 32 * 32; }
 int g_conv_debug = 0;
+int g_conv_cfg = 0;  // tuning key 2: bit0 -> Cout<=64 uses 64x128 (WM 2); bit1 -> Cout<=32 uses 32x512
 
 // Tile-shape selection (host).  BM follows Cout; the pixel tile is a stack of 32-pixel MFMA groups.
 Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
@@ -515,8 +515,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         else pl.bm = 64, pl.wm = 2, pl.bn = 64;
     } else {
         g.GH = h, g.GW = w, g.OH = h, g.OW = w;
-        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 256;
-        else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 256;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = (g_conv_cfg & 2) ? 512 : 256;
+        else if (cout <= 64) pl.bm = 64, pl.wm = (g_conv_cfg & 1) ? 2 : 1, pl.bn = (g_conv_cfg & 1) ? 128 : 256;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
     }
     auto shape = [&](int bn) {
@@ -544,13 +544,13 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         g.PSTRIDE = ni * g.PH * g.PWS;
     };
     shape(pl.bn);
-    if (g.PSTRIDE > 512) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
+    if (g.PSTRIDE > (pl.bn >= 512 ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
         shape(pl.bn);
         pl.fallback = true;
     }
-    const int CC = chunk_channels(pl.bm);
+    const int CC = chunk_channels(pl.bm, pl.bn);
     g.n_chunks = ceil_div(cin, CC);
     g.m_tiles = ceil_div(g.CoutPad, pl.bm);
     g.n_tiles = g.tiles_x * g.tiles_y * g.img_groups;
@@ -584,13 +584,14 @@ int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST>
 int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     if (pl.g.PSTRIDE <= 256) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 1>(pl, ptrs, st);
-    return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
+    if (pl.g.PSTRIDE <= 512 || BN < 512) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
+    return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, (BN >= 512 ? 3 : 2)>(pl, ptrs, st);
 }
 
 template <int BM, int BN, int WM, bool UP>
 int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
-    constexpr int CC = chunk_channels(BM);
-    if (pl.g.PSTRIDE > 512) return MAUA_EINVAL;
+    constexpr int CC = chunk_channels(BM, BN);
+    if (pl.g.PSTRIDE > 768) return MAUA_EINVAL;
     const bool fast = (pl.g.Cin % CC == 0) && (pl.g.CoutPad % BM == 0);
     if (pl.g.lni > 0) return fast ? launch_conv_impl<BM, BN, WM, UP, true, true>(pl, ptrs, st)
                                   : launch_conv_impl<BM, BN, WM, UP, true, false>(pl, ptrs, st);
@@ -601,6 +602,7 @@ int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 }  // namespace
 
 int maua_conv_debug_set(int v) { g_conv_debug = v; return 0; }
+int maua_conv_cfg_set(int v) { g_conv_cfg = v; return 0; }
 
 extern "C" int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream) {
     if (!w || cout <= 0 || cin <= 0 || ktaps <= 0) return MAUA_EINVAL;
@@ -641,7 +643,9 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
         else if (pl.bm == 32) rc = launch_conv<32, 128, 1, true>(pl, ptrs, st);
         else rc = launch_conv<64, 64, 2, true>(pl, ptrs, st);
     } else {
-        if (pl.bm == 32) rc = launch_conv<32, 256, 1, false>(pl, ptrs, st);
+        if (pl.bm == 32 && pl.bn == 512) rc = launch_conv<32, 512, 1, false>(pl, ptrs, st);
+        else if (pl.bm == 32) rc = launch_conv<32, 256, 1, false>(pl, ptrs, st);
+        else if (pl.bm == 64 && pl.bn == 128) rc = launch_conv<64, 128, 2, false>(pl, ptrs, st);
         else if (pl.bm == 64) rc = launch_conv<64, 256, 1, false>(pl, ptrs, st);
         else rc = launch_conv<128, 128, 2, false>(pl, ptrs, st);
     }

@@ -24,10 +24,12 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--conv-debug", type=int, default=0)
+    ap.add_argument("--conv-cfg", type=int, default=0)
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     lib = _lib.load()
     lib.maua_tuning_set(1, args.conv_debug)
+    lib.maua_tuning_set(2, args.conv_cfg)
     dev = torch.device("cuda:0")
     stream = torch.cuda.Stream(dev)
     sp = stream.cuda_stream
