@@ -104,12 +104,25 @@ def layer_breakdown(g, batch, static, stream):
         blur_bytes = 4 * batch * cout * ((2 * h + 1) ** 2 + (2 * h) ** 2)
         rows.append((f"convs.{2*n}.blur+noise+act", "upfirdn2d_tail", max(t_all - t_up, 1e-6), 16 * 2 * batch * cout * (2 * h) ** 2, blur_bytes))
         mid = g._buf(batch, f"convs.{2*n}", (batch, cout, 2 * h, 2 * h))
-        t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}"), 10, sp)
-        rows.append((f"convs.{2*n+1}", "modconv", t_pl, 2 * cout * cout * 9 * (2 * h) ** 2 * batch, 0))
+        img_in = image
+        rgb_buf = bufs(f"rgb{n}", (batch, 3, 2 * h, 2 * h))
+        is_last = n == g.log_size - 3
+        fuse = dict(module=rgb, s_off=e_rgb["s_off"], skip=img_in, out=rgb_buf, store=not is_last)
+        plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=fuse)
+        fused = bool(fuse.get("done"))  # the generator folds ToRGB into the conv epilogue for <= 64-channel layers
+        conv_flops = 2 * cout * cout * 9 * (2 * h) ** 2 * batch
+        rgb_flops = 2 * cout * 3 * (2 * h) ** 2 * batch
+        if fused:
+            t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=dict(fuse)), 10, sp)
+            rows.append((f"convs.{2*n+1}+to_rgbs.{n} (fused)", "modconv", t_pl, conv_flops + rgb_flops, 0))
+        else:
+            t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}"), 10, sp)
+            rows.append((f"convs.{2*n+1}", "modconv", t_pl, conv_flops, 0))
         out = g._buf(batch, f"convs.{2*n+1}", (batch, cout, 2 * h, 2 * h))
-        o2, img_in = out, image
-        t_rgb = time_calls(lambda: rgb.run(o2, s, e_rgb["s_off"], img_in, bufs(f"rgb{n}", (batch, 3, 2 * h, 2 * h))), 10, sp)
-        rows.append((f"to_rgbs.{n}", "torgb", t_rgb, 2 * cout * 3 * (2 * h) ** 2 * batch, 4 * batch * (cout + 3 + 1) * (2 * h) ** 2))
+        o2 = out
+        if not fused:
+            t_rgb = time_calls(lambda: rgb.run(o2, s, e_rgb["s_off"], img_in, rgb_buf), 10, sp)
+            rows.append((f"to_rgbs.{n}", "torgb", t_rgb, rgb_flops, 4 * batch * (cout + 3 + 1) * (2 * h) ** 2))
         image = g._buf(batch, f"rgbs.{n}", (batch, 3, 2 * h, 2 * h))
         li += 3
     return rows

@@ -94,6 +94,18 @@ int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_s
                         const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                         float* ws, void* stream);
 
+/* Plain StyledConv with the following ToRGB (models/stylegan2.py:338-343 then :356-365) fused into its epilogue: the
+ * activated feature map is reduced to RGB while it is still in registers (all channels of a pixel sit in one wave).
+ * Only for layers whose channels fit one weight tile in a single wave row (cout <= 64); returns MAUA_ENOSYS otherwise
+ * (the caller then runs maua_modconv3x3_f32 + maua_torgb_f32).  rgb_s = the ToRGB layer's styles [B, s_stride] (same
+ * stride as s).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
+int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
+                              float* y, int batch, int cin, int cout, int h, int w, float wscale,
+                              const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
+                              const float* rgb_w, const float* rgb_s, float rgb_wscale, const float* rgb_bias,
+                              const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,
+                              void* stream);
+
 /* ToRGB (models/stylegan2.py:356-365): 1x1 modulated conv without demod + bias + 2x FIR-upsampled skip
  * (Upsample :34-52, kernel k4 = 4x4 taps in device memory, pad (2,1)).  skip == NULL: no skip.
  *   y[b,c,Y,X] = sum_i (wscale * w[c,i] * s[b,i]) * x[b,i,Y,X] + bias[c] + up2(skip)[b,c,Y,X] */

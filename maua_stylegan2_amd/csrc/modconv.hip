@@ -48,6 +48,8 @@ struct ConvGeom {
     int fuse_act;
     int64_t noise_batch_stride;
     int64_t ws_slab;  // floats per split slab
+    int rgb;          // fused ToRGB epilogue: 0 off, 1 on, 2 on and the feature map itself is not stored
+    float rgb_wscale;
     int debug;        // ablation switches (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads
 };
 
@@ -61,6 +63,13 @@ struct ConvPtrs {
     const float* bias;
     float* y;
     float* ws;
+    // fused ToRGB (models/stylegan2.py:346-365) — only for single-M-tile plain configs
+    const float* rgb_w;     // [3, Cout]
+    const float* rgb_s;     // styles of the ToRGB layer, [B, s_stride] (already offset to the layer's slice)
+    const float* rgb_bias;  // [3]
+    const float* rgb_skip;  // [B, 3, H/2, W/2] or null
+    const float* rgb_k4;    // 4x4 upsample taps
+    float* rgb_out;         // [B, 3, H, W]
 };
 
 // UP = false : plain 3x3, pad 1.           per wave: TM x TN MFMA tiles.
@@ -377,6 +386,13 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             }
             Eg[i] = gain;
             Eb[i] = bias;
+            if (!UP && WM == 1 && g.rgb) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    lds[(2 + c) * BM + i] = (o < g.Cout && b0 < g.B)
+                                                ? g.rgb_wscale * p.rgb_w[c * g.Cout + o] * p.rgb_s[b0 * g.s_stride + o]
+                                                : 0.f;
+            }
         }
         __syncthreads();
     }
@@ -407,6 +423,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                     nzv[px] = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox + px];
             }
             float* obase = outp + (size_t)b * g.Cout * plane_out + (size_t)oy * g.OW + ox;
+            float rgbp[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
@@ -429,6 +446,11 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                         v[px] = acc[mt][n * NPH + (UP ? py * 2 + px : 0)][e] * gain;
                         if (!to_ws && g.fuse_act) v[px] = lrelu_gain(v[px] + nzv[px] + bias);
                     }
+                    if (!UP && WM == 1 && !MULTI && g.rgb) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) rgbp[c] = fmaf(lds[(2 + c) * BM + ol], v[0], rgbp[c]);
+                        if (g.rgb == 2) continue;  // last layer: nothing downstream reads the feature map
+                    }
                     if ((g.debug & 1) && v[0] != 123.456f) continue;
                     float* dst = obase + (size_t)o * plane_out;
                     if (UP) {
@@ -436,6 +458,51 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                         else if (ok0 && o < g.Cout) dst[0] = v[0];
                     } else if (ok0 && o < g.Cout) {
                         dst[0] = v[0];
+                    }
+                }
+            }
+            if (!UP && WM == 1 && !MULTI && g.rgb) {
+                // all channels of a pixel live in one wave: lanes l and l+32 hold the two halves of the channel set
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgbp[c] += __shfl_xor(rgbp[c], 32, 64);
+                if (hi == 0 && ok0) {
+                    // upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, ox): exactly two source rows / columns are live,
+                    // iy0 = floor((oy-1)/2), iy0+1 (taps k4[1]/k4[3] for even oy, k4[0]/k4[2] for odd) — all 12 loads
+                    // (3 channels x 2 x 2) are unconditional (clamped) and in flight together, masked by weight 0.
+                    const int sh = g.H >> 1, sw = g.W >> 1;
+                    const int iy0 = (oy - 1) >> 1, ix0 = (ox - 1) >> 1;
+                    const int ty_ = (oy & 1) ? 2 : 3, tx_ = (ox & 1) ? 2 : 3;  // tap index of the FIRST live row / column
+                    float wy[2], wx[2];
+                    int ry[2], rx[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int yy = iy0 + q, xx = ix0 + q;
+                        ry[q] = min(max(yy, 0), sh - 1), rx[q] = min(max(xx, 0), sw - 1);
+                        wy[q] = (yy >= 0 && yy < sh) ? 1.f : 0.f;
+                        wx[q] = (xx >= 0 && xx < sw) ? 1.f : 0.f;
+                    }
+                    float wgt[2][2];
+#pragma unroll
+                    for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                        for (int qx = 0; qx < 2; ++qx)
+                            wgt[qy][qx] = p.rgb_skip ? p.rgb_k4[(ty_ - 2 * qy) * 4 + (tx_ - 2 * qx)] * wy[qy] * wx[qx] : 0.f;
+                    float sv[3][2][2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                            for (int qx = 0; qx < 2; ++qx)
+                                sv[c][qy][qx] = p.rgb_skip ? p.rgb_skip[(((size_t)b * 3 + c) * sh + ry[qy]) * sw + rx[qx]] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float val = rgbp[c] + p.rgb_bias[c];
+#pragma unroll
+                        for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                            for (int qx = 0; qx < 2; ++qx) val = fmaf(wgt[qy][qx], sv[c][qy][qx], val);
+                        p.rgb_out[((size_t)b * 3 + c) * plane_out + (size_t)oy * g.OW + ox] = val;
                     }
                 }
             }
@@ -621,10 +688,16 @@ extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, i
     return pl.g.splits > 1 ? pl.g.ws_slab * pl.g.splits : 0;
 }
 
-extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
-                                   float* y, int batch, int cin, int cout, int h, int w, int up, float wscale,
-                                   int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
-                                   const float* bias, float* ws, void* stream) {
+namespace {
+struct RgbArgs {
+    const float* w; const float* s; const float* bias; const float* skip; const float* k4; float* out;
+    float wscale; int store_features;
+};
+
+int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, int batch,
+                 int cin, int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise,
+                 int64_t noise_batch_stride, const float* noise_w, const float* bias, float* ws, const RgbArgs* rgb,
+                 void* stream) {
     if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     if (noise && !noise_w) return MAUA_EINVAL;
     if ((int64_t)batch * cin * h * w > 0x7fffffffLL) return MAUA_EINVAL;  // 32-bit patch offsets
@@ -635,7 +708,20 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
     pl.g.fuse_act = fuse_act;
     pl.g.noise_batch_stride = noise_batch_stride;
     pl.g.debug = g_conv_debug;
-    ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws};
+    pl.g.rgb = 0;
+    pl.g.rgb_wscale = 0.f;
+    ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (rgb) {
+        // fusable only when one workgroup holds every channel of its pixels in a single wave row (BM >= Cout, WM == 1),
+        // no split-K, one image per tile, the tail fused
+        const bool ok = !up && fuse_act && pl.wm == 1 && pl.g.m_tiles == 1 && pl.g.splits == 1 && pl.g.lni == 0 &&
+                        rgb->w && rgb->s && rgb->bias && rgb->out && (!rgb->skip || (rgb->k4 && !(h & 1) && !(w & 1)));
+        if (!ok) return MAUA_ENOSYS;
+        pl.g.rgb = rgb->store_features ? 1 : 2;
+        pl.g.rgb_wscale = rgb->wscale;
+        ptrs.rgb_w = rgb->w, ptrs.rgb_s = rgb->s, ptrs.rgb_bias = rgb->bias, ptrs.rgb_skip = rgb->skip;
+        ptrs.rgb_k4 = rgb->k4, ptrs.rgb_out = rgb->out;
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (up) {
@@ -659,4 +745,24 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
         MAUA_LAUNCH_CHECK();
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
+                                   float* y, int batch, int cin, int cout, int h, int w, int up, float wscale,
+                                   int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                   const float* bias, float* ws, void* stream) {
+    return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, up, wscale, fuse_act, noise, noise_batch_stride,
+                        noise_w, bias, ws, nullptr, stream);
+}
+
+extern "C" int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
+                                         float* y, int batch, int cin, int cout, int h, int w, float wscale,
+                                         const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                         const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
+                                         const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out,
+                                         int store_features, void* stream) {
+    RgbArgs rgb{rgb_w, rgb_s, rgb_bias, rgb_skip, rgb_k4, rgb_out, rgb_wscale, store_features};
+    return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, 0, wscale, 1, noise, noise_batch_stride, noise_w,
+                        bias, nullptr, &rgb, stream);
 }

@@ -254,8 +254,10 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
         self.manipulation = ManipulationLayer(layerID)
 
-    def run(self, x, s, s_off, d, noise, bufs, tag):
-        """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers."""
+    def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None):
+        """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers.
+        ``rgb`` (plain layers only): dict(module=ToRGB, s_off, skip, out, store) — fold the following ToRGB into the conv
+        epilogue when the layer qualifies; on success ``rgb["done"]`` is set and ``rgb["out"]`` holds the image."""
         lib = _lib.load()
         conv = self.conv
         b, cin, h, w = x.shape
@@ -265,6 +267,26 @@ class StyledConv(nn.Module):
             noise = _lib.require_cuda(noise, "noise")
         if not conv.upsample:
             out = bufs(tag, (b, conv.out_channel, h, w))
+            if rgb is not None and conv.out_channel <= 64 and n_ws == 0:
+                t = rgb["module"]
+                skip = rgb["skip"]
+                fusable = skip is None or (tuple(t.upsample.kernel.shape) == (4, 4) and t.upsample.factor == 2
+                                           and skip.shape[2] * 2 == h and skip.shape[3] * 2 == w)
+                if fusable:
+                    wp, _ = conv.packed()
+                    nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
+                    rc = lib.maua_styledconv_torgb_f32(
+                        x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b,
+                        cin, conv.out_channel, h, w, float(conv.scale), _lib.ptr(noise), nstride,
+                        self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
+                        s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), t.bias.data_ptr(), _lib.ptr(skip),
+                        _lib.ptr(t.upsample.kernel) if skip is not None else None, rgb["out"].data_ptr(),
+                        int(rgb.get("store", True)), _lib.stream_ptr(x.device))
+                    if rc == 0:
+                        rgb["done"] = True
+                        return out
+                    if rc != -38:  # MAUA_ENOSYS = layer shape not fusable -> two launches below
+                        _lib.check(rc, "maua_styledconv_torgb_f32")
             return conv.run(x, s, s_off, d, out, ws, fuse_act=True, noise=noise, noise_w=self.noise.weight,
                             bias=self.activate.bias)
         raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
@@ -562,12 +584,25 @@ class Generator(nn.Module):
             out = up.manipulation(out, bends)
             acts.append(out)
             li += 1
+            # fold ToRGB into the conv epilogue where the layer qualifies (<= 64 channels) and nothing needs the feature
+            # map in between (a bend on this layer id would); the last layer then never writes its feature map at all
+            layer_id = 2 * n + 3
+            bent = any(bd["layer"] == layer_id for bd in bends)
+            rgb_buf = bufs(f"rgbs.{n}", (batch, 3, out.shape[2], out.shape[3]))
+            fuse = None
+            if not bent and not getattr(self, "disable_rgb_fusion", False):
+                is_last = n == self.log_size - 3
+                fuse = dict(module=rgb, s_off=ent[li + 1]["s_off"], skip=image, out=rgb_buf,
+                            store=(not is_last) or want_acts)
             out = plain.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 2, out.shape[2], out.shape[3]),
-                            bufs, f"convs.{2 * n + 1}")
+                            bufs, f"convs.{2 * n + 1}", rgb=fuse)
             out = plain.manipulation(out, bends)
             acts.append(out)
             li += 1
-            image = rgb.run(out, s, ent[li]["s_off"], image, bufs(f"rgbs.{n}", (batch, 3) + tuple(out.shape[2:])))
+            if fuse is not None and fuse.get("done"):
+                image = rgb_buf
+            else:
+                image = rgb.run(out, s, ent[li]["s_off"], image, rgb_buf)
             li += 1
         lat_out = None
         if want_latents:

@@ -140,3 +140,44 @@ def test_oracle_audio_features_are_sane():
     # a pure A4 sine lands in pitch class A (index 9 with C-based chroma)
     tone = np.sin(2 * np.pi * 440.0 * np.arange(sr) / sr).astype(np.float32)
     assert int(np.argmax(signal_oracle.chroma_stft(tone, sr).mean(axis=1))) == 9
+
+
+def test_c_restatement_matches_golden(golden):
+    """oracle/c/ops_ref.c (scalar loops, independent of the conv2d-based oracle) against the reference's outputs."""
+    import ctypes
+    import os
+    import subprocess
+
+    from conftest import REPO
+
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=True, capture_output=True)
+    lib = ctypes.CDLL(os.path.join(REPO, "oracle", "c", "libops_ref.so"))
+    fp = ctypes.POINTER(ctypes.c_float)
+    g = golden("ops_upfirdn2d.npz")
+    for name in g["cases"]:
+        up, down, p0, p1 = (int(v) for v in g[f"{name}.cfg"])
+        x = np.ascontiguousarray(g[f"{name}.x"], dtype=np.float32)
+        k = np.ascontiguousarray(g[f"{name}.k"], dtype=np.float32)
+        want = g[f"{name}.y"]
+        n, c, h, w = x.shape
+        y = np.zeros(want.shape, np.float32)
+        rc = lib.ref_upfirdn2d(x.ctypes.data_as(fp), k.ctypes.data_as(fp), y.ctypes.data_as(fp), n * c, h, w, 1,
+                               k.shape[0], k.shape[1], up, up, down, down, p0, p1, p0, p1)
+        assert rc == 0
+        np.testing.assert_allclose(y, want, atol=1e-5, err_msg=str(name))
+    g = golden("ops_fused_leaky_relu.npz")
+    lib.ref_fused_bias_act.argtypes = [fp, fp, fp, fp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_float, ctypes.c_float]
+    for name in g["cases"]:
+        x = np.ascontiguousarray(g[f"{name}.x"], dtype=np.float32)
+        b = np.ascontiguousarray(g[f"{name}.b"], dtype=np.float32)
+        y = np.zeros_like(x)
+        step = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+        lib.ref_fused_bias_act(x.ctypes.data_as(fp), b.ctypes.data_as(fp), None, y.ctypes.data_as(fp), x.size, b.size,
+                               step, 3, 0, 0.2, 2 ** 0.5)
+        np.testing.assert_allclose(y, g[f"{name}.y"], atol=1e-6)
+    g = golden("postprocess.npz")
+    x = np.ascontiguousarray(g["x"], dtype=np.float32)
+    out = np.zeros(g["y"].shape, np.uint8)
+    lib.ref_frames_to_u8(x.ctypes.data_as(fp), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 1, 4, 8)
+    assert (out == g["y"]).all()
