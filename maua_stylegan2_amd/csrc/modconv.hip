@@ -396,6 +396,24 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         }
         __syncthreads();
     }
+    // every noise value this lane needs, fetched before the first store (loads cannot be hoisted above stores later)
+    float nz_all[TN][NPH];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int sub = wn * TN + n;
+        const int jx = l31 & (SW - 1), jy = l31 >> g.lsw;
+        const int sx = sub & ((1 << g.lnsx) - 1);
+        const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
+        const int b = b0 + (sub >> (g.lnsx + g.lnsy));
+        const int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = UP ? 2 * gx + (ph & 1) : gx;
+            nz_all[n][ph] = 0.f;
+            if (nw != 0.f && b < g.B && gy < g.GH && gx < g.GW && oy < g.OH && ox < g.OW)
+                nz_all[n][ph] = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox];
+        }
+    }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
         const int sub = wn * TN + n;
@@ -417,11 +435,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const bool ok1 = UP && ok0 && (ox + 1 < g.OW);
             float nzv[PXN];
 #pragma unroll
-            for (int px = 0; px < PXN; ++px) {
-                nzv[px] = 0.f;
-                if ((px ? ok1 : ok0) && nw != 0.f)
-                    nzv[px] = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox + px];
-            }
+            for (int px = 0; px < PXN; ++px) nzv[px] = nz_all[n][UP ? py * 2 + px : 0];
             float* obase = outp + (size_t)b * g.Cout * plane_out + (size_t)oy * g.OW + ox;
             float rgbp[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -520,7 +534,13 @@ __global__ __launch_bounds__(256) void reduce_tail_kernel(const float* __restric
     const float nw = (fuse_act && noise) ? noise_w[0] : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += ws[(size_t)s * slab + i];
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {  // 4 independent loads in flight
+            const float a0 = ws[(size_t)s * slab + i], a1 = ws[(size_t)(s + 1) * slab + i];
+            const float a2 = ws[(size_t)(s + 2) * slab + i], a3 = ws[(size_t)(s + 3) * slab + i];
+            v += (a0 + a1) + (a2 + a3);
+        }
+        for (; s < splits; ++s) v += ws[(size_t)s * slab + i];
         const int64_t bc = i / plane;
         const int64_t pix = i - bc * plane;
         const int b = (int)(bc / cout), o = (int)(bc - (int64_t)b * cout);
