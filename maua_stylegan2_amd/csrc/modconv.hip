@@ -173,36 +173,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     f32x4 av[A_VEC_ITERS];
     float pv[MAX_POS][CC];
     constexpr bool one_image = !MULTI;  // every patch position belongs to image b0: styles are block-uniform
-    // per-thread constant part of the weight-tile addresses (FAST): (tap*Cin + c)*CoutPad + col
-    int a_off[A_VEC_ITERS];
-#pragma unroll
-    for (int it = 0; it < A_VEC_ITERS; ++it) {
-        const int f = tid + it * 256;
-        const int row = f / (BM / 4);
-        const int col = (f - row * (BM / 4)) * 4;
-        const int tap = row / CC, c = row - tap * CC;
-        a_off[it] = (f < A_FLOATS / 4) ? (tap * g.Cin + c) * g.CoutPad + col : 0;
-    }
-    auto issue_loads = [&](int chunk) {
+    auto issue_loads = [&](int chunk) {  // generic path only (the FAST path below has its own DMA pipeline)
         const int c0 = chunk * CC;
-        if (FAST) {
-            const float* __restrict__ wbase = p.wp + (size_t)c0 * g.CoutPad + m0;  // uniform
-#pragma unroll
-            for (int it = 0; it < A_VEC_ITERS; ++it)
-                av[it] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)a_off[it]);
-#pragma unroll
-            for (int c = 0; c < CC; ++c) {
-                const float* __restrict__ xbase = p.x + (size_t)(c0 + c) * plane_in;  // uniform
-#pragma unroll
-                for (int i = 0; i < MAX_POS; ++i) pv[i][c] = xbase[(unsigned)src_off[i]];
-            }
-            if (MULTI) {
-#pragma unroll
-                for (int i = 0; i < MAX_POS; ++i)
-#pragma unroll
-                    for (int c = 0; c < CC; ++c) pv[i][c] *= p.s[sb_off[i] + c0 + c];
-            }
-        } else {
+        {
 #pragma unroll
         for (int it = 0; it < A_VEC_ITERS; ++it) {
             const int f = tid + it * 256;  // float4 index in As
@@ -244,7 +217,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int pp = tid + i * 256;
             if (pp < g.PSTRIDE) {
 #pragma unroll
-                for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = pv[i][c] * (FAST ? sc[c] * src_mask[i] : sc[c]);
+                for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = pv[i][c] * sc[c];
             }
         }
     };

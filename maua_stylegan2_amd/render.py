@@ -235,7 +235,10 @@ def render(generator, latents, noise, offset, duration, batch_size, out_size, ou
             if shard is None:
                 shard = th.empty((sharding.max_shard(n_frames, world),) + tuple(u8.shape[1:]), dtype=th.uint8, device=dev)
             shard[first - lo: first - lo + u8.shape[0]].copy_(u8)
-        th.cuda.synchronize(dev)
+        if dev.type == "cuda":
+            th.cuda.synchronize(dev)
+        if shard is None:  # a rank whose block is empty (more ranks than frames) still takes part in the gather
+            shard = th.zeros((sharding.max_shard(n_frames, world), height, width, 3), dtype=th.uint8, device=dev)
         gathered = sharding.gather_frames(shard, n_frames)
         if rank == 0:
             for frame in gathered:
