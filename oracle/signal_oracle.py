@@ -266,3 +266,19 @@ def affine_reflect_warp(x, inv_maps, pads, add_noise=None):
                 wgt = np.where(dy, fy, 1 - fy) * np.where(dx, fx, 1 - fx) * ok
                 out[i] += wgt[None] * canvas[i][:, np.clip(yy, 0, ch - 1), np.clip(xx, 0, cw - 1)]
     return out
+
+
+def rms(y, sr, n_frames, fmin=20, fmax=8000, smooth=180, clip=50, power=6, smf=1.0):
+    """signal.py:76-99: 12th-order Butterworth band-pass (scipy, installed), STFT magnitude -> librosa.feature.rms(S=...)
+    = sqrt(2 * sum_k w_k |S_k|^2 / n_fft^2) with the DC and Nyquist bins halved, then the same envelope post-processing."""
+    y_filt = scipy.signal.sosfilt(scipy.signal.butter(12, [fmin, fmax], "bp", fs=sr, output="sos"), np.asarray(y, dtype=np.float64))
+    n_fft = 2048
+    p = stft_power(y_filt, n_fft, 512)
+    p[0] *= 0.5
+    p[-1] *= 0.5
+    env = np.sqrt(2.0 * p.sum(axis=0) / n_fft ** 2)
+    env = np.clip(resample(env, n_frames), env.min(), env.max())
+    env = torch.from_numpy(env).float()
+    env = gaussian_filter(env, smooth, causal=0.05, smf=smf)
+    env = percentile_clip(env, clip)
+    return env ** power

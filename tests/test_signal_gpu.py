@@ -140,3 +140,32 @@ def test_bends_vs_oracle(gpu):
     got = bend.Rotate(a, h, w)(xd).cpu().numpy()
     np.testing.assert_allclose(got, want, atol=1e-5)
     np.testing.assert_allclose(got[0], x[0], atol=1e-6)
+
+
+def test_rms_envelope_vs_oracle(gpu):
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    sr = 22050
+    y = seeding.synthetic_audio(6.0, sr)
+    want = signal_oracle.rms(y, sr, 180, smooth=10, clip=50, power=2).numpy()
+    got = sig.rms(y, sr, 180, smooth=10, clip=50, power=2)
+    assert got.shape == (180,) and got.device.type == "cpu"
+    np.testing.assert_allclose(got.numpy(), want, atol=5e-3)
+
+
+def test_generate_latents_maps_through_the_mapping_network(gpu):
+    """generate_latents = mapping network (8 x EqualLinear + fused leaky ReLU on the HIP op) applied to z, repeated to
+    n_latent — the evident intent of the reference; checked against the oracle's mapping_network."""
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+    from oracle import stylegan2_oracle as so
+
+    sd = seeding.seeded_state_dict(32, seed=3)
+    g = Generator(32, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(sd)
+    g = g.to(gpu)
+    z = torch.from_numpy(seeding.seeded_array(4, "z", (5, 512)))
+    got = g(z.to(gpu), map_latents=True).cpu()
+    want = so.mapping_network(sd, z)
+    assert got.shape == (5, g.n_latent, 512)
+    np.testing.assert_allclose(got[:, 0].numpy(), want.numpy(), atol=2e-4, rtol=1e-3)
+    assert torch.equal(got[:, 0], got[:, -1])
