@@ -1,46 +1,59 @@
-"""The default audio-reactive plugin (mirror of /root/reference/audioreactive/examples/default.py:6-45):
-low / high onset envelopes drive latent jumps and noise blending, a 12-bin chromagram weights the latent selection.
-The noise tensors stay in HBM (the reference's ``.cpu()`` at :45 exists only because it re-uploads per batch)."""
-import torch as th
+"""Default audio-reactive plugin for the MI355X path.
+
+Behaviour contract = /root/reference/audioreactive/examples/default.py:6-45 (what ``--audioreactive_file`` defaults
+to): two band-limited onset envelopes (bass <= 150 Hz, treble >= 500 Hz) computed once in ``initialize``; latents = the
+12-bin chromagram weighting of the latent selection, smoothed, with onset-driven jumps toward two fixed selection
+entries; noise (scales up to 256 px) = a fast and a slow temporally-filtered Gaussian field cross-faded by the onsets.
+Expressed here through a few small helpers, and everything that is large (the [n_frames,1,h,w] noise fields) is created,
+filtered and left on the HIP device — the reference round-trips it through host memory (``.cpu()`` at :45).
+"""
+import torch
 
 import maua_stylegan2_amd.audioreactive as ar
 
+# band name -> onset-analysis settings (shared: smooth 5, power 2)
+ONSET_BANDS = {
+    "lo_onsets": {"fmax": 150, "clip": 97},
+    "hi_onsets": {"fmin": 500, "clip": 99},
+}
+JUMP_TARGETS = {"hi_onsets": -4, "lo_onsets": -7}  # selection index each band pulls the latents toward
+NOISE_MAX_WIDTH = 256  # wider noise maps stay on the checkpoint's static buffers (get_noise -> None)
+FAST_SIGMA, SLOW_SIGMA = 5, 128
+
+
+def _crossfade(envelope, toward, base):
+    """envelope in [0,1] (broadcast over trailing dims): 1 -> ``toward``, 0 -> ``base``."""
+    return envelope * toward + (1 - envelope) * base
+
 
 def initialize(args):
-    args.lo_onsets = ar.onsets(args.audio, args.sr, args.n_frames, fmax=150, smooth=5, clip=97, power=2)
-    args.hi_onsets = ar.onsets(args.audio, args.sr, args.n_frames, fmin=500, smooth=5, clip=99, power=2)
+    for name, band in ONSET_BANDS.items():
+        setattr(args, name, ar.onsets(args.audio, args.sr, args.n_frames, smooth=5, power=2, **band))
     return args
 
 
 def get_latents(selection, args):
-    chroma = ar.chroma(args.audio, args.sr, args.n_frames)
-    chroma_latents = ar.chroma_weight_latents(chroma, selection)
-    latents = ar.gaussian_filter(chroma_latents, 4)
+    weights = ar.chroma(args.audio, args.sr, args.n_frames)
+    latents = ar.gaussian_filter(ar.chroma_weight_latents(weights, selection), 4)
+    for band in ("hi_onsets", "lo_onsets"):  # treble first, bass on top of it
+        envelope = getattr(args, band)[:, None, None]
+        latents = _crossfade(envelope, selection[[JUMP_TARGETS[band]]], latents)
+    return ar.gaussian_filter(latents, 2, causal=0.2)
 
-    lo_onsets = args.lo_onsets[:, None, None]
-    hi_onsets = args.hi_onsets[:, None, None]
 
-    latents = hi_onsets * selection[[-4]] + (1 - hi_onsets) * latents
-    latents = lo_onsets * selection[[-7]] + (1 - lo_onsets) * latents
-
-    latents = ar.gaussian_filter(latents, 2, causal=0.2)
-    return latents
+def _filtered_field(n_frames, height, width, sigma):
+    return ar.gaussian_filter(torch.randn((n_frames, 1, height, width), device="cuda"), sigma)
 
 
 def get_noise(height, width, scale, num_scales, args):
-    if width > 256:
+    if width > NOISE_MAX_WIDTH:
         return None
-
-    lo_onsets = args.lo_onsets[:, None, None, None].cuda()
-    hi_onsets = args.hi_onsets[:, None, None, None].cuda()
-
-    noise_noisy = ar.gaussian_filter(th.randn((args.n_frames, 1, height, width), device="cuda"), 5)
-    noise = ar.gaussian_filter(th.randn((args.n_frames, 1, height, width), device="cuda"), 128)
-
-    if width < 128:
-        noise = lo_onsets * noise_noisy + (1 - lo_onsets) * noise
-    if width > 32:
-        noise = hi_onsets * noise_noisy + (1 - hi_onsets) * noise
-
-    noise /= noise.std() * 2.5
-    return noise
+    bass = args.lo_onsets[:, None, None, None].cuda()
+    treble = args.hi_onsets[:, None, None, None].cuda()
+    jittery = _filtered_field(args.n_frames, height, width, FAST_SIGMA)
+    field = _filtered_field(args.n_frames, height, width, SLOW_SIGMA)
+    if width < 128:  # coarse scales follow the bass
+        field = _crossfade(bass, jittery, field)
+    if width > 32:  # fine scales follow the treble
+        field = _crossfade(treble, jittery, field)
+    return field / (field.std() * 2.5)

@@ -1,13 +1,16 @@
-"""Audio-reactive video synthesis — drop-in for /root/reference/generate_audiovisual.py on MI355X.
+"""Audio-reactive video synthesis on MI355X — the drop-in for /root/reference/generate_audiovisual.py.
 
-``generate(...)`` keeps the reference's keyword contract (generate_audiovisual.py:59-91), the ``args`` namespace it
-builds and extends (:94-113), the callback protocol (initialize / get_latents / get_noise / get_bends / get_rewrites /
-get_truncation, :115-186) and the CLI flags + ``OVERRIDE`` dict (:234-299).  Underneath: HIP STFT/mel/chroma features,
-HBM-resident latents and noise, hipGraph-replayed generator, uint8 frame epilogue, frame sharding over the GPUs of the
-node when launched with torchrun (``--dataparallel`` is accepted and ignored: there is no DataParallel here).
+What is kept from the reference: the keyword contract and defaults of ``generate(...)``
+(generate_audiovisual.py:59-91), the ``args`` namespace it builds from its own arguments and extends with ``audio``,
+``sr``, ``duration``, ``n_frames`` (:94-113), the callback protocol — ``initialize(args)``, ``get_latents(selection,
+args)``, ``get_noise(height, width, scale, num_scales, args)``, ``get_bends(args)``, ``get_rewrites(args)``,
+``get_truncation(args)`` (:115-186) — the CLI flags and the plugin file's ``OVERRIDE`` dict (:234-299), and the side
+effects ``workspace/last-latents.npy`` / ``output/<track>_<ckpt>_<id>.mp4``.
 
-Existing plugin files written for the reference (``import audioreactive as ar``) work unchanged because importing this
-module registers ``audioreactive`` / ``render`` / ``models.stylegan2`` / ``op`` aliases for this package's mirrors.
+What is different: features come from HIP STFT/mel/chroma kernels, latents and noise stay in HBM, the generator is
+hipGraph-replayed, frames leave as uint8, and under ``torchrun`` every GPU renders a contiguous shard of the frames
+(``--dataparallel`` is accepted and ignored).  Importing this module aliases ``audioreactive``, ``render``,
+``models.stylegan2`` and ``op`` to this package's mirrors so unmodified reference plugin files run.
 """
 import argparse
 import gc
@@ -27,13 +30,43 @@ from . import audioreactive as ar
 from . import render, sharding
 from .models.stylegan2 import Generator
 
+CALLBACK_NAMES = ("initialize", "get_latents", "get_noise", "get_bends", "get_rewrites", "get_truncation")
+
+# (flag, argparse keyword arguments) — the reference's 24 flags with their defaults (generate_audiovisual.py:236-259)
+CLI_FLAGS = (
+    ("--ckpt", dict(type=str)),
+    ("--audio_file", dict(type=str)),
+    ("--audioreactive_file", dict(type=str, default="audioreactive/examples/default.py")),
+    ("--output_dir", dict(type=str, default="./output")),
+    ("--offset", dict(type=float, default=0)),
+    ("--duration", dict(type=float, default=-1, help="length of rendered video in seconds")),
+    ("--latent_file", dict(type=str, default=None)),
+    ("--shuffle_latents", dict(action="store_true")),
+    ("--G_res", dict(type=int, default=1024)),
+    ("--out_size", dict(type=int, default=1024, help="rendered video size. Options: 512, 1024, 1920")),
+    ("--fps", dict(type=int, default=30)),
+    ("--latent_count", dict(type=int, default=12)),
+    ("--batch", dict(type=int, default=8)),
+    ("--dataparallel", dict(action="store_true")),
+    ("--truncation", dict(type=float, default=1.0)),
+    ("--stylegan1", dict(action="store_true")),
+    ("--noconst", dict(action="store_true")),
+    ("--latent_dim", dict(type=int, default=512)),
+    ("--n_mlp", dict(type=int, default=8)),
+    ("--channel_multiplier", dict(type=int, default=2)),
+    ("--randomize_noise", dict(action="store_true")),
+    ("--base_res_factor", dict(type=float, default=1)),
+    ("--ffmpeg_preset", dict(type=str, default="slow")),
+    ("--output_file", dict(type=str, default=None)),
+)
+
 
 def _install_aliases():
     from . import models, op
     from .models import stylegan2
 
-    for name, mod in [("audioreactive", ar), ("render", render), ("op", op), ("models", models),
-                      ("models.stylegan2", stylegan2)]:
+    for name, mod in (("audioreactive", ar), ("render", render), ("op", op), ("models", models),
+                      ("models.stylegan2", stylegan2)):
         sys.modules.setdefault(name, mod)
 
 
@@ -41,25 +74,59 @@ _install_aliases()
 
 
 def get_noise_range(out_size, generator_resolution, is_stylegan1):
-    """Number of noise scales for an output size / generator resolution (reference :22-34)."""
-    log_max_res = int(np.log2(out_size))
-    log_min_res = 2 + (log_max_res - int(np.log2(generator_resolution)))
+    """(first scale, one-past-last scale, scale -> log2 side) for an output size / generator resolution.
+    StyleGAN2 has two noise maps per resolution above 4 px and one at 4 px (reference :22-34)."""
+    top = int(np.log2(out_size))
+    bottom = 2 + (top - int(np.log2(generator_resolution)))
     if is_stylegan1:
-        return log_min_res, log_max_res + 1, (lambda x: x)
-    return 2 * log_min_res + 1, 2 * (log_max_res + 1), (lambda x: int(x / 2))
+        return bottom, top + 1, (lambda s: s)
+    return 2 * bottom + 1, 2 * (top + 1), (lambda s: int(s / 2))
 
 
 def load_generator(ckpt, is_stylegan1, G_res, out_size, noconst, latent_dim, n_mlp, channel_multiplier, dataparallel,
                    base_res_factor):
-    """Reference :37-56.  Rank 0 reads the checkpoint; other ranks receive the weights over RCCL."""
+    """Reference :37-56.  Only rank 0 reads the checkpoint; the other ranks receive the weights over RCCL."""
     if is_stylegan1:
         raise NotImplementedError("--stylegan1: only the StyleGAN2 generator is built (SURVEY.md §2 row 13)")
-    rank, world = sharding.rank_world()
+    rank, _ = sharding.rank_world()
     generator = Generator(G_res, latent_dim, n_mlp, channel_multiplier=channel_multiplier, constant_input=not noconst,
                           checkpoint=ckpt if rank == 0 else None, output_size=out_size,
                           base_res_factor=base_res_factor).cuda()
-    sharding.broadcast_module(generator)
-    return generator.eval()
+    return sharding.broadcast_module(generator).eval()
+
+
+def _noise_sides(out_size):
+    """(height multiplier, width multiplier) of the noise maps for portrait / landscape HD output (reference :150-151)."""
+    return (2 if out_size == 1080 else 1), (2 if out_size == 1920 else 1)
+
+
+def _collect_noise(get_noise, args, out_size, G_res, stylegan1):
+    first, stop, log_side = get_noise_range(out_size, G_res, stylegan1)
+    mul_h, mul_w = _noise_sides(out_size)
+    maps = []
+    for scale in range(first, stop):
+        side = 2 ** log_side(scale)
+        nz = get_noise(height=mul_h * side, width=mul_w * side, scale=scale - first, num_scales=stop - first, args=args)
+        if nz is not None:
+            print(list(nz.shape), f"amplitude={nz.std()}")
+        maps.append(nz)
+        gc.collect()
+    return maps
+
+
+def _share_from_rank0(latents, noise, truncation, bends):
+    """One process per GPU: every rank ran the callbacks (they may draw random numbers); rank 0's results win."""
+    def bc(t):
+        return sharding.broadcast_tensor(t.cuda().float().contiguous())
+
+    latents = bc(latents)
+    noise = [None if nz is None else bc(nz) for nz in noise]
+    if not isinstance(truncation, float):
+        truncation = bc(truncation)
+    for bend in bends:
+        if "modulation" in bend:
+            bend["modulation"] = bc(bend["modulation"])
+    return latents, noise, truncation
 
 
 def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None, get_bends=None, get_rewrites=None,
@@ -68,150 +135,105 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
              latent_count=12, batch=8, dataparallel=False, truncation=1.0, stylegan1=False, noconst=False,
              latent_dim=512, n_mlp=8, channel_multiplier=2, randomize_noise=False, ffmpeg_preset="slow",
              base_res_factor=1, output_file=None, args=None):
-    if args is None:  # called directly (notebook): build the namespace from the local variables, as the reference does
-        kwargs = locals()
-        args = argparse.Namespace()
-        for k, v in kwargs.items():
-            setattr(args, k, v)
+    if args is None:  # direct (notebook) call: the namespace is this call's own arguments, as in the reference (:94-98)
+        args = argparse.Namespace(**{k: v for k, v in locals().items() if k != "args"})
+        args.args = None
 
-    ar.set_SMF(args.fps / 30)  # smoothing independent of frame rate
-    time_taken = time.time()
+    started = time.time()
     th.set_grad_enabled(False)
+    ar.set_SMF(args.fps / 30)  # temporal smoothing independent of the frame rate
 
-    audio, sr, duration = ar.load_audio(audio_file, offset, duration)
-    args.audio = audio
-    args.sr = sr
-    n_frames = int(round(duration * fps))
+    args.audio, args.sr, duration = ar.load_audio(audio_file, offset, duration)
     args.duration = duration
-    args.n_frames = n_frames
-
+    args.n_frames = n_frames = int(round(duration * fps))
     if initialize is not None:
         args = initialize(args)
 
     from .audioreactive.examples import default as default_plugin
 
-    print("\ngenerating latents...")
-    if get_latents is None:
-        get_latents = default_plugin.get_latents
-    if latent_file is not None:
-        latent_selection = ar.load_latents(latent_file)
-    else:
-        latent_selection = ar.generate_latents(args.latent_count, ckpt, G_res, noconst, latent_dim, n_mlp, channel_multiplier)
-        latent_selection = sharding.broadcast_tensor(latent_selection.cuda()).cpu()
-    if shuffle_latents:
-        random_indices = random.sample(range(len(latent_selection)), len(latent_selection))
-        latent_selection = latent_selection[random_indices]
-    os.makedirs("workspace", exist_ok=True)
-    np.save("workspace/last-latents.npy", latent_selection.numpy())
+    get_latents = get_latents or default_plugin.get_latents
+    get_noise = get_noise or default_plugin.get_noise
 
-    latents = get_latents(selection=latent_selection, args=args)
+    print("\ngenerating latents...")
+    if latent_file is not None:
+        selection = ar.load_latents(latent_file)
+    else:
+        selection = ar.generate_latents(args.latent_count, ckpt, G_res, noconst, latent_dim, n_mlp, channel_multiplier)
+        selection = sharding.broadcast_tensor(selection.cuda()).cpu()
+    if shuffle_latents:
+        selection = selection[random.sample(range(len(selection)), len(selection))]
+    os.makedirs("workspace", exist_ok=True)
+    np.save("workspace/last-latents.npy", selection.numpy())
+    latents = get_latents(selection=selection, args=args)
     print(f"{list(latents.shape)} amplitude={latents.std()}\n")
 
     print("generating noise...")
-    if get_noise is None:
-        get_noise = default_plugin.get_noise
-    noise = []
-    range_min, range_max, exponent = get_noise_range(out_size, G_res, stylegan1)
-    for scale in range(range_min, range_max):
-        h = (2 if out_size == 1080 else 1) * 2 ** exponent(scale)
-        w = (2 if out_size == 1920 else 1) * 2 ** exponent(scale)
-        noise.append(get_noise(height=h, width=w, scale=scale - range_min, num_scales=range_max - range_min, args=args))
-        if noise[-1] is not None:
-            print(list(noise[-1].shape), f"amplitude={noise[-1].std()}")
-        gc.collect()
+    noise = _collect_noise(get_noise, args, out_size, G_res, stylegan1)
     print()
 
+    bends, rewrites = [], {}
     if get_bends is not None:
         print("generating network bends...")
         bends = get_bends(args=args)
-    else:
-        bends = []
     if get_rewrites is not None:
         print("generating model rewrites...")
         rewrites = get_rewrites(args=args)
-    else:
-        rewrites = {}
     if get_truncation is not None:
         print("generating truncation...")
         truncation = get_truncation(args=args)
     else:
         truncation = float(truncation)
 
-    # one process per GPU: callbacks run on every rank (they may draw random numbers), rank 0's results win
     if sharding.rank_world()[1] > 1:
-        latents = sharding.broadcast_tensor(latents.cuda().float().contiguous())
-        noise = [None if nz is None else sharding.broadcast_tensor(nz.cuda().float().contiguous()) for nz in noise]
-        if not isinstance(truncation, float):
-            truncation = sharding.broadcast_tensor(truncation.cuda().float().contiguous())
-        for bend in bends:
-            if "modulation" in bend:
-                bend["modulation"] = sharding.broadcast_tensor(bend["modulation"].cuda().float().contiguous())
+        latents, noise, truncation = _share_from_rank0(latents, noise, truncation, bends)
 
     gc.collect()
     generator = load_generator(ckpt=ckpt, is_stylegan1=stylegan1, G_res=G_res, out_size=out_size, noconst=noconst,
                                latent_dim=latent_dim, n_mlp=n_mlp, channel_multiplier=channel_multiplier,
                                dataparallel=dataparallel, base_res_factor=base_res_factor)
-    print(f"\npreprocessing took {time.time() - time_taken:.2f}s\n")
+    print(f"\npreprocessing took {time.time() - started:.2f}s\n")
 
     print(f"rendering {n_frames} frames...")
     if output_file is None:
-        checkpoint_title = str(ckpt).split("/")[-1].split(".")[0].lower()
-        track_title = audio_file.split("/")[-1].split(".")[0].lower()
-        output_file = f"{output_dir}/{track_title}_{checkpoint_title}_{uuid.uuid4().hex[:8]}.mp4"
+        stem = lambda path: str(path).split("/")[-1].split(".")[0].lower()  # noqa: E731
+        output_file = f"{output_dir}/{stem(audio_file)}_{stem(ckpt)}_{uuid.uuid4().hex[:8]}.mp4"
     t0 = time.time()
-    n_written = render.render(generator=generator, latents=latents, noise=noise, audio_file=audio_file, offset=offset,
-                              duration=duration, batch_size=batch, truncation=truncation, bends=bends, rewrites=rewrites,
-                              out_size=out_size, output_file=output_file, randomize_noise=randomize_noise,
-                              ffmpeg_preset=ffmpeg_preset)
-    dt = time.time() - t0
-    print(f"\nrendered {n_written} frames in {dt:.2f}s ({n_written / max(dt, 1e-9):.1f} frames/s)")
-    print(f"total time taken: {(time.time() - time_taken)/60:.2f} minutes")
+    written = render.render(generator=generator, latents=latents, noise=noise, audio_file=audio_file, offset=offset,
+                            duration=duration, batch_size=batch, truncation=truncation, bends=bends, rewrites=rewrites,
+                            out_size=out_size, output_file=output_file, randomize_noise=randomize_noise,
+                            ffmpeg_preset=ffmpeg_preset)
+    dt = max(time.time() - t0, 1e-9)
+    print(f"\nrendered {written} frames in {dt:.2f}s ({written / dt:.1f} frames/s)")
+    print(f"total time taken: {(time.time() - started) / 60:.2f} minutes")
     return output_file
 
 
 def load_plugin(audioreactive_file):
-    """Reference :262-292: resolve the six optional callbacks and the OVERRIDE dict from a plugin file."""
+    """Import a plugin file (path or dotted module) and pick out the optional callbacks and its ``OVERRIDE`` dict
+    (reference :262-292: a missing callback falls back to the default, any other import error is fatal)."""
     if os.path.exists(audioreactive_file):
         spec = importlib.util.spec_from_file_location("maua_audioreactive_plugin", audioreactive_file)
         module = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(module)
     else:
         module = importlib.import_module(audioreactive_file.replace(".py", "").replace("/", "."))
-    funcs = {}
-    for func in ["initialize", "get_latents", "get_noise", "get_bends", "get_rewrites", "get_truncation"]:
-        funcs[func] = getattr(module, func, None)
-        if funcs[func] is None:
-            print(f"No '{func}' function found in --audioreactive_file, using default...")
-    return funcs, dict(getattr(module, "OVERRIDE", {}))
+    callbacks = {}
+    for name in CALLBACK_NAMES:
+        callbacks[name] = getattr(module, name, None)
+        if callbacks[name] is None:
+            print(f"No '{name}' function found in --audioreactive_file, using default...")
+    return callbacks, dict(getattr(module, "OVERRIDE", {}))
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    for flag, kwargs in CLI_FLAGS:
+        parser.add_argument(flag, **kwargs)
+    return parser
 
 
 def main(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--ckpt", type=str)
-    parser.add_argument("--audio_file", type=str)
-    parser.add_argument("--audioreactive_file", type=str, default="audioreactive/examples/default.py")
-    parser.add_argument("--output_dir", type=str, default="./output")
-    parser.add_argument("--offset", type=float, default=0)
-    parser.add_argument("--duration", type=float, default=-1, help="length of rendered video in seconds")
-    parser.add_argument("--latent_file", type=str, default=None)
-    parser.add_argument("--shuffle_latents", action="store_true")
-    parser.add_argument("--G_res", type=int, default=1024)
-    parser.add_argument("--out_size", type=int, default=1024, help="rendered video size. Options: 512, 1024, 1920")
-    parser.add_argument("--fps", type=int, default=30)
-    parser.add_argument("--latent_count", type=int, default=12)
-    parser.add_argument("--batch", type=int, default=8)
-    parser.add_argument("--dataparallel", action="store_true")
-    parser.add_argument("--truncation", type=float, default=1.0)
-    parser.add_argument("--stylegan1", action="store_true")
-    parser.add_argument("--noconst", action="store_true")
-    parser.add_argument("--latent_dim", type=int, default=512)
-    parser.add_argument("--n_mlp", type=int, default=8)
-    parser.add_argument("--channel_multiplier", type=int, default=2)
-    parser.add_argument("--randomize_noise", action="store_true")
-    parser.add_argument("--base_res_factor", type=float, default=1)
-    parser.add_argument("--ffmpeg_preset", type=str, default="slow")
-    parser.add_argument("--output_file", type=str, default=None)
-    args = parser.parse_args(argv)
+    args = build_parser().parse_args(argv)
     os.makedirs(args.output_dir, exist_ok=True)
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not th.distributed.is_initialized():
@@ -219,22 +241,22 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         th.distributed.init_process_group("nccl")
 
-    plugin = args.audioreactive_file
-    if plugin == "audioreactive/examples/default.py" and not os.path.exists(plugin):
-        plugin = os.path.join(os.path.dirname(os.path.abspath(__file__)), "audioreactive", "examples", "default.py")
+    plugin_path = args.audioreactive_file
+    if not os.path.exists(plugin_path) and plugin_path == build_parser().get_default("audioreactive_file"):
+        plugin_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "audioreactive", "examples", "default.py")
     try:
-        funcs, override = load_plugin(plugin)
+        callbacks, override = load_plugin(plugin_path)
     except Exception:
         print("Error while loading --audioreactive_file...")
         traceback.print_exc()
         sys.exit(1)
-    arg_dict = vars(args).copy()
-    for arg, val in override.items():
-        arg_dict[arg] = val
-        setattr(args, arg, val)
-    ckpt = arg_dict.pop("ckpt", None)
-    audio_file = arg_dict.pop("audio_file", None)
-    generate(ckpt=ckpt, audio_file=audio_file, **funcs, **arg_dict, args=args)
+
+    settings = vars(args).copy()
+    for key, value in override.items():  # the plugin's OVERRIDE dict beats the command line
+        settings[key] = value
+        setattr(args, key, value)
+    ckpt, audio_file = settings.pop("ckpt", None), settings.pop("audio_file", None)
+    generate(ckpt=ckpt, audio_file=audio_file, **callbacks, **settings, args=args)
 
 
 if __name__ == "__main__":
