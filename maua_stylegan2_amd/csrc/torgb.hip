@@ -142,8 +142,11 @@ extern "C" int maua_torgb_f32(const float* x, const float* w, const float* s, in
     const int vec = (wdt % 4 == 0) ? 4 : 1;      // a 4-pixel group must stay inside one row
     if (skip && (!k4 || (h & 1) || (wdt & 1))) return MAUA_EINVAL;
     const int quads = h * wdt / vec;
+    // Small planes are latency bound (a 512-deep channel loop is 64 dependent trips): trade pixel groups per workgroup
+    // for channel slices until the grid has ~512 workgroups or a slice is down to 8 channels.
     int qpb = 256, ks_log2 = 0;
-    while (qpb > 4 && qpb / 2 >= quads) qpb >>= 1, ++ks_log2;
+    while (qpb > 4 && (qpb / 2 >= quads || ((int64_t)ceil_div(quads, qpb) * batch < 512 && (cin >> ks_log2) > 8)))
+        qpb >>= 1, ++ks_log2;
     const int ks = 1 << ks_log2;
     const size_t lds = ((size_t)((3 * cin + 3) & ~3) + (ks > 1 ? (size_t)ks * qpb * 12 : 0)) * sizeof(float);
     if (vec == 4)

@@ -144,3 +144,26 @@ def test_frames_to_u8(gpu, golden):
     out = torch.empty((1, 4, 8, 3), dtype=torch.uint8, device=gpu)
     _lib.check(_lib.load().maua_frames_to_u8(x.data_ptr(), out.data_ptr(), 1, 4, 8, _lib.stream_ptr()), "u8")
     assert (out.cpu().numpy() == g["y"]).all()
+
+
+def test_empty_and_degenerate_inputs(gpu):
+    """Edge cases: empty batch, 1x1 planes, a single row / column, output smaller than one tile."""
+    from maua_stylegan2_amd.op import fused_leaky_relu, upfirdn2d
+
+    k = torch.ones(4, 4, device=gpu) / 16
+    y = upfirdn2d(torch.empty(0, 3, 9, 9, device=gpu), k, pad=(1, 1))
+    assert y.shape == (0, 3, 8, 8)
+    assert fused_leaky_relu(torch.empty(0, 4, 2, 2, device=gpu), torch.zeros(4, device=gpu)).shape == (0, 4, 2, 2)
+    for shape, kk, up, down, pad in [((1, 1, 1, 1), 2, 1, 1, (1, 0)), ((2, 1, 1, 37), 2, 2, 1, (1, 0)), ((1, 2, 41, 1), 3, 1, 1, (1, 1)),
+                                     ((1, 1, 4, 4), 4, 1, 1, (0, 0)), ((1, 1, 3, 3), 4, 2, 2, (2, 1))]:
+        r = np.random.default_rng(sum(shape))
+        x = r.standard_normal(shape).astype(np.float32)
+        kern = r.standard_normal((kk, kk)).astype(np.float32)
+        want = ops_oracle.upfirdn2d(torch.from_numpy(x), torch.from_numpy(kern), up=up, down=down, pad=pad).numpy()
+        got = upfirdn2d(t(x, gpu), t(kern, gpu), up=up, down=down, pad=pad).cpu().numpy()
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, atol=2e-5)
+    with pytest.raises(RuntimeError):
+        upfirdn2d(torch.zeros(1, 1, 2, 2, device=gpu), k)  # 2 + 0 - 4 -> empty output, as the reference would fail
+    with pytest.raises(RuntimeError, match="float32"):
+        upfirdn2d(torch.zeros(1, 1, 8, 8, device=gpu, dtype=torch.float16), k)
