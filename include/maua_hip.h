@@ -127,6 +127,18 @@ int maua_temporal_fir_f32(const float* x, const float* taps, float* y, int n_fra
  * frames, window[n_fft] in device memory, n_fft a power of two <= 4096.  y[n_samples] -> p[n_bins = n_fft/2+1, n_frames]. */
 int maua_stft_power_f32(const float* y, int64_t n_samples, const float* window, int n_fft, int hop, float* p,
                         int n_frames, void* stream);
+/* Harmonic / percussive source separation pieces (librosa.effects.percussive / harmonic, audioreactive/signal.py:49,150):
+ *   complex STFT -> re/im [n_fft/2+1, n_frames];  inverse STFT (frames_ws: n_frames*n_fft floats of workspace; window-sum-
+ *   square normalised overlap-add, centre padding removed, output length n_samples);
+ *   median filter of x[rows, cols] along axis 0 (frequency) or 1 (time), size in {3,5,9,17,31}, scipy 'reflect' boundary;
+ *   soft mask (x / z)^p / ((x/z)^p + (x_ref*margin/z)^p) applied to the complex spectrum. */
+int maua_stft_complex_f32(const float* y, int64_t n_samples, const float* window, int n_fft, int hop, float* out_re,
+                          float* out_im, int n_frames, void* stream);
+int maua_istft_f32(const float* in_re, const float* in_im, const float* window, int n_fft, int hop, int n_frames,
+                   float* frames_ws, float* y, int64_t n_samples, void* stream);
+int maua_median_filter_f32(const float* x, float* y, int rows, int cols, int size, int axis, void* stream);
+int maua_softmask_apply_f32(const float* re, const float* im, const float* x, const float* x_ref, float margin, float power,
+                            int split_zeros, float* out_re, float* out_im, int64_t n, void* stream);
 /* out[M,N] = fb[M,K] @ p[K,N] (mel / chroma filterbank projection), optional 10*log10(max(amin, .)) when to_db. */
 int maua_filterbank_f32(const float* fb, const float* p, float* out, int m, int k, int n, int to_db, float amin,
                         void* stream);

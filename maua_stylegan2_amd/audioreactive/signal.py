@@ -12,9 +12,9 @@ results come back on the device the reference would have produced them on (envel
 ``device=`` says otherwise, so existing plugins keep working while the heavy tensors can stay in HBM.
 
 Divergences from the reference, all stated in DESIGN.md ("parity unpinned" rows): librosa / madmom are not
-dependencies here.  ``onsets`` implements the spectral-flux definition of the type="rosa" branch for both ``type``
-values and skips the percussive separation (``margin`` is accepted and ignored); ``chroma`` implements the
-type="stft" filterbank for every ``type`` and skips harmonic separation / nn_filter.
+dependencies here.  ``onsets`` = median-filter percussive separation (``margin``) + the spectral-flux definition of the
+type="rosa" branch, for both ``type`` values (madmom's five onset functions are not built); ``chroma`` = harmonic
+separation + the type="stft" filterbank for every ``type`` (no CENS/CQT, no nn_filter) — SURVEY.md §8f rank 3.
 """
 import math
 import os
@@ -116,6 +116,57 @@ def project(fb, p, to_db=False, amin=1e-10):
     return out
 
 
+def _hann(n_fft, device):
+    return th.from_numpy((0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32)).to(device)
+
+
+def hpss(audio, margin=1.0, kernel_size=31, power=2.0, n_fft=2048, hop=512):
+    """Harmonic / percussive source separation on device (librosa.effects.hpss as the reference uses it through
+    effects.percussive / effects.harmonic, signal.py:49,150): complex STFT -> |D| median-filtered along time
+    (harmonic-enhanced) and along frequency (percussive-enhanced), soft masks with ``margin``, inverse STFT.
+    Returns (y_harmonic, y_percussive) as device tensors of the input length."""
+    lib = _lib.load()
+    y = _to_dev(audio)
+    n = y.numel()
+    n_frames = 1 + n // hop
+    n_bins = n_fft // 2 + 1
+    dev = y.device
+    win = _hann(n_fft, dev)
+    re = th.empty((n_bins, n_frames), dtype=th.float32, device=dev)
+    im = th.empty_like(re)
+    outs = []
+    with th.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        _lib.check(lib.maua_stft_complex_f32(y.data_ptr(), n, win.data_ptr(), n_fft, hop, re.data_ptr(), im.data_ptr(),
+                                             n_frames, st), "maua_stft_complex_f32")
+        mag = th.sqrt(re * re + im * im)
+        harm, perc = th.empty_like(mag), th.empty_like(mag)
+        _lib.check(lib.maua_median_filter_f32(mag.data_ptr(), harm.data_ptr(), n_bins, n_frames, kernel_size, 1, st),
+                   "maua_median_filter_f32")
+        _lib.check(lib.maua_median_filter_f32(mag.data_ptr(), perc.data_ptr(), n_bins, n_frames, kernel_size, 0, st),
+                   "maua_median_filter_f32")
+        split = int(margin == 1)
+        frames_ws = th.empty((n_frames, n_fft), dtype=th.float32, device=dev)
+        for own, other in ((harm, perc), (perc, harm)):
+            mre, mim = th.empty_like(re), th.empty_like(im)
+            _lib.check(lib.maua_softmask_apply_f32(re.data_ptr(), im.data_ptr(), own.data_ptr(), other.data_ptr(),
+                                                   float(margin), float(power), split, mre.data_ptr(), mim.data_ptr(),
+                                                   re.numel(), st), "maua_softmask_apply_f32")
+            out = th.empty(n, dtype=th.float32, device=dev)
+            _lib.check(lib.maua_istft_f32(mre.data_ptr(), mim.data_ptr(), win.data_ptr(), n_fft, hop, n_frames,
+                                          frames_ws.data_ptr(), out.data_ptr(), n, st), "maua_istft_f32")
+            outs.append(out)
+    return outs[0], outs[1]
+
+
+def percussive(audio, margin=1.0):
+    return hpss(audio, margin)[1]
+
+
+def harmonic(audio, margin=1.0):
+    return hpss(audio, margin)[0]
+
+
 def resample(x, num):
     """Fourier-method resampling along dim 0 (what scipy.signal.resample does at reference :68,152), on device."""
     n = x.shape[0]
@@ -211,7 +262,8 @@ def onset_strength(audio, sr, fmin=0.0, fmax=None, n_fft=2048, hop=512, n_mels=1
 
 
 def onsets(audio, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, type="mm", device=None):
-    env = onset_strength(audio, sr, fmin=fmin, fmax=fmax)
+    y_perc = percussive(audio, margin=margin) if margin else audio  # reference :49 (margin=0/None skips the separation)
+    env = onset_strength(y_perc, sr, fmin=fmin, fmax=fmax)
     onset = resample(env, n_frames).clamp(float(env.min()), float(env.max())).float()
     onset = gaussian_filter(onset, smooth, causal=0)
     onset = percentile_clip(onset, clip)
@@ -243,9 +295,10 @@ def raw_chroma(audio, sr, type="cens", nearest_neighbor=True):
 
 
 def chroma(audio, sr, n_frames, margin=16, type="cens", notes=12, device=None):
+    y_harm = harmonic(audio, margin=margin) if margin else audio  # reference :150
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        ch = th.from_numpy(raw_chroma(audio, sr, type=type)).to(_dev()).t()
+        ch = th.from_numpy(raw_chroma(y_harm, sr, type=type)).to(_dev()).t()
     ch = resample(ch, n_frames)
     keep = th.argsort(th.quantile(ch, 0.5, dim=0))[:notes]  # np.median semantics (mean of the two middle values)
     ch = ch[:, keep]

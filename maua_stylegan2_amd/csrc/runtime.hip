@@ -33,7 +33,7 @@ extern "C" int maua_graph_end_capture(void* stream, void** graph_exec_out) {
     if (e != hipSuccess) return (int)e;
     hipGraphExec_t exec = nullptr;
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return (int)e;
     *graph_exec_out = (void*)exec;
     return 0;

@@ -102,6 +102,170 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict
     for (int k = tid; k <= n_fft / 2; k += 256) p[(int64_t)k * n_frames + frame] = re[k] * re[k] + im[k] * im[k];
 }
 
+// ------------------------------------------------------------------------------------------------ HPSS building blocks
+// Complex STFT / inverse STFT (same LDS radix-2 FFT as stft_power_kernel), 31-tap median filters along time and
+// frequency, soft masks: the pieces of librosa.effects.percussive / harmonic as called at
+// /root/reference/audioreactive/signal.py:49,150.
+__device__ __forceinline__ void lds_fft_radix2(float* re, float* im, const float* twc, const float* tws, int n_fft, int log2n,
+                                               int tid) {
+    for (int st = 1; st <= log2n; ++st) {
+        const int half = 1 << (st - 1);
+        const int tw_stride = n_fft >> st;
+        for (int bfly = tid; bfly < n_fft / 2; bfly += 256) {
+            const int grp = bfly / half, k = bfly - grp * half;
+            const int a = grp * 2 * half + k, b = a + half;
+            const float c_ = twc[k * tw_stride], s_ = tws[k * tw_stride];
+            const float br = re[b] * c_ - im[b] * s_;
+            const float bi = re[b] * s_ + im[b] * c_;
+            const float ar = re[a], ai = im[a];
+            re[a] = ar + br, im[a] = ai + bi;
+            re[b] = ar - br, im[b] = ai - bi;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void stft_complex_kernel(const float* __restrict__ y, int64_t n, const float* __restrict__ win,
+                                                           int n_fft, int log2n, int hop, float* __restrict__ out_re,
+                                                           float* __restrict__ out_im, int n_frames) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* re = sm;
+    float* im = sm + n_fft;
+    float* twc = sm + 2 * n_fft;
+    float* tws = twc + n_fft / 2;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int64_t start = (int64_t)frame * hop - n_fft / 2;
+    for (int i = tid; i < n_fft; i += 256) {
+        int64_t src = start + i;
+        if (n > 1) {
+            const int64_t period = 2 * (n - 1);
+            src %= period;
+            if (src < 0) src += period;
+            if (src >= n) src = period - src;
+        } else {
+            src = 0;
+        }
+        const int rev = (int)(__brev((unsigned)i) >> (32 - log2n));
+        re[rev] = y[src] * win[i];
+        im[rev] = 0.f;
+    }
+    for (int k = tid; k < n_fft / 2; k += 256) {
+        float s_, c_;
+        sincospif(-2.0f * (float)k / (float)n_fft, &s_, &c_);
+        twc[k] = c_, tws[k] = s_;
+    }
+    __syncthreads();
+    lds_fft_radix2(re, im, twc, tws, n_fft, log2n, tid);
+    for (int k = tid; k <= n_fft / 2; k += 256) {
+        out_re[(int64_t)k * n_frames + frame] = re[k];
+        out_im[(int64_t)k * n_frames + frame] = im[k];
+    }
+}
+
+// One workgroup = one frame: Hermitian-extend the half spectrum, inverse FFT (conj . FFT . conj / N), window, and write the
+// windowed frame to frames[frame][n_fft]; overlap-add happens in istft_ola_kernel.
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ in_re, const float* __restrict__ in_im,
+                                                           const float* __restrict__ win, int n_fft, int log2n,
+                                                           int n_frames, float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* re = sm;
+    float* im = sm + n_fft;
+    float* twc = sm + 2 * n_fft;
+    float* tws = twc + n_fft / 2;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < n_fft; k += 256) {
+        const int kk = k <= n_fft / 2 ? k : n_fft - k;
+        const float r = in_re[(int64_t)kk * n_frames + frame];
+        float i_ = in_im[(int64_t)kk * n_frames + frame];
+        if (k > n_fft / 2) i_ = -i_;          // X[N-k] = conj(X[k])
+        if (kk == 0 || kk == n_fft / 2) i_ = 0.f;  // DC / Nyquist are real for a real signal
+        const int rev = (int)(__brev((unsigned)k) >> (32 - log2n));
+        re[rev] = r;
+        im[rev] = -i_;  // conj before the forward transform
+    }
+    for (int k = tid; k < n_fft / 2; k += 256) {
+        float s_, c_;
+        sincospif(-2.0f * (float)k / (float)n_fft, &s_, &c_);
+        twc[k] = c_, tws[k] = s_;
+    }
+    __syncthreads();
+    lds_fft_radix2(re, im, twc, tws, n_fft, log2n, tid);
+    const float inv = 1.0f / (float)n_fft;
+    for (int i = tid; i < n_fft; i += 256) frames[(int64_t)frame * n_fft + i] = re[i] * inv * win[i];
+}
+
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ win, int n_fft,
+                                                        int hop, int n_frames, float* __restrict__ y, int64_t n_samples) {
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < n_samples; s += (int64_t)gridDim.x * 256) {
+        const int64_t pos = s + n_fft / 2;  // position in the centre-padded signal
+        int64_t t_hi = pos / hop;
+        if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+        float acc = 0.f, wss = 0.f;
+        for (int64_t t = t_hi; t >= 0; --t) {
+            const int64_t off = pos - t * hop;
+            if (off >= n_fft) break;
+            acc += frames[t * n_fft + off];
+            const float w = win[off];
+            wss = fmaf(w, w, wss);
+        }
+        y[s] = wss > 1.17549435e-38f ? acc / wss : acc;
+    }
+}
+
+// Median of a centred `size`-tap window (size odd, <= 31) along one axis of x[rows, cols]; scipy.ndimage 'reflect'
+// boundary (d c b a | a b c d | d c b a).  Rank counting instead of sorting: branch-free and register resident.
+template <int SIZE>
+__global__ __launch_bounds__(256) void median_filter_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols,
+                                                            int axis) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int r = (int)(idx / cols), c = (int)(idx - (int64_t)r * cols);
+        const int len = axis == 0 ? rows : cols;
+        const int pos = axis == 0 ? r : c;
+        float v[SIZE];
+#pragma unroll
+        for (int i = 0; i < SIZE; ++i) {
+            int q = pos + i - SIZE / 2;
+            // reflect with edge repeat, period 2*len
+            const int period = 2 * len;
+            q %= period;
+            if (q < 0) q += period;
+            if (q >= len) q = period - 1 - q;
+            v[i] = axis == 0 ? x[(int64_t)q * cols + c] : x[(int64_t)r * cols + q];
+        }
+        float med = v[0];
+#pragma unroll
+        for (int i = 0; i < SIZE; ++i) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < SIZE; ++j) rank += (v[j] < v[i] || (v[j] == v[i] && j < i)) ? 1 : 0;
+            if (rank == SIZE / 2) med = v[i];
+        }
+        y[idx] = med;
+    }
+}
+
+// librosa.util.softmask + mask application: out = D * mask(X, X_ref * margin)   (X = |D| median-filtered one way,
+// X_ref the other way).  mask = (X/Z)^p / ((X/Z)^p + (Xr/Z)^p), Z = max(X, Xr); where Z underflows: 0.5 if split else 0.
+__global__ __launch_bounds__(256) void softmask_apply_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                             const float* __restrict__ xs, const float* __restrict__ xref,
+                                                             float margin, float power, int split_zeros,
+                                                             float* __restrict__ out_re, float* __restrict__ out_im, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = xs[i], b = xref[i] * margin;
+        const float z = fmaxf(a, b);
+        float m;
+        if (z < 1.17549435e-38f) {
+            m = split_zeros ? 0.5f : 0.f;
+        } else {
+            const float pa = powf(a / z, power), pb = powf(b / z, power);
+            m = pa / (pa + pb);
+        }
+        out_re[i] = re[i] * m;
+        out_im[i] = im[i] * m;
+    }
+}
+
 __global__ __launch_bounds__(256) void filterbank_kernel(const float* __restrict__ fb, const float* __restrict__ p,
                                                          float* __restrict__ out, int m, int k, int n, int to_db,
                                                          float amin) {
@@ -246,6 +410,62 @@ extern "C" int maua_affine_reflect_warp_f32(const float* x, const float* m, floa
     if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || channels > 65535 || batch > 65535) return MAUA_EINVAL;
     hipLaunchKernelGGL(affine_reflect_warp_kernel, dim3(ceil_div(h * w, 256), channels, batch), dim3(256), 0,
                        (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_stft_complex_f32(const float* y, int64_t n_samples, const float* window, int n_fft, int hop, float* out_re,
+                                     float* out_im, int n_frames, void* stream) {
+    if (!y || !window || !out_re || !out_im || n_samples <= 0 || hop <= 0 || n_frames <= 0) return MAUA_EINVAL;
+    int log2n = 0;
+    while ((1 << log2n) < n_fft) ++log2n;
+    if ((1 << log2n) != n_fft || n_fft < 64 || n_fft > 4096) return MAUA_EINVAL;
+    hipLaunchKernelGGL(stft_complex_kernel, dim3(n_frames), dim3(256), (size_t)3 * n_fft * sizeof(float), (hipStream_t)stream, y,
+                       n_samples, window, n_fft, log2n, hop, out_re, out_im, n_frames);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_istft_f32(const float* in_re, const float* in_im, const float* window, int n_fft, int hop, int n_frames,
+                              float* frames_ws, float* y, int64_t n_samples, void* stream) {
+    if (!in_re || !in_im || !window || !frames_ws || !y || hop <= 0 || n_frames <= 0 || n_samples <= 0) return MAUA_EINVAL;
+    int log2n = 0;
+    while ((1 << log2n) < n_fft) ++log2n;
+    if ((1 << log2n) != n_fft || n_fft < 64 || n_fft > 4096) return MAUA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(istft_frames_kernel, dim3(n_frames), dim3(256), (size_t)3 * n_fft * sizeof(float), st, in_re, in_im, window,
+                       n_fft, log2n, n_frames, frames_ws);
+    MAUA_LAUNCH_CHECK();
+    const int64_t blocks = ceil_div64(n_samples, 256);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, frames_ws, window, n_fft,
+                       hop, n_frames, y, n_samples);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_median_filter_f32(const float* x, float* y, int rows, int cols, int size, int axis, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || (axis != 0 && axis != 1)) return MAUA_EINVAL;
+    const int64_t blocks = ceil_div64((int64_t)rows * cols, 256);
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192));
+    hipStream_t st = (hipStream_t)stream;
+    switch (size) {
+        case 31: hipLaunchKernelGGL(median_filter_kernel<31>, grid, dim3(256), 0, st, x, y, rows, cols, axis); break;
+        case 17: hipLaunchKernelGGL(median_filter_kernel<17>, grid, dim3(256), 0, st, x, y, rows, cols, axis); break;
+        case 9: hipLaunchKernelGGL(median_filter_kernel<9>, grid, dim3(256), 0, st, x, y, rows, cols, axis); break;
+        case 5: hipLaunchKernelGGL(median_filter_kernel<5>, grid, dim3(256), 0, st, x, y, rows, cols, axis); break;
+        case 3: hipLaunchKernelGGL(median_filter_kernel<3>, grid, dim3(256), 0, st, x, y, rows, cols, axis); break;
+        default: return MAUA_ENOSYS;
+    }
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_softmask_apply_f32(const float* re, const float* im, const float* x, const float* x_ref, float margin,
+                                       float power, int split_zeros, float* out_re, float* out_im, int64_t n, void* stream) {
+    if (!re || !im || !x || !x_ref || !out_re || !out_im || n <= 0) return MAUA_EINVAL;
+    const int64_t blocks = ceil_div64(n, 256);
+    hipLaunchKernelGGL(softmask_apply_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, re,
+                       im, x, x_ref, margin, power, split_zeros, out_re, out_im, n);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

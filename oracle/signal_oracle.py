@@ -186,8 +186,59 @@ def chroma_stft(y, sr, n_fft=2048, hop=512):
     return raw / np.where(peak > np.finfo(np.float64).tiny, peak, 1.0)
 
 
-def onsets(y, sr, n_frames, fmin=20, fmax=8000, smooth=1, clip=100, power=1, smf=1.0):
-    """signal.py:31-73, type="rosa" branch, WITHOUT the percussive separation at :49."""
+def stft_complex(y, n_fft=2048, hop=512):
+    y = np.asarray(y, dtype=np.float64)
+    ypad = np.pad(y, n_fft // 2, mode="reflect")
+    n_frames = 1 + (len(ypad) - n_fft) // hop
+    win = hann_periodic(n_fft)
+    frames = np.stack([ypad[t * hop: t * hop + n_fft] * win for t in range(n_frames)], axis=1)
+    return np.fft.rfft(frames, axis=0)
+
+
+def istft(spec, length, n_fft=2048, hop=512):
+    """Window-sum-square normalised overlap-add, centre padding removed (librosa.istft)."""
+    n_frames = spec.shape[1]
+    win = hann_periodic(n_fft)
+    frames = np.fft.irfft(spec, n=n_fft, axis=0) * win[:, None]
+    total = n_fft + hop * (n_frames - 1)
+    y = np.zeros(total)
+    wss = np.zeros(total)
+    for t in range(n_frames):
+        y[t * hop: t * hop + n_fft] += frames[:, t]
+        wss[t * hop: t * hop + n_fft] += win ** 2
+    ok = wss > np.finfo(np.float32).tiny
+    y[ok] /= wss[ok]
+    return y[n_fft // 2: n_fft // 2 + length]
+
+
+def softmask(x, x_ref, power=2.0, split_zeros=False):
+    z = np.maximum(x, x_ref)
+    bad = z < np.finfo(np.float32).tiny
+    z = np.where(bad, 1.0, z)
+    m, r = (x / z) ** power, (x_ref / z) ** power
+    out = np.where(bad, 0.5 if split_zeros else 0.0, m / np.where(bad, 1.0, m + r))
+    return out
+
+
+def hpss(y, margin=1.0, kernel_size=31, power=2.0):
+    """librosa.decompose.hpss + effects.harmonic/percussive: median filters (scipy.ndimage, mode 'reflect') along time
+    and frequency of |STFT|, soft masks with margin, inverse STFT.  Returns (y_harmonic, y_percussive)."""
+    import scipy.ndimage
+
+    d = stft_complex(y)
+    s = np.abs(d)
+    harm = scipy.ndimage.median_filter(s, size=(1, kernel_size), mode="reflect")
+    perc = scipy.ndimage.median_filter(s, size=(kernel_size, 1), mode="reflect")
+    split = margin == 1
+    mask_h = softmask(harm, perc * margin, power, split)
+    mask_p = softmask(perc, harm * margin, power, split)
+    return istft(d * mask_h, len(y)), istft(d * mask_p, len(y))
+
+
+def onsets(y, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, smf=1.0):
+    """signal.py:31-73, type="rosa" branch (percussive separation at :49, then spectral-flux onset strength)."""
+    if margin:
+        y = hpss(y, margin)[1]
     env = onset_strength(y, sr, fmin=fmin, fmax=fmax)
     env = np.clip(resample(env, n_frames), env.min(), env.max())
     env = torch.from_numpy(env).float()
@@ -196,8 +247,10 @@ def onsets(y, sr, n_frames, fmin=20, fmax=8000, smooth=1, clip=100, power=1, smf
     return env ** power
 
 
-def chroma(y, sr, n_frames, notes=12):
-    """signal.py:136-156 with type="stft" and without the harmonic separation at :150 / nn_filter at :130-131."""
+def chroma(y, sr, n_frames, margin=16, notes=12):
+    """signal.py:136-156 with type="stft" (harmonic separation at :150; no nn_filter)."""
+    if margin:
+        y = hpss(y, margin)[0]
     ch = chroma_stft(y, sr).T
     ch = resample(ch, n_frames)
     keep = np.argsort(np.median(ch, axis=0))[:notes]

@@ -169,3 +169,41 @@ def test_generate_latents_maps_through_the_mapping_network(gpu):
     assert got.shape == (5, g.n_latent, 512)
     np.testing.assert_allclose(got[:, 0].numpy(), want.numpy(), atol=2e-4, rtol=1e-3)
     assert torch.equal(got[:, 0], got[:, -1])
+
+
+def test_hpss_pieces_vs_oracle(gpu):
+    """Complex STFT / inverse STFT round trip, 31-tap median filters (both axes, reflect boundary) vs scipy.ndimage, and the
+    full harmonic / percussive separation vs the oracle restatement of librosa's hpss."""
+    import ctypes
+
+    import scipy.ndimage
+
+    from maua_stylegan2_amd import _lib
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    lib = _lib.load()
+    r = np.random.default_rng(2)
+    x = np.abs(r.standard_normal((70, 45))).astype(np.float32)
+    xd = torch.from_numpy(x).to(gpu)
+    for axis, size in [(0, 31), (1, 31), (0, 5), (1, 9)]:
+        out = torch.empty_like(xd)
+        _lib.check(lib.maua_median_filter_f32(xd.data_ptr(), out.data_ptr(), 70, 45, size, axis, _lib.stream_ptr()), "median")
+        shape = (size, 1) if axis == 0 else (1, size)
+        want = scipy.ndimage.median_filter(x, size=shape, mode="reflect")
+        assert np.array_equal(out.cpu().numpy(), want), (axis, size)
+
+    sr = 22050
+    y = seeding.synthetic_audio(3.0, sr)
+    harm, perc = sig.hpss(y, margin=1.0)
+    # margin 1 with split masks: the two components add back up to the signal (masks sum to one, istft(stft) = identity)
+    recon = (harm + perc).cpu().numpy()
+    assert np.abs(recon - y).max() < 1e-4
+    for margin in (1.0, 8.0):
+        wh, wp = signal_oracle.hpss(y, margin)
+        gh, gp = sig.hpss(y, margin)
+        scale = np.abs(y).max()
+        assert np.abs(gh.cpu().numpy() - wh).max() < 2e-4 * scale + 1e-5
+        assert np.abs(gp.cpu().numpy() - wp).max() < 2e-4 * scale + 1e-5
+    # the kick lives in the percussive part, the chord in the harmonic part
+    gh, gp = sig.hpss(y, 4.0)
+    assert float(gp.abs().max()) > 0.05 and float(gh.std()) > 0.02
