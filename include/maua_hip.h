@@ -80,11 +80,17 @@ int maua_demod_f32(const maua_style_layer_t* table, int n_layers, int max_cout, 
 /* Sum of squared taps wsq[o,i] and the tap-major repack wp[tap][i][o] of a [cout,cin,k,k] weight (one-off, at load). */
 int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream);
 
+/* Winograd F(2,3) form of the same weight, transformed along kx: wq[(ky*4+xi)][i][o_pad] with
+ * xi 0: g0, 1: (g0+g1+g2)/2, 2: (g0-g1+g2)/2, 3: g2.  The operand of maua_modconv3x3_f32 in mode 2. */
+int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, int cin, void* stream);
+
 /* ModulatedConv2d 3x3 (models/stylegan2.py:217-254) as input-scale -> shared-weight implicit GEMM on MFMA ->
  * output-demod, with the StyledConv tail (noise + bias + leaky ReLU, :338-343) fused when `fuse_act`:
  *   plain   : x[B,cin,H,W] -> y[B,cout,H,W]        (pad 1)
- *   up != 0 : x[B,cin,H,W] -> y[B,cout,2H+1,2W+1]  (conv_transpose2d stride 2, :229-237) — raw, un-demodulated
+ *   up == 1 : x[B,cin,H,W] -> y[B,cout,2H+1,2W+1]  (conv_transpose2d stride 2, :229-237) — raw, un-demodulated
  *             when fuse_act == 0 (the blur kernel applies gain/noise/bias/act).
+ *   up == 2 : the plain convolution evaluated through Winograd F(2,3) along x (W even): 1.5x fewer MFMA cycles,
+ *             same result to fp32 rounding; wp is then the maua_pack_weight_wino_f32 weight.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
  * floats used for split-K partial sums on small feature maps (may be NULL when that returns 0). */
@@ -98,9 +104,9 @@ int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_s
  * activated feature map is reduced to RGB while it is still in registers (all channels of a pixel sit in one wave).
  * Only for layers whose channels fit one weight tile in a single wave row (cout <= 64); returns MAUA_ENOSYS otherwise
  * (the caller then runs maua_modconv3x3_f32 + maua_torgb_f32).  rgb_s = the ToRGB layer's styles [B, s_stride] (same
- * stride as s).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
+ * stride as s).  mode = 0 (direct) or 2 (Winograd, wp from maua_pack_weight_wino_f32).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
 int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
-                              float* y, int batch, int cin, int cout, int h, int w, float wscale,
+                              float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
                               const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                               const float* rgb_w, const float* rgb_s, float rgb_wscale, const float* rgb_bias,
                               const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,

@@ -77,15 +77,25 @@ struct ConvPtrs {
 // FAST (Cin % 8 == 0 and the padded weight covers whole BM tiles — every layer of a real generator): loads are
 // unconditional (masked by multiplication at LDS-write time) and addressed as uniform base + 32-bit lane offset,
 // which removes the exec-mask / 64-bit-address scalar work that dominated the short-K (32/64-channel) layers.
-template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST, int MAXP>
-__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (UP ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
+// MODE 2 (WINO): plain 3x3 through Winograd F(2,3) along x — two adjacent output columns share four "frequency" products
+//   m0 = (d0-d2) g0, m1 = (d1+d2)(g0+g1+g2)/2, m2 = (d2-d1)(g0-g1+g2)/2, m3 = (d1-d3) g2;  y0 = m0+m1+m2, y1 = m1-m2-m3
+// so a pair of outputs costs 4 MFMA K-steps per (channel, ky) instead of 6: 1.5x fewer matrix-core cycles on the
+// MFMA-bound >= 128-channel layers.  A "position" is an output PAIR; the four frequencies take the place of the four
+// parities of the transposed mode (same accumulator layout), weights are pre-transformed (pack_weight_wino_kernel),
+// the B operand is formed from two 8-byte LDS reads of the ordinary patch, the epilogue undoes the transform in
+// registers and stores 8 bytes per lane.  fp32 F(2,3) has transform constants {1, 1/2}: error stays at the 1e-6 level.
+template <int BM, int BN, int WM, int MODE, bool MULTI, bool FAST, int MAXP>
+__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (MODE ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
+    constexpr bool UP = MODE == 1;
+    constexpr bool WINO = MODE == 2;
+    constexpr int NTAPS = WINO ? 12 : 9;  // weight rows per channel: 9 taps, or 3 ky x 4 frequencies
     constexpr int CC = chunk_channels(BM, BN);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int NPH = UP ? 4 : 1;
-    constexpr int A_FLOATS = 9 * CC * BM;
+    constexpr int NPH = (UP || WINO) ? 4 : 1;
+    constexpr int A_FLOATS = NTAPS * CC * BM;
     constexpr int A_VEC_ITERS = (A_FLOATS / 4 + 255) / 256;
     constexpr int MAX_POS = MAXP;  // patch positions per thread (PSTRIDE <= 256 * MAX_POS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -132,7 +142,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int img = pp / per_img;
             const int rem = pp - img * per_img;
             const int pr = rem / g.PWS, pc = rem - pr * g.PWS;
-            const int b = b0 + img, yy = ty0 + pr - 1, xx = tx0 + pc - 1;
+            const int b = b0 + img, yy = ty0 + pr - 1, xx = (WINO ? 2 * tx0 : tx0) + pc - 1;
             if (pc < g.PW && img < NI && b < g.B && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
                 src_off[i] = (int)(((size_t)b * g.Cin * g.H + yy) * g.W + xx);
                 src_mask[i] = 1.f;
@@ -151,7 +161,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
         const int img = sub >> (g.lnsx + g.lnsy);
         const int tyy = sy * SH + jy, txx = sx * SW + jx;
-        boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PWS + txx;
+        boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PWS + (WINO ? 2 * txx : txx);
     }
     const int aoff = hi * BM + wm * (TM * 32) + l31;
 
@@ -224,6 +234,38 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 
     // ---- MFMA phase over one staged chunk
     auto mfma_chunk = [&](const float* __restrict__ Ac, const float* __restrict__ Pc) {
+        if (WINO) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int q = 0; q < CC / 2; ++q) {
+                    float bv[TN][4];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        const float* dp = Pc + 2 * q * g.PSTRIDE + boff[n] + ky * g.PWS;  // even float offset: 8-byte aligned
+                        const f32x2 d01 = *reinterpret_cast<const f32x2*>(dp);
+                        const f32x2 d23 = *reinterpret_cast<const f32x2*>(dp + 2);
+                        bv[n][0] = d01.x - d23.x;
+                        bv[n][1] = d01.y + d23.x;
+                        bv[n][2] = d23.x - d01.y;
+                        bv[n][3] = d01.y - d23.y;
+                    }
+#pragma unroll
+                    for (int xi = 0; xi < 4; ++xi) {
+                        float a[TM];
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 4 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                            for (int n = 0; n < TN; ++n)
+                                acc[mt][n * NPH + xi] =
+                                    __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bv[n][xi], acc[mt][n * NPH + xi], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -255,7 +297,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         // through registers because it is scaled by the style and masked at the image border on the way in.
         constexpr int RPI = 256 / BM;              // weight rows (BM floats) per 1-KiB DMA instruction
         constexpr int LPR = 64 / RPI;              // lanes per row
-        constexpr int A_INSTR = (9 * CC + RPI - 1) / RPI;  // DMA instructions per tile (the last one may be partial)
+        constexpr int A_INSTR = (NTAPS * CC + RPI - 1) / RPI;  // DMA instructions per tile (the last one may be partial)
         constexpr int A_PER_WAVE = (A_INSTR + 3) / 4;
         int a_goff[A_PER_WAVE];
 #pragma unroll
@@ -263,7 +305,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int row = (wave + 4 * k) * RPI + lane / LPR;
             const int col = (lane % LPR) * 4;
             const int tap = row / CC, c = row - tap * CC;
-            a_goff[k] = row < 9 * CC ? (tap * g.Cin + c) * g.CoutPad + col : -1;  // -1: lane past the tile, masked off
+            a_goff[k] = row < NTAPS * CC ? (tap * g.Cin + c) * g.CoutPad + col : -1;  // -1: lane past the tile, masked off
         }
         auto issue_dma = [&](int chunk, int buf) {
             const float* __restrict__ wbase = p.wp + (size_t)chunk * CC * g.CoutPad + m0;  // uniform
@@ -381,7 +423,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = UP ? 2 * gx + (ph & 1) : gx;
+            const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = (UP || WINO) ? 2 * gx + (ph & 1) : gx;
             nz_all[n][ph] = 0.f;
             if (nw != 0.f && b < g.B && gy < g.GH && gx < g.GW && oy < g.OH && ox < g.OW)
                 nz_all[n][ph] = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox];
@@ -399,18 +441,20 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const bool pos_ok = (b < g.B) && (gy < g.GH) && (gx < g.GW);
         // transposed conv: the two x-parities of a position are adjacent in memory -> one 8-byte store per lane
         // (rows of the (2W+1)-wide plane are only 4-byte aligned: f32x2u is an align-4 vector type)
-        constexpr int PXN = UP ? 2 : 1;
+        constexpr int PXN = (UP || WINO) ? 2 : 1;  // Winograd positions are output pairs as well
 #pragma unroll
         for (int py = 0; py < (UP ? 2 : 1); ++py) {
             const int oy = UP ? 2 * gy + py : gy;
-            const int ox = UP ? 2 * gx : gx;
+            const int ox = (UP || WINO) ? 2 * gx : gx;
             const bool ok0 = pos_ok && oy < g.OH && ox < g.OW;
-            const bool ok1 = UP && ok0 && (ox + 1 < g.OW);
+            const bool ok1 = (UP || WINO) && ok0 && (ox + 1 < g.OW);
             float nzv[PXN];
 #pragma unroll
-            for (int px = 0; px < PXN; ++px) nzv[px] = nz_all[n][UP ? py * 2 + px : 0];
+            for (int px = 0; px < PXN; ++px) nzv[px] = nz_all[n][UP ? py * 2 + px : (WINO ? px : 0)];
             float* obase = outp + (size_t)b * g.Cout * plane_out + (size_t)oy * g.OW + ox;
-            float rgbp[3] = {0.f, 0.f, 0.f};
+            float rgbp[PXN][3];
+#pragma unroll
+            for (int px = 0; px < PXN; ++px) rgbp[px][0] = rgbp[px][1] = rgbp[px][2] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
@@ -430,17 +474,29 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                     float v[PXN];
 #pragma unroll
                     for (int px = 0; px < PXN; ++px) {
-                        v[px] = acc[mt][n * NPH + (UP ? py * 2 + px : 0)][e] * gain;
+                        float raw;
+                        if (WINO) {  // inverse transform: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
+                            const float m0_ = acc[mt][n * NPH + 0][e], m1_ = acc[mt][n * NPH + 1][e];
+                            const float m2_ = acc[mt][n * NPH + 2][e], m3_ = acc[mt][n * NPH + 3][e];
+                            raw = px == 0 ? (m0_ + m1_) + m2_ : (m1_ - m2_) - m3_;
+                        } else {
+                            raw = acc[mt][n * NPH + (UP ? py * 2 + px : 0)][e];
+                        }
+                        v[px] = raw * gain;
                         if (!to_ws && g.fuse_act) v[px] = lrelu_gain(v[px] + nzv[px] + bias);
                     }
                     if (!UP && WM == 1 && !MULTI && g.rgb) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) rgbp[c] = fmaf(lds[(2 + c) * BM + ol], v[0], rgbp[c]);
+                        for (int c = 0; c < 3; ++c) {
+                            const float rw = lds[(2 + c) * BM + ol];
+#pragma unroll
+                            for (int px = 0; px < PXN; ++px) rgbp[px][c] = fmaf(rw, v[px], rgbp[px][c]);
+                        }
                         if (g.rgb == 2) continue;  // last layer: nothing downstream reads the feature map
                     }
                     if ((g.debug & 1) && v[0] != 123.456f) continue;
                     float* dst = obase + (size_t)o * plane_out;
-                    if (UP) {
+                    if (UP || WINO) {
                         if (ok1 && o < g.Cout) *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
                         else if (ok0 && o < g.Cout) dst[0] = v[0];
                     } else if (ok0 && o < g.Cout) {
@@ -451,45 +507,68 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             if (!UP && WM == 1 && !MULTI && g.rgb) {
                 // all channels of a pixel live in one wave: lanes l and l+32 hold the two halves of the channel set
 #pragma unroll
-                for (int c = 0; c < 3; ++c) rgbp[c] += __shfl_xor(rgbp[c], 32, 64);
+                for (int px = 0; px < PXN; ++px)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) rgbp[px][c] += __shfl_xor(rgbp[px][c], 32, 64);
                 if (hi == 0 && ok0) {
-                    // upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, ox): exactly two source rows / columns are live,
-                    // iy0 = floor((oy-1)/2), iy0+1 (taps k4[1]/k4[3] for even oy, k4[0]/k4[2] for odd) — all 12 loads
-                    // (3 channels x 2 x 2) are unconditional (clamped) and in flight together, masked by weight 0.
+                    // upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, x): exactly two source rows / columns are live,
+                    // iy0 = floor((oy-1)/2), iy0+1 (taps k4[1]/k4[3] for even oy, k4[0]/k4[2] for odd) — all loads
+                    // (3 channels x 2 x 2 per pixel) are unconditional (clamped) and in flight together, masked by weight 0.
                     const int sh = g.H >> 1, sw = g.W >> 1;
-                    const int iy0 = (oy - 1) >> 1, ix0 = (ox - 1) >> 1;
-                    const int ty_ = (oy & 1) ? 2 : 3, tx_ = (ox & 1) ? 2 : 3;  // tap index of the FIRST live row / column
-                    float wy[2], wx[2];
-                    int ry[2], rx[2];
+                    const int iy0 = (oy - 1) >> 1;
+                    const int ty_ = (oy & 1) ? 2 : 3;  // tap index of the FIRST live row
+                    float wy[2];
+                    int ry[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int yy = iy0 + q, xx = ix0 + q;
-                        ry[q] = min(max(yy, 0), sh - 1), rx[q] = min(max(xx, 0), sw - 1);
+                        const int yy = iy0 + q;
+                        ry[q] = min(max(yy, 0), sh - 1);
                         wy[q] = (yy >= 0 && yy < sh) ? 1.f : 0.f;
-                        wx[q] = (xx >= 0 && xx < sw) ? 1.f : 0.f;
                     }
-                    float wgt[2][2];
+                    float wgt[PXN][2][2];
+                    float sv[PXN][3][2][2];
 #pragma unroll
-                    for (int qy = 0; qy < 2; ++qy)
+                    for (int px = 0; px < PXN; ++px) {
+                        const int x = ox + px;
+                        const int ix0 = (x - 1) >> 1;
+                        const int tx_ = (x & 1) ? 2 : 3;
+                        float wx[2];
+                        int rx[2];
 #pragma unroll
-                        for (int qx = 0; qx < 2; ++qx)
-                            wgt[qy][qx] = p.rgb_skip ? p.rgb_k4[(ty_ - 2 * qy) * 4 + (tx_ - 2 * qx)] * wy[qy] * wx[qx] : 0.f;
-                    float sv[3][2][2];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
+                        for (int q = 0; q < 2; ++q) {
+                            const int xx = ix0 + q;
+                            rx[q] = min(max(xx, 0), sw - 1);
+                            wx[q] = (xx >= 0 && xx < sw) ? 1.f : 0.f;
+                        }
 #pragma unroll
                         for (int qy = 0; qy < 2; ++qy)
 #pragma unroll
                             for (int qx = 0; qx < 2; ++qx)
-                                sv[c][qy][qx] = p.rgb_skip ? p.rgb_skip[(((size_t)b * 3 + c) * sh + ry[qy]) * sw + rx[qx]] : 0.f;
+                                wgt[px][qy][qx] =
+                                    p.rgb_skip ? p.rgb_k4[(ty_ - 2 * qy) * 4 + (tx_ - 2 * qx)] * wy[qy] * wx[qx] : 0.f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+#pragma unroll
+                            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                                for (int qx = 0; qx < 2; ++qx)
+                                    sv[px][c][qy][qx] =
+                                        p.rgb_skip ? p.rgb_skip[(((size_t)b * 3 + c) * sh + ry[qy]) * sw + rx[qx]] : 0.f;
+                    }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        float val = rgbp[c] + p.rgb_bias[c];
+                        float val[PXN];
 #pragma unroll
-                        for (int qy = 0; qy < 2; ++qy)
+                        for (int px = 0; px < PXN; ++px) {
+                            val[px] = rgbp[px][c] + p.rgb_bias[c];
 #pragma unroll
-                            for (int qx = 0; qx < 2; ++qx) val = fmaf(wgt[qy][qx], sv[c][qy][qx], val);
-                        p.rgb_out[((size_t)b * 3 + c) * plane_out + (size_t)oy * g.OW + ox] = val;
+                            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                                for (int qx = 0; qx < 2; ++qx) val[px] = fmaf(wgt[px][qy][qx], sv[px][c][qy][qx], val[px]);
+                        }
+                        float* ro = p.rgb_out + ((size_t)b * 3 + c) * plane_out + (size_t)oy * g.OW + ox;
+                        if (PXN == 2 && ok1) *reinterpret_cast<f32x2u*>(ro) = f32x2{val[0], val[PXN - 1]};
+                        else ro[0] = val[0];
                     }
                 }
             }
@@ -545,6 +624,26 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// Winograd F(2,3) weight transform along kx, tap-major repack: wq[(ky*4 + xi)][i][o_pad],
+//   xi 0: g0   1: (g0+g1+g2)/2   2: (g0-g1+g2)/2   3: g2        (g = W[o][i][ky][0..2])
+__global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wq, int cout,
+                                                               int cout_pad, int cin) {
+    const int64_t total = (int64_t)cout_pad * cin;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int o = (int)(idx % cout_pad);
+        const int i = (int)(idx / cout_pad);
+        for (int ky = 0; ky < 3; ++ky) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (o < cout) {
+                const float* gp = w + (((size_t)o * cin + i) * 3 + ky) * 3;
+                g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            }
+            const float u[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
+            for (int xi = 0; xi < 4; ++xi) wq[((size_t)(ky * 4 + xi) * cin + i) * cout_pad + o] = u[xi];
+        }
+    }
+}
+
 inline int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -565,11 +664,17 @@ int g_conv_debug = 0;
 int g_conv_cfg = 0;  // tuning key 2: bit0 -> Cout<=64 uses 64x128 (WM 2); bit1 -> Cout<=32 uses 32x512
 
 // Tile-shape selection (host).  BM follows Cout; the pixel tile is a stack of 32-pixel MFMA groups.
-Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
+// mode 0 plain, 1 transposed stride 2, 2 plain through Winograd F(2,3) along x (needs an even width)
+Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     Plan pl{};
     ConvGeom& g = pl.g;
+    const bool up = mode == 1, wino = mode == 2;
     g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = pad32(cout), g.H = h, g.W = w;
-    if (up) {
+    if (wino) {
+        g.GH = h, g.GW = w / 2, g.OH = h, g.OW = w;  // positions are output pairs
+        if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
+        else pl.bm = 128, pl.wm = 2, pl.bn = 64;
+    } else if (up) {
         g.GH = h + 1, g.GW = w + 1, g.OH = 2 * h + 1, g.OW = 2 * w + 1;
         if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 128;
         else pl.bm = 64, pl.wm = 2, pl.bn = 64;
@@ -581,7 +686,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     }
     auto shape = [&](int bn) {
         const int nsub = bn / 32;
-        int sw = up ? 8 : 32;
+        int sw = up ? 8 : (wino ? 16 : 32);
         if (sw > pow2_ceil(g.GW)) sw = pow2_ceil(g.GW);
         const int sh = 32 / sw;
         int nsx = pow2_ceil(ceil_div(g.GW, sw));
@@ -593,11 +698,11 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
         g.lsw = ilog2(sw), g.lsh = ilog2(sh), g.lnsx = ilog2(nsx), g.lnsy = ilog2(nsy), g.lni = ilog2(ni);
         const int tw = sw * nsx, th = sh * nsy;
         g.tiles_x = ceil_div(g.GW, tw), g.tiles_y = ceil_div(g.GH, th), g.img_groups = ceil_div(batch, ni);
-        g.PH = th + 2, g.PW = tw + 2;
+        g.PH = th + 2, g.PW = (wino ? 2 * tw : tw) + 2;
         // LDS row stride: with sub-tiles narrower than 32 pixels the 32 lanes of one MFMA group read SH rows at once;
         // a stride of SW * odd puts the rows on disjoint bank groups (conflict-free ds_read_b32)
         g.PWS = g.PW;
-        if (sw < 32) {
+        if (sw < 32 && !wino) {  // (Winograd reads 8-byte pairs: the even PW is kept)
             while (g.PWS % (2 * sw) != sw) ++g.PWS;
             if (ni * g.PH * g.PWS > 512) g.PWS = g.PW;  // tiny maps, many images per tile: take the conflicts
         }
@@ -605,7 +710,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     };
     shape(pl.bn);
     if (g.PSTRIDE > (pl.bn >= 512 ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
-        if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
+        if (wino) pl.bm = 128, pl.wm = 2, pl.bn = 64;
+        else if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
         shape(pl.bn);
         pl.fallback = true;
@@ -623,12 +729,12 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int up) {
     g.splits = ceil_div(g.n_chunks, g.chunks_per_split);
     g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
     pl.blocks = base_blocks * g.splits;
-    pl.lds_bytes = 2 * ((size_t)9 * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
+    pl.lds_bytes = 2 * ((size_t)(wino ? 12 : 9) * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
     if (pl.lds_bytes < (size_t)2 * pl.bm * sizeof(float)) pl.lds_bytes = (size_t)2 * pl.bm * sizeof(float);
     return pl;
 }
 
-template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST, int MAXP>
+template <int BM, int BN, int WM, int UP, bool MULTI, bool FAST, int MAXP>
 int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI, FAST, MAXP>;
     static bool attr_set = false;
@@ -641,14 +747,14 @@ int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     return 0;
 }
 
-template <int BM, int BN, int WM, bool UP, bool MULTI, bool FAST>
+template <int BM, int BN, int WM, int UP, bool MULTI, bool FAST>
 int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     if (pl.g.PSTRIDE <= 256) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 1>(pl, ptrs, st);
     if (pl.g.PSTRIDE <= 512 || BN < 512) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
     return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, (BN >= 512 ? 3 : 2)>(pl, ptrs, st);
 }
 
-template <int BM, int BN, int WM, bool UP>
+template <int BM, int BN, int WM, int UP>
 int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     constexpr int CC = chunk_channels(BM, BN);
     if (pl.g.PSTRIDE > 768) return MAUA_EINVAL;
@@ -675,6 +781,16 @@ extern "C" int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int c
     return 0;
 }
 
+extern "C" int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, int cin, void* stream) {
+    if (!w || !wq || cout <= 0 || cin <= 0) return MAUA_EINVAL;
+    const int cout_pad = pad32(cout);
+    const int64_t blocks = ceil_div64((int64_t)cout_pad * cin, 256);
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, w, wq, cout, cout_pad, cin);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
     Plan pl = make_plan(batch, cin, cout, h, w, up);
@@ -694,6 +810,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     if (noise && !noise_w) return MAUA_EINVAL;
     if ((int64_t)batch * cin * h * w > 0x7fffffffLL) return MAUA_EINVAL;  // 32-bit patch offsets
+    if (up < 0 || up > 2 || (up == 2 && (w & 1))) return MAUA_EINVAL;
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     if (pl.g.splits > 1 && !ws) return MAUA_EINVAL;
     pl.g.s_stride = s_stride;
@@ -707,7 +824,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     if (rgb) {
         // fusable only when one workgroup holds every channel of its pixels in a single wave row (BM >= Cout, WM == 1),
         // no split-K, one image per tile, the tail fused
-        const bool ok = !up && fuse_act && pl.wm == 1 && pl.g.m_tiles == 1 && pl.g.splits == 1 && pl.g.lni == 0 &&
+        const bool ok = up != 1 && fuse_act && pl.wm == 1 && pl.g.m_tiles == 1 && pl.g.splits == 1 && pl.g.lni == 0 &&
                         rgb->w && rgb->s && rgb->bias && rgb->out && (!rgb->skip || (rgb->k4 && !(h & 1) && !(w & 1)));
         if (!ok) return MAUA_ENOSYS;
         pl.g.rgb = rgb->store_features ? 1 : 2;
@@ -717,16 +834,19 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     }
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (up) {
-        if (pl.fallback) rc = launch_conv<64, 64, 2, true>(pl, ptrs, st);
-        else if (pl.bm == 32) rc = launch_conv<32, 128, 1, true>(pl, ptrs, st);
-        else rc = launch_conv<64, 64, 2, true>(pl, ptrs, st);
+    if (up == 2) {
+        if (pl.bm == 64) rc = launch_conv<64, 128, 1, 2>(pl, ptrs, st);
+        else rc = launch_conv<128, 64, 2, 2>(pl, ptrs, st);
+    } else if (up) {
+        if (pl.fallback) rc = launch_conv<64, 64, 2, 1>(pl, ptrs, st);
+        else if (pl.bm == 32) rc = launch_conv<32, 128, 1, 1>(pl, ptrs, st);
+        else rc = launch_conv<64, 64, 2, 1>(pl, ptrs, st);
     } else {
-        if (pl.bm == 32 && pl.bn == 512) rc = launch_conv<32, 512, 1, false>(pl, ptrs, st);
-        else if (pl.bm == 32) rc = launch_conv<32, 256, 1, false>(pl, ptrs, st);
-        else if (pl.bm == 64 && pl.bn == 128) rc = launch_conv<64, 128, 2, false>(pl, ptrs, st);
-        else if (pl.bm == 64) rc = launch_conv<64, 256, 1, false>(pl, ptrs, st);
-        else rc = launch_conv<128, 128, 2, false>(pl, ptrs, st);
+        if (pl.bm == 32 && pl.bn == 512) rc = launch_conv<32, 512, 1, 0>(pl, ptrs, st);
+        else if (pl.bm == 32) rc = launch_conv<32, 256, 1, 0>(pl, ptrs, st);
+        else if (pl.bm == 64 && pl.bn == 128) rc = launch_conv<64, 128, 2, 0>(pl, ptrs, st);
+        else if (pl.bm == 64) rc = launch_conv<64, 256, 1, 0>(pl, ptrs, st);
+        else rc = launch_conv<128, 128, 2, 0>(pl, ptrs, st);
     }
     if (rc) return rc;
     if (pl.g.splits > 1) {
@@ -750,12 +870,13 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
 }
 
 extern "C" int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
-                                         float* y, int batch, int cin, int cout, int h, int w, float wscale,
+                                         float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
                                          const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                          const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                                          const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out,
                                          int store_features, void* stream) {
     RgbArgs rgb{rgb_w, rgb_s, rgb_bias, rgb_skip, rgb_k4, rgb_out, rgb_wscale, store_features};
-    return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, 0, wscale, 1, noise, noise_batch_stride, noise_w,
+    if (mode == 1) return MAUA_ENOSYS;
+    return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, mode, wscale, 1, noise, noise_batch_stride, noise_w,
                         bias, nullptr, &rgb, stream);
 }

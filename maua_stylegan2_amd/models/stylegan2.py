@@ -126,6 +126,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
         self._packed = None  # (key, wp, wsq)
+        self._packed_wino = None
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -147,7 +148,35 @@ class ModulatedConv2d(nn.Module):
                                                       self.in_channel, k2, _lib.stream_ptr(w.device))
             _lib.check(rc, "maua_pack_weight_f32")
             self._packed = (key, wp, wsq)
+            self._packed_wino = None
         return self._packed[1], self._packed[2]
+
+    # plain 3x3 layers with at least this many output channels run through Winograd F(2,3) (MFMA-bound layers);
+    # a huge value turns it off
+    winograd_min_cout = 64
+
+    def conv_mode(self, h, w):
+        """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd plain, 0 plain."""
+        if self.upsample:
+            return 1
+        if self.out_channel >= self.winograd_min_cout and w % 2 == 0 and w >= 32:
+            return 2
+        return 0
+
+    def packed_wino(self):
+        """Winograd-domain weight [(ky*4+xi), Cin, Cout_pad] (maua_pack_weight_wino_f32), cached like ``packed()``."""
+        self.packed()  # refreshes / invalidates on weight change
+        if self._packed_wino is None:
+            w = self.weight
+            wd = _lib.require_cuda(w.detach(), "weight")
+            cpad = (self.out_channel + 31) // 32 * 32
+            wq = th.empty((12, self.in_channel, cpad), dtype=th.float32, device=w.device)
+            with th.cuda.device(w.device):
+                rc = _lib.load().maua_pack_weight_wino_f32(wd.data_ptr(), wq.data_ptr(), self.out_channel,
+                                                           self.in_channel, _lib.stream_ptr(w.device))
+            _lib.check(rc, "maua_pack_weight_wino_f32")
+            self._packed_wino = wq
+        return self._packed_wino
 
     def table_entry(self, lat_idx, s_off, d_off):
         wp, wsq = self.packed()
@@ -159,12 +188,13 @@ class ModulatedConv2d(nn.Module):
         """3x3 only. x [B,Cin,H,W]; s [B,S] (this layer's slice at s_off); d [B,Cout] or None.
         Writes ``out`` ([B,Cout,H,W] or [B,Cout,2H+1,2W+1] when upsample)."""
         lib = _lib.load()
-        wp, _ = self.packed()
         b, cin, h, w = x.shape
+        mode = self.conv_mode(h, w)
+        wp = self.packed_wino() if mode == 2 else self.packed()[0]
         nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
         rc = lib.maua_modconv3x3_f32(
             x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b, cin,
-            self.out_channel, h, w, int(self.upsample), float(self.scale), int(fuse_act), _lib.ptr(noise), nstride,
+            self.out_channel, h, w, mode, float(self.scale), int(fuse_act), _lib.ptr(noise), nstride,
             _lib.ptr(noise_w), _lib.ptr(bias), _lib.ptr(ws), _lib.stream_ptr(x.device),
         )
         _lib.check(rc, "maua_modconv3x3_f32")
@@ -196,7 +226,7 @@ class ModulatedConv2d(nn.Module):
                 return out
             oh, ow = (2 * h + 1, 2 * w + 1) if self.upsample else (h, w)
             out = th.empty((b, self.out_channel, oh, ow), dtype=th.float32, device=dev)
-            n_ws = lib.maua_modconv_ws_floats(b, cin, self.out_channel, h, w, int(self.upsample))
+            n_ws = lib.maua_modconv_ws_floats(b, cin, self.out_channel, h, w, self.conv_mode(h, w))
             ws = th.empty(n_ws, dtype=th.float32, device=dev) if n_ws else None
             self.run(x, s, 0, d, out, ws)
             if self.upsample:
@@ -261,7 +291,7 @@ class StyledConv(nn.Module):
         lib = _lib.load()
         conv = self.conv
         b, cin, h, w = x.shape
-        n_ws = lib.maua_modconv_ws_floats(b, cin, conv.out_channel, h, w, int(conv.upsample))
+        n_ws = lib.maua_modconv_ws_floats(b, cin, conv.out_channel, h, w, conv.conv_mode(h, w))
         ws = bufs("ws", (n_ws,)) if n_ws else None
         if noise is not None:
             noise = _lib.require_cuda(noise, "noise")
@@ -273,11 +303,12 @@ class StyledConv(nn.Module):
                 fusable = skip is None or (tuple(t.upsample.kernel.shape) == (4, 4) and t.upsample.factor == 2
                                            and skip.shape[2] * 2 == h and skip.shape[3] * 2 == w)
                 if fusable:
-                    wp, _ = conv.packed()
+                    mode = conv.conv_mode(h, w)
+                    wp = conv.packed_wino() if mode == 2 else conv.packed()[0]
                     nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
                     rc = lib.maua_styledconv_torgb_f32(
                         x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b,
-                        cin, conv.out_channel, h, w, float(conv.scale), _lib.ptr(noise), nstride,
+                        cin, conv.out_channel, h, w, mode, float(conv.scale), _lib.ptr(noise), nstride,
                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
                         s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), t.bias.data_ptr(), _lib.ptr(skip),
                         _lib.ptr(t.upsample.kernel) if skip is not None else None, rgb["out"].data_ptr(),

@@ -96,3 +96,24 @@ def test_randomize_noise_and_float_truncation(gpu):
     b, _ = g(styles=lat, truncation=0.5, randomize_noise=True, input_is_latent=True)
     assert a.shape == (2, 3, 16, 16) and not torch.equal(a, b)
     assert g.truncation_latent is not None and g.truncation_latent.shape == (1, 512)
+
+
+def test_fused_torgb_and_winograd_match_separate_direct_kernels(gpu):
+    """1024^2: the default path (Winograd for >= 64-channel plain layers, ToRGB folded into the 64- and 32-channel
+    conv epilogues) against the same generator with both switched off (direct 3x3 kernel + separate ToRGB launch)."""
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+
+    g = build(1024, gpu, 2)
+    lat = seeding.seeded_latents(1, g.n_latent, seed=6).to(gpu)
+    noise = [n.to(gpu) for n in seeding.seeded_noise(1, 1024, seed=7)]
+    fast, _ = g(styles=lat, noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    fast = fast.clone()
+    keep = ModulatedConv2d.winograd_min_cout
+    try:
+        ModulatedConv2d.winograd_min_cout = 1 << 30
+        g.disable_rgb_fusion = True
+        plain, _ = g(styles=lat, noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    finally:
+        ModulatedConv2d.winograd_min_cout = keep
+        g.disable_rgb_fusion = False
+    assert float((fast - plain).abs().max()) < 2e-4

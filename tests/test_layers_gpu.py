@@ -125,3 +125,41 @@ def test_styled_conv_up_wide_vs_oracle(gpu):
         want = so.styled_conv(sd, "L", x, s, nz, True).numpy()
         got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
         np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [
+    (128, 128, 64, 64, 2),    # FAST path, whole tiles
+    (256, 256, 32, 36, 1),    # ragged pair grid (18 pairs -> 2 tiles of 16), split-K
+    (136, 200, 40, 70, 3),    # Cout not a multiple of the 128-row weight tile, Cin % 4 == 0 only -> generic loads
+    (64, 160, 9, 34, 2),      # short map, several images... one image per tile, ragged rows
+    (130, 128, 16, 32, 2),    # Cin % 4 != 0 -> generic path with a partial last chunk
+])
+def test_modconv_winograd_vs_oracle(gpu, cin, cout, h, w, batch):
+    """Plain 3x3 layers with >= 128 output channels run the Winograd F(2,3) mode (mode 2 of maua_modconv3x3_f32);
+    the StyledConv tail (noise + bias + leaky ReLU) is applied to both outputs of a pair in the epilogue."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(cin + 3 * cout + h + w)
+    m = StyledConv(cin, cout, 3, 512, upsample=False)
+    assert m.conv.conv_mode(h, w) == 2
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.37]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((batch, 1, h, w)).astype(np.float32))
+    want = so.styled_conv(sd, "L", x, s, nz, False).numpy()
+    got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-4)
+    # and against the direct (mode 0) kernel of the same layer: the two differ only by fp32 rounding
+    m.conv.winograd_min_cout = 1 << 30
+    assert m.conv.conv_mode(h, w) == 0
+    direct = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, direct, atol=1e-4, rtol=1e-4)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--conv-debug", type=int, default=0)
     ap.add_argument("--conv-cfg", type=int, default=0)
+    ap.add_argument("--wino-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd_min_cout")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     lib = _lib.load()
@@ -83,6 +84,8 @@ def main():
             from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
 
             B = args.batch
+            if args.wino_min_cout is not None:
+                ModulatedConv2d.winograd_min_cout = args.wino_min_cout
             for name, cin, cout, h, up in [("plain32@1024", 32, 32, 1024, 0), ("plain64@512", 64, 64, 512, 0),
                                            ("plain128@256", 128, 128, 256, 0), ("plain256@128", 256, 256, 128, 0),
                                            ("plain512@64", 512, 512, 64, 0), ("up64-32@512", 64, 32, 512, 1),
@@ -96,7 +99,7 @@ def main():
                 nz = torch.randn(B, 1, oh, oh, device=dev)
                 nw = torch.full((1,), 0.1, device=dev)
                 bias = torch.randn(cout, device=dev)
-                nws = lib.maua_modconv_ws_floats(B, cin, cout, h, h, up)
+                nws = lib.maua_modconv_ws_floats(B, cin, cout, h, h, m.conv_mode(h, h))
                 ws = torch.empty(max(nws, 1), device=dev)
                 run = lambda: m.run(x, s, 0, d, yv, ws if nws else None, fuse_act=not up, noise=None if up else nz, noise_w=nw, bias=bias)  # noqa: E731
                 run()
