@@ -48,6 +48,7 @@ struct ConvGeom {
     int fuse_act;
     int64_t noise_batch_stride;
     int64_t ws_slab;  // floats per split slab
+    int flat;         // transposed mode: tiles are runs of BN consecutive positions of the row-major (H+1)x(W+1) grid
     int rgb;          // fused ToRGB epilogue: 0 off, 1 on, 2 on and the feature map itself is not stored
     float rgb_wscale;
     int debug;        // ablation switches (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads
@@ -142,7 +143,15 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int img = pp / per_img;
             const int rem = pp - img * per_img;
             const int pr = rem / g.PWS, pc = rem - pr * g.PWS;
-            const int b = b0 + img, yy = ty0 + pr - 1, xx = (WINO ? 2 * tx0 : tx0) + pc - 1;
+            const int b = b0 + img;
+            int yy = ty0 + pr - 1, xx = (WINO ? 2 * tx0 : tx0) + pc - 1;
+            if (UP && g.flat) {
+                // flat run: patch row 1 holds positions p0-1 .. p0+BN-1 of the pitch-(W+1) flattened input (column W and
+                // row H are the zero padding), patch row 0 the same run one input row up (p - GW)
+                const int fi = tx0 + pc - 1 - (1 - pr) * g.GW;
+                yy = fi >= 0 ? fi / g.GW : -1;
+                xx = fi - yy * g.GW;
+            }
             if (pc < g.PW && img < NI && b < g.B && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
                 src_off[i] = (int)(((size_t)b * g.Cin * g.H + yy) * g.W + xx);
                 src_mask[i] = 1.f;
@@ -325,7 +334,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             for (int c = 0; c < CC; ++c) {
                 const float* __restrict__ xbase = p.x + (size_t)(c0 + c) * plane_in;  // uniform
 #pragma unroll
-                for (int i = 0; i < MAX_POS; ++i) pv[i][c] = xbase[(unsigned)src_off[i]];
+                for (int i = 0; i < MAX_POS; ++i)
+                    if (i == 0 || tid + i * 256 < g.PSTRIDE) pv[i][c] = xbase[(unsigned)src_off[i]];
             }
             if (MULTI) {
 #pragma unroll
@@ -420,7 +430,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const int sx = sub & ((1 << g.lnsx) - 1);
         const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
         const int b = b0 + (sub >> (g.lnsx + g.lnsy));
-        const int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
+        int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
+        if (UP && g.flat) gy = gx / g.GW, gx -= gy * g.GW;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = (UP || WINO) ? 2 * gx + (ph & 1) : gx;
@@ -437,7 +448,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
         const int img = sub >> (g.lnsx + g.lnsy);
         const int b = b0 + img;
-        const int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
+        int gy = ty0 + sy * SH + jy, gx = tx0 + sx * SW + jx;
+        if (UP && g.flat) gy = gx / g.GW, gx -= gy * g.GW;
         const bool pos_ok = (b < g.B) && (gy < g.GH) && (gx < g.GW);
         // transposed conv: the two x-parities of a position are adjacent in memory -> one 8-byte store per lane
         // (rows of the (2W+1)-wide plane are only 4-byte aligned: f32x2u is an align-4 vector type)
@@ -709,6 +721,16 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.PSTRIDE = ni * g.PH * g.PWS;
     };
     shape(pl.bn);
+    if (up && g.GH * g.GW >= 2 * pl.bn && !(g_conv_cfg & 4)) {
+        // The (H+1)x(W+1) position grid never fits power-of-two 2-D tiles (29 % idle MFMA columns at 65x65); tiles are
+        // instead runs of BN consecutive positions of the flattened grid, one image each.  A position reads inputs
+        // p, p-1, p-GW, p-GW-1 of the pitch-GW flattened (zero-padded) input: two runs of BN+1 floats per channel.
+        g.flat = 1;
+        g.lsw = 5, g.lsh = 0, g.lnsx = ilog2(pl.bn / 32), g.lnsy = 0, g.lni = 0;
+        g.tiles_x = ceil_div(g.GH * g.GW, pl.bn), g.tiles_y = 1, g.img_groups = batch;
+        g.PH = 2, g.PW = pl.bn + 1, g.PWS = pl.bn + 2;
+        g.PSTRIDE = g.PH * g.PWS;
+    }
     if (g.PSTRIDE > (pl.bn >= 512 ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (wino) pl.bm = 128, pl.wm = 2, pl.bn = 64;
         else if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
