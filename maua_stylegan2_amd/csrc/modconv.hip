@@ -684,7 +684,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = pad32(cout), g.H = h, g.W = w;
     if (wino) {
         g.GH = h, g.GW = w / 2, g.OH = h, g.OW = w;  // positions are output pairs
-        if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = (g_conv_cfg & 2) ? 256 : 128;
+        else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
         else pl.bm = 128, pl.wm = 2, pl.bn = 64;
     } else if (up) {
         g.GH = h + 1, g.GW = w + 1, g.OH = 2 * h + 1, g.OW = 2 * w + 1;
@@ -731,7 +732,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.PH = 2, g.PW = pl.bn + 1, g.PWS = pl.bn + 2;
         g.PSTRIDE = g.PH * g.PWS;
     }
-    if (g.PSTRIDE > (pl.bn >= 512 ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
+    if (g.PSTRIDE > ((pl.bn >= 512 || (wino && pl.bn >= 256)) ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (wino) pl.bm = 128, pl.wm = 2, pl.bn = 64;
         else if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
@@ -772,8 +773,9 @@ int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 template <int BM, int BN, int WM, int UP, bool MULTI, bool FAST>
 int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     if (pl.g.PSTRIDE <= 256) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 1>(pl, ptrs, st);
-    if (pl.g.PSTRIDE <= 512 || BN < 512) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
-    return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, (BN >= 512 ? 3 : 2)>(pl, ptrs, st);
+    constexpr bool WIDE = BN >= 512 || (UP == 2 && BN >= 256);  // configs whose patch can exceed 512 floats per channel
+    if (pl.g.PSTRIDE <= 512 || !WIDE) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
+    return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, (WIDE ? 3 : 2)>(pl, ptrs, st);
 }
 
 template <int BM, int BN, int WM, int UP>
@@ -857,7 +859,9 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (up == 2) {
-        if (pl.bm == 64) rc = launch_conv<64, 128, 1, 2>(pl, ptrs, st);
+        if (pl.bm == 32 && pl.bn == 256) rc = launch_conv<32, 256, 1, 2>(pl, ptrs, st);
+        else if (pl.bm == 32) rc = launch_conv<32, 128, 1, 2>(pl, ptrs, st);
+        else if (pl.bm == 64) rc = launch_conv<64, 128, 1, 2>(pl, ptrs, st);
         else rc = launch_conv<128, 64, 2, 2>(pl, ptrs, st);
     } else if (up) {
         if (pl.fallback) rc = launch_conv<64, 64, 2, 1>(pl, ptrs, st);

@@ -153,7 +153,7 @@ class ModulatedConv2d(nn.Module):
 
     # plain 3x3 layers with at least this many output channels run through Winograd F(2,3) (MFMA-bound layers);
     # a huge value turns it off
-    winograd_min_cout = 64
+    winograd_min_cout = 32
 
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd plain, 0 plain."""

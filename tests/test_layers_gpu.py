@@ -133,6 +133,9 @@ def test_styled_conv_up_wide_vs_oracle(gpu):
     (136, 200, 40, 70, 3),    # Cout not a multiple of the 128-row weight tile, Cin % 4 == 0 only -> generic loads
     (64, 160, 9, 34, 2),      # short map, several images... one image per tile, ragged rows
     (130, 128, 16, 32, 2),    # Cin % 4 != 0 -> generic path with a partial last chunk
+    (32, 32, 72, 96, 2),      # 32-row weight tile (BM 32), 8-row tiles with a ragged last row block
+    (64, 64, 48, 64, 1),      # 64-row weight tile
+    (24, 40, 20, 38, 2),      # generic path: Cin % 8 != 0, Cout not a multiple of 32
 ])
 def test_modconv_winograd_vs_oracle(gpu, cin, cout, h, w, batch):
     """Plain 3x3 layers with >= 128 output channels run the Winograd F(2,3) mode (mode 2 of maua_modconv3x3_f32);
