@@ -458,6 +458,7 @@ class Generator(nn.Module):
                          int(base_res_factor * 2 ** res * (2 if output_size == 1920 else 1))]
                 setattr(self.noises, f"noise_{layer_idx}", th.randn(*shape))
         self._bufs = {}
+        self._lane = 0  # static-buffer namespace: concurrent hipGraphs of one generator each own a lane
         self._tables = {}
 
     # ------------------------------------------------------------------ helpers shared with the reference API
@@ -478,7 +479,7 @@ class Generator(nn.Module):
 
     # ------------------------------------------------------------------ static buffers / tables
     def _buf(self, batch, name, shape, dtype=th.float32):
-        key = (batch, name)
+        key = (batch, name, self._lane)
         t = self._bufs.get(key)
         shape = tuple(int(v) for v in shape)
         if t is None or tuple(t.shape) != shape or t.device != self.input.input.device:
@@ -641,10 +642,19 @@ class Generator(nn.Module):
         return image, acts, lat_out
 
     # ------------------------------------------------------------------ hipGraph
-    def capture_graph(self, batch, noise_static, truncated=False):
+    def capture_graph(self, batch, noise_static, truncated=False, lane=0):
         """Capture one forward of ``batch`` frames into a hipGraph.  Returns (graph, static) where static holds the
         input buffers to overwrite before each ``graph.replay()`` (latents, truncation, per-layer noise or None for
-        checkpoint noise buffers) and ``static["image"]`` is the output buffer.  Bends are not capturable."""
+        checkpoint noise buffers) and ``static["image"]`` is the output buffer.  Bends are not capturable.
+        Graphs captured under different ``lane`` ids share the weights but no activation / input buffer, so they can
+        be replayed concurrently on different streams."""
+        self._lane = lane
+        try:
+            return self._capture_graph(batch, noise_static, truncated)
+        finally:
+            self._lane = 0
+
+    def _capture_graph(self, batch, noise_static, truncated):
         dev = self.input.input.device
         with th.cuda.device(dev):
             static = {

@@ -107,9 +107,14 @@ def frames_to_uint8(images, out=None):
 
 
 def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), rewrites=None, randomize_noise=False,
-               use_graph=True, frame_range=None):
+               use_graph=True, frame_range=None, lanes=2):
     """Generator -> uint8 frames for ``frame_range`` (default: all) of the sequence.  Yields (first_frame_index,
-    uint8 device tensor [b, H, W, 3]) per batch; the tensor is only valid until the next iteration."""
+    uint8 device tensor [b, H, W, 3]) per batch, in order, with the producing stream current; the tensor stays valid
+    until ``lanes`` further batches have been requested.
+
+    hipGraph path: ``lanes`` graphs of ``batch_size`` frames (same weights, private activations) are replayed round-robin
+    on their own streams, so consecutive batches overlap on the device — the small, latency-bound 4^2..32^2 layers and
+    the last partial wave of every big launch of one batch run underneath the other batch's MFMA-bound layers."""
     dev = generator.input.input.device
     n_total = len(latents)
     lo, hi = frame_range if frame_range is not None else (0, n_total)
@@ -132,25 +137,38 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
         original_weights[name] = param_dict[name].detach().clone()
     capturable = (use_graph and not bends and not rewrites and not randomize_noise
                   and hasattr(generator, "capture_graph"))
-    graph = static = None
-    u8 = None
-    stream = th.cuda.Stream(dev)
-    stream.wait_stream(th.cuda.current_stream(dev))
-    with th.cuda.stream(stream):
-        for n in range(lo, hi, batch_size):
-            m = min(n + batch_size, hi)
-            b = m - n
+    n_lanes = max(1, int(lanes)) if capturable else 1
+    caller_stream = th.cuda.current_stream(dev)
+    lane_state = []  # per lane: dict(stream, graph, static, u8)
+
+    def lane_for(k):
+        if k < len(lane_state):
+            return lane_state[k]
+        stream = th.cuda.Stream(dev)
+        stream.wait_stream(caller_stream)
+        lane_state.append({"stream": stream, "graph": None, "static": None, "u8": None})
+        return lane_state[k]
+
+    k = 0
+    for n in range(lo, hi, batch_size):
+        m = min(n + batch_size, hi)
+        b = m - n
+        lane_id = k % n_lanes
+        lane = lane_for(lane_id)
+        with th.cuda.stream(lane["stream"]):
             if capturable and b == batch_size:
-                if graph is None:
+                if lane["graph"] is None:
                     shapes = [None if nz is None else tuple(nz.shape[-2:]) for nz in noise]
-                    graph, static = generator.capture_graph(batch_size, shapes, truncated=trunc_t is not None)
+                    lane["graph"], lane["static"] = generator.capture_graph(batch_size, shapes, truncated=trunc_t is not None,
+                                                                            lane=lane_id)
+                static = lane["static"]
                 static["latents"].copy_(latents[n:m])
                 for dst, src in zip(static["noise"], noise):
                     if src is not None:
                         dst.copy_(src[n:m])
                 if trunc_t is not None:
                     static["trunc"].copy_(trunc_t[n:m])
-                graph.replay()
+                lane["graph"].replay()
                 images = static["image"]
             else:
                 noise_batch = [None if nz is None else nz[n:m] for nz in noise]
@@ -167,20 +185,26 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
                     for attr in path:
                         module = getattr(module, attr)
                     setattr(module, leaf, th.nn.Parameter(new_weight, requires_grad=False))
+                if n_lanes > 1:  # the eager tail batch shares lane 0's activation namespace: let the other lanes drain first
+                    for other in lane_state:
+                        lane["stream"].wait_stream(other["stream"])
                 images, _ = generator(styles=latents[n:m], noise=noise_batch,
                                       truncation=truncation if trunc_t is None else trunc_t[n:m],
                                       transform_dict_list=bend_batch, randomize_noise=randomize_noise, input_is_latent=True)
+            u8 = lane["u8"]
             if u8 is None or u8.shape[0] != b or u8.shape[1:3] != images.shape[2:]:
-                u8 = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
+                u8 = lane["u8"] = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
             frames_to_uint8(images, u8)
             yield n, u8
+        k += 1
     for name, w in original_weights.items():  # leave the generator as it was found
         module = generator
         *path, leaf = name.split(".")
         for attr in path:
             module = getattr(module, attr)
         setattr(module, leaf, th.nn.Parameter(w, requires_grad=False))
-    th.cuda.current_stream(dev).wait_stream(stream)
+    for lane in lane_state:
+        caller_stream.wait_stream(lane["stream"])
 
 
 def render(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file=None,

@@ -175,3 +175,27 @@ def test_rewrites_vs_oracle(gpu):
         assert diff.max() <= 1 and (diff > 0).mean() < 5e-3
     # the generator is restored afterwards
     assert torch.equal(g.convs[2].conv.weight.cpu(), sd["convs.2.conv.weight"])
+
+
+def test_concurrent_graph_lanes_give_the_same_frames(gpu):
+    """synthesize() replays ``lanes`` hipGraphs round-robin on their own streams; the frames must not depend on it
+    (same kernels, same batch size -> bit-identical), including the eager tail batch."""
+    from maua_stylegan2_amd import render, seeding
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    g = Generator(64, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(64, seed=5), strict=True)
+    g = g.to(gpu).eval()
+    n = 14  # 4 full batches of 3 + a tail of 2
+    lat = seeding.seeded_latents(n, g.n_latent, seed=6)
+    noise = [torch.from_numpy(seeding.seeded_array(7, f"n{i}", (n, 1, r, r))) if r <= 16 else None
+             for i, r in enumerate(seeding.noise_sizes(64))]
+    out = {}
+    for lanes in (1, 2, 3):
+        frames = []
+        for first, u8 in render.synthesize(g, lat, noise, 3, lanes=lanes):
+            assert first == len(frames)
+            frames.extend(u8.cpu().numpy())
+        out[lanes] = np.stack(frames)
+        assert out[lanes].shape == (n, 64, 64, 3)
+    assert np.array_equal(out[1], out[2]) and np.array_equal(out[1], out[3])
