@@ -3,14 +3,18 @@
 // Behavioural contract: /root/reference/models/stylegan2.py:140-146 (EqualLinear), :207,220 (modulation, bias_init 1),
 // :223-225 (demodulation), :541-543 (truncation lerp).  The reference runs 26 F.linear + 17 pow/sum/rsqrt launches
 // per forward at 1024^2; these are GEMV-sized (<= 512 x 512 per layer), so the only goal here is to not pay 43
-// launch boundaries: a workgroup owns 64 output rows of one layer, keeps the (truncated) latent rows / squared styles
-// of up to 16 frames in LDS, holds each weight row in registers and reduces with wave64 butterfly shuffles.
+// launch boundaries: a workgroup owns 16 output rows of one layer (4 per wave, their weight rows all fetched up front so
+// the loads overlap), keeps the (truncated) latent rows / squared styles of up to 16 frames in LDS and reduces with
+// wave64 butterfly shuffles.  The forward waits on these two launches before its first conv, so they are sized for
+// latency (832 small workgroups), not for bandwidth.
 #include "common.h"
 
 namespace {
 
 constexpr int BCHUNK = 16;   // frames staged in LDS per pass
 constexpr int MAX_PER_LANE = 16;  // style_dim, cin <= 1024
+constexpr int ROWS = 16;          // output rows per workgroup
+constexpr int RPW = ROWS / 4;     // rows per wave
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -25,7 +29,7 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
                                                            float* __restrict__ s, int s_stride) {
     extern __shared__ __attribute__((aligned(16))) float lat[];  // [BCHUNK][style_dim]
     const maua_style_layer_t L = table[blockIdx.x];
-    const int row0 = blockIdx.y * 64;
+    const int row0 = blockIdx.y * ROWS;
     if (row0 >= L.cin) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float inv = 1.0f / sqrtf((float)style_dim);
@@ -44,20 +48,31 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
             lat[e] = v;
         }
         __syncthreads();
-        for (int rr = wave; rr < 64; rr += 4) {
-            const int i = row0 + rr;
-            if (i >= L.cin) break;
-            float w[MAX_PER_LANE];
+        float w[RPW][MAX_PER_LANE], bias[RPW];
 #pragma unroll
-            for (int q = 0; q < MAX_PER_LANE; ++q) w[q] = (q < per_lane) ? L.mod_w[(size_t)i * style_dim + q * 64 + lane] : 0.f;
-            const float bias = L.mod_b[i];
-            for (int b = 0; b < nb; ++b) {
-                float acc = 0.f;
+        for (int r = 0; r < RPW; ++r) {
+            const int i = min(row0 + wave * RPW + r, L.cin - 1);
 #pragma unroll
-                for (int q = 0; q < MAX_PER_LANE; ++q)
-                    if (q < per_lane) acc = fmaf(w[q], lat[b * style_dim + q * 64 + lane], acc);
-                acc = wave_sum(acc);
-                if (lane == 0) s[(size_t)(bc + b) * s_stride + L.s_off + i] = acc * inv + bias;
+            for (int q = 0; q < MAX_PER_LANE; ++q)
+                w[r][q] = (q < per_lane) ? L.mod_w[(size_t)i * style_dim + q * 64 + lane] : 0.f;
+            bias[r] = L.mod_b[i];
+        }
+        for (int b = 0; b < nb; ++b) {
+            float acc[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < MAX_PER_LANE; ++q)
+                if (q < per_lane) {
+                    const float lv = lat[b * style_dim + q * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) acc[r] = fmaf(w[r][q], lv, acc[r]);
+                }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float v = wave_sum(acc[r]);
+                const int i = row0 + wave * RPW + r;
+                if (lane == 0 && i < L.cin) s[(size_t)(bc + b) * s_stride + L.s_off + i] = v * inv + bias[r];
             }
         }
     }
@@ -69,7 +84,7 @@ __global__ __launch_bounds__(256) void demod_kernel(const maua_style_layer_t* __
     extern __shared__ __attribute__((aligned(16))) float s2[];  // [BCHUNK][cin]
     const maua_style_layer_t L = table[blockIdx.x];
     if (!L.wsq) return;
-    const int row0 = blockIdx.y * 64;
+    const int row0 = blockIdx.y * ROWS;
     if (row0 >= L.cout) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_lane = (L.cin + 63) / 64;
@@ -84,24 +99,34 @@ __global__ __launch_bounds__(256) void demod_kernel(const maua_style_layer_t* __
             s2[e] = v * v;
         }
         __syncthreads();
-        for (int rr = wave; rr < 64; rr += 4) {
-            const int o = row0 + rr;
-            if (o >= L.cout) break;
-            float w[MAX_PER_LANE];
+        float w[RPW][MAX_PER_LANE];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int o = min(row0 + wave * RPW + r, L.cout - 1);
 #pragma unroll
             for (int q = 0; q < MAX_PER_LANE; ++q) {
                 const int i = q * 64 + lane;
-                w[q] = (q < per_lane && i < L.cin) ? L.wsq[(size_t)o * L.cin + i] : 0.f;
+                w[r][q] = (q < per_lane && i < L.cin) ? L.wsq[(size_t)o * L.cin + i] : 0.f;
             }
-            for (int b = 0; b < nb; ++b) {
-                float acc = 0.f;
+        }
+        for (int b = 0; b < nb; ++b) {
+            float acc[RPW];
 #pragma unroll
-                for (int q = 0; q < MAX_PER_LANE; ++q) {
-                    const int i = q * 64 + lane;
-                    if (q < per_lane && i < L.cin) acc = fmaf(w[q], s2[b * L.cin + i], acc);
+            for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < MAX_PER_LANE; ++q) {
+                const int i = q * 64 + lane;
+                if (q < per_lane && i < L.cin) {
+                    const float sv = s2[b * L.cin + i];
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) acc[r] = fmaf(w[r][q], sv, acc[r]);
                 }
-                acc = wave_sum(acc);
-                if (lane == 0) d[L.d_off + (size_t)(bc + b) * L.cout + o] = rsqrtf(acc * ws2 + 1e-8f);
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float v = wave_sum(acc[r]);
+                const int o = row0 + wave * RPW + r;
+                if (lane == 0 && o < L.cout) d[L.d_off + (size_t)(bc + b) * L.cout + o] = rsqrtf(v * ws2 + 1e-8f);
             }
         }
     }
@@ -115,7 +140,7 @@ extern "C" int maua_style_affine_f32(const float* latents, int batch, int n_late
     if (!latents || !table || !s || batch <= 0 || n_layers <= 0 || max_cin <= 0) return MAUA_EINVAL;
     if (style_dim <= 0 || style_dim % 64 || style_dim > 64 * MAX_PER_LANE) return MAUA_EINVAL;
     const size_t lds = (size_t)BCHUNK * style_dim * sizeof(float);
-    hipLaunchKernelGGL(style_affine_kernel, dim3(n_layers, ceil_div(max_cin, 64)), dim3(256), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL(style_affine_kernel, dim3(n_layers, ceil_div(max_cin, ROWS)), dim3(256), lds, (hipStream_t)stream,
                        latents, batch, n_latent, style_dim, trunc, trunc_latent, table, s, s_stride);
     MAUA_LAUNCH_CHECK();
     return 0;
@@ -125,7 +150,7 @@ extern "C" int maua_demod_f32(const maua_style_layer_t* table, int n_layers, int
                               float* d, int batch, void* stream) {
     if (!table || !s || !d || batch <= 0 || n_layers <= 0 || max_cout <= 0) return MAUA_EINVAL;
     const size_t lds = (size_t)BCHUNK * 64 * MAX_PER_LANE * sizeof(float);
-    hipLaunchKernelGGL(demod_kernel, dim3(n_layers, ceil_div(max_cout, 64)), dim3(256), lds, (hipStream_t)stream, table,
+    hipLaunchKernelGGL(demod_kernel, dim3(n_layers, ceil_div(max_cout, ROWS)), dim3(256), lds, (hipStream_t)stream, table,
                        s, s_stride, d, batch);
     MAUA_LAUNCH_CHECK();
     return 0;
