@@ -51,7 +51,8 @@ struct ConvGeom {
     int flat;         // transposed mode: tiles are runs of BN consecutive positions of the row-major (H+1)x(W+1) grid
     int rgb;          // fused ToRGB epilogue: 0 off, 1 on, 2 on and the feature map itself is not stored
     float rgb_wscale;
-    int debug;        // ablation switches (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads
+    int debug;        // ablation switches (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads, 32 skip weight DMA,
+                      // 64 skip patch loads, 128 fold the patch loads onto 4 KB per channel (always cache hits; wrong results)
 };
 
 struct ConvPtrs {
@@ -158,6 +159,11 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 sb_off[i] = b * g.s_stride;
             }
         }
+    }
+
+    if (g.debug & 128) {
+#pragma unroll
+        for (int i = 0; i < MAX_POS; ++i) src_off[i] = src_off[i] < 0 ? src_off[i] : (src_off[i] & 0x3ff);
     }
 
     // ---- per-lane B-fragment base offsets (top-left of the 3x3 window of this lane's pixel, channel parity hi)
@@ -370,11 +376,11 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
             const bool more = chunk + 1 < chunk_end;
             if (more && !(g.debug & 4)) {
-                issue_dma(chunk + 1, cur ^ 1);
-                load_patch(chunk + 1);
+                if (!(g.debug & 32)) issue_dma(chunk + 1, cur ^ 1);
+                if (!(g.debug & 64)) load_patch(chunk + 1);
             }
             if (!(g.debug & 2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * (CC * g.PSTRIDE));
-            if (more && !(g.debug & 4)) write_patch(chunk + 1, cur ^ 1);
+            if (more && !(g.debug & (4 | 64))) write_patch(chunk + 1, cur ^ 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             cur ^= 1;

@@ -25,9 +25,12 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--conv-debug", type=int, default=0)
     ap.add_argument("--conv-cfg", type=int, default=0)
+    ap.add_argument("--lib", default=None, help="experimental build of libmaua_hip.so to load instead (tools/bin/...)")
     ap.add_argument("--wino-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd_min_cout")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     lib = _lib.load()
     lib.maua_tuning_set(1, args.conv_debug)
     lib.maua_tuning_set(2, args.conv_cfg)
