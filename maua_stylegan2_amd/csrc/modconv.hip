@@ -248,7 +248,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     };
 
     // ---- MFMA phase over one staged chunk
-    auto mfma_chunk = [&](const float* __restrict__ Ac, const float* __restrict__ Pc) {
+    // Sc != nullptr: the staged patch holds RAW features (DMA path) and the style of channel 2q+hi is applied to the B
+    // operand here, one VALU multiply per operand next to a 64-cycle MFMA.
+    auto mfma_chunk = [&](const float* __restrict__ Ac, const float* __restrict__ Pc, const float* __restrict__ Sc) {
         if (WINO) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
@@ -264,6 +266,11 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                         bv[n][1] = d01.y + d23.x;
                         bv[n][2] = d23.x - d01.y;
                         bv[n][3] = d01.y - d23.y;
+                        if (Sc) {
+                            const float sc = Sc[2 * q + hi];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) bv[n][k] *= sc;
+                        }
                     }
 #pragma unroll
                     for (int xi = 0; xi < 4; ++xi) {
@@ -296,6 +303,11 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[(tap * CC + 2 * q) * BM + mt * 32 + aoff];
 #pragma unroll
                 for (int n = 0; n < TN; ++n) bv[n] = Pc[2 * q * g.PSTRIDE + boff[n] + tapoff];
+                if (Sc) {
+                    const float sc = Sc[2 * q + hi];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) bv[n] *= sc;
+                }
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -366,6 +378,49 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             }
         };
         int cur = 0;
+        // measured (30-launch averages): -4..5 % on the transposed 64-row configs, -1 % on the 128-row Winograd config,
+        // +4 % on the two-slot (MAXP 2) 32/64-channel configs, which therefore keep the register-staged patch
+        constexpr bool PDMA = !MULTI && MAXP == 1;
+        if (PDMA) {
+            // Feature patch by DMA as well: raw features go L2/HBM -> LDS without staging registers or ds_write, double
+            // buffered like the weight tile.  Out-of-image patch elements are never written: their lanes are masked out of
+            // the DMA and both buffers are zeroed once.  The style scale moves to the B-operand read (mfma_chunk Sc).
+            // (A three-deep patch ring with a two-chunk prefetch distance measured the same and was dropped.)
+            const int PBUF = CC * g.PSTRIDE;
+            float* Ss = Ps + 2 * PBUF;
+            const bool pvalid = src_mask[0] != 0.f;
+            for (int e = tid; e < 2 * PBUF; e += 256) Ps[e] = 0.f;
+            const int nK = (chunk_end - chunk_begin) * CC;
+            for (int e = tid; e < nK; e += 256) Ss[e] = p.s[b0 * g.s_stride + chunk_begin * CC + e];
+            __syncthreads();
+            auto issue_patch = [&](int chunk, int buf) {
+                float* dst = Ps + buf * PBUF + wave * 64;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    const float* __restrict__ xbase = p.x + (size_t)(chunk * CC + c) * plane_in;  // uniform
+                    if (pvalid)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(xbase + (unsigned)src_off[0]),
+                            (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE), 4, 0, 0);
+                }
+            };
+            if (chunk_begin < chunk_end) {
+                issue_dma(chunk_begin, 0);
+                issue_patch(chunk_begin, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+                if (chunk + 1 < chunk_end) {
+                    issue_dma(chunk + 1, cur ^ 1);
+                    issue_patch(chunk + 1, cur ^ 1);
+                }
+                mfma_chunk(As + cur * A_FLOATS, Ps + cur * PBUF, Ss + (chunk - chunk_begin) * CC);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
+        } else {
         if (chunk_begin < chunk_end) {
             issue_dma(chunk_begin, 0);
             load_patch(chunk_begin);
@@ -379,11 +434,12 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 if (!(g.debug & 32)) issue_dma(chunk + 1, cur ^ 1);
                 if (!(g.debug & 64)) load_patch(chunk + 1);
             }
-            if (!(g.debug & 2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * (CC * g.PSTRIDE));
+            if (!(g.debug & 2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * (CC * g.PSTRIDE), nullptr);
             if (more && !(g.debug & (4 | 64))) write_patch(chunk + 1, cur ^ 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             cur ^= 1;
+        }
         }
     } else {
     if (chunk_begin < chunk_end) issue_loads(chunk_begin);
@@ -392,7 +448,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         __syncthreads();
         if (chunk + 1 < chunk_end) issue_loads(chunk + 1);
 
-        mfma_chunk(As, Ps);
+        mfma_chunk(As, Ps, nullptr);
         __syncthreads();
     }
     }
@@ -759,6 +815,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
     pl.blocks = base_blocks * g.splits;
     pl.lds_bytes = 2 * ((size_t)(wino ? 12 : 9) * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
+    if (g.lni == 0 && g.PSTRIDE <= 256)  // DMA patch path (MAXP 1 kernels) also stages the styles of one image
+        pl.lds_bytes += (size_t)cin * sizeof(float);
     if (pl.lds_bytes < (size_t)2 * pl.bm * sizeof(float)) pl.lds_bytes = (size_t)2 * pl.bm * sizeof(float);
     return pl;
 }

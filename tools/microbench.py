@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="*", default=["fir", "copy"])
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--conv-debug", type=int, default=0)
     ap.add_argument("--conv-cfg", type=int, default=0)
     ap.add_argument("--lib", default=None, help="experimental build of libmaua_hip.so to load instead (tools/bin/...)")
