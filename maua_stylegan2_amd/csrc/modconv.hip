@@ -378,30 +378,40 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             }
         };
         int cur = 0;
-        // measured (30-launch averages): -4..5 % on the transposed 64-row configs, -1 % on the 128-row Winograd config,
-        // +4 % on the two-slot (MAXP 2) 32/64-channel configs, which therefore keep the register-staged patch
-        constexpr bool PDMA = !MULTI && MAXP == 1;
+        // measured (30-launch averages): -6..7 % on the transposed 64-row configs, -4 % on the transposed 32-row config,
+        // -3 % on the 64/128-row Winograd configs, +1 % on the 32-channel 1024^2 Winograd layer (its features stream from
+        // HBM; the register-staged patch tolerates that latency better), which keeps the register path
+        constexpr bool PDMA = !MULTI && !(WINO && BM == 32);
         if (PDMA) {
             // Feature patch by DMA as well: raw features go L2/HBM -> LDS without staging registers or ds_write, double
             // buffered like the weight tile.  Out-of-image patch elements are never written: their lanes are masked out of
-            // the DMA and both buffers are zeroed once.  The style scale moves to the B-operand read (mfma_chunk Sc).
+            // the DMA and their LDS slots are zeroed once by the owning thread.  The style scale moves to the B-operand read (mfma_chunk Sc).
             // (A three-deep patch ring with a two-chunk prefetch distance measured the same and was dropped.)
             const int PBUF = CC * g.PSTRIDE;
             float* Ss = Ps + 2 * PBUF;
-            const bool pvalid = src_mask[0] != 0.f;
-            for (int e = tid; e < 2 * PBUF; e += 256) Ps[e] = 0.f;
+            bool pvalid[MAX_POS];
+#pragma unroll
+            for (int i = 0; i < MAX_POS; ++i) {
+                pvalid[i] = src_mask[i] != 0.f;
+                const int pp = tid + i * 256;
+                if (!pvalid[i] && pp < g.PSTRIDE) {  // border / padding element of this thread: zero in both buffers, for good
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) Ps[c * g.PSTRIDE + pp] = 0.f, Ps[PBUF + c * g.PSTRIDE + pp] = 0.f;
+                }
+            }
             const int nK = (chunk_end - chunk_begin) * CC;
             for (int e = tid; e < nK; e += 256) Ss[e] = p.s[b0 * g.s_stride + chunk_begin * CC + e];
-            __syncthreads();
             auto issue_patch = [&](int chunk, int buf) {
                 float* dst = Ps + buf * PBUF + wave * 64;
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
                     const float* __restrict__ xbase = p.x + (size_t)(chunk * CC + c) * plane_in;  // uniform
-                    if (pvalid)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(xbase + (unsigned)src_off[0]),
-                            (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE), 4, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MAX_POS; ++i)
+                        if (pvalid[i])
+                            __builtin_amdgcn_global_load_lds(
+                                (const __attribute__((address_space(1))) void*)(xbase + (unsigned)src_off[i]),
+                                (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE + i * 256), 4, 0, 0);
                 }
             };
             if (chunk_begin < chunk_end) {
@@ -815,7 +825,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
     pl.blocks = base_blocks * g.splits;
     pl.lds_bytes = 2 * ((size_t)(wino ? 12 : 9) * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
-    if (g.lni == 0 && g.PSTRIDE <= 256)  // DMA patch path (MAXP 1 kernels) also stages the styles of one image
+    if (g.lni == 0)  // the DMA patch path also stages the styles of one image
         pl.lds_bytes += (size_t)cin * sizeof(float);
     if (pl.lds_bytes < (size_t)2 * pl.bm * sizeof(float)) pl.lds_bytes = (size_t)2 * pl.bm * sizeof(float);
     return pl;
