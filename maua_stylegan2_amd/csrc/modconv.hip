@@ -22,6 +22,8 @@
 // split-K through a caller-owned workspace, reduced by reduce_tail_kernel together with the tail).
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -106,7 +108,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     float* Ps = lds + 2 * A_FLOATS;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
 
@@ -154,7 +157,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 xx = fi - yy * g.GW;
             }
             if (pc < g.PW && img < NI && b < g.B && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
-                src_off[i] = (int)(((size_t)b * g.Cin * g.H + yy) * g.W + xx);
+                src_off[i] = ((b * g.Cin * g.H + yy) * g.W + xx);  // < 2^31: checked on the host
                 src_mask[i] = 1.f;
                 sb_off[i] = b * g.s_stride;
             }
@@ -509,7 +512,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = (UP || WINO) ? 2 * gx + (ph & 1) : gx;
             nz_all[n][ph] = 0.f;
             if (nw != 0.f && b < g.B && gy < g.GH && gx < g.GW && oy < g.OH && ox < g.OW)
-                nz_all[n][ph] = nw * p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox];
+                nz_all[n][ph] = nw * (MULTI ? p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox]
+                                            : (p.noise + (size_t)b0 * g.noise_batch_stride)[(unsigned)(oy * g.OW + ox)]);
         }
     }
 #pragma unroll
@@ -535,59 +539,83 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             float nzv[PXN];
 #pragma unroll
             for (int px = 0; px < PXN; ++px) nzv[px] = nz_all[n][UP ? py * 2 + px : (WINO ? px : 0)];
-            float* obase = outp + (size_t)b * g.Cout * plane_out + (size_t)oy * g.OW + ox;
+            // row pointer of this wave's first output channel (block-uniform unless several images share a tile) + a
+            // 32-bit lane offset: the per-element address is scalar base + VGPR offset, no 64-bit vector arithmetic
+            float* blk = outp + ((size_t)(MULTI ? b : b0) * g.Cout + m0 + wm * (TM * 32)) * plane_out;
+            const unsigned lane_off = (unsigned)oy * (unsigned)g.OW + (unsigned)ox + (unsigned)(4 * hi) * (unsigned)plane_out;
             float rgbp[PXN][3];
 #pragma unroll
             for (int px = 0; px < PXN; ++px) rgbp[px][0] = rgbp[px][1] = rgbp[px][2] = 0.f;
+            // Everything that does not depend on the accumulator element is decided once per (n, py): whether the tail is
+            // applied, whether the feature map is stored, and the lane's store class.  Tiles that lie completely inside the
+            // image and the channel range (every tile of the power-of-two plain layers) take the INTERIOR instance of the
+            // element loop, which has no per-lane predication at all — on the 32/64-channel 1024^2/512^2 layers (4-8 K-chunks
+            // per workgroup) the epilogue's instruction count is a first-order cost.
+            const bool apply_act = !to_ws && g.fuse_act;
+            const bool do_rgb = !UP && WM == 1 && !MULTI && g.rgb;
+            const bool store_feat = !(do_rgb && g.rgb == 2) && !(g.debug & 1);
+            const int n_ok = g.Cout - m0 - wm * (TM * 32) - 4 * hi;  // this lane's channel rows oe < n_ok exist
+            const unsigned lane_bytes = lane_off * 4u;
+            auto elements = [&](auto interior_tag) {
+                constexpr bool IN = decltype(interior_tag)::value;
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
+                for (int mt = 0; mt < TM; ++mt) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ol = wm * (TM * 32) + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    const int o = m0 + ol;
-                    float gain, bias;
-                    if (MULTI) {
-                        gain = g.wscale, bias = 0.f;
-                        if (!to_ws && ok0 && o < g.Cout) {
-                            if (p.d) gain *= p.d[b * g.Cout + o];
-                            if (g.fuse_act && p.bias) bias = p.bias[o];
-                        }
-                    } else {
-                        gain = Eg[ol], bias = Eb[ol];
-                    }
-                    float v[PXN];
-#pragma unroll
-                    for (int px = 0; px < PXN; ++px) {
-                        float raw;
-                        if (WINO) {  // inverse transform: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
-                            const float m0_ = acc[mt][n * NPH + 0][e], m1_ = acc[mt][n * NPH + 1][e];
-                            const float m2_ = acc[mt][n * NPH + 2][e], m3_ = acc[mt][n * NPH + 3][e];
-                            raw = px == 0 ? (m0_ + m1_) + m2_ : (m1_ - m2_) - m3_;
+                    for (int e = 0; e < 16; ++e) {
+                        const int oe = mt * 32 + (e & 3) + 8 * (e >> 2);
+                        const int ol = wm * (TM * 32) + oe + 4 * hi;
+                        const int o = m0 + ol;
+                        float gain, bias;
+                        if (MULTI) {
+                            gain = g.wscale, bias = 0.f;
+                            if (!to_ws && ok0 && o < g.Cout) {
+                                if (p.d) gain *= p.d[b * g.Cout + o];
+                                if (g.fuse_act && p.bias) bias = p.bias[o];
+                            }
                         } else {
-                            raw = acc[mt][n * NPH + (UP ? py * 2 + px : 0)][e];
+                            gain = Eg[ol], bias = Eb[ol];
                         }
-                        v[px] = raw * gain;
-                        if (!to_ws && g.fuse_act) v[px] = lrelu_gain(v[px] + nzv[px] + bias);
-                    }
-                    if (!UP && WM == 1 && !MULTI && g.rgb) {
+                        float v[PXN];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float rw = lds[(2 + c) * BM + ol];
-#pragma unroll
-                            for (int px = 0; px < PXN; ++px) rgbp[px][c] = fmaf(rw, v[px], rgbp[px][c]);
+                        for (int px = 0; px < PXN; ++px) {
+                            float raw;
+                            if (WINO) {  // inverse transform: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
+                                const float m0_ = acc[mt][n * NPH + 0][e], m1_ = acc[mt][n * NPH + 1][e];
+                                const float m2_ = acc[mt][n * NPH + 2][e], m3_ = acc[mt][n * NPH + 3][e];
+                                raw = px == 0 ? (m0_ + m1_) + m2_ : (m1_ - m2_) - m3_;
+                            } else {
+                                raw = acc[mt][n * NPH + (UP ? py * 2 + px : 0)][e];
+                            }
+                            const float lin = raw * gain;
+                            const float act = lrelu_gain(lin + nzv[px] + bias);
+                            v[px] = apply_act ? act : lin;
                         }
-                        if (g.rgb == 2) continue;  // last layer: nothing downstream reads the feature map
-                    }
-                    if ((g.debug & 1) && v[0] != 123.456f) continue;
-                    float* dst = obase + (size_t)o * plane_out;
-                    if (UP || WINO) {
-                        if (ok1 && o < g.Cout) *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
-                        else if (ok0 && o < g.Cout) dst[0] = v[0];
-                    } else if (ok0 && o < g.Cout) {
-                        dst[0] = v[0];
+                        if (do_rgb) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const float rw = lds[(2 + c) * BM + ol];
+#pragma unroll
+                                for (int px = 0; px < PXN; ++px) rgbp[px][c] = fmaf(rw, v[px], rgbp[px][c]);
+                            }
+                        }
+                        if (!store_feat) continue;
+                        // scalar row base + 32-bit lane byte offset
+                        char* rowb = reinterpret_cast<char*>(blk + (size_t)oe * plane_out);
+                        float* dst = reinterpret_cast<float*>(rowb + lane_bytes);
+                        if (IN) {
+                            if (UP || WINO) *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
+                            else dst[0] = v[0];
+                        } else if (oe < n_ok) {
+                            if ((UP || WINO) && ok1) *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
+                            else if (ok0) dst[0] = v[0];
+                        }
                     }
                 }
-            }
+            };
+            const bool interior = !UP && !MULTI && (m0 + BM <= g.Cout) && (ty0 + THt <= g.GH) && (tx0 + TWd <= g.GW) &&
+                                  (!WINO || !(g.OW & 1));
+            if (interior) elements(std::true_type{});
+            else elements(std::false_type{});
             if (!UP && WM == 1 && !MULTI && g.rgb) {
                 // all channels of a pixel live in one wave: lanes l and l+32 hold the two halves of the channel set
 #pragma unroll
@@ -611,6 +639,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                     }
                     float wgt[PXN][2][2];
                     float sv[PXN][3][2][2];
+                    // (this branch is only compiled for single-image tiles: b == b0, bases are scalar, offsets 32-bit)
+                    const float* __restrict__ skip_img = p.rgb_skip ? p.rgb_skip + (size_t)b0 * 3 * sh * sw : nullptr;
 #pragma unroll
                     for (int px = 0; px < PXN; ++px) {
                         const int x = ox + px;
@@ -627,18 +657,25 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                         for (int qy = 0; qy < 2; ++qy)
 #pragma unroll
-                            for (int qx = 0; qx < 2; ++qx)
-                                wgt[px][qy][qx] =
-                                    p.rgb_skip ? p.rgb_k4[(ty_ - 2 * qy) * 4 + (tx_ - 2 * qx)] * wy[qy] * wx[qx] : 0.f;
+                            for (int qx = 0; qx < 2; ++qx) {
+                                wgt[px][qy][qx] = 0.f;
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
+                                for (int c = 0; c < 3; ++c) sv[px][c][qy][qx] = 0.f;
+                            }
+                        if (skip_img) {
 #pragma unroll
                             for (int qy = 0; qy < 2; ++qy)
 #pragma unroll
-                                for (int qx = 0; qx < 2; ++qx)
-                                    sv[px][c][qy][qx] =
-                                        p.rgb_skip ? p.rgb_skip[(((size_t)b * 3 + c) * sh + ry[qy]) * sw + rx[qx]] : 0.f;
+                                for (int qx = 0; qx < 2; ++qx) {
+                                    wgt[px][qy][qx] = p.rgb_k4[(ty_ - 2 * qy) * 4 + (tx_ - 2 * qx)] * wy[qy] * wx[qx];
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c)
+                                        sv[px][c][qy][qx] = skip_img[(unsigned)((c * sh + ry[qy]) * sw + rx[qx])];
+                                }
+                        }
                     }
+                    float* __restrict__ rgb_img = p.rgb_out + (size_t)b0 * 3 * plane_out;
+                    const unsigned rgb_off = (unsigned)(oy * g.OW + ox);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         float val[PXN];
@@ -650,7 +687,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                                 for (int qx = 0; qx < 2; ++qx) val[px] = fmaf(wgt[px][qy][qx], sv[px][c][qy][qx], val[px]);
                         }
-                        float* ro = p.rgb_out + ((size_t)b * 3 + c) * plane_out + (size_t)oy * g.OW + ox;
+                        float* ro = rgb_img + (size_t)c * plane_out + rgb_off;
                         if (PXN == 2 && ok1) *reinterpret_cast<f32x2u*>(ro) = f32x2{val[0], val[PXN - 1]};
                         else ro[0] = val[0];
                     }
