@@ -338,14 +338,15 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             a_goff[k] = row < NTAPS * CC ? (tap * g.Cin + c) * g.CoutPad + col : -1;  // -1: lane past the tile, masked off
         }
         auto issue_dma = [&](int chunk, int buf) {
-            const float* __restrict__ wbase = p.wp + (size_t)chunk * CC * g.CoutPad + m0;  // uniform
+            const char* wbase = reinterpret_cast<const char*>(p.wp + (size_t)chunk * CC * g.CoutPad + m0);  // uniform
             float* dst = As + buf * A_FLOATS;
 #pragma unroll
             for (int k = 0; k < A_PER_WAVE; ++k) {
-                const int i = wave + 4 * k;
-                if (i < A_INSTR && a_goff[k] >= 0)
+                const int i = wave + 4 * k;  // scalar
+                constexpr bool RAGGED = (NTAPS * CC) % RPI != 0;  // only then can lanes of the last instruction be masked
+                if (i < A_INSTR && (!RAGGED || a_goff[k] >= 0))
                     __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(wbase + (unsigned)a_goff[k]),
+                        (const __attribute__((address_space(1))) void*)(wbase + (unsigned)a_goff[k] * 4u),
                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
             }
         };
@@ -404,17 +405,26 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             }
             const int nK = (chunk_end - chunk_begin) * CC;
             for (int e = tid; e < nK; e += 256) Ss[e] = p.s[b0 * g.s_stride + chunk_begin * CC + e];
+            // lane offsets relative to the image (bytes, < 4 MiB) on a scalar running channel pointer: the DMA address is
+            // SGPR base + 32-bit VGPR offset, two scalar adds per channel
+            unsigned rel_bytes[MAX_POS];
+#pragma unroll
+            for (int i = 0; i < MAX_POS; ++i)
+                rel_bytes[i] = pvalid[i] ? (unsigned)(src_off[i] - b0 * g.Cin * (int)plane_in) * 4u : 0u;
+            const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * g.Cin * plane_in);
+            const size_t plane_bytes = plane_in * sizeof(float);
             auto issue_patch = [&](int chunk, int buf) {
                 float* dst = Ps + buf * PBUF + wave * 64;
+                const char* xc = ximg + (size_t)(chunk * CC) * plane_bytes;  // uniform
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
-                    const float* __restrict__ xbase = p.x + (size_t)(chunk * CC + c) * plane_in;  // uniform
 #pragma unroll
                     for (int i = 0; i < MAX_POS; ++i)
                         if (pvalid[i])
                             __builtin_amdgcn_global_load_lds(
-                                (const __attribute__((address_space(1))) void*)(xbase + (unsigned)src_off[i]),
+                                (const __attribute__((address_space(1))) void*)(xc + rel_bytes[i]),
                                 (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE + i * 256), 4, 0, 0);
+                    xc += plane_bytes;
                 }
             };
             if (chunk_begin < chunk_end) {
