@@ -83,6 +83,9 @@ int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int ci
 /* Winograd F(2,3) form of the same weight, transformed along kx: wq[(ky*4+xi)][i][o_pad] with
  * xi 0: g0, 1: (g0+g1+g2)/2, 2: (g0-g1+g2)/2, 3: g2.  The operand of maua_modconv3x3_f32 in mode 2. */
 int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, int cin, void* stream);
+/* Winograd F(4,3) form (interpolation points 0, +-1, +-2, inf): wq[(ky*6+xi)][i][o_pad] with xi 0: g0/4,
+ * 1: -(g0+g1+g2)/6, 2: -(g0-g1+g2)/6, 3: (g0+2g1+4g2)/24, 4: (g0-2g1+4g2)/24, 5: g2.  Operand of mode 3. */
+int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, void* stream);
 
 /* ModulatedConv2d 3x3 (models/stylegan2.py:217-254) as input-scale -> shared-weight implicit GEMM on MFMA ->
  * output-demod, with the StyledConv tail (noise + bias + leaky ReLU, :338-343) fused when `fuse_act`:
@@ -91,6 +94,8 @@ int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, int cin, void
  *             when fuse_act == 0 (the blur kernel applies gain/noise/bias/act).
  *   up == 2 : the plain convolution evaluated through Winograd F(2,3) along x (W even): 1.5x fewer MFMA cycles,
  *             same result to fp32 rounding; wp is then the maua_pack_weight_wino_f32 weight.
+ *   up == 3 : the same through Winograd F(4,3) (W % 4 == 0): 2x fewer MFMA cycles than direct, |error| ~2e-5 of
+ *             the output scale; wp from maua_pack_weight_wino43_f32.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
  * floats used for split-K partial sums on small feature maps (may be NULL when that returns 0). */
@@ -104,7 +109,7 @@ int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_s
  * activated feature map is reduced to RGB while it is still in registers (all channels of a pixel sit in one wave).
  * Only for layers whose channels fit one weight tile in a single wave row (cout <= 64); returns MAUA_ENOSYS otherwise
  * (the caller then runs maua_modconv3x3_f32 + maua_torgb_f32).  rgb_s = the ToRGB layer's styles [B, s_stride] (same
- * stride as s).  mode = 0 (direct) or 2 (Winograd, wp from maua_pack_weight_wino_f32).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
+ * stride as s).  mode = 0 (direct), 2 or 3 (Winograd F(2,3) / F(4,3), wp from the matching pack function).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
 int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                               float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
                               const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,

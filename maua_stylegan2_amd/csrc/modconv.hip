@@ -30,9 +30,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x2 f32x2u __attribute__((aligned(4)));
+typedef f32x4 f32x4u __attribute__((aligned(4)));
 
 // channels per K chunk: the weight tile As[9][CC][BM] is kept at <= 18 KB so that two of them (double buffer) fit 3x per CU
-constexpr int chunk_channels(int bm, int bn = 0) { return (bm >= 128 || bn >= 512) ? 4 : 8; }
+constexpr int chunk_channels(int bm, int bn = 0, int mode = 0) {
+    if (mode == 3) return bm >= 128 ? 2 : 4;  // F(4,3): 18 weight rows per channel
+    return (bm >= 128 || bn >= 512) ? 4 : 8;
+}
 
 struct ConvGeom {
     int B, Cin, Cout, CoutPad, H, W;  // input feature map
@@ -89,16 +93,24 @@ struct ConvPtrs {
 // the B operand is formed from two 8-byte LDS reads of the ordinary patch, the epilogue undoes the transform in
 // registers and stores 8 bytes per lane.  fp32 F(2,3) has transform constants {1, 1/2}: error stays at the 1e-6 level.
 template <int BM, int BN, int WM, int MODE, bool MULTI, bool FAST, int MAXP>
-__global__ __launch_bounds__(256, ((BM / WM / 32) * (BN / (4 / WM) / 32) * (MODE ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
+#ifndef MAUA_EXP_LB43
+#define MAUA_EXP_LB43 2
+#endif
+__global__ __launch_bounds__(256, MODE == 3 ? MAUA_EXP_LB43
+                                            : ((BM / WM / 32) * (BN / (4 / WM) / 32) * (MODE ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     constexpr bool UP = MODE == 1;
-    constexpr bool WINO = MODE == 2;
-    constexpr int NTAPS = WINO ? 12 : 9;  // weight rows per channel: 9 taps, or 3 ky x 4 frequencies
-    constexpr int CC = chunk_channels(BM, BN);
+    constexpr bool W23 = MODE == 2;             // Winograd F(2,3): positions are output pairs, 4 frequencies
+    constexpr bool W43 = MODE == 3;             // Winograd F(4,3): positions are output quads, 6 frequencies
+    constexpr bool WINO = W23 || W43;
+    constexpr int WX = W43 ? 4 : (W23 ? 2 : 1);  // output columns per position (Winograd modes)
+    constexpr int NFREQ = W43 ? 6 : 4;
+    constexpr int NTAPS = WINO ? 3 * NFREQ : 9;  // weight rows per channel: 9 taps, or 3 ky x NFREQ frequencies
+    constexpr int CC = chunk_channels(BM, BN, MODE);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int NPH = (UP || WINO) ? 4 : 1;
+    constexpr int NPH = UP ? 4 : (WINO ? NFREQ : 1);
     constexpr int A_FLOATS = NTAPS * CC * BM;
     constexpr int A_VEC_ITERS = (A_FLOATS / 4 + 255) / 256;
     constexpr int MAX_POS = MAXP;  // patch positions per thread (PSTRIDE <= 256 * MAX_POS)
@@ -148,7 +160,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int rem = pp - img * per_img;
             const int pr = rem / g.PWS, pc = rem - pr * g.PWS;
             const int b = b0 + img;
-            int yy = ty0 + pr - 1, xx = (WINO ? 2 * tx0 : tx0) + pc - 1;
+            int yy = ty0 + pr - 1, xx = WX * tx0 + pc - 1;
             if (UP && g.flat) {
                 // flat run: patch row 1 holds positions p0-1 .. p0+BN-1 of the pitch-(W+1) flattened input (column W and
                 // row H are the zero padding), patch row 0 the same run one input row up (p - GW)
@@ -179,7 +191,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const int sy = (sub >> g.lnsx) & ((1 << g.lnsy) - 1);
         const int img = sub >> (g.lnsx + g.lnsy);
         const int tyy = sy * SH + jy, txx = sx * SW + jx;
-        boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PWS + (WINO ? 2 * txx : txx);
+        boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PWS + WX * txx;
     }
     const int aoff = hi * BM + wm * (TM * 32) + l31;
 
@@ -254,7 +266,52 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     // Sc != nullptr: the staged patch holds RAW features (DMA path) and the style of channel 2q+hi is applied to the B
     // operand here, one VALU multiply per operand next to a 64-cycle MFMA.
     auto mfma_chunk = [&](const float* __restrict__ Ac, const float* __restrict__ Pc, const float* __restrict__ Sc) {
-        if (WINO) {
+        if (W43) {
+            // B^T d for F(4,3) (interpolation points 0, +-1, +-2, inf) on six consecutive patch floats:
+            //   t0 = 4 d0 - 5 d2 + d4          t1 = (d4 - 4 d2) + (d3 - 4 d1)     t2 = (d4 - 4 d2) - (d3 - 4 d1)
+            //   t5 = 4 d1 - 5 d3 + d5          t3 = (d4 - d2) + 2 (d3 - d1)       t4 = (d4 - d2) - 2 (d3 - d1)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int q = 0; q < CC / 2; ++q) {
+                    float bv[TN][6];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        const float* dp = Pc + 2 * q * g.PSTRIDE + boff[n] + ky * g.PWS;  // offset is a multiple of 4 floats
+                        const f32x2 d01 = *reinterpret_cast<const f32x2*>(dp);
+                        const f32x2 d23 = *reinterpret_cast<const f32x2*>(dp + 2);
+                        const f32x2 d45 = *reinterpret_cast<const f32x2*>(dp + 4);
+                        const float a_ = fmaf(-4.f, d23.x, d45.x), b_ = fmaf(-4.f, d01.y, d23.y);
+                        const float c_ = d45.x - d23.x, e_ = d23.y - d01.y;
+                        bv[n][0] = fmaf(4.f, d01.x, fmaf(-5.f, d23.x, d45.x));
+                        bv[n][1] = a_ + b_;
+                        bv[n][2] = a_ - b_;
+                        bv[n][3] = fmaf(2.f, e_, c_);
+                        bv[n][4] = fmaf(-2.f, e_, c_);
+                        bv[n][5] = fmaf(4.f, d01.y, fmaf(-5.f, d23.y, d45.y));
+                        if (Sc) {
+                            const float sc = Sc[2 * q + hi];
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) bv[n][k] *= sc;
+                        }
+                    }
+#pragma unroll
+                    for (int xi = 0; xi < 6; ++xi) {
+                        float a[TM];
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 6 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                            for (int n = 0; n < TN; ++n)
+                                acc[mt][n * NPH + xi] =
+                                    __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bv[n][xi], acc[mt][n * NPH + xi], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
+        if (W23) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -385,7 +442,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         // measured (30-launch averages): -6..7 % on the transposed 64-row configs, -4 % on the transposed 32-row config,
         // -3 % on the 64/128-row Winograd configs, +1 % on the 32-channel 1024^2 Winograd layer (its features stream from
         // HBM; the register-staged patch tolerates that latency better), which keeps the register path
-        constexpr bool PDMA = !MULTI && !(WINO && BM == 32);
+        constexpr bool PDMA = !MULTI && !(W23 && BM == 32);
         if (PDMA) {
             // Feature patch by DMA as well: raw features go L2/HBM -> LDS without staging registers or ds_write, double
             // buffered like the weight tile.  Out-of-image patch elements are never written: their lanes are masked out of
@@ -519,8 +576,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         if (UP && g.flat) gy = gx / g.GW, gx -= gy * g.GW;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = (UP || WINO) ? 2 * gx + (ph & 1) : gx;
+            const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = UP ? 2 * gx + (ph & 1) : (WINO ? WX * gx + (ph < WX ? ph : 0) : gx);
             nz_all[n][ph] = 0.f;
+            if (WINO && ph >= WX) continue;
             if (nw != 0.f && b < g.B && gy < g.GH && gx < g.GW && oy < g.OH && ox < g.OW)
                 nz_all[n][ph] = nw * (MULTI ? p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox]
                                             : (p.noise + (size_t)b0 * g.noise_batch_stride)[(unsigned)(oy * g.OW + ox)]);
@@ -539,13 +597,13 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const bool pos_ok = (b < g.B) && (gy < g.GH) && (gx < g.GW);
         // transposed conv: the two x-parities of a position are adjacent in memory -> one 8-byte store per lane
         // (rows of the (2W+1)-wide plane are only 4-byte aligned: f32x2u is an align-4 vector type)
-        constexpr int PXN = (UP || WINO) ? 2 : 1;  // Winograd positions are output pairs as well
+        constexpr int PXN = UP ? 2 : WX;  // outputs per position along x (Winograd positions are pairs / quads)
 #pragma unroll
         for (int py = 0; py < (UP ? 2 : 1); ++py) {
             const int oy = UP ? 2 * gy + py : gy;
-            const int ox = (UP || WINO) ? 2 * gx : gx;
+            const int ox = UP ? 2 * gx : WX * gx;
             const bool ok0 = pos_ok && oy < g.OH && ox < g.OW;
-            const bool ok1 = (UP || WINO) && ok0 && (ox + 1 < g.OW);
+            const bool ok1 = (UP || WINO) && ok0 && (ox + PXN - 1 < g.OW);  // the whole pair / quad is inside the row
             float nzv[PXN];
 #pragma unroll
             for (int px = 0; px < PXN; ++px) nzv[px] = nz_all[n][UP ? py * 2 + px : (WINO ? px : 0)];
@@ -589,7 +647,16 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                         for (int px = 0; px < PXN; ++px) {
                             float raw;
-                            if (WINO) {  // inverse transform: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
+                            if (W43) {
+                                // A^T m: y0 = m0+m1+m2+m3+m4, y1 = (m1-m2) + 2(m3-m4), y2 = (m1+m2) + 4(m3+m4),
+                                //        y3 = (m1-m2) + 8(m3-m4) + m5
+                                const float m0_ = acc[mt][n * NPH + 0][e], m1_ = acc[mt][n * NPH + 1][e];
+                                const float m2_ = acc[mt][n * NPH + 2][e], m3_ = acc[mt][n * NPH + 3][e];
+                                const float m4_ = acc[mt][n * NPH + 4][e], m5_ = acc[mt][n * NPH + 5][e];
+                                const float s12 = m1_ + m2_, d12 = m1_ - m2_, s34 = m3_ + m4_, d34 = m3_ - m4_;
+                                raw = px == 0 ? (m0_ + s12) + s34 : px == 1 ? fmaf(2.f, d34, d12)
+                                    : px == 2 ? fmaf(4.f, s34, s12) : fmaf(8.f, d34, d12) + m5_;
+                            } else if (W23) {  // inverse transform: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
                                 const float m0_ = acc[mt][n * NPH + 0][e], m1_ = acc[mt][n * NPH + 1][e];
                                 const float m2_ = acc[mt][n * NPH + 2][e], m3_ = acc[mt][n * NPH + 3][e];
                                 raw = px == 0 ? (m0_ + m1_) + m2_ : (m1_ - m2_) - m3_;
@@ -612,18 +679,22 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                         // scalar row base + 32-bit lane byte offset
                         char* rowb = reinterpret_cast<char*>(blk + (size_t)oe * plane_out);
                         float* dst = reinterpret_cast<float*>(rowb + lane_bytes);
+                        auto store_all = [&]() {
+                            if (PXN == 4) *reinterpret_cast<f32x4u*>(dst) = f32x4{v[0], v[1 % PXN], v[2 % PXN], v[3 % PXN]};
+                            else *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
+                        };
                         if (IN) {
-                            if (UP || WINO) *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
+                            if (UP || WINO) store_all();
                             else dst[0] = v[0];
                         } else if (oe < n_ok) {
-                            if ((UP || WINO) && ok1) *reinterpret_cast<f32x2u*>(dst) = f32x2{v[0], v[PXN - 1]};
+                            if ((UP || WINO) && ok1) store_all();
                             else if (ok0) dst[0] = v[0];
                         }
                     }
                 }
             };
             const bool interior = !UP && !MULTI && (m0 + BM <= g.Cout) && (ty0 + THt <= g.GH) && (tx0 + TWd <= g.GW) &&
-                                  (!WINO || !(g.OW & 1));
+                                  (!WINO || g.OW % WX == 0);
             if (interior) elements(std::true_type{});
             else elements(std::false_type{});
             if (!UP && WM == 1 && !MULTI && g.rgb) {
@@ -698,7 +769,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                                 for (int qx = 0; qx < 2; ++qx) val[px] = fmaf(wgt[px][qy][qx], sv[px][c][qy][qx], val[px]);
                         }
                         float* ro = rgb_img + (size_t)c * plane_out + rgb_off;
-                        if (PXN == 2 && ok1) *reinterpret_cast<f32x2u*>(ro) = f32x2{val[0], val[PXN - 1]};
+                        if (PXN == 4 && ok1) *reinterpret_cast<f32x4u*>(ro) = f32x4{val[0], val[1 % PXN], val[2 % PXN], val[3 % PXN]};
+                        else if (PXN == 2 && ok1) *reinterpret_cast<f32x2u*>(ro) = f32x2{val[0], val[PXN - 1]};
                         else ro[0] = val[0];
                     }
                 }
@@ -775,6 +847,31 @@ __global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __re
     }
 }
 
+// Winograd F(4,3) weight transform along kx (G g, interpolation points 0, +-1, +-2, inf): wq[(ky*6 + xi)][i][o_pad],
+//   xi 0: g0/4   1: -(g0+g1+g2)/6   2: -(g0-g1+g2)/6   3: (g0+2g1+4g2)/24   4: (g0-2g1+4g2)/24   5: g2
+__global__ __launch_bounds__(256) void pack_weight_wino43_kernel(const float* __restrict__ w, float* __restrict__ wq,
+                                                                 int cout, int cout_pad, int cin) {
+    const int64_t total = (int64_t)cout_pad * cin;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int o = (int)(idx % cout_pad);
+        const int i = (int)(idx / cout_pad);
+        for (int ky = 0; ky < 3; ++ky) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (o < cout) {
+                const float* gp = w + (((size_t)o * cin + i) * 3 + ky) * 3;
+                g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            }
+            const float u[6] = {g0 * 0.25f,
+                                -(g0 + g1 + g2) * (1.f / 6.f),
+                                -(g0 - g1 + g2) * (1.f / 6.f),
+                                (g0 + 2.f * g1 + 4.f * g2) * (1.f / 24.f),
+                                (g0 - 2.f * g1 + 4.f * g2) * (1.f / 24.f),
+                                g2};
+            for (int xi = 0; xi < 6; ++xi) wq[((size_t)(ky * 6 + xi) * cin + i) * cout_pad + o] = u[xi];
+        }
+    }
+}
+
 inline int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -799,9 +896,14 @@ int g_conv_cfg = 0;  // tuning key 2: bit0 -> Cout<=64 uses 64x128 (WM 2); bit1 
 Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     Plan pl{};
     ConvGeom& g = pl.g;
-    const bool up = mode == 1, wino = mode == 2;
+    const bool up = mode == 1, wino = mode == 2 || mode == 3, w43 = mode == 3;
+    const int wx = w43 ? 4 : 2;  // outputs per Winograd position
     g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = pad32(cout), g.H = h, g.W = w;
-    if (wino) {
+    if (w43) {
+        g.GH = h, g.GW = w / 4, g.OH = h, g.OW = w;  // positions are output quads
+        if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
+        else pl.bm = 128, pl.wm = 2, pl.bn = 64;
+    } else if (wino) {
         g.GH = h, g.GW = w / 2, g.OH = h, g.OW = w;  // positions are output pairs
         if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = (g_conv_cfg & 2) ? 256 : 128;
         else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
@@ -830,7 +932,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.lsw = ilog2(sw), g.lsh = ilog2(sh), g.lnsx = ilog2(nsx), g.lnsy = ilog2(nsy), g.lni = ilog2(ni);
         const int tw = sw * nsx, th = sh * nsy;
         g.tiles_x = ceil_div(g.GW, tw), g.tiles_y = ceil_div(g.GH, th), g.img_groups = ceil_div(batch, ni);
-        g.PH = th + 2, g.PW = (wino ? 2 * tw : tw) + 2;
+        g.PH = th + 2, g.PW = (wino ? wx * tw : tw) + 2;
         // LDS row stride: with sub-tiles narrower than 32 pixels the 32 lanes of one MFMA group read SH rows at once;
         // a stride of SW * odd puts the rows on disjoint bank groups (conflict-free ds_read_b32)
         g.PWS = g.PW;
@@ -851,14 +953,14 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.PH = 2, g.PW = pl.bn + 1, g.PWS = pl.bn + 2;
         g.PSTRIDE = g.PH * g.PWS;
     }
-    if (g.PSTRIDE > ((pl.bn >= 512 || (wino && pl.bn >= 256)) ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
+    if (g.PSTRIDE > ((pl.bn >= 512 || (wino && pl.bn >= 256) || (w43 && pl.bn >= 128)) ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (wino) pl.bm = 128, pl.wm = 2, pl.bn = 64;
         else if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
         shape(pl.bn);
         pl.fallback = true;
     }
-    const int CC = chunk_channels(pl.bm, pl.bn);
+    const int CC = chunk_channels(pl.bm, pl.bn, mode);
     g.n_chunks = ceil_div(cin, CC);
     g.m_tiles = ceil_div(g.CoutPad, pl.bm);
     g.n_tiles = g.tiles_x * g.tiles_y * g.img_groups;
@@ -871,7 +973,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     g.splits = ceil_div(g.n_chunks, g.chunks_per_split);
     g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
     pl.blocks = base_blocks * g.splits;
-    pl.lds_bytes = 2 * ((size_t)(wino ? 12 : 9) * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
+    pl.lds_bytes = 2 * ((size_t)(w43 ? 18 : wino ? 12 : 9) * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
     if (g.lni == 0)  // the DMA patch path also stages the styles of one image
         pl.lds_bytes += (size_t)cin * sizeof(float);
     if (pl.lds_bytes < (size_t)2 * pl.bm * sizeof(float)) pl.lds_bytes = (size_t)2 * pl.bm * sizeof(float);
@@ -894,14 +996,14 @@ int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 template <int BM, int BN, int WM, int UP, bool MULTI, bool FAST>
 int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     if (pl.g.PSTRIDE <= 256) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 1>(pl, ptrs, st);
-    constexpr bool WIDE = BN >= 512 || (UP == 2 && BN >= 256);  // configs whose patch can exceed 512 floats per channel
+    constexpr bool WIDE = BN >= 512 || (UP == 2 && BN >= 256) || (UP == 3 && BN >= 128);  // configs whose patch can exceed 512 floats per channel
     if (pl.g.PSTRIDE <= 512 || !WIDE) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
     return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, (WIDE ? 3 : 2)>(pl, ptrs, st);
 }
 
 template <int BM, int BN, int WM, int UP>
 int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
-    constexpr int CC = chunk_channels(BM, BN);
+    constexpr int CC = chunk_channels(BM, BN, UP);
     if (pl.g.PSTRIDE > 768) return MAUA_EINVAL;
     const bool fast = (pl.g.Cin % CC == 0) && (pl.g.CoutPad % BM == 0);
     if (pl.g.lni > 0) return fast ? launch_conv_impl<BM, BN, WM, UP, true, true>(pl, ptrs, st)
@@ -936,6 +1038,16 @@ extern "C" int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, in
     return 0;
 }
 
+extern "C" int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, void* stream) {
+    if (!w || !wq || cout <= 0 || cin <= 0) return MAUA_EINVAL;
+    const int cout_pad = pad32(cout);
+    const int64_t blocks = ceil_div64((int64_t)cout_pad * cin, 256);
+    hipLaunchKernelGGL(pack_weight_wino43_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, w, wq, cout, cout_pad, cin);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
     Plan pl = make_plan(batch, cin, cout, h, w, up);
@@ -955,7 +1067,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     if (noise && !noise_w) return MAUA_EINVAL;
     if ((int64_t)batch * cin * h * w > 0x7fffffffLL) return MAUA_EINVAL;  // 32-bit patch offsets
-    if (up < 0 || up > 2 || (up == 2 && (w & 1))) return MAUA_EINVAL;
+    if (up < 0 || up > 3 || (up == 2 && (w & 1)) || (up == 3 && (w & 3))) return MAUA_EINVAL;
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     if (pl.g.splits > 1 && !ws) return MAUA_EINVAL;
     pl.g.s_stride = s_stride;
@@ -979,7 +1091,10 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     }
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (up == 2) {
+    if (up == 3) {
+        if (pl.bm == 64) rc = launch_conv<64, 128, 1, 3>(pl, ptrs, st);
+        else rc = launch_conv<128, 64, 2, 3>(pl, ptrs, st);
+    } else if (up == 2) {
         if (pl.bm == 32 && pl.bn == 256) rc = launch_conv<32, 256, 1, 2>(pl, ptrs, st);
         else if (pl.bm == 32) rc = launch_conv<32, 128, 1, 2>(pl, ptrs, st);
         else if (pl.bm == 64) rc = launch_conv<64, 128, 1, 2>(pl, ptrs, st);

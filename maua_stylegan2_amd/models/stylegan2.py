@@ -155,28 +155,38 @@ class ModulatedConv2d(nn.Module):
     # a huge value turns it off
     winograd_min_cout = 32
 
+    # ... and from this many output channels, on maps at least 64 wide, through F(4,3) (6 products per 4 outputs)
+    winograd43_min_cout = 64
+
     def conv_mode(self, h, w):
-        """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd plain, 0 plain."""
+        """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd F(2,3), 3 Winograd
+        F(4,3), 0 direct."""
         if self.upsample:
             return 1
+        if self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= 64:
+            return 3
         if self.out_channel >= self.winograd_min_cout and w % 2 == 0 and w >= 32:
             return 2
         return 0
 
-    def packed_wino(self):
-        """Winograd-domain weight [(ky*4+xi), Cin, Cout_pad] (maua_pack_weight_wino_f32), cached like ``packed()``."""
+    def packed_wino(self, mode=2):
+        """Winograd-domain weight [(ky*F+xi), Cin, Cout_pad], F = 4 for mode 2 (maua_pack_weight_wino_f32) or 6 for mode 3
+        (maua_pack_weight_wino43_f32); cached like ``packed()``."""
         self.packed()  # refreshes / invalidates on weight change
         if self._packed_wino is None:
+            self._packed_wino = {}
+        if mode not in self._packed_wino:
             w = self.weight
             wd = _lib.require_cuda(w.detach(), "weight")
             cpad = (self.out_channel + 31) // 32 * 32
-            wq = th.empty((12, self.in_channel, cpad), dtype=th.float32, device=w.device)
+            wq = th.empty((12 if mode == 2 else 18, self.in_channel, cpad), dtype=th.float32, device=w.device)
+            fn = "maua_pack_weight_wino_f32" if mode == 2 else "maua_pack_weight_wino43_f32"
             with th.cuda.device(w.device):
-                rc = _lib.load().maua_pack_weight_wino_f32(wd.data_ptr(), wq.data_ptr(), self.out_channel,
-                                                           self.in_channel, _lib.stream_ptr(w.device))
-            _lib.check(rc, "maua_pack_weight_wino_f32")
-            self._packed_wino = wq
-        return self._packed_wino
+                rc = getattr(_lib.load(), fn)(wd.data_ptr(), wq.data_ptr(), self.out_channel, self.in_channel,
+                                              _lib.stream_ptr(w.device))
+            _lib.check(rc, fn)
+            self._packed_wino[mode] = wq
+        return self._packed_wino[mode]
 
     def table_entry(self, lat_idx, s_off, d_off):
         wp, wsq = self.packed()
@@ -190,7 +200,7 @@ class ModulatedConv2d(nn.Module):
         lib = _lib.load()
         b, cin, h, w = x.shape
         mode = self.conv_mode(h, w)
-        wp = self.packed_wino() if mode == 2 else self.packed()[0]
+        wp = self.packed_wino(mode) if mode >= 2 else self.packed()[0]
         nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
         rc = lib.maua_modconv3x3_f32(
             x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b, cin,
@@ -304,7 +314,7 @@ class StyledConv(nn.Module):
                                            and skip.shape[2] * 2 == h and skip.shape[3] * 2 == w)
                 if fusable:
                     mode = conv.conv_mode(h, w)
-                    wp = conv.packed_wino() if mode == 2 else conv.packed()[0]
+                    wp = conv.packed_wino(mode) if mode >= 2 else conv.packed()[0]
                     nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
                     rc = lib.maua_styledconv_torgb_f32(
                         x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b,

@@ -145,6 +145,7 @@ def test_modconv_winograd_vs_oracle(gpu, cin, cout, h, w, batch):
 
     r = np.random.default_rng(cin + 3 * cout + h + w)
     m = StyledConv(cin, cout, 3, 512, upsample=False)
+    m.conv.winograd43_min_cout = 1 << 30  # this test pins the F(2,3) mode
     assert m.conv.conv_mode(h, w) == 2
     sd = {
         "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
@@ -162,7 +163,43 @@ def test_modconv_winograd_vs_oracle(gpu, cin, cout, h, w, batch):
     got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
     np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-4)
     # and against the direct (mode 0) kernel of the same layer: the two differ only by fp32 rounding
-    m.conv.winograd_min_cout = 1 << 30
+    m.conv.winograd_min_cout = m.conv.winograd43_min_cout = 1 << 30
     assert m.conv.conv_mode(h, w) == 0
     direct = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
     np.testing.assert_allclose(got, direct, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [
+    (128, 128, 64, 64, 2),    # 128-row weight tile, FAST path, whole tiles
+    (64, 64, 40, 128, 1),     # 64-row tile (TM 2 in one wave row), ragged row blocks
+    (136, 200, 24, 72, 2),    # generic loads: Cout not a multiple of the tile, ragged quads (18 per row -> 2 sub-tiles)
+    (256, 256, 8, 64, 1),     # short map, split-K
+])
+def test_modconv_winograd43_vs_oracle(gpu, cin, cout, h, w, batch):
+    """Plain 3x3 layers with >= 64 output channels on maps >= 64 wide (W % 4 == 0) run Winograd F(4,3) (mode 3).  Its
+    transform constants span 1/24 .. 8, so the fp32 error is ~2e-5 of the output scale instead of ~1e-6: the tolerance
+    against the oracle is 5e-4 (north_star budget 1e-3), and the direct kernel must agree to 2e-4."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(2 * cin + cout + h + w)
+    m = StyledConv(cin, cout, 3, 512, upsample=False)
+    assert m.conv.conv_mode(h, w) == 3
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.29]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((batch, 1, h, w)).astype(np.float32))
+    want = so.styled_conv(sd, "L", x, s, nz, False).numpy()
+    got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-4, rtol=1e-4)
+    m.conv.winograd_min_cout = m.conv.winograd43_min_cout = 1 << 30
+    direct = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, direct, atol=2e-4, rtol=1e-4)

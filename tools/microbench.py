@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--conv-cfg", type=int, default=0)
     ap.add_argument("--lib", default=None, help="experimental build of libmaua_hip.so to load instead (tools/bin/...)")
     ap.add_argument("--wino-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd_min_cout")
+    ap.add_argument("--wino43-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd43_min_cout")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     if args.lib:
@@ -89,6 +90,8 @@ def main():
             B = args.batch
             if args.wino_min_cout is not None:
                 ModulatedConv2d.winograd_min_cout = args.wino_min_cout
+            if args.wino43_min_cout is not None:
+                ModulatedConv2d.winograd43_min_cout = args.wino43_min_cout
             for name, cin, cout, h, up in [("plain32@1024", 32, 32, 1024, 0), ("plain64@512", 64, 64, 512, 0),
                                            ("plain128@256", 128, 128, 256, 0), ("plain256@128", 256, 256, 128, 0),
                                            ("plain512@64", 512, 512, 64, 0), ("up64-32@512", 64, 32, 512, 1),
