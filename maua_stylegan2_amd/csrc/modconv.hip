@@ -96,7 +96,7 @@ template <int BM, int BN, int WM, int MODE, bool MULTI, bool FAST, int MAXP>
 #ifndef MAUA_EXP_LB43
 #define MAUA_EXP_LB43 2
 #endif
-__global__ __launch_bounds__(256, MODE == 3 ? MAUA_EXP_LB43
+__global__ __launch_bounds__(256, (MODE == 3 && BM >= 64) ? MAUA_EXP_LB43
                                             : ((BM / WM / 32) * (BN / (4 / WM) / 32) * (MODE ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     constexpr bool UP = MODE == 1;
@@ -901,7 +901,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = pad32(cout), g.H = h, g.W = w;
     if (w43) {
         g.GH = h, g.GW = w / 4, g.OH = h, g.OW = w;  // positions are output quads
-        if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 128;
+        else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
         else pl.bm = 128, pl.wm = 2, pl.bn = 64;
     } else if (wino) {
         g.GH = h, g.GW = w / 2, g.OH = h, g.OW = w;  // positions are output pairs
@@ -1092,7 +1093,8 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (up == 3) {
-        if (pl.bm == 64) rc = launch_conv<64, 128, 1, 3>(pl, ptrs, st);
+        if (pl.bm == 32) rc = launch_conv<32, 128, 1, 3>(pl, ptrs, st);
+        else if (pl.bm == 64) rc = launch_conv<64, 128, 1, 3>(pl, ptrs, st);
         else rc = launch_conv<128, 64, 2, 3>(pl, ptrs, st);
     } else if (up == 2) {
         if (pl.bm == 32 && pl.bn == 256) rc = launch_conv<32, 256, 1, 2>(pl, ptrs, st);

@@ -156,7 +156,7 @@ class ModulatedConv2d(nn.Module):
     winograd_min_cout = 32
 
     # ... and from this many output channels, on maps at least 64 wide, through F(4,3) (6 products per 4 outputs)
-    winograd43_min_cout = 64
+    winograd43_min_cout = 32
 
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd F(2,3), 3 Winograd

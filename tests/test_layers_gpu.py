@@ -174,6 +174,8 @@ def test_modconv_winograd_vs_oracle(gpu, cin, cout, h, w, batch):
     (64, 64, 40, 128, 1),     # 64-row tile (TM 2 in one wave row), ragged row blocks
     (136, 200, 24, 72, 2),    # generic loads: Cout not a multiple of the tile, ragged quads (18 per row -> 2 sub-tiles)
     (256, 256, 8, 64, 1),     # short map, split-K
+    (32, 32, 48, 192, 2),     # 32-row weight tile (three patch slots per thread)
+    (18, 32, 20, 68, 1),      # generic path at the 32-row tile: Cin % 4 != 0
 ])
 def test_modconv_winograd43_vs_oracle(gpu, cin, cout, h, w, batch):
     """Plain 3x3 layers with >= 64 output channels on maps >= 64 wide (W % 4 == 0) run Winograd F(4,3) (mode 3).  Its
