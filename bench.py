@@ -301,10 +301,15 @@ def main():
                     if base.startswith("convs.") and "upconv" not in base:
                         n_conv = int(base.split(".")[1])
                         res = 4 * 2 ** ((n_conv + 1) // 2)
-                        if g.convs[n_conv].conv.conv_mode(res, res) == 2:
-                            result["roofline"]["algorithm"] = "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic"
-                            result["roofline"]["executed"] = ach * 2.0 / 3.0
-                            result["roofline"]["executed_frac"] = ach * 2.0 / 3.0 / MFMA_F32_PEAK_TFLOPS
+                        mode = g.convs[n_conv].conv.conv_mode(res, res)
+                        if mode in (2, 3):
+                            ratio = 2.0 / 3.0 if mode == 2 else 0.5
+                            result["roofline"]["algorithm"] = (
+                                "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic" if mode == 2 else
+                                "winograd F(4,3) along x: executed MFMA flops = 1/2 algorithmic (frac counts algorithmic "
+                                "direct-conv flops as SURVEY 8d defines them and can therefore exceed 1)")
+                            result["roofline"]["executed"] = ach * ratio
+                            result["roofline"]["executed_frac"] = ach * ratio / MFMA_F32_PEAK_TFLOPS
                     if size == 1024 and B == 8 and dom[0].startswith("convs.15"):
                         # HBM bytes of this launch from the PMC passes (FETCH_SIZE x2 correction, WRITE_SIZE exact):
                         # 2 x 553,329 KB read + 98,304 KB written; algorithmic 1,077,252 KB + 98,304 KB
