@@ -96,7 +96,7 @@ def layer_breakdown(g, batch, static, stream):
         xin = out
         # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
         raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
-        n_ws = _lib.load().maua_modconv_ws_floats(batch, cin, cout, h, h, 1)
+        n_ws = _lib.load().maua_modconv_ws_floats(batch, cin, cout, h, h, up.conv.conv_mode(h, h))
         ws = g._buf(batch, "bench.ws", (max(n_ws, 1),)) if n_ws else None
         t_up = time_calls(lambda: up.conv.run(xin, s, e_up["s_off"], demod_of(e_up), raw, ws), 10, sp)
         rows.append((f"convs.{2*n}.upconv", "modconv_up", t_up, 2 * cin * cout * 9 * h * h * batch, 0))

@@ -86,6 +86,9 @@ int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, int cin, void
 /* Winograd F(4,3) form (interpolation points 0, +-1, +-2, inf): wq[(ky*6+xi)][i][o_pad] with xi 0: g0/4,
  * 1: -(g0+g1+g2)/6, 2: -(g0-g1+g2)/6, 3: (g0+2g1+4g2)/24, 4: (g0-2g1+4g2)/24, 5: g2.  Operand of mode 3. */
 int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, void* stream);
+/* Transposed-conv form for mode 4 (F(2,2) on the even x-phase of the polyphase decomposition):
+ * wq[(ky*4+j)][i][o_pad] with j 0: g2, 1: g0+g2, 2: g0, 3: g1. */
+int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, void* stream);
 
 /* ModulatedConv2d 3x3 (models/stylegan2.py:217-254) as input-scale -> shared-weight implicit GEMM on MFMA ->
  * output-demod, with the StyledConv tail (noise + bias + leaky ReLU, :338-343) fused when `fuse_act`:
@@ -94,6 +97,8 @@ int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, vo
  *             when fuse_act == 0 (the blur kernel applies gain/noise/bias/act).
  *   up == 2 : the plain convolution evaluated through Winograd F(2,3) along x (W even): 1.5x fewer MFMA cycles,
  *             same result to fp32 rounding; wp is then the maua_pack_weight_wino_f32 weight.
+ *   up == 4 : the transposed convolution of up == 1 with F(2,2) on its even x-phase (W even, fuse_act == 0): 5 instead
+ *             of 6 MFMA K-steps per position pair and kernel row; wp from maua_pack_weight_upwino_f32.
  *   up == 3 : the same through Winograd F(4,3) (W % 4 == 0): 2x fewer MFMA cycles than direct, |error| ~2e-5 of
  *             the output scale; wp from maua_pack_weight_wino43_f32.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];

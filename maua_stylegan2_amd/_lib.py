@@ -48,6 +48,7 @@ _SIGNATURES = {
     "maua_pack_weight_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "maua_pack_weight_wino_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "maua_pack_weight_wino43_f32": (c_int, [_P, _P, c_int, c_int, _P]),
+    "maua_pack_weight_upwino_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "maua_modconv_ws_floats": (c_int64, [c_int] * 6),
     "maua_modconv3x3_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, _P, c_int64, _P, _P, _P, _P]),
     "maua_styledconv_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,

@@ -96,21 +96,22 @@ template <int BM, int BN, int WM, int MODE, bool MULTI, bool FAST, int MAXP>
 #ifndef MAUA_EXP_LB43
 #define MAUA_EXP_LB43 2
 #endif
-__global__ __launch_bounds__(256, (MODE == 3 && BM >= 64) ? MAUA_EXP_LB43
+__global__ __launch_bounds__(256, (MODE == 3 && BM >= 64) ? MAUA_EXP_LB43 : MODE == 4 ? 2
                                             : ((BM / WM / 32) * (BN / (4 / WM) / 32) * (MODE ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
-    constexpr bool UP = MODE == 1;
+    constexpr bool UP = MODE == 1 || MODE == 4;
+    constexpr bool UW = MODE == 4;  // transposed conv with Winograd F(2,2) on the even x-phase: positions are position PAIRS
     constexpr bool W23 = MODE == 2;             // Winograd F(2,3): positions are output pairs, 4 frequencies
     constexpr bool W43 = MODE == 3;             // Winograd F(4,3): positions are output quads, 6 frequencies
     constexpr bool WINO = W23 || W43;
-    constexpr int WX = W43 ? 4 : (W23 ? 2 : 1);  // output columns per position (Winograd modes)
+    constexpr int WX = W43 ? 4 : ((W23 || UW) ? 2 : 1);  // patch columns advanced per position
     constexpr int NFREQ = W43 ? 6 : 4;
-    constexpr int NTAPS = WINO ? 3 * NFREQ : 9;  // weight rows per channel: 9 taps, or 3 ky x NFREQ frequencies
+    constexpr int NTAPS = WINO ? 3 * NFREQ : (UW ? 12 : 9);  // weight rows per channel: 9 taps, or 3 ky x NFREQ frequencies
     constexpr int CC = chunk_channels(BM, BN, MODE);
     constexpr int WN = 4 / WM;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int NPH = UP ? 4 : (WINO ? NFREQ : 1);
+    constexpr int NPH = UW ? 10 : (UP ? 4 : (WINO ? NFREQ : 1));
     constexpr int A_FLOATS = NTAPS * CC * BM;
     constexpr int A_VEC_ITERS = (A_FLOATS / 4 + 255) / 256;
     constexpr int MAX_POS = MAXP;  // patch positions per thread (PSTRIDE <= 256 * MAX_POS)
@@ -164,9 +165,11 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             if (UP && g.flat) {
                 // flat run: patch row 1 holds positions p0-1 .. p0+BN-1 of the pitch-(W+1) flattened input (column W and
                 // row H are the zero padding), patch row 0 the same run one input row up (p - GW)
-                const int fi = tx0 + pc - 1 - (1 - pr) * g.GW;
-                yy = fi >= 0 ? fi / g.GW : -1;
-                xx = fi - yy * g.GW;
+                // (UW: g.GW counts position pairs per row, the flattened input pitch is 2 * g.GW = W + 2)
+                const int pitch = UW ? 2 * g.GW : g.GW;
+                const int fi = WX * tx0 + pc - 1 - (1 - pr) * pitch;
+                yy = fi >= 0 ? fi / pitch : -1;
+                xx = fi - yy * pitch;
             }
             if (pc < g.PW && img < NI && b < g.B && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W) {
                 src_off[i] = ((b * g.Cin * g.H + yy) * g.W + xx);  // < 2^31: checked on the host
@@ -266,6 +269,57 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     // Sc != nullptr: the staged patch holds RAW features (DMA path) and the style of channel 2q+hi is applied to the B
     // operand here, one VALU multiply per operand next to a 64-cycle MFMA.
     auto mfma_chunk = [&](const float* __restrict__ Ac, const float* __restrict__ Pc, const float* __restrict__ Sc) {
+        if (UW) {
+            // Polyphase transposed conv, x direction through F(2,2): for the position pair (p, p+1) with inputs
+            // d0 = x[p-1], d1 = x[p], d2 = x[p+1] of one input row and the kernel row (g0, g1, g2):
+            //   even columns  e_p = g0 d1 + g2 d0,  e_p+1 = g0 d2 + g2 d1   =  (m0 + m1, m1 + m2) with
+            //                 m0 = g2 (d0 - d1),  m1 = (g0 + g2) d1,  m2 = g0 (d2 - d1)            (3 products instead of 4)
+            //   odd columns   o_p = g1 d1,  o_p+1 = g1 d2
+            // 5 MFMA K-steps per (kernel row, channel pair) instead of 6.  Kernel row 0 / 1 read input row y (output row
+            // parity 0 / 1), kernel row 2 reads input row y-1 (parity 0): accumulator slots [parity][m0, m1, m2, o_p, o_p+1].
+            // Weight rows per kernel row (maua_pack_weight_upwino_f32): g2, g0 + g2, g0, g1.
+#pragma unroll
+            for (int q = 0; q < CC / 2; ++q) {
+                float tb[2][TN][4];  // [patch row][n][d0-d1, d1, d2-d1, d2]
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        const float* dp = Pc + 2 * q * g.PSTRIDE + boff[n] + r * g.PWS;  // even float offset
+                        const f32x2 d01 = *reinterpret_cast<const f32x2*>(dp);
+                        const float d2 = dp[2];
+                        tb[r][n][0] = d01.x - d01.y;
+                        tb[r][n][1] = d01.y;
+                        tb[r][n][2] = d2 - d01.y;
+                        tb[r][n][3] = d2;
+                        if (Sc) {
+                            const float sc = Sc[2 * q + hi];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) tb[r][n][k] *= sc;
+                        }
+                    }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int r = ky == 2 ? 0 : 1;       // patch row: 1 = input row y, 0 = input row y-1
+                    const int base = ky == 1 ? 5 : 0;    // accumulator slots of the output-row parity
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const int wrow = j < 3 ? j : 3;              // weight row within the kernel row
+                        const int bk = j < 3 ? j : (j == 3 ? 1 : 3);  // which transformed input
+                        float a[TM];
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 4 + wrow) * CC + 2 * q) * BM + mt * 32 + aoff];
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                            for (int n = 0; n < TN; ++n)
+                                acc[mt][n * NPH + base + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    a[mt], tb[r][n][bk], acc[mt][n * NPH + base + j], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         if (W43) {
             // B^T d for F(4,3) (interpolation points 0, +-1, +-2, inf) on six consecutive patch floats:
             //   t0 = 4 d0 - 5 d2 + d4          t1 = (d4 - 4 d2) + (d3 - 4 d1)     t2 = (d4 - 4 d2) - (d3 - 4 d1)
@@ -576,7 +630,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         if (UP && g.flat) gy = gx / g.GW, gx -= gy * g.GW;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            const int oy = UP ? 2 * gy + (ph >> 1) : gy, ox = UP ? 2 * gx + (ph & 1) : (WINO ? WX * gx + (ph < WX ? ph : 0) : gx);
+            const int oy = UP ? 2 * gy + ((ph >> 1) & 1) : gy, ox = UP ? 2 * gx + (ph & 1) : (WINO ? WX * gx + (ph < WX ? ph : 0) : gx);
             nz_all[n][ph] = 0.f;
             if (WINO && ph >= WX) continue;
             if (nw != 0.f && b < g.B && gy < g.GH && gx < g.GW && oy < g.OH && ox < g.OW)
@@ -597,16 +651,16 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         const bool pos_ok = (b < g.B) && (gy < g.GH) && (gx < g.GW);
         // transposed conv: the two x-parities of a position are adjacent in memory -> one 8-byte store per lane
         // (rows of the (2W+1)-wide plane are only 4-byte aligned: f32x2u is an align-4 vector type)
-        constexpr int PXN = UP ? 2 : WX;  // outputs per position along x (Winograd positions are pairs / quads)
+        constexpr int PXN = UW ? 4 : (UP ? 2 : WX);  // outputs per position along x (pairs / quads in the Winograd modes)
 #pragma unroll
         for (int py = 0; py < (UP ? 2 : 1); ++py) {
             const int oy = UP ? 2 * gy + py : gy;
-            const int ox = UP ? 2 * gx : WX * gx;
+            const int ox = UW ? 4 * gx : (UP ? 2 * gx : WX * gx);
             const bool ok0 = pos_ok && oy < g.OH && ox < g.OW;
             const bool ok1 = (UP || WINO) && ok0 && (ox + PXN - 1 < g.OW);  // the whole pair / quad is inside the row
             float nzv[PXN];
 #pragma unroll
-            for (int px = 0; px < PXN; ++px) nzv[px] = nz_all[n][UP ? py * 2 + px : (WINO ? px : 0)];
+            for (int px = 0; px < PXN; ++px) nzv[px] = UW ? 0.f : nz_all[n][UP ? py * 2 + px : (WINO ? px : 0)];
             // row pointer of this wave's first output channel (block-uniform unless several images share a tile) + a
             // 32-bit lane offset: the per-element address is scalar base + VGPR offset, no 64-bit vector arithmetic
             float* blk = outp + ((size_t)(MULTI ? b : b0) * g.Cout + m0 + wm * (TM * 32)) * plane_out;
@@ -647,7 +701,12 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                         for (int px = 0; px < PXN; ++px) {
                             float raw;
-                            if (W43) {
+                            if (UW) {  // columns 4 gx .. 4 gx + 3 = e_p, o_p, e_p+1, o_p+1
+                                const int sb = n * NPH + py * 5;
+                                raw = px == 0 ? acc[mt][sb + 0][e] + acc[mt][sb + 1][e]
+                                    : px == 1 ? acc[mt][sb + 3][e]
+                                    : px == 2 ? acc[mt][sb + 1][e] + acc[mt][sb + 2][e] : acc[mt][sb + 4][e];
+                            } else if (W43) {
                                 // A^T m: y0 = m0+m1+m2+m3+m4, y1 = (m1-m2) + 2(m3-m4), y2 = (m1+m2) + 4(m3+m4),
                                 //        y3 = (m1-m2) + 8(m3-m4) + m5
                                 const float m0_ = acc[mt][n * NPH + 0][e], m1_ = acc[mt][n * NPH + 1][e];
@@ -872,6 +931,25 @@ __global__ __launch_bounds__(256) void pack_weight_wino43_kernel(const float* __
     }
 }
 
+// Transposed conv, F(2,2) on the even x-phase: wq[(ky*4 + j)][i][o_pad],  j 0: g2   1: g0 + g2   2: g0   3: g1
+__global__ __launch_bounds__(256) void pack_weight_upwino_kernel(const float* __restrict__ w, float* __restrict__ wq,
+                                                                 int cout, int cout_pad, int cin) {
+    const int64_t total = (int64_t)cout_pad * cin;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int o = (int)(idx % cout_pad);
+        const int i = (int)(idx / cout_pad);
+        for (int ky = 0; ky < 3; ++ky) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (o < cout) {
+                const float* gp = w + (((size_t)o * cin + i) * 3 + ky) * 3;
+                g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            }
+            const float u[4] = {g2, g0 + g2, g0, g1};
+            for (int j = 0; j < 4; ++j) wq[((size_t)(ky * 4 + j) * cin + i) * cout_pad + o] = u[j];
+        }
+    }
+}
+
 inline int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -896,7 +974,7 @@ int g_conv_cfg = 0;  // tuning key 2: bit0 -> Cout<=64 uses 64x128 (WM 2); bit1 
 Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     Plan pl{};
     ConvGeom& g = pl.g;
-    const bool up = mode == 1, wino = mode == 2 || mode == 3, w43 = mode == 3;
+    const bool up = mode == 1 || mode == 4, uw = mode == 4, wino = mode == 2 || mode == 3, w43 = mode == 3;
     const int wx = w43 ? 4 : 2;  // outputs per Winograd position
     g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = pad32(cout), g.H = h, g.W = w;
     if (w43) {
@@ -909,6 +987,10 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = (g_conv_cfg & 2) ? 256 : 128;
         else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
         else pl.bm = 128, pl.wm = 2, pl.bn = 64;
+    } else if (uw) {
+        g.GH = h + 1, g.GW = w / 2 + 1, g.OH = 2 * h + 1, g.OW = 2 * w + 1;  // positions are pairs; W + 2 positions per row
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 128;
+        else pl.bm = 64, pl.wm = 2, pl.bn = 64;
     } else if (up) {
         g.GH = h + 1, g.GW = w + 1, g.OH = 2 * h + 1, g.OW = 2 * w + 1;
         if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 128;
@@ -951,10 +1033,10 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.flat = 1;
         g.lsw = 5, g.lsh = 0, g.lnsx = ilog2(pl.bn / 32), g.lnsy = 0, g.lni = 0;
         g.tiles_x = ceil_div(g.GH * g.GW, pl.bn), g.tiles_y = 1, g.img_groups = batch;
-        g.PH = 2, g.PW = pl.bn + 1, g.PWS = pl.bn + 2;
+        g.PH = 2, g.PW = (uw ? 2 : 1) * pl.bn + 1, g.PWS = (uw ? 2 : 1) * pl.bn + 2;
         g.PSTRIDE = g.PH * g.PWS;
     }
-    if (g.PSTRIDE > ((pl.bn >= 512 || (wino && pl.bn >= 256) || (w43 && pl.bn >= 128)) ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
+    if (g.PSTRIDE > ((pl.bn >= 512 || (wino && pl.bn >= 256) || ((w43 || uw) && pl.bn >= 128)) ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
         if (wino) pl.bm = 128, pl.wm = 2, pl.bn = 64;
         else if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
@@ -974,7 +1056,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     g.splits = ceil_div(g.n_chunks, g.chunks_per_split);
     g.ws_slab = (int64_t)batch * cout * g.OH * g.OW;
     pl.blocks = base_blocks * g.splits;
-    pl.lds_bytes = 2 * ((size_t)(w43 ? 18 : wino ? 12 : 9) * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
+    pl.lds_bytes = 2 * ((size_t)(w43 ? 18 : (wino || uw) ? 12 : 9) * CC * pl.bm + (size_t)CC * g.PSTRIDE) * sizeof(float);
     if (g.lni == 0)  // the DMA patch path also stages the styles of one image
         pl.lds_bytes += (size_t)cin * sizeof(float);
     if (pl.lds_bytes < (size_t)2 * pl.bm * sizeof(float)) pl.lds_bytes = (size_t)2 * pl.bm * sizeof(float);
@@ -997,7 +1079,7 @@ int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 template <int BM, int BN, int WM, int UP, bool MULTI, bool FAST>
 int launch_conv_impl(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     if (pl.g.PSTRIDE <= 256) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 1>(pl, ptrs, st);
-    constexpr bool WIDE = BN >= 512 || (UP == 2 && BN >= 256) || (UP == 3 && BN >= 128);  // configs whose patch can exceed 512 floats per channel
+    constexpr bool WIDE = BN >= 512 || (UP == 2 && BN >= 256) || ((UP == 3 || UP == 4) && BN >= 128);  // configs whose patch can exceed 512 floats per channel
     if (pl.g.PSTRIDE <= 512 || !WIDE) return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, 2>(pl, ptrs, st);
     return launch_conv_impl2<BM, BN, WM, UP, MULTI, FAST, (WIDE ? 3 : 2)>(pl, ptrs, st);
 }
@@ -1039,6 +1121,16 @@ extern "C" int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, in
     return 0;
 }
 
+extern "C" int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, void* stream) {
+    if (!w || !wq || cout <= 0 || cin <= 0) return MAUA_EINVAL;
+    const int cout_pad = pad32(cout);
+    const int64_t blocks = ceil_div64((int64_t)cout_pad * cin, 256);
+    hipLaunchKernelGGL(pack_weight_upwino_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, w, wq, cout, cout_pad, cin);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, void* stream) {
     if (!w || !wq || cout <= 0 || cin <= 0) return MAUA_EINVAL;
     const int cout_pad = pad32(cout);
@@ -1068,7 +1160,8 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     if (noise && !noise_w) return MAUA_EINVAL;
     if ((int64_t)batch * cin * h * w > 0x7fffffffLL) return MAUA_EINVAL;  // 32-bit patch offsets
-    if (up < 0 || up > 3 || (up == 2 && (w & 1)) || (up == 3 && (w & 3))) return MAUA_EINVAL;
+    if (up < 0 || up > 4 || ((up == 2 || up == 4) && (w & 1)) || (up == 3 && (w & 3))) return MAUA_EINVAL;
+    if (up == 4 && (fuse_act || rgb)) return MAUA_EINVAL;  // raw output only: the blur kernel applies the tail
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     if (pl.g.splits > 1 && !ws) return MAUA_EINVAL;
     pl.g.s_stride = s_stride;
@@ -1082,7 +1175,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     if (rgb) {
         // fusable only when one workgroup holds every channel of its pixels in a single wave row (BM >= Cout, WM == 1),
         // no split-K, one image per tile, the tail fused
-        const bool ok = up != 1 && fuse_act && pl.wm == 1 && pl.g.m_tiles == 1 && pl.g.splits == 1 && pl.g.lni == 0 &&
+        const bool ok = up != 1 && up != 4 && fuse_act && pl.wm == 1 && pl.g.m_tiles == 1 && pl.g.splits == 1 && pl.g.lni == 0 &&
                         rgb->w && rgb->s && rgb->bias && rgb->out && (!rgb->skip || (rgb->k4 && !(h & 1) && !(w & 1)));
         if (!ok) return MAUA_ENOSYS;
         pl.g.rgb = rgb->store_features ? 1 : 2;
@@ -1092,7 +1185,11 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     }
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (up == 3) {
+    if (up == 4) {
+        if (!pl.g.flat || pl.fallback) return MAUA_EINVAL;  // grids too small for flat pair runs use mode 1
+        if (pl.bm == 32) rc = launch_conv<32, 128, 1, 4>(pl, ptrs, st);
+        else rc = launch_conv<64, 64, 2, 4>(pl, ptrs, st);
+    } else if (up == 3) {
         if (pl.bm == 32) rc = launch_conv<32, 128, 1, 3>(pl, ptrs, st);
         else if (pl.bm == 64) rc = launch_conv<64, 128, 1, 3>(pl, ptrs, st);
         else rc = launch_conv<128, 64, 2, 3>(pl, ptrs, st);
@@ -1101,7 +1198,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
         else if (pl.bm == 32) rc = launch_conv<32, 128, 1, 2>(pl, ptrs, st);
         else if (pl.bm == 64) rc = launch_conv<64, 128, 1, 2>(pl, ptrs, st);
         else rc = launch_conv<128, 64, 2, 2>(pl, ptrs, st);
-    } else if (up) {
+    } else if (up == 1) {
         if (pl.fallback) rc = launch_conv<64, 64, 2, 1>(pl, ptrs, st);
         else if (pl.bm == 32) rc = launch_conv<32, 128, 1, 1>(pl, ptrs, st);
         else rc = launch_conv<64, 64, 2, 1>(pl, ptrs, st);

@@ -155,6 +155,7 @@ class ModulatedConv2d(nn.Module):
     # a huge value turns it off
     winograd_min_cout = 32
 
+    upconv_winograd = True
     # ... and from this many output channels, on maps at least 64 wide, through F(4,3) (6 products per 4 outputs)
     winograd43_min_cout = 32
 
@@ -162,6 +163,11 @@ class ModulatedConv2d(nn.Module):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd F(2,3), 3 Winograd
         F(4,3), 0 direct."""
         if self.upsample:
+            # F(2,2) on the even x-phase of the polyphase transposed conv (mode 4) whenever the flattened pair grid fills
+            # at least two tiles; tiny maps keep the plain polyphase kernel (mode 1)
+            pairs_per_tile = 128 if self.out_channel <= 32 else 64
+            if self.upconv_winograd and w % 2 == 0 and (h + 1) * (w // 2 + 1) >= 2 * pairs_per_tile:
+                return 4
             return 1
         if self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= 64:
             return 3
@@ -170,8 +176,8 @@ class ModulatedConv2d(nn.Module):
         return 0
 
     def packed_wino(self, mode=2):
-        """Winograd-domain weight [(ky*F+xi), Cin, Cout_pad], F = 4 for mode 2 (maua_pack_weight_wino_f32) or 6 for mode 3
-        (maua_pack_weight_wino43_f32); cached like ``packed()``."""
+        """Winograd-domain weight [(ky*F+xi), Cin, Cout_pad], F = 4 for mode 2 (maua_pack_weight_wino_f32) and mode 4
+        (maua_pack_weight_upwino_f32), 6 for mode 3 (maua_pack_weight_wino43_f32); cached like ``packed()``."""
         self.packed()  # refreshes / invalidates on weight change
         if self._packed_wino is None:
             self._packed_wino = {}
@@ -179,8 +185,8 @@ class ModulatedConv2d(nn.Module):
             w = self.weight
             wd = _lib.require_cuda(w.detach(), "weight")
             cpad = (self.out_channel + 31) // 32 * 32
-            wq = th.empty((12 if mode == 2 else 18, self.in_channel, cpad), dtype=th.float32, device=w.device)
-            fn = "maua_pack_weight_wino_f32" if mode == 2 else "maua_pack_weight_wino43_f32"
+            wq = th.empty((18 if mode == 3 else 12, self.in_channel, cpad), dtype=th.float32, device=w.device)
+            fn = {2: "maua_pack_weight_wino_f32", 3: "maua_pack_weight_wino43_f32", 4: "maua_pack_weight_upwino_f32"}[mode]
             with th.cuda.device(w.device):
                 rc = getattr(_lib.load(), fn)(wd.data_ptr(), wq.data_ptr(), self.out_channel, self.in_channel,
                                               _lib.stream_ptr(w.device))

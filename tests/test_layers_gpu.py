@@ -205,3 +205,36 @@ def test_modconv_winograd43_vs_oracle(gpu, cin, cout, h, w, batch):
     m.conv.winograd_min_cout = m.conv.winograd43_min_cout = 1 << 30
     direct = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
     np.testing.assert_allclose(got, direct, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [
+    (128, 64, 64, 64, 2),     # 64-row tile, flat pair runs, FAST path
+    (64, 32, 48, 96, 1),      # 32-row tile (three patch slots per thread)
+    (24, 72, 12, 20, 2),      # generic loads (Cin % 8 != 0), Cout not a multiple of the tile, small ragged grid
+    (512, 256, 16, 16, 1),    # split-K
+])
+def test_upconv_winograd_matches_polyphase_and_oracle(gpu, cin, cout, h, w, batch):
+    """Up-sampling ModulatedConv2d: mode 4 (F(2,2) on the even x-phase) against the oracle's conv_transpose2d + blur and
+    against the plain polyphase kernel (mode 1) of the same layer."""
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(cin + cout + h + w)
+    m = ModulatedConv2d(cin, cout, 3, 512, upsample=True)
+    assert m.conv_mode(h, w) == 4
+    wgt = r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)
+    mw = r.standard_normal((cin, 512)).astype(np.float32)
+    mb = (1 + 0.1 * r.standard_normal(cin)).astype(np.float32)
+    m.weight.copy_(torch.from_numpy(wgt)), m.modulation.weight.copy_(torch.from_numpy(mw)), m.modulation.bias.copy_(torch.from_numpy(mb))
+    m = m.to(gpu)
+    x = r.standard_normal((batch, cin, h, w)).astype(np.float32)
+    s = r.standard_normal((batch, 512)).astype(np.float32)
+    want = so.modulated_conv2d(torch.from_numpy(x), torch.from_numpy(s), torch.from_numpy(wgt), torch.from_numpy(mw),
+                               torch.from_numpy(mb), upsample=True, blur_kernel=m.blur.kernel.cpu()).numpy()
+    got = m(t(x, gpu), t(s, gpu)).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-4)
+    m.upconv_winograd = False
+    assert m.conv_mode(h, w) == 1
+    ref = m(t(x, gpu), t(s, gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--conv-cfg", type=int, default=0)
     ap.add_argument("--lib", default=None, help="experimental build of libmaua_hip.so to load instead (tools/bin/...)")
     ap.add_argument("--wino-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd_min_cout")
+    ap.add_argument("--no-up-wino", action="store_true", help="transposed layers use the plain polyphase kernel (mode 1)")
     ap.add_argument("--wino43-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd43_min_cout")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
@@ -90,6 +91,8 @@ def main():
             B = args.batch
             if args.wino_min_cout is not None:
                 ModulatedConv2d.winograd_min_cout = args.wino_min_cout
+            if args.no_up_wino:
+                ModulatedConv2d.upconv_winograd = False
             if args.wino43_min_cout is not None:
                 ModulatedConv2d.winograd43_min_cout = args.wino43_min_cout
             for name, cin, cout, h, up in [("plain32@1024", 32, 32, 1024, 0), ("plain64@512", 64, 64, 512, 0),
