@@ -163,10 +163,12 @@ class ModulatedConv2d(nn.Module):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd F(2,3), 3 Winograd
         F(4,3), 0 direct."""
         if self.upsample:
-            # F(2,2) on the even x-phase of the polyphase transposed conv (mode 4) whenever the flattened pair grid fills
-            # at least two tiles; tiny maps keep the plain polyphase kernel (mode 1)
+            # F(2,2) on the even x-phase of the polyphase transposed conv (mode 4: -17 % MFMA work, but 2 instead of 3-4
+            # workgroups per CU) once a batch of 8 frames yields at least ~4 rounds of workgroups; smaller grids lose more
+            # to the partially filled last round than they gain and keep the plain polyphase kernel (mode 1)
             pairs_per_tile = 128 if self.out_channel <= 32 else 64
-            if self.upconv_winograd and w % 2 == 0 and (h + 1) * (w // 2 + 1) >= 2 * pairs_per_tile:
+            tiles = -(-((h + 1) * (w // 2 + 1)) // pairs_per_tile) * -(-self.out_channel // (32 if self.out_channel <= 32 else 64))
+            if self.upconv_winograd and w % 2 == 0 and tiles >= 256:
                 return 4
             return 1
         if self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= 64:
