@@ -312,8 +312,8 @@ def main():
                             result["roofline"]["executed_frac"] = ach * ratio / MFMA_F32_PEAK_TFLOPS
                     if size == 1024 and B == 8 and dom[0].startswith("convs.15"):
                         # HBM bytes of this launch from the PMC passes (FETCH_SIZE x2 correction, WRITE_SIZE exact):
-                        # 2 x 553,329 KB read + 98,304 KB written; algorithmic 1,077,252 KB + 98,304 KB
-                        result["roofline"]["traffic"] = (2 * 553329.2 + 98304.0) * 1024
+                        # 2 x 555,601 KB read + 131,072 KB written; algorithmic 1,077,252 KB + 98,304 KB
+                        result["roofline"]["traffic"] = (2 * 555601.4 + 131072.0) * 1024
                         result["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_traffic.md"
                         result["roofline"]["algorithmic_bytes"] = (1077252 + 98304) * 1024
                 else:

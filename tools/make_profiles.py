@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_final/ (written by tools/profile_round.sh on the GPU box) into the tracked summaries under profiles/.
+
+    python tools/make_profiles.py [round-tag, default r01]
+"""
+import json
+import re
+import shutil
+import sqlite3
+import subprocess
+import sys
+
+O = "gpurun_out/prof_final"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def table(db, keep=("modconv_mfma", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel", "reduce_tail")):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                       "group by kernel_name, counter_name").fetchall()
+    tab = {}
+    for n, c, k, v, dur in rows:
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"\(.*", "", n).replace("void ", "")
+        if not any(s in n for s in keep):
+            continue
+        tab.setdefault(n, {})[c] = v
+        tab[n]["n"] = k
+        tab[n]["us"] = dur / 1e3
+    return tab
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def main():
+    shutil.copy(f"{O}/pytest_gpu.log", f"profiles/{TAG}_pytest_gpu.log")
+    for src, dst in (("bench_default", "bench_default"), ("bench_trace_lanes1", "bench_rocprof_lanes1"),
+                     ("bench_trace_lanes2", "bench_rocprof_lanes2")):
+        shutil.copy(f"{O}/{src}.json", f"profiles/{TAG}_{dst}.json")
+    l1, l2 = last_json(f"{O}/bench_trace_lanes1.json"), last_json(f"{O}/bench_trace_lanes2.json")
+
+    def stats(db):
+        out = subprocess.run([sys.executable, "tools/rocpd_summary.py", db], capture_output=True, text=True).stdout
+        return "\n".join(line for line in out.splitlines()[1:] if "at::native" not in line)
+
+    with open(f"profiles/{TAG}_bench_kernel_stats.md", "w") as f:
+        f.write(f"""# rocprofv3 --kernel-trace --stats of bench.py ({TAG}, final kernels of the round)
+
+Commands (tools/profile_round.sh, run through gpurun on one MI355X):
+
+    rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --lanes 1 --no-cpu-baseline   # strictly serial steps
+    rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline             # default: 2 graph lanes
+
+The serial run is the one whose per-kernel averages are comparable with the live HIP-event numbers in the bench JSON
+(profiles/{TAG}_bench_rocprof_lanes1.json: {l1['value']:.0f} frames/s, roofline.launch_ms {l1['roofline']['launch_ms']:.3f} ms for
+{l1['roofline']['kernel']}).  Under two lanes ({l2['value']:.0f} frames/s) the kernels of consecutive batches share the device, so
+individual durations stretch while the step time drops.  Each trace also contains bench.py's per-layer breakdown pass (eager
+launches), which is why calls != steps x layers.  Template arguments of modconv_mfma_kernel: <BM, BN, WM, MODE, MULTI, FAST, MAXP>,
+MODE 0 direct, 1 transposed (polyphase), 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed with F(2,2) on the even x-phase.
+
+## --lanes 1
+{stats(f'{O}/trace_lanes1/bench_results.db')}
+
+## default (2 lanes)
+{stats(f'{O}/trace_lanes2/bench_results.db')}
+""")
+
+    sq, lds = table(f"{O}/pmc_sq/bench_results.db"), table(f"{O}/pmc_lds/bench_results.db")
+    fe, wr = table(f"{O}/pmc_FETCH_SIZE/bench_results.db"), table(f"{O}/pmc_WRITE_SIZE/bench_results.db")
+    lines = [f"""
+## Final kernels of {TAG}, measured inside bench.py
+
+Command (tools/profile_round.sh): `rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
+SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown` and a second
+pass with `--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32` (counters only, with --kernel-trace; no
+sys/hip/hsa trace domains).  Averages over every dispatch of the template instance in the run (batch 8, 1024^2 generator).
+MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); clock = (GRBM_GUI_ACTIVE / 8) / duration.
+Template arguments: <BM, BN, WM, MODE (0 direct, 1 transposed, 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed + F(2,2)),
+MULTI, FAST, MAXP>.
+
+| kernel instance | dispatches | avg us | clock GHz | MFMA busy % | wave cycles waiting on an instruction % | LDS bank conflicts % of LDS active |
+|---|---:|---:|---:|---:|---:|---:|"""]
+    for n, t in sorted(sq.items(), key=lambda kv: -kv[1]["us"] * kv[1]["n"]):
+        if "modconv" not in n:
+            continue
+        cyc = t["GRBM_GUI_ACTIVE"] / 8
+        ll = lds.get(n, {})
+        lines.append(f"| `{n}` | {t['n']} | {t['us']:.0f} | {cyc / t['us'] / 1e3:.2f} | "
+                     f"{t['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024) * 100:.1f} | "
+                     f"{t['SQ_WAIT_INST_ANY'] / t['SQ_WAVE_CYCLES'] * 100:.0f} | "
+                     f"{100 * ll.get('SQ_LDS_BANK_CONFLICT', 0) / max(ll.get('SQ_LDS_IDX_ACTIVE', 1), 1):.1f} |")
+    open(f"/tmp/{TAG}_pmc_modconv_final.md", "w").write("\n".join(lines) + "\n")
+
+    tr = [f"# HBM traffic per launch inside bench.py ({TAG}; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)", "",
+          "Command: `rocprofv3 --pmc <CTR> --kernel-trace -- python bench.py --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown`",
+          "(tools/profile_round.sh).  Units: KB per dispatch, averaged over the dispatches of one template instance.  Corrections as calibrated",
+          f"in {TAG}_pmc_upfirdn2d.md against kernels of known traffic (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of",
+          "the bytes read -> x2; WRITE_SIZE is exact.", "",
+          "| kernel instance | dispatches | FETCH_SIZE KB | read KB (x2) | WRITE_SIZE KB | avg us |", "|---|---:|---:|---:|---:|---:|"]
+    for n, t in sorted(fe.items(), key=lambda kv: -kv[1]["us"] * kv[1]["n"]):
+        w = wr.get(n, {})
+        tr.append(f"| `{n}` | {t['n']} | {t['FETCH_SIZE']:.0f} | {2 * t['FETCH_SIZE']:.0f} | {w.get('WRITE_SIZE', float('nan')):.0f} | {t['us']:.0f} |")
+    open(f"/tmp/{TAG}_pmc_traffic_table.md", "w").write("\n".join(tr) + "\n")
+    print("wrote profiles/*; tables in /tmp for the hand-annotated files")
+
+
+if __name__ == "__main__":
+    main()
