@@ -158,6 +158,7 @@ class ModulatedConv2d(nn.Module):
     upconv_winograd = True
     # ... and from this many output channels, on maps at least 64 wide, through F(4,3) (6 products per 4 outputs)
     winograd43_min_cout = 32
+    winograd43_min_width = 32
 
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd F(2,3), 3 Winograd
@@ -171,7 +172,7 @@ class ModulatedConv2d(nn.Module):
             if self.upconv_winograd and w % 2 == 0 and tiles >= 256:
                 return 4
             return 1
-        if self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= 64:
+        if self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= self.winograd43_min_width:
             return 3
         if self.out_channel >= self.winograd_min_cout and w % 2 == 0 and w >= 32:
             return 2
