@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--conv-debug", type=int, default=0)
     ap.add_argument("--conv-cfg", type=int, default=0)
+    ap.add_argument("--fir-path", type=int, default=0, help="maua_tuning_set key 0 (upfirdn2d kernel selection)")
     ap.add_argument("--lib", default=None, help="experimental build of libmaua_hip.so to load instead (tools/bin/...)")
     ap.add_argument("--wino-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd_min_cout")
     ap.add_argument("--no-up-wino", action="store_true", help="transposed layers use the plain polyphase kernel (mode 1)")
@@ -36,6 +37,7 @@ def main():
     lib = _lib.load()
     lib.maua_tuning_set(1, args.conv_debug)
     lib.maua_tuning_set(2, args.conv_cfg)
+    lib.maua_tuning_set(0, args.fir_path)
     dev = torch.device("cuda:0")
     stream = torch.cuda.Stream(dev)
     sp = stream.cuda_stream
