@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per rank per step (reference default --batch 8)")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="hipGraphs replayed round-robin on their own streams (consecutive steps overlap on the device, "
                          "as render.synthesize does); 1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -107,7 +107,7 @@ def frames_to_uint8(images, out=None):
 
 
 def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), rewrites=None, randomize_noise=False,
-               use_graph=True, frame_range=None, lanes=2):
+               use_graph=True, frame_range=None, lanes=3):
     """Generator -> uint8 frames for ``frame_range`` (default: all) of the sequence.  Yields (first_frame_index,
     uint8 device tensor [b, H, W, 3]) per batch, in order, with the producing stream current; the tensor stays valid
     until ``lanes`` further batches have been requested.
@@ -221,9 +221,10 @@ def render(generator, latents, noise, offset, duration, batch_size, out_size, ou
         sink = FrameSink(output_file, width, height, n_frames / duration, audio_file, offset, duration, ffmpeg_preset)
 
     if world == 1:
-        # double-buffered pinned staging: D2H of batch k overlaps the graph replay of batch k+1
+        # pinned staging ring, one slot per graph lane: the D2H of batch k overlaps the graph replays of the next batches
+        n_slots = 3
         copy_stream = th.cuda.Stream(dev)
-        pinned, events, pending = [None, None], [None, None], []
+        pinned, events, pending = [None] * n_slots, [None] * n_slots, []
 
         def drain(slot_first):
             slot, first, count = slot_first
@@ -233,9 +234,10 @@ def render(generator, latents, noise, offset, duration, batch_size, out_size, ou
                 sink.write(host[i])
 
         k = 0
-        for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites, randomize_noise):
-            slot = k % 2
-            if len(pending) == 2:
+        for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites, randomize_noise,
+                                    lanes=n_slots):
+            slot = k % n_slots
+            if len(pending) == n_slots:
                 drain(pending.pop(0))
             if pinned[slot] is None or pinned[slot].shape != u8.shape:
                 pinned[slot] = th.empty(u8.shape, dtype=th.uint8).pin_memory()
