@@ -982,8 +982,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     if (w43) {
         g.GH = h, g.GW = w / 4, g.OH = h, g.OW = w;  // positions are output quads
         if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 128;
-        else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
-        else pl.bm = 128, pl.wm = 2, pl.bn = 64;
+        else pl.bm = 64, pl.wm = 1, pl.bn = 128;  // (a 128-row tile holds 192 accumulator registers per wave as well, but its
+                                                  // 18-row weight tile only leaves room for 2-channel chunks: 4-7 % slower)
     } else if (wino) {
         g.GH = h, g.GW = w / 2, g.OH = h, g.OW = w;  // positions are output pairs
         if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = (g_conv_cfg & 2) ? 256 : 128;
@@ -1039,7 +1039,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.PSTRIDE = g.PH * g.PWS;
     }
     if (g.PSTRIDE > ((pl.bn >= 512 || (wino && pl.bn >= 256) || ((w43 || uw) && pl.bn >= 128)) ? 768 : 512)) {  // tiny feature maps under a wide-N config: fall back to the 128-pixel tile
-        if (wino) pl.bm = 128, pl.wm = 2, pl.bn = 64;
+        if (w43) pl.bm = 64, pl.wm = 1, pl.bn = 128;
+        else if (wino) pl.bm = 128, pl.wm = 2, pl.bn = 64;
         else if (up) pl.bm = 64, pl.wm = 2, pl.bn = 64;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
         shape(pl.bn);
@@ -1193,8 +1194,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
         else rc = launch_conv<64, 64, 2, 4>(pl, ptrs, st);
     } else if (up == 3) {
         if (pl.bm == 32) rc = launch_conv<32, 128, 1, 3>(pl, ptrs, st);
-        else if (pl.bm == 64) rc = launch_conv<64, 128, 1, 3>(pl, ptrs, st);
-        else rc = launch_conv<128, 64, 2, 3>(pl, ptrs, st);
+        else rc = launch_conv<64, 128, 1, 3>(pl, ptrs, st);
     } else if (up == 2) {
         if (pl.bm == 32 && pl.bn == 256) rc = launch_conv<32, 256, 1, 2>(pl, ptrs, st);
         else if (pl.bm == 32) rc = launch_conv<32, 128, 1, 2>(pl, ptrs, st);
