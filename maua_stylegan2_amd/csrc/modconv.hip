@@ -20,6 +20,18 @@
 // staged patch — 9 MACs per input pixel per channel pair, exactly the reference's FLOPs, no zero-stuffing.
 // Small feature maps (4^2..32^2) are weight-streaming bound: K is split across workgroups (deterministic two-pass
 // split-K through a caller-owned workspace, reduced by reduce_tail_kernel together with the tail).
+//
+// Kernel modes (template MODE = the `up` argument of maua_modconv3x3_f32), all on the same tile / pipeline skeleton:
+//   0  direct 3x3                      9 weight rows per channel, 1 accumulator tile per position group
+//   1  transposed, polyphase           9 rows, 4 tiles (output parities); tiles = flat runs of the (H+1)x(W+1) grid
+//   2  Winograd F(2,3) along x         12 rows (3 ky x 4 frequencies), positions = output pairs, 4 tiles
+//   3  Winograd F(4,3) along x         18 rows (3 ky x 6 frequencies), positions = output quads, 6 tiles
+//   4  transposed + F(2,2) on the even x-phase   12 rows, positions = position pairs, 10 tiles
+// Both operands reach LDS by global_load_lds DMA, double buffered, one barrier per K chunk; the style scale of the
+// input channel is applied when the B operand is read (a register-staged, pre-scaled patch remains for tiles that hold
+// several images and for the 32-channel F(2,3) config).  Measured rule of this chip that shapes everything above: VALU /
+// SALU instructions of co-resident waves do NOT hide under the 64-cycle MFMAs (profiles/r01_pmc_modconv.md) — fewer
+// MFMAs per output (Winograd) and fewer non-MFMA instructions are what pay, not occupancy or prefetch depth.
 #include "common.h"
 
 #include <type_traits>
@@ -32,7 +44,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x2 f32x2u __attribute__((aligned(4)));
 typedef f32x4 f32x4u __attribute__((aligned(4)));
 
-// channels per K chunk: the weight tile As[9][CC][BM] is kept at <= 18 KB so that two of them (double buffer) fit 3x per CU
+// channels per K chunk: the weight tile As[rows][CC][BM] is kept at <= 18..24 KB so that the double buffer fits 2-3x per CU
 constexpr int chunk_channels(int bm, int bn = 0, int mode = 0) {
     if (mode == 3) return bm >= 128 ? 2 : 4;  // F(4,3): 18 weight rows per channel
     return (bm >= 128 || bn >= 512) ? 4 : 8;
@@ -93,10 +105,7 @@ struct ConvPtrs {
 // the B operand is formed from two 8-byte LDS reads of the ordinary patch, the epilogue undoes the transform in
 // registers and stores 8 bytes per lane.  fp32 F(2,3) has transform constants {1, 1/2}: error stays at the 1e-6 level.
 template <int BM, int BN, int WM, int MODE, bool MULTI, bool FAST, int MAXP>
-#ifndef MAUA_EXP_LB43
-#define MAUA_EXP_LB43 2
-#endif
-__global__ __launch_bounds__(256, (MODE == 3 && BM >= 64) ? MAUA_EXP_LB43 : MODE == 4 ? 2
+__global__ __launch_bounds__(256, ((MODE == 3 && BM >= 64) || MODE == 4) ? 2
                                             : ((BM / WM / 32) * (BN / (4 / WM) / 32) * (MODE ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
 void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     constexpr bool UP = MODE == 1 || MODE == 4;
