@@ -117,3 +117,20 @@ def test_fused_torgb_and_winograd_match_separate_direct_kernels(gpu):
         ModulatedConv2d.winograd_min_cout, ModulatedConv2d.winograd43_min_cout = keep, keep43
         g.disable_rgb_fusion = False
     assert float((fast - plain).abs().max()) < 5e-4
+
+
+def test_generator_512_channel_multiplier_1_vs_oracle(gpu):
+    """A narrower generator (channel_multiplier 1: 128 / 64 / 32 / 16 channels at 64..512^2) exercises the tile configs
+    below the Winograd thresholds (16-channel layers: direct mode on a 32-row tile) next to every Winograd mode."""
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+    from oracle import stylegan2_oracle as so
+
+    sd = seeding.seeded_state_dict(512, seed=11, channel_multiplier=1)
+    g = Generator(512, 512, 8, channel_multiplier=1, constant_input=True)
+    g.load_state_dict(sd, strict=True)
+    g = g.to(gpu).eval()
+    lat = seeding.seeded_latents(2, g.n_latent, seed=12)
+    noise = seeding.seeded_noise(2, 512, seed=13)
+    want = so.generator_forward(sd, lat, noise)
+    got, _ = g(styles=lat.to(gpu), noise=[n.to(gpu) for n in noise], truncation=1.0, randomize_noise=False, input_is_latent=True)
+    assert float((got.cpu() - want).abs().max()) < TOL
