@@ -311,7 +311,9 @@ class StyledConv(nn.Module):
         conv = self.conv
         b, cin, h, w = x.shape
         n_ws = lib.maua_modconv_ws_floats(b, cin, conv.out_channel, h, w, conv.conv_mode(h, w))
-        ws = bufs("ws", (n_ws,)) if n_ws else None
+        # one split-K workspace PER LAYER: a shared name would be re-allocated whenever the size changes, and a captured
+        # hipGraph keeps writing through the pointer of the buffer that was freed
+        ws = bufs(tag + ".ws", (n_ws,)) if n_ws else None
         if noise is not None:
             noise = _lib.require_cuda(noise, "noise")
         if not conv.upsample:
@@ -477,6 +479,8 @@ class Generator(nn.Module):
                          int(base_res_factor * 2 ** res * (2 if output_size == 1920 else 1))]
                 setattr(self.noises, f"noise_{layer_idx}", th.randn(*shape))
         self._bufs = {}
+        self._retired = []  # replaced static buffers, kept alive for graphs that still reference them
+        self._captured = False
         self._lane = 0  # static-buffer namespace: concurrent hipGraphs of one generator each own a lane
         self._tables = {}
 
@@ -498,10 +502,14 @@ class Generator(nn.Module):
 
     # ------------------------------------------------------------------ static buffers / tables
     def _buf(self, batch, name, shape, dtype=th.float32):
+        """Static device buffer keyed by (batch, name, lane).  A buffer that has to change shape is RETIRED, not freed:
+        hipGraphs captured earlier still launch kernels on its address."""
         key = (batch, name, self._lane)
         t = self._bufs.get(key)
         shape = tuple(int(v) for v in shape)
         if t is None or tuple(t.shape) != shape or t.device != self.input.input.device:
+            if t is not None and self._captured:
+                self._retired.append(t)
             t = th.empty(shape, dtype=dtype, device=self.input.input.device)
             self._bufs[key] = t
         return t
@@ -668,6 +676,7 @@ class Generator(nn.Module):
         Graphs captured under different ``lane`` ids share the weights but no activation / input buffer, so they can
         be replayed concurrently on different streams."""
         self._lane = lane
+        self._captured = True
         try:
             return self._capture_graph(batch, noise_static, truncated)
         finally:

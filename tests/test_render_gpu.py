@@ -199,3 +199,27 @@ def test_concurrent_graph_lanes_give_the_same_frames(gpu):
         out[lanes] = np.stack(frames)
         assert out[lanes].shape == (n, 64, 64, 3)
     assert np.array_equal(out[1], out[2]) and np.array_equal(out[1], out[3])
+
+
+def test_graph_replay_never_writes_outside_its_static_buffers(gpu):
+    """Regression: every address a captured graph writes must stay owned by the generator.  (A split-K workspace that was
+    re-allocated per layer under one name left the graph writing into freed memory — found by a soak test.)  Device
+    memory handed out by the allocator after the capture is filled with a pattern and must survive the replays."""
+    from maua_stylegan2_amd import seeding
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    g = Generator(256, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(256, seed=5), strict=True)
+    g = g.to(gpu).eval()
+    lat = seeding.seeded_latents(16, g.n_latent, seed=6).to(gpu)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        graph, static = g.capture_graph(8, [None] * g.num_layers)
+        stream.synchronize()
+        sentinels = [torch.full((size,), 7, dtype=torch.uint8, device=gpu)
+                     for size in [1 << 12, 1 << 16, 1 << 20, 3 << 19, 1 << 22, 1 << 24, 1 << 26] * 6]
+        for k in range(2):
+            static["latents"].copy_(lat[8 * k: 8 * k + 8])
+            graph.replay()
+        stream.synchronize()
+        assert all(bool((s == 7).all()) for s in sentinels)
