@@ -223,3 +223,27 @@ def test_graph_replay_never_writes_outside_its_static_buffers(gpu):
             graph.replay()
         stream.synchronize()
         assert all(bool((s == 7).all()) for s in sentinels)
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_synthesize_graph_lanes_match_eager_256_batch8(gpu, lanes):
+    """The configuration in which the freed-workspace bug showed (256^2, 8 frames per batch, clones of every batch's
+    uint8 frames allocated while later batches replay): graph path with 1 and 3 lanes == eager path, bit for bit."""
+    from maua_stylegan2_amd import render, seeding
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    g = Generator(256, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(256, seed=5), strict=True)
+    g = g.to(gpu).eval()
+    n, bs = 40, 8
+    lat = seeding.seeded_latents(n, g.n_latent, seed=6)
+    noise = [torch.from_numpy(seeding.seeded_array(7, f"n{i}", (n, 1, r, r))) if r <= 64 else None
+             for i, r in enumerate(seeding.noise_sizes(256))]
+
+    def run(**kw):
+        frames = [u8.clone() for _, u8 in render.synthesize(g, lat, noise, bs, **kw)]
+        torch.cuda.synchronize()
+        return torch.cat(frames).cpu().numpy()
+
+    eager = run(use_graph=False)
+    assert np.array_equal(run(lanes=lanes), eager)
