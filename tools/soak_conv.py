@@ -1,0 +1,49 @@
+"""Determinism soak for modconv_mfma_kernel: every kernel mode / tile config, 30 launches each on fresh output buffers
+(poisoned with NaN first), outputs must be bit-identical to the first launch and free of NaN.  A missing barrier or an
+unwritten output element shows up here long before it shows up in a parity test."""
+import sys
+
+import torch
+
+sys.path.insert(0, '/root/repo')
+from maua_stylegan2_amd.models.stylegan2 import StyledConv  # noqa: E402
+
+torch.set_grad_enabled(False)
+dev = torch.device("cuda:0")
+cases = [  # cin, cout, h, w, up, batch
+    (512, 512, 4, 4, False, 8), (512, 512, 8, 8, True, 8), (512, 512, 16, 16, False, 8), (512, 512, 16, 16, True, 8),
+    (512, 512, 32, 32, False, 8), (512, 512, 32, 32, True, 4), (512, 512, 64, 64, False, 4), (512, 256, 64, 64, True, 4),
+    (256, 256, 128, 128, False, 4), (256, 128, 128, 128, True, 4), (128, 128, 256, 256, False, 2), (128, 64, 256, 256, True, 2),
+    (64, 64, 512, 512, False, 2), (64, 32, 512, 512, True, 2), (32, 32, 1024, 1024, False, 2), (32, 32, 96, 68, False, 3),
+    (64, 64, 40, 34, False, 3), (24, 40, 20, 38, False, 2), (72, 24, 33, 20, True, 3), (16, 16, 128, 128, False, 2),
+]
+_empty = torch.empty
+
+
+def poisoned_empty(*args, **kwargs):  # every buffer the layer allocates starts as NaN: an unwritten element cannot hide
+    t = _empty(*args, **kwargs)
+    return t.fill_(float("nan")) if t.is_floating_point() else t
+
+
+bad = 0
+for cin, cout, h, w, up, b in cases:
+    m = StyledConv(cin, cout, 3, 512, upsample=up).to(dev)
+    m.conv.weight.normal_(), m.noise.weight.fill_(0.3), m.activate.bias.normal_(0, 0.2)
+    x = torch.randn(b, cin, h, w, device=dev)
+    s = torch.randn(b, 512, device=dev)
+    oh, ow = (2 * h, 2 * w) if up else (h, w)
+    nz = torch.randn(b, 1, oh, ow, device=dev)
+    torch.empty = poisoned_empty
+    ref = m(x, s, noise=nz).clone()
+    ok = bool(torch.isfinite(ref).all())
+    for _ in range(30):
+        y = m(x, s, noise=nz)
+        if not torch.equal(y, ref):
+            ok = False
+            break
+    torch.empty = _empty
+    mode = m.conv.conv_mode(h, w)
+    print(f"cin {cin:4d} cout {cout:4d} {h}x{w} up={int(up)} batch {b} mode {mode}: {'ok' if ok else 'MISMATCH'}")
+    bad += not ok
+print("soak:", "all deterministic" if not bad else f"{bad} cases nondeterministic")
+sys.exit(1 if bad else 0)
