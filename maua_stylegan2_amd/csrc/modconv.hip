@@ -602,10 +602,13 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     // trips behind the stores — that was ~45 % of the lifetime of a 32-channel 1024^2 workgroup.)
     const bool to_ws = g.splits > 1;
     float* outp = to_ws ? (p.ws + (size_t)split * g.ws_slab) : p.y;
-    const float nw = (!to_ws && g.fuse_act && p.noise) ? p.noise_w[0] : 0.f;
+    const float nw = (!to_ws && g.fuse_act && p.noise) ? p.noise_w[0] : 0.f;  // (scaled by act_gain where it is applied)
     const size_t plane_out = (size_t)g.OH * g.OW;
     float* Eg = lds;        // [BM] gain
     float* Eb = lds + BM;   // [BM] bias
+    // leaky ReLU is positively homogeneous: its sqrt(2) gain is folded into gain, bias and noise once, and the activation
+    // itself is max(t, 0.2 t) — 4 instead of 7 VALU operations per output value
+    const float act_gain = (!to_ws && g.fuse_act) ? 1.41421356237309515f : 1.f;
     if (!MULTI) {
         for (int i = tid; i < BM; i += 256) {
             const int o = m0 + i;
@@ -614,8 +617,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 if (p.d) gain *= p.d[b0 * g.Cout + o];
                 if (g.fuse_act && p.bias) bias = p.bias[o];
             }
-            Eg[i] = gain;
-            Eb[i] = bias;
+            Eg[i] = gain * act_gain;
+            Eb[i] = bias * act_gain;
             if (!UP && WM == 1 && g.rgb) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
@@ -643,8 +646,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             nz_all[n][ph] = 0.f;
             if (WINO && ph >= WX) continue;
             if (nw != 0.f && b < g.B && gy < g.GH && gx < g.GW && oy < g.OH && ox < g.OW)
-                nz_all[n][ph] = nw * (MULTI ? p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox]
-                                            : (p.noise + (size_t)b0 * g.noise_batch_stride)[(unsigned)(oy * g.OW + ox)]);
+                nz_all[n][ph] = nw * act_gain * (MULTI ? p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox]
+                                                       : (p.noise + (size_t)b0 * g.noise_batch_stride)[(unsigned)(oy * g.OW + ox)]);
         }
     }
 #pragma unroll
@@ -703,6 +706,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                                 if (p.d) gain *= p.d[b * g.Cout + o];
                                 if (g.fuse_act && p.bias) bias = p.bias[o];
                             }
+                            gain *= act_gain, bias *= act_gain;
                         } else {
                             gain = Eg[ol], bias = Eb[ol];
                         }
@@ -731,9 +735,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                             } else {
                                 raw = acc[mt][n * NPH + (UP ? py * 2 + px : 0)][e];
                             }
-                            const float lin = raw * gain;
-                            const float act = lrelu_gain(lin + nzv[px] + bias);
-                            v[px] = apply_act ? act : lin;
+                            const float t = fmaf(raw, gain, nzv[px] + bias);  // bias and noise are 0 unless the tail is fused
+                            v[px] = apply_act ? fmaxf(t, 0.2f * t) : t;
                         }
                         if (do_rgb) {
 #pragma unroll
