@@ -247,3 +247,33 @@ def test_synthesize_graph_lanes_match_eager_256_batch8(gpu, lanes):
 
     eager = run(use_graph=False)
     assert np.array_equal(run(lanes=lanes), eager)
+
+
+def test_render_rank_shards_on_device_equal_single_rank(gpu, tmp_path, monkeypatch):
+    """The multi-rank branch of render() (device shard buffer filled from the graph lanes, then gathered) on ONE GPU:
+    rank_world / gather are stubbed so that this process plays rank 0 and rank 1 of a 2-rank job in turn; the two shards
+    concatenated must equal the single-rank render, frame for frame."""
+    from maua_stylegan2_amd import render, sharding
+
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)
+    g = build(512, gpu, 1)
+    n = 11  # uneven shards: 6 + 5, batches of 2 -> graph batches and an eager tail on each rank
+    lat = seeding.seeded_latents(n, g.n_latent, seed=2)
+    noise = [None] * g.num_layers
+    single = str(tmp_path / "single.mp4")
+    assert render.render(g, lat, noise, 0, n / 30, 2, 512, single) == n
+    want = np.fromfile(single + ".rgb24", dtype=np.uint8).reshape(n, 512, 512, 3)
+
+    shards = {}
+    for rank in (0, 1):
+        monkeypatch.setattr(sharding, "rank_world", lambda r=rank: (r, 2))
+        lo, hi = sharding.shard_bounds(n, rank, 2)
+
+        def fake_gather(shard, n_frames, dst=0, r=rank, lo=lo, hi=hi):
+            shards[r] = shard[: hi - lo].cpu().numpy()
+            return [] if r == 0 else None  # rank 0 "receives" nothing here: the comparison below does the ordering
+
+        monkeypatch.setattr(sharding, "gather_frames", fake_gather)
+        render.render(g, lat, noise, 0, n / 30, 2, 512, str(tmp_path / f"rank{rank}.mp4"))
+    got = np.concatenate([shards[0], shards[1]])
+    assert got.shape == want.shape and np.array_equal(got, want)
