@@ -80,7 +80,9 @@ int maua_demod_f32(const maua_style_layer_t* table, int n_layers, int max_cout, 
 /* Sum of squared taps wsq[o,i] and the tap-major repack wp[tap][i][o] of a [cout,cin,k,k] weight (one-off, at load). */
 int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream);
 
-/* Winograd F(2,3) form of the same weight, transformed along kx: wq[(ky*4+xi)][i][o_pad] with
+/* Winograd F(2,3) form of the same weight, transformed along kx: wq[(ky*4+xi)][i][o_pad] (o_pad = cout padded to 32;
+ * above 32 channels padded to 64 with the columns of every 64-group interleaved [o % 32][o / 32 % 2], both here and in the
+ * F(4,3) pack) with
  * xi 0: g0, 1: (g0+g1+g2)/2, 2: (g0-g1+g2)/2, 3: g2.  The operand of maua_modconv3x3_f32 in mode 2. */
 int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, int cin, void* stream);
 /* Winograd F(4,3) form (interpolation points 0, +-1, +-2, inf): wq[(ky*6+xi)][i][o_pad] with xi 0: g0/4,

@@ -206,6 +206,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         boff[n] = hi * g.PSTRIDE + (img * g.PH + tyy) * g.PWS + WX * txx;
     }
     const int aoff = hi * BM + wm * (TM * 32) + l31;
+    const int aoff2 = hi * BM + wm * (TM * 32) + 2 * l31;  // interleaved [lane][mt] layout of the Winograd weight packs
 
     f32x16 acc[TM][TN * NPH];
 #pragma unroll
@@ -344,7 +345,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                         const f32x2 d01 = *reinterpret_cast<const f32x2*>(dp);
                         const f32x2 d23 = *reinterpret_cast<const f32x2*>(dp + 2);
                         const f32x2 d45 = *reinterpret_cast<const f32x2*>(dp + 4);
-                        const float a_ = fmaf(-4.f, d23.x, d45.x), b_ = fmaf(-4.f, d01.y, d23.y);
+                        float a_ = fmaf(-4.f, d23.x, d45.x);
+                        asm volatile("" : "+v"(a_));  // keeps the compiler from pairing a_/b_ into v_pk_fma_f32 behind 4 v_movs
+                        const float b_ = fmaf(-4.f, d01.y, d23.y);
                         const float c_ = d45.x - d23.x, e_ = d23.y - d01.y;
                         bv[n][0] = fmaf(4.f, d01.x, fmaf(-5.f, d23.x, d45.x));
                         bv[n][1] = a_ + b_;
@@ -361,8 +364,13 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                     for (int xi = 0; xi < 6; ++xi) {
                         float a[TM];
+                        if (TM == 2) {  // weight rows are packed [lane][mt] per 64 output channels: one 8-byte read, immediate offset
+                            const f32x2 a2 = *reinterpret_cast<const f32x2*>(Ac + ((ky * 6 + xi) * CC + 2 * q) * BM + aoff2);
+                            a[0] = a2.x, a[TM - 1] = a2.y;
+                        } else {
 #pragma unroll
-                        for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 6 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
+                            for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 6 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
+                        }
 #pragma unroll
                         for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -398,8 +406,13 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                     for (int xi = 0; xi < 4; ++xi) {
                         float a[TM];
+                        if (TM == 2) {  // weight rows are packed [lane][mt] per 64 output channels: one 8-byte read, immediate offset
+                            const f32x2 a2 = *reinterpret_cast<const f32x2*>(Ac + ((ky * 4 + xi) * CC + 2 * q) * BM + aoff2);
+                            a[0] = a2.x, a[TM - 1] = a2.y;
+                        } else {
 #pragma unroll
-                        for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 4 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
+                            for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 4 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
+                        }
 #pragma unroll
                         for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -900,13 +913,22 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+// Column layout of the Winograd weight packs (modes 2 and 3).  Layers above 32 output channels run with two 32-channel
+// M-tiles per wave; their columns are interleaved [lane][m-tile] inside every group of 64 channels (and padded to a multiple
+// of 64) so that a lane fetches both A operands with one 8-byte LDS read.  Destination column -> source channel:
+__host__ __device__ inline int wino_cout_pad(int cout) { return cout > 32 ? (cout + 63) / 64 * 64 : (cout + 31) / 32 * 32; }
+__device__ inline int wino_src_channel(int od, int cout) {
+    return cout > 32 ? (od & ~63) + ((od & 1) << 5) + ((od & 63) >> 1) : od;
+}
+
 // Winograd F(2,3) weight transform along kx, tap-major repack: wq[(ky*4 + xi)][i][o_pad],
 //   xi 0: g0   1: (g0+g1+g2)/2   2: (g0-g1+g2)/2   3: g2        (g = W[o][i][ky][0..2])
 __global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ wq, int cout,
                                                                int cout_pad, int cin) {
     const int64_t total = (int64_t)cout_pad * cin;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int o = (int)(idx % cout_pad);
+        const int od = (int)(idx % cout_pad);  // destination column
+        const int o = wino_src_channel(od, cout);
         const int i = (int)(idx / cout_pad);
         for (int ky = 0; ky < 3; ++ky) {
             float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -915,7 +937,7 @@ __global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __re
                 g0 = gp[0], g1 = gp[1], g2 = gp[2];
             }
             const float u[4] = {g0, 0.5f * (g0 + g1 + g2), 0.5f * (g0 - g1 + g2), g2};
-            for (int xi = 0; xi < 4; ++xi) wq[((size_t)(ky * 4 + xi) * cin + i) * cout_pad + o] = u[xi];
+            for (int xi = 0; xi < 4; ++xi) wq[((size_t)(ky * 4 + xi) * cin + i) * cout_pad + od] = u[xi];
         }
     }
 }
@@ -926,7 +948,8 @@ __global__ __launch_bounds__(256) void pack_weight_wino43_kernel(const float* __
                                                                  int cout, int cout_pad, int cin) {
     const int64_t total = (int64_t)cout_pad * cin;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int o = (int)(idx % cout_pad);
+        const int od = (int)(idx % cout_pad);  // destination column
+        const int o = wino_src_channel(od, cout);
         const int i = (int)(idx / cout_pad);
         for (int ky = 0; ky < 3; ++ky) {
             float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -940,7 +963,7 @@ __global__ __launch_bounds__(256) void pack_weight_wino43_kernel(const float* __
                                 (g0 + 2.f * g1 + 4.f * g2) * (1.f / 24.f),
                                 (g0 - 2.f * g1 + 4.f * g2) * (1.f / 24.f),
                                 g2};
-            for (int xi = 0; xi < 6; ++xi) wq[((size_t)(ky * 6 + xi) * cin + i) * cout_pad + o] = u[xi];
+            for (int xi = 0; xi < 6; ++xi) wq[((size_t)(ky * 6 + xi) * cin + i) * cout_pad + od] = u[xi];
         }
     }
 }
@@ -990,7 +1013,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     ConvGeom& g = pl.g;
     const bool up = mode == 1 || mode == 4, uw = mode == 4, wino = mode == 2 || mode == 3, w43 = mode == 3;
     const int wx = w43 ? 4 : 2;  // outputs per Winograd position
-    g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = pad32(cout), g.H = h, g.W = w;
+    g.B = batch, g.Cin = cin, g.Cout = cout, g.CoutPad = wino ? wino_cout_pad(cout) : pad32(cout), g.H = h, g.W = w;
     if (w43) {
         g.GH = h, g.GW = w / 4, g.OH = h, g.OW = w;  // positions are output quads
         if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = 128;
@@ -1128,7 +1151,7 @@ extern "C" int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int c
 
 extern "C" int maua_pack_weight_wino_f32(const float* w, float* wq, int cout, int cin, void* stream) {
     if (!w || !wq || cout <= 0 || cin <= 0) return MAUA_EINVAL;
-    const int cout_pad = pad32(cout);
+    const int cout_pad = wino_cout_pad(cout);
     const int64_t blocks = ceil_div64((int64_t)cout_pad * cin, 256);
     hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
                        (hipStream_t)stream, w, wq, cout, cout_pad, cin);
@@ -1148,7 +1171,7 @@ extern "C" int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, 
 
 extern "C" int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, void* stream) {
     if (!w || !wq || cout <= 0 || cin <= 0) return MAUA_EINVAL;
-    const int cout_pad = pad32(cout);
+    const int cout_pad = wino_cout_pad(cout);
     const int64_t blocks = ceil_div64((int64_t)cout_pad * cin, 256);
     hipLaunchKernelGGL(pack_weight_wino43_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
                        (hipStream_t)stream, w, wq, cout, cout_pad, cin);

@@ -187,7 +187,9 @@ class ModulatedConv2d(nn.Module):
         if mode not in self._packed_wino:
             w = self.weight
             wd = _lib.require_cuda(w.detach(), "weight")
-            cpad = (self.out_channel + 31) // 32 * 32
+            # modes 2 / 3 above 32 channels: columns padded to 64 and interleaved [lane][m-tile] (see pack_weight_wino_kernel)
+            pad = 64 if (mode in (2, 3) and self.out_channel > 32) else 32
+            cpad = (self.out_channel + pad - 1) // pad * pad
             wq = th.empty((18 if mode == 3 else 12, self.in_channel, cpad), dtype=th.float32, device=w.device)
             fn = {2: "maua_pack_weight_wino_f32", 3: "maua_pack_weight_wino43_f32", 4: "maua_pack_weight_upwino_f32"}[mode]
             with th.cuda.device(w.device):
