@@ -172,9 +172,12 @@ class ModulatedConv2d(nn.Module):
             if self.upconv_winograd and w % 2 == 0 and tiles >= 256:
                 return 4
             return 1
-        if self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= self.winograd43_min_width:
+        # (the Winograd kernels want at least one full 128-position tile per image; shorter maps would pack several images
+        # into a tile, which only the direct mode implements)
+        if (self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= self.winograd43_min_width
+                and h * (w // 4) >= 128):
             return 3
-        if self.out_channel >= self.winograd_min_cout and w % 2 == 0 and w >= 32:
+        if self.out_channel >= self.winograd_min_cout and w % 2 == 0 and w >= 32 and h * (w // 2) >= 128:
             return 2
         return 0
 
