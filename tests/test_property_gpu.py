@@ -134,3 +134,24 @@ def test_generator_random_configs_vs_oracle(gpu, size, cm, batch, trunc, per_fra
                truncation=trunc if trunc == 1.0 else torch.full((batch,), trunc, device=gpu), randomize_noise=False,
                input_is_latent=True)
     assert float((got.cpu() - want).abs().max()) < 1e-3
+
+
+@settings(max_examples=40, **COMMON)
+@given(n=st.integers(2, 300), trail=st.sampled_from([(), (3,), (2, 5), (1, 4, 6)]), sigma=st.sampled_from([0.5, 1, 2, 4.5, 5, 17, 64, 128]),
+       causal=st.sampled_from([None, 0, 1, 0.2, 0.75]), smf=st.sampled_from([1.0, 0.8, 2.0]), seed=st.integers(0, 1 << 16))
+def test_gaussian_filter_random_vs_oracle(gpu, n, trail, sigma, causal, smf, seed):
+    """Temporal Gaussian FIR (audioreactive/signal.py:319-368): every (length, trailing shape, sigma, causal factor, SMF) draw
+    incl. radius > n_frames (the reference's wrap-around padding) and integer `causal` (which zeroes the future half)."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+    from oracle import signal_oracle
+
+    r = np.random.default_rng(seed)
+    x = torch.from_numpy(r.standard_normal((n,) + trail).astype(np.float32))
+    want = signal_oracle.gaussian_filter(x, sigma, causal=causal, smf=smf).numpy()
+    sig.set_SMF(smf)
+    try:
+        got = sig.gaussian_filter(x.to(gpu), sigma, causal=causal).cpu().numpy()
+    finally:
+        sig.set_SMF(1)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=3e-5, rtol=1e-5)
