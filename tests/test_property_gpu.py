@@ -155,3 +155,45 @@ def test_gaussian_filter_random_vs_oracle(gpu, n, trail, sigma, causal, smf, see
         sig.set_SMF(1)
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, atol=3e-5, rtol=1e-5)
+
+
+@settings(max_examples=25, **COMMON)
+@given(batch=st.integers(1, 3), h=st.integers(1, 40), w=st.integers(1, 70), seed=st.integers(0, 1 << 16))
+def test_frames_to_uint8_random_shapes_bit_exact(gpu, batch, h, w, seed):
+    """The uint8 NHWC frame epilogue (render.py:40-43) is integer work: bit-exact for every width (packed 4-pixel path and
+    the scalar path), values straddling the clamp and exact half-levels included."""
+    from maua_stylegan2_amd import render
+
+    r = np.random.default_rng(seed)
+    x = (1.3 * r.standard_normal((batch, 3, h, w))).astype(np.float32)
+    x.flat[:: 7] = np.round(x.flat[:: 7] * 127.5) / 127.5  # exact grey levels
+    x.flat[:: 11] = np.float32(1.0)
+    x.flat[:: 13] = np.float32(-1.0)
+    want = so.frames_to_uint8(torch.from_numpy(x))
+    got = render.frames_to_uint8(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@settings(max_examples=25, **COMMON)
+@given(b=st.integers(1, 3), c=st.integers(1, 5), h=st.integers(2, 20), w=st.integers(2, 24), kind=st.sampled_from(["zoom", "rotate"]),
+       seed=st.integers(0, 1 << 16))
+def test_bends_random_vs_oracle(gpu, b, c, h, w, kind, seed):
+    """Zoom / Rotate bends (ReflectionPad2d -> affine warp -> CenterCrop, audioreactive/bend.py:52-102) with random
+    per-frame parameters against the oracle's composition."""
+    from maua_stylegan2_amd.audioreactive import bend
+    from oracle import signal_oracle
+
+    r = np.random.default_rng(seed)
+    x = r.standard_normal((b, c, h, w)).astype(np.float32)
+    xd = torch.from_numpy(x).to(gpu)
+    if kind == "zoom":
+        z = torch.from_numpy(r.uniform(0.4, 2.5, b).astype(np.float32))
+        pad = max(h, w) - 1
+        want = signal_oracle.affine_reflect_warp(x, bend._inverse_maps_scale(z, w + 2 * pad, h + 2 * pad).numpy(), (pad,) * 4)
+        got = bend.Zoom(z, h, w)(xd).cpu().numpy()
+    else:
+        a = torch.from_numpy(r.uniform(-180, 180, b).astype(np.float32))
+        pad = int(max(h, w) * (1 - np.sqrt(2) / 2))
+        want = signal_oracle.affine_reflect_warp(x, bend._inverse_maps_rotate(a, w + 2 * pad, h + 2 * pad).numpy(), (pad,) * 4)
+        got = bend.Rotate(a, h, w)(xd).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=2e-5)
