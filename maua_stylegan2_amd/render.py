@@ -106,6 +106,9 @@ def frames_to_uint8(images, out=None):
     return out
 
 
+_LANE_STREAMS = {}
+
+
 def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), rewrites=None, randomize_noise=False,
                use_graph=True, frame_range=None, lanes=3):
     """Generator -> uint8 frames for ``frame_range`` (default: all) of the sequence.  Yields (first_frame_index,
@@ -144,7 +147,10 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
     def lane_for(k):
         if k < len(lane_state):
             return lane_state[k]
-        stream = th.cuda.Stream(dev)
+        # lane streams are kept per device: the caching allocator pools freed blocks per stream, so fresh streams on
+        # every call would strand the staging buffers of the previous render
+        stream = _LANE_STREAMS.setdefault((dev.index, k), None) or th.cuda.Stream(dev)
+        _LANE_STREAMS[(dev.index, k)] = stream
         stream.wait_stream(caller_stream)
         lane_state.append({"stream": stream, "graph": None, "static": None, "u8": None})
         return lane_state[k]
