@@ -321,8 +321,6 @@ def main():
                     result["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": dom[2]}
             # standalone upfirdn2d on the 1024-res Blur shape (the op BASELINE.json's metric names)
-            from maua_stylegan2_amd.op import upfirdn2d
-
             r_out = size
             xin = torch.randn(B, 32 if size == 1024 else 64, r_out + 1, r_out + 1, device=dev)
             kern = torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)).to(dev)

@@ -14,7 +14,6 @@ Same class names, constructor arguments, ``forward`` signatures and state-dict k
 All activations live in a per-batch-size cache of static device buffers, so a forward performs no allocation after
 its first call and can be captured into a hipGraph (``capture_graph``).  There is no CPU path: CPU tensors raise.
 """
-import ctypes
 import math
 
 import torch as th
