@@ -161,6 +161,13 @@ int maua_softmask_apply_f32(const float* re, const float* im, const float* x, co
 int maua_filterbank_f32(const float* fb, const float* p, float* out, int m, int k, int n, int to_db, float amin,
                         void* stream);
 
+/* Chroma post-processing for audioreactive/signal.py:102-133 (ch / out are [n_bins <= 32, n_frames], fp32):
+ * CENS = per-frame L1 normalisation, 4-level quantisation, Hann smoothing over win_len (odd) frames, L2 normalisation;
+ * nn_median = per-frame median over the k frames of highest cosine similarity outside |i-j| < width (the
+ * aggregate=np.median, metric="cosine" nearest-neighbour filter at :131).  n_frames * 8 + k * (4 + 4 n_bins) bytes of LDS. */
+int maua_chroma_cens_f32(const float* ch, float* out, int n_bins, int n_frames, int win_len, void* stream);
+int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, void* stream);
+
 /* 3-D tileable Perlin noise (audioreactive/latent.py:188-246): grad [r0+1,r1+1,r2+1,3] -> out [n0,n1,n2]. */
 int maua_perlin3d_f32(const float* grad, float* out, int n0, int n1, int n2, int r0, int r1, int r2, void* stream);
 

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "maua_istft_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     "maua_median_filter_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "maua_softmask_apply_f32": (c_int, [_P, _P, _P, _P, c_float, c_float, c_int, _P, _P, c_int64, _P]),
+    "maua_chroma_cens_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "maua_nn_median_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "maua_filterbank_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_perlin3d_f32": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "maua_affine_reflect_warp_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P]),

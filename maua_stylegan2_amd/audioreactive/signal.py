@@ -285,13 +285,51 @@ def rms(y, sr, n_frames, fmin=20, fmax=8000, smooth=180, clip=50, power=6, devic
     return env.to(device if device is not None else "cpu")
 
 
+def cens(ch, win_len=41):
+    """CENS post-processing of a [n_bins, T] chromagram on the device (maua_chroma_cens_f32): L1 normalise, quantise,
+    Hann-smooth over ``win_len`` frames, L2 normalise — the steps of librosa.feature.chroma_cens after its chromagram."""
+    ch = _to_dev(ch).float().contiguous()
+    out = th.empty_like(ch)
+    with th.cuda.device(ch.device):
+        _lib.check(_lib.load().maua_chroma_cens_f32(ch.data_ptr(), out.data_ptr(), ch.shape[0], ch.shape[1], win_len,
+                                                    _lib.stream_ptr(ch.device)), "maua_chroma_cens_f32")
+    return out
+
+
+def nn_filter(ch, width=1):
+    """Nearest-neighbour median filter of a [n_bins, T] sequence on the device (maua_nn_median_f32): per frame, the median
+    over the k = 2 ceil(sqrt(T - 2 width + 1)) most cosine-similar frames (reference signal.py:131).  Tracks too long for
+    the kernel's LDS budget (> ~16k frames) are returned unfiltered with a warning."""
+    ch = _to_dev(ch).float().contiguous()
+    t = ch.shape[1]
+    k = int(min(t - 1, 2 * math.ceil(math.sqrt(max(t - 2 * width + 1, 1)))))
+    if k < 1:
+        return ch
+    out = th.empty_like(ch)
+    with th.cuda.device(ch.device):
+        rc = _lib.load().maua_nn_median_f32(ch.data_ptr(), out.data_ptr(), ch.shape[0], t, k, width, _lib.stream_ptr(ch.device))
+    if rc == -22:
+        warnings.warn(f"nn_filter: {t} frames exceed the nearest-neighbour kernel's LDS budget; chromagram left unfiltered",
+                      stacklevel=2)
+        return ch
+    _lib.check(rc, "maua_nn_median_f32")
+    return out
+
+
 def raw_chroma(audio, sr, type="cens", nearest_neighbor=True):
-    """[12, n_stft_frames] numpy chromagram (STFT filterbank, per-frame max normalisation)."""
-    if type not in ("stft",):
-        warnings.warn(f"chroma type {type!r}: only the STFT filterbank chroma is built on this path; using it", stacklevel=2)
+    """[12, n_stft_frames] numpy chromagram (reference :102-133).  The chromagram itself is the STFT filterbank one for
+    every ``type`` (no CQT / deep-chroma on this path); ``type="cens"`` (the default) adds the CENS post-processing and
+    ``nearest_neighbor`` the median filter over cosine-nearest frames, both on the device."""
+    if type not in ("stft", "cens"):
+        warnings.warn(f"chroma type {type!r}: no CQT / deep-chroma model on this path; using the STFT chromagram", stacklevel=2)
     raw = project(chroma_filterbank(sr), stft_power(audio))
     peak = raw.max(dim=0, keepdim=True).values
-    return (raw / th.where(peak > 0, peak, th.ones_like(peak))).cpu().numpy()
+    ch = raw / th.where(peak > 0, peak, th.ones_like(peak))
+    if type == "cens":
+        ch = cens(ch)
+    if nearest_neighbor:
+        ch = th.minimum(ch, nn_filter(ch))
+    return ch.cpu().numpy()
 
 
 def chroma(audio, sr, n_frames, margin=16, type="cens", notes=12, device=None):

@@ -354,6 +354,127 @@ __global__ __launch_bounds__(256) void affine_reflect_warp_kernel(const float* _
     y[((size_t)b * channels + ch) * h * w + pix] = acc;
 }
 
+
+// ------------------------------------------------------------------------------------------------ chroma post-processing
+// CENS (Mueller & Ewert 2011; what librosa.feature.chroma_cens does after its chromagram, signal.py:115): per-frame L1
+// normalisation -> 4-level quantisation -> Hann smoothing along time ('same', zero padded) -> per-frame L2 normalisation.
+// ch / out are [n_bins, n_frames].  One thread per output frame: the 41 neighbour frames are re-normalised and re-quantised
+// on the fly (12 x 41 loads per thread) — there is no intermediate array.
+constexpr int CENS_MAX_BINS = 32;
+__global__ __launch_bounds__(256) void chroma_cens_kernel(const float* __restrict__ ch, float* __restrict__ out, int n_bins,
+                                                          int n_frames, int win_len) {
+    extern __shared__ float cens_win[];  // [win_len] sum-normalised Hann taps (the interior of a win_len + 2 point window)
+    if ((int)threadIdx.x < win_len) cens_win[threadIdx.x] = 0.5f - 0.5f * cospif(2.f * (threadIdx.x + 1) / (win_len + 1));
+    __syncthreads();
+    float wsum = 0.f;
+    for (int j = 0; j < win_len; ++j) wsum += cens_win[j];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_frames) return;
+    float acc[CENS_MAX_BINS];
+#pragma unroll
+    for (int b = 0; b < CENS_MAX_BINS; ++b) acc[b] = 0.f;
+    const int half = win_len / 2;
+    for (int j = 0; j < win_len; ++j) {
+        const int tt = t + j - half;
+        if (tt < 0 || tt >= n_frames) continue;
+        float v[CENS_MAX_BINS], l1 = 0.f;
+#pragma unroll
+        for (int b = 0; b < CENS_MAX_BINS; ++b) {
+            v[b] = b < n_bins ? ch[(size_t)b * n_frames + tt] : 0.f;
+            l1 += fabsf(v[b]);
+        }
+        const float inv = l1 > 1.17549435e-38f ? 1.f / l1 : 1.f;
+        const float w = cens_win[win_len - 1 - j] / wsum;
+#pragma unroll
+        for (int b = 0; b < CENS_MAX_BINS; ++b) {
+            const float c = v[b] * inv;
+            const float q = 0.25f * ((c > 0.4f) + (c > 0.2f) + (c > 0.1f) + (c > 0.05f));
+            acc[b] = fmaf(w, q, acc[b]);
+        }
+    }
+    float l2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < CENS_MAX_BINS; ++b) l2 = fmaf(acc[b], acc[b], l2);
+    l2 = sqrtf(l2);
+    const float inv2 = l2 > 1.17549435e-38f ? 1.f / l2 : 1.f;
+    for (int b = 0; b < n_bins; ++b) out[(size_t)b * n_frames + t] = acc[b] * inv2;
+}
+
+// Nearest-neighbour median filter (the role of librosa.decompose.nn_filter(S, aggregate=np.median, metric="cosine"),
+// signal.py:131).  One workgroup per frame i: cosine similarity to every frame in fp64 (the neighbour ORDER has to match
+// the float64 oracle), the k best frames outside |i-j| < width by k rounds of block-wide arg-max (ties -> lower index,
+// i.e. a stable descending sort), then a per-feature median over those k frames.
+__global__ __launch_bounds__(256) void nn_median_kernel(const float* __restrict__ ch, float* __restrict__ out, int n_bins,
+                                                        int n_frames, int k, int width) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char nn_lds[];
+    double* sims = reinterpret_cast<double*>(nn_lds);                      // [n_frames]
+    int* picked = reinterpret_cast<int*>(sims + n_frames);                 // [k]
+    float* vals = reinterpret_cast<float*>(picked + k);                    // [n_bins][k]
+    __shared__ double red_v[256];
+    __shared__ int red_i[256];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    double ui[CENS_MAX_BINS];
+    {
+        double ni = 0.0;
+        for (int b = 0; b < n_bins; ++b) ni += (double)ch[(size_t)b * n_frames + i] * (double)ch[(size_t)b * n_frames + i];
+        ni = sqrt(ni);
+        const double inv_i = ni > 1.17549435e-38 ? 1.0 / ni : 1.0;
+        for (int b = 0; b < CENS_MAX_BINS; ++b) ui[b] = b < n_bins ? (double)ch[(size_t)b * n_frames + i] * inv_i : 0.0;
+    }
+    for (int j = tid; j < n_frames; j += 256) {
+        double nj = 0.0, vj[CENS_MAX_BINS];
+        for (int b = 0; b < n_bins; ++b) {
+            vj[b] = (double)ch[(size_t)b * n_frames + j];
+            nj += vj[b] * vj[b];
+        }
+        nj = sqrt(nj);
+        const double inv_j = nj > 1.17549435e-38 ? 1.0 / nj : 1.0;
+        double dot = 0.0;
+        for (int b = 0; b < n_bins; ++b) dot += ui[b] * (vj[b] * inv_j);
+        const int dist = j > i ? j - i : i - j;
+        sims[j] = dist < width ? -INFINITY : dot;
+    }
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = tid; j < n_frames; j += 256) {
+            const double v = sims[j];
+            if (v > bv || (v == bv && j < bi)) bv = v, bi = j;
+        }
+        red_v[tid] = bv, red_i[tid] = bi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                const double v = red_v[tid + off];
+                const int j = red_i[tid + off];
+                if (v > red_v[tid] || (v == red_v[tid] && j < red_i[tid])) red_v[tid] = v, red_i[tid] = j;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            picked[r] = red_i[0];
+            sims[red_i[0]] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n_bins * k; e += 256) {
+        const int b = e / k, m = e - b * k;
+        vals[e] = ch[(size_t)b * n_frames + picked[m]];
+    }
+    __syncthreads();
+    if (tid < n_bins) {  // insertion sort of this feature's k values, then np.median
+        float* v = vals + tid * k;
+        for (int a = 1; a < k; ++a) {
+            const float x = v[a];
+            int c = a - 1;
+            while (c >= 0 && v[c] > x) v[c + 1] = v[c], --c;
+            v[c + 1] = x;
+        }
+        out[(size_t)tid * n_frames + i] = (k & 1) ? v[k / 2] : (float)(0.5 * ((double)v[k / 2 - 1] + (double)v[k / 2]));
+    }
+}
+
 }  // namespace
 
 extern "C" int maua_temporal_fir_f32(const float* x, const float* taps, float* y, int n_frames, int64_t features,
@@ -466,6 +587,32 @@ extern "C" int maua_softmask_apply_f32(const float* re, const float* im, const f
     const int64_t blocks = ceil_div64(n, 256);
     hipLaunchKernelGGL(softmask_apply_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, re,
                        im, x, x_ref, margin, power, split_zeros, out_re, out_im, n);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_chroma_cens_f32(const float* ch, float* out, int n_bins, int n_frames, int win_len, void* stream) {
+    if (!ch || !out || n_bins <= 0 || n_bins > CENS_MAX_BINS || n_frames <= 0 || win_len <= 0 || win_len > 255 || !(win_len & 1))
+        return MAUA_EINVAL;
+    hipLaunchKernelGGL(chroma_cens_kernel, dim3(ceil_div(n_frames, 256)), dim3(256), (size_t)win_len * sizeof(float),
+                       (hipStream_t)stream, ch, out, n_bins, n_frames, win_len);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, void* stream) {
+    if (!ch || !out || n_bins <= 0 || n_bins > CENS_MAX_BINS || n_frames <= 1 || k <= 0 || k >= n_frames || k > 512 || width < 1)
+        return MAUA_EINVAL;
+    const size_t lds = (size_t)n_frames * sizeof(double) + (size_t)k * sizeof(int) + (size_t)n_bins * k * sizeof(float);
+    if (lds > 150 * 1024) return MAUA_EINVAL;  // ~16k frames (6 min of audio at hop 512): longer tracks skip the filter
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nn_median_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, ch, out, n_bins, n_frames, k,
+                       width);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

@@ -247,11 +247,61 @@ def onsets(y, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, po
     return env ** power
 
 
-def chroma(y, sr, n_frames, margin=16, notes=12):
-    """signal.py:136-156 with type="stft" (harmonic separation at :150; no nn_filter)."""
+def cens_from_chroma(ch, win_len=41):
+    """CENS post-processing (Mueller & Ewert 2011, the steps librosa.feature.chroma_cens applies after its chromagram):
+    per-frame L1 normalisation -> quantisation with thresholds .05/.1/.2/.4 (0.25 each) -> smoothing along time with a
+    sum-normalised Hann window of ``win_len`` taps (zero-padded 'same' convolution) -> per-frame L2 normalisation.
+    ``ch`` [12, T] non-negative.  **parity unpinned** (librosa absent); the chromagram fed in is the STFT one, not a CQT."""
+    ch = np.asarray(ch, dtype=np.float64)
+    l1 = np.abs(ch).sum(axis=0, keepdims=True)
+    c = ch / np.where(l1 > np.finfo(np.float32).tiny, l1, 1.0)
+    q = np.zeros_like(c)
+    for thr in (0.4, 0.2, 0.1, 0.05):
+        q += 0.25 * (c > thr)
+    n = win_len + 2
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / (n - 1))  # scipy get_window("hann", n, fftbins=False)
+    win = win[1:-1]
+    win = win / win.sum()
+    half = win_len // 2
+    padded = np.pad(q, ((0, 0), (half, half)))
+    sm = np.stack([(padded[:, t: t + win_len] * win[::-1]).sum(axis=1) for t in range(ch.shape[1])], axis=1)
+    l2 = np.sqrt((sm ** 2).sum(axis=0, keepdims=True))
+    return sm / np.where(l2 > np.finfo(np.float32).tiny, l2, 1.0)
+
+
+def nn_filter_median(ch, width=1):
+    """Nearest-neighbour median filter of a [F, T] feature sequence (the role of librosa.decompose.nn_filter(S,
+    aggregate=np.median, metric="cosine") in signal.py:131): for every frame, the k = 2*ceil(sqrt(T - 2*width + 1)) frames
+    of highest cosine similarity (frames closer than ``width`` excluded; ties broken toward the lower index) are
+    aggregated by the per-feature median.  **parity unpinned.**"""
+    ch = np.asarray(ch, dtype=np.float64)
+    f, t = ch.shape
+    k = int(min(t - 1, 2 * np.ceil(np.sqrt(max(t - 2 * width + 1, 1)))))
+    norms = np.sqrt((ch ** 2).sum(axis=0))
+    inv = 1.0 / np.where(norms > np.finfo(np.float32).tiny, norms, 1.0)
+    unit = ch * inv
+    sim = unit.T @ unit  # [T, T]
+    out = np.empty_like(ch)
+    idx = np.arange(t)
+    for i in range(t):
+        s = sim[i].copy()
+        s[np.abs(idx - i) < width] = -np.inf
+        nb = np.argsort(-s, kind="stable")[:k]
+        out[:, i] = np.median(ch[:, nb], axis=1)
+    return out
+
+
+def chroma(y, sr, n_frames, margin=16, notes=12, type="stft", nearest_neighbor=False):
+    """signal.py:136-156: harmonic separation (:150) -> raw_chroma (:102-133; "stft" chromagram, optionally CENS
+    post-processed and nearest-neighbour median filtered) -> resample -> note selection -> per-frame normalisation."""
     if margin:
         y = hpss(y, margin)[0]
-    ch = chroma_stft(y, sr).T
+    raw = chroma_stft(y, sr)
+    if type == "cens":
+        raw = cens_from_chroma(raw)
+    if nearest_neighbor:
+        raw = np.minimum(raw, nn_filter_median(raw))
+    ch = raw.T
     ch = resample(ch, n_frames)
     keep = np.argsort(np.median(ch, axis=0))[:notes]
     ch = ch[:, keep]

@@ -60,7 +60,7 @@ def test_stft_mel_chroma_vs_oracle(gpu):
     env_g = sig.onset_strength(y, sr, fmin=20, fmax=8000).cpu().numpy()
     np.testing.assert_allclose(env_g, env_w, atol=2e-3)
     ch_w = signal_oracle.chroma_stft(y, sr)
-    ch_g = sig.raw_chroma(y, sr, type="stft")
+    ch_g = sig.raw_chroma(y, sr, type="stft", nearest_neighbor=False)
     np.testing.assert_allclose(ch_g, ch_w, atol=2e-4)
 
 
@@ -75,12 +75,13 @@ def test_onsets_and_chroma_features_vs_oracle(gpu):
         got = sig.onsets(y, sr, n_frames, **kw)
         assert got.device.type == "cpu" and got.shape == (n_frames,)
         np.testing.assert_allclose(got.numpy(), want, atol=5e-3)
-    want = signal_oracle.chroma(y, sr, n_frames).numpy()
-    got = sig.chroma(y, sr, n_frames, type="stft").numpy()
-    assert np.allclose(got.sum(1), 1.0, atol=1e-5)
-    # columns are ordered by their median (reference signal.py:153-154); near-equal medians may swap between the fp32
-    # device path and the float64 oracle, so compare after a canonical re-ordering by column mean
-    np.testing.assert_allclose(got[:, np.argsort(got.mean(0))], want[:, np.argsort(want.mean(0))], atol=1e-3)
+    for kind in ("stft", "cens"):  # "cens" is the reference's default chroma type; both go through the nn median filter
+        want = signal_oracle.chroma(y, sr, n_frames, type=kind, nearest_neighbor=True).numpy()
+        got = sig.chroma(y, sr, n_frames, type=kind).numpy()
+        assert np.allclose(got.sum(1), 1.0, atol=1e-5)
+        # columns are ordered by their median (reference signal.py:153-154); near-equal medians may swap between the fp32
+        # device path and the float64 oracle, so compare after a canonical re-ordering by column mean
+        np.testing.assert_allclose(got[:, np.argsort(got.mean(0))], want[:, np.argsort(want.mean(0))], atol=2e-3, err_msg=kind)
 
 
 def test_resample_on_device_matches_scipy(gpu):
@@ -207,3 +208,25 @@ def test_hpss_pieces_vs_oracle(gpu):
     # the kick lives in the percussive part, the chord in the harmonic part
     gh, gp = sig.hpss(y, 4.0)
     assert float(gp.abs().max()) > 0.05 and float(gh.std()) > 0.02
+
+
+def test_cens_and_nn_filter_vs_oracle(gpu):
+    """Chroma post-processing kernels (signal.py:115,131 roles): CENS quantise/smooth/normalise and the nearest-neighbour
+    median filter, on random chromagrams (ragged lengths, zero frames) and on the chromagram of the synthetic track."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    rng = np.random.default_rng(4)
+    cases = [np.abs(rng.standard_normal((12, t))).astype(np.float32) for t in (3, 40, 41, 257, 700)]
+    cases[1][:, 5:9] = 0.0  # silent frames: L1 / L2 / cosine norms of zero
+    cases.append(sig.raw_chroma(seeding.synthetic_audio(8.0), 22050, type="stft", nearest_neighbor=False).astype(np.float32))
+    for ch in cases:
+        want = signal_oracle.cens_from_chroma(ch)
+        got = sig.cens(torch.from_numpy(ch)).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=2e-6)
+        if ch.shape[1] > 2:
+            want = signal_oracle.nn_filter_median(ch)
+            got = sig.nn_filter(torch.from_numpy(ch)).cpu().numpy()
+            # the neighbour order comes from fp64 cosine similarities on both sides; allow a vanishing number of
+            # near-tie swaps (they move a median by one order statistic)
+            close = np.isclose(got, want, atol=1e-6)
+            assert close.mean() > 0.999, (ch.shape, close.mean())
