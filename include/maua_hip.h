@@ -161,6 +161,12 @@ int maua_softmask_apply_f32(const float* re, const float* im, const float* x, co
 int maua_filterbank_f32(const float* fb, const float* p, float* out, int m, int k, int n, int to_db, float amin,
                         void* stream);
 
+/* |constant-Q transform| (librosa.cqt role inside chroma_cqt / chroma_cens, signal.py:115-117): out[k][t] for n_bins
+ * geometrically spaced frequencies freqs[k] (Hz) with window lengths lengths[k] (samples), centred frames every `hop`
+ * samples with reflect padding, periodic-Hann kernels of unit L1 norm, scaled by 1/sqrt(length). */
+int maua_cqt_mag_f32(const float* y, int64_t n_samples, const float* freqs, const int* lengths, int n_bins, int hop,
+                     float sr, float* out, int n_frames, void* stream);
+
 /* Chroma post-processing for audioreactive/signal.py:102-133 (ch / out are [n_bins <= 32, n_frames], fp32):
  * CENS = per-frame L1 normalisation, 4-level quantisation, Hann smoothing over win_len (odd) frames, L2 normalisation;
  * nn_median = per-frame median over the k frames of highest cosine similarity outside |i-j| < width (the

@@ -316,13 +316,48 @@ def nn_filter(ch, width=1):
     return out
 
 
+CQT_FMIN = 32.70319566257483  # C1, librosa's default
+
+
+def cqt_magnitude(audio, sr, hop=512, n_bins=252, fmin=CQT_FMIN, bins_per_octave=36):
+    """|constant-Q transform| on the device, [n_bins, 1 + len/hop] float32 (maua_cqt_mag_f32): 7 octaves x 36 bins from
+    C1 as librosa.feature.chroma_cqt asks of librosa.cqt, evaluated directly from the definition."""
+    y = _to_dev(audio).float().contiguous()
+    freqs = (fmin * 2.0 ** (np.arange(n_bins) / bins_per_octave))
+    q = 1.0 / (2.0 ** (1.0 / bins_per_octave) - 1.0)
+    lengths = np.ceil(q * sr / freqs).astype(np.int32)
+    n_frames = 1 + y.numel() // hop
+    out = th.empty((n_bins, n_frames), dtype=th.float32, device=y.device)
+    f_dev = th.from_numpy(freqs.astype(np.float32)).to(y.device)
+    l_dev = th.from_numpy(lengths).to(y.device)
+    with th.cuda.device(y.device):
+        _lib.check(_lib.load().maua_cqt_mag_f32(y.data_ptr(), y.numel(), f_dev.data_ptr(), l_dev.data_ptr(), n_bins, hop,
+                                                float(sr), out.data_ptr(), n_frames, _lib.stream_ptr(y.device)),
+                   "maua_cqt_mag_f32")
+    return out
+
+
+def cq_to_chroma_matrix(n_bins=252, bins_per_octave=36, n_chroma=12):
+    """[12, n_bins] fold of constant-Q bins onto pitch classes (every semitone owns the 3 bins centred on it; row 0 = C)."""
+    merge = bins_per_octave // n_chroma
+    w = np.zeros((n_chroma, n_bins), dtype=np.float32)
+    semitone = (np.arange(n_bins) + merge // 2) // merge
+    w[semitone % n_chroma, np.arange(n_bins)] = 1.0
+    return w
+
+
 def raw_chroma(audio, sr, type="cens", nearest_neighbor=True):
-    """[12, n_stft_frames] numpy chromagram (reference :102-133).  The chromagram itself is the STFT filterbank one for
-    every ``type`` (no CQT / deep-chroma on this path); ``type="cens"`` (the default) adds the CENS post-processing and
-    ``nearest_neighbor`` the median filter over cosine-nearest frames, both on the device."""
-    if type not in ("stft", "cens"):
-        warnings.warn(f"chroma type {type!r}: no CQT / deep-chroma model on this path; using the STFT chromagram", stacklevel=2)
-    raw = project(chroma_filterbank(sr), stft_power(audio))
+    """[12, n_frames] numpy chromagram (reference :102-133).  ``type``: "stft" = STFT filterbank chromagram; "cqt" =
+    constant-Q chromagram (direct CQT on the device); "cens" (the default) = the constant-Q chromagram with the CENS
+    post-processing; the madmom "deep" / "clp" models are not built (constant-Q chromagram + a warning).
+    ``nearest_neighbor`` adds the median filter over cosine-nearest frames (:131)."""
+    if type not in ("stft", "cqt", "cens"):
+        warnings.warn(f"chroma type {type!r}: madmom's chroma models are not on this path; using the constant-Q chromagram",
+                      stacklevel=2)
+    if type == "stft":
+        raw = project(chroma_filterbank(sr), stft_power(audio))
+    else:
+        raw = project(cq_to_chroma_matrix(), cqt_magnitude(audio, sr))
     peak = raw.max(dim=0, keepdim=True).values
     ch = raw / th.where(peak > 0, peak, th.ones_like(peak))
     if type == "cens":

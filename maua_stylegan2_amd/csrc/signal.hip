@@ -355,6 +355,45 @@ __global__ __launch_bounds__(256) void affine_reflect_warp_kernel(const float* _
 }
 
 
+// |constant-Q transform| by definition (Brown 1991): out[k][t] = | sum_n y[t hop - N_k/2 + n] w_k[n] e^{-2 pi i f_k (n - N_k/2) / sr} |
+// / sqrt(N_k), w_k = periodic Hann of N_k = lengths[k] samples normalised to unit L1, reflect padding at the ends.
+// One workgroup per (frame, bin); phases and sums in fp64 (up to ~35k taps per low bin).  1.7 G taps for 30 s of audio:
+// a few milliseconds, so the multirate / sparse-kernel machinery librosa needs on a CPU is unnecessary here.
+__global__ __launch_bounds__(256) void cqt_mag_kernel(const float* __restrict__ y, int64_t n_samples,
+                                                      const float* __restrict__ freqs, const int* __restrict__ lengths,
+                                                      int hop, float sr, float* __restrict__ out, int n_frames) {
+    __shared__ double red_re[256], red_im[256];
+    const int t = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    const int n = lengths[k];
+    const double cyc = (double)freqs[k] / (double)sr;  // cycles per sample
+    const int64_t start = (int64_t)t * hop - n / 2;
+    const int64_t period = n_samples > 1 ? 2 * (n_samples - 1) : 1;
+    double re = 0.0, im = 0.0;
+    for (int m = tid; m < n; m += 256) {
+        int64_t j = start + m;
+        j %= period;  // general reflect padding: ... 2 1 0 1 2 ... L-1 L-2 ...
+        if (j < 0) j += period;
+        if (j >= n_samples) j = period - j;
+        const double w = 0.5 - 0.5 * cospi(2.0 * (double)m / (double)n);
+        const double ph = cyc * (double)(m - n / 2);
+        double sn, cs;
+        sincospi(2.0 * (ph - floor(ph)), &sn, &cs);
+        const double v = (double)y[j] * w;
+        re += v * cs;
+        im -= v * sn;
+    }
+    red_re[tid] = re, red_im[tid] = im;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red_re[tid] += red_re[tid + off], red_im[tid] += red_im[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double wsum = 0.5 * (double)n;  // sum of a periodic Hann window
+        out[(size_t)k * n_frames + t] = (float)(sqrt(red_re[0] * red_re[0] + red_im[0] * red_im[0]) / wsum / sqrt((double)n));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ chroma post-processing
 // CENS (Mueller & Ewert 2011; what librosa.feature.chroma_cens does after its chromagram, signal.py:115): per-frame L1
 // normalisation -> 4-level quantisation -> Hann smoothing along time ('same', zero padded) -> per-frame L2 normalisation.
@@ -613,6 +652,17 @@ extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n
     }
     hipLaunchKernelGGL(nn_median_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, ch, out, n_bins, n_frames, k,
                        width);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_cqt_mag_f32(const float* y, int64_t n_samples, const float* freqs, const int* lengths, int n_bins,
+                                int hop, float sr, float* out, int n_frames, void* stream) {
+    if (!y || !freqs || !lengths || !out || n_samples <= 0 || n_bins <= 0 || n_bins > 65535 || hop <= 0 || sr <= 0.f ||
+        n_frames <= 0)
+        return MAUA_EINVAL;
+    hipLaunchKernelGGL(cqt_mag_kernel, dim3(n_frames, n_bins), dim3(256), 0, (hipStream_t)stream, y, n_samples, freqs,
+                       lengths, hop, sr, out, n_frames);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

@@ -247,6 +247,59 @@ def onsets(y, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, po
     return env ** power
 
 
+def cqt_frequencies(n_bins=252, fmin=32.70319566257483, bins_per_octave=36):
+    return fmin * 2.0 ** (np.arange(n_bins) / bins_per_octave)
+
+
+def cqt_lengths(sr, freqs, bins_per_octave=36, filter_scale=1.0):
+    """Filter lengths of a constant-Q analysis: N_k = ceil(Q sr / f_k), Q = filter_scale / (2**(1/bpo) - 1)."""
+    q = filter_scale / (2.0 ** (1.0 / bins_per_octave) - 1.0)
+    return np.ceil(q * sr / freqs).astype(np.int64)
+
+
+def cqt_magnitude(y, sr, hop=512, n_bins=252, fmin=32.70319566257483, bins_per_octave=36):
+    """|constant-Q transform| by its definition (Brown 1991): for every frame t (centred, reflect padded, hop 512) and
+    bin k, correlate N_k samples with a periodic-Hann-windowed complex exponential at f_k, window normalised to unit L1
+    and scaled by 1/sqrt(N_k) (librosa.cqt: norm=1, scale=True).  librosa evaluates the same transform recursively with
+    down-sampling and sparsified FFT-domain kernels; this direct form is its definition.  **parity unpinned.**
+    Returns [n_bins, 1 + len(y)//hop] float64."""
+    y = np.asarray(y, dtype=np.float64)
+    freqs = cqt_frequencies(n_bins, fmin, bins_per_octave)
+    lengths = cqt_lengths(sr, freqs, bins_per_octave)
+    n_frames = 1 + len(y) // hop
+    pad = int(lengths.max() // 2 + 1)
+    ypad = np.pad(y, pad, mode="reflect")  # (numpy reflects repeatedly when pad exceeds the signal length)
+    out = np.zeros((n_bins, n_frames))
+    for k in range(n_bins):
+        n = int(lengths[k])
+        m = np.arange(n)
+        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * m / n)
+        kern = win / win.sum() * np.exp(-2j * np.pi * freqs[k] * (m - n // 2) / sr)
+        start = pad - n // 2
+        idx = start + hop * np.arange(n_frames)[:, None] + m[None, :]
+        out[k] = np.abs(ypad[idx] @ kern) / np.sqrt(n)
+    return out
+
+
+def cq_to_chroma_matrix(n_bins=252, bins_per_octave=36, n_chroma=12):
+    """Fold constant-Q bins to pitch classes: every semitone owns the bins_per_octave/n_chroma bins centred on it (the
+    bin below C1's centre does not exist and is dropped); fmin = C1, so chroma row 0 is C."""
+    merge = bins_per_octave // n_chroma
+    w = np.zeros((n_chroma, n_bins))
+    for b in range(n_bins):
+        semitone = int(np.floor((b + merge // 2) / merge))
+        w[semitone % n_chroma, b] = 1.0
+    return w
+
+
+def chroma_cqt(y, sr, hop=512):
+    """Constant-Q chromagram, each frame normalised by its max (librosa.feature.chroma_cqt defaults without its
+    tuning estimation)."""
+    raw = cq_to_chroma_matrix() @ cqt_magnitude(y, sr, hop)
+    peak = raw.max(axis=0, keepdims=True)
+    return raw / np.where(peak > np.finfo(np.float64).tiny, peak, 1.0)
+
+
 def cens_from_chroma(ch, win_len=41):
     """CENS post-processing (Mueller & Ewert 2011, the steps librosa.feature.chroma_cens applies after its chromagram):
     per-frame L1 normalisation -> quantisation with thresholds .05/.1/.2/.4 (0.25 each) -> smoothing along time with a
@@ -296,7 +349,7 @@ def chroma(y, sr, n_frames, margin=16, notes=12, type="stft", nearest_neighbor=F
     post-processed and nearest-neighbour median filtered) -> resample -> note selection -> per-frame normalisation."""
     if margin:
         y = hpss(y, margin)[0]
-    raw = chroma_stft(y, sr)
+    raw = chroma_stft(y, sr) if type == "stft" else chroma_cqt(y, sr)
     if type == "cens":
         raw = cens_from_chroma(raw)
     if nearest_neighbor:

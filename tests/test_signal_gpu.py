@@ -75,7 +75,7 @@ def test_onsets_and_chroma_features_vs_oracle(gpu):
         got = sig.onsets(y, sr, n_frames, **kw)
         assert got.device.type == "cpu" and got.shape == (n_frames,)
         np.testing.assert_allclose(got.numpy(), want, atol=5e-3)
-    for kind in ("stft", "cens"):  # "cens" is the reference's default chroma type; both go through the nn median filter
+    for kind in ("stft", "cqt", "cens"):  # "cens" is the reference's default chroma type; all go through the nn median filter
         want = signal_oracle.chroma(y, sr, n_frames, type=kind, nearest_neighbor=True).numpy()
         got = sig.chroma(y, sr, n_frames, type=kind).numpy()
         assert np.allclose(got.sum(1), 1.0, atol=1e-5)
@@ -230,3 +230,21 @@ def test_cens_and_nn_filter_vs_oracle(gpu):
             # near-tie swaps (they move a median by one order statistic)
             close = np.isclose(got, want, atol=1e-6)
             assert close.mean() > 0.999, (ch.shape, close.mean())
+
+
+def test_constant_q_transform_vs_oracle(gpu):
+    """Direct constant-Q magnitude (252 bins from C1, hop 512) and the chroma fold against the oracle, on the synthetic
+    track, on a pure tone (peak bin / pitch class known in closed form) and on a clip shorter than the longest filter."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    sr = 22050
+    tone = np.sin(2 * np.pi * 220.0 * np.arange(sr) / sr).astype(np.float32)
+    c = sig.cqt_magnitude(tone, sr).cpu().numpy()
+    assert c.shape == (252, 1 + sr // 512) and int(c[:, 20].argmax()) == 99  # 36 * log2(220 / C1) = 99 exactly
+    assert int(sig.raw_chroma(tone, sr, type="cqt", nearest_neighbor=False)[:, 20].argmax()) == 9  # pitch class A
+    for y in (seeding.synthetic_audio(1.5, sr), seeding.synthetic_audio(0.4, sr)):
+        want = signal_oracle.cqt_magnitude(y, sr)
+        got = sig.cqt_magnitude(y, sr).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=1e-6 + 1e-5 * want.max())
+        np.testing.assert_allclose(sig.raw_chroma(y, sr, type="cqt", nearest_neighbor=False), signal_oracle.chroma_cqt(y, sr),
+                                   atol=2e-4)
