@@ -182,3 +182,26 @@ def test_bend_inverse_maps_are_inverses(built_lib):
     mz = bend._inverse_maps_scale(s, cw, ch).numpy()[0].reshape(2, 3)
     fwd = np.array([[2.0, 0, (1 - 2.0) * cx], [0, 0.5, (1 - 0.5) * cy], [0, 0, 1]])
     np.testing.assert_allclose(np.vstack([mz, [0, 0, 1]]) @ fwd, np.eye(3), atol=1e-6)
+
+
+def test_chroma_chain_oracle_properties():
+    """The unpinned half of the oracle (no librosa here) is at least held to closed-form facts: a pure tone peaks in the
+    constant-Q bin / pitch class its frequency dictates, CENS frames are unit-L2 (or zero), the nearest-neighbour median of a
+    sequence made of two repeated frames returns those frames."""
+    from oracle import signal_oracle as so
+
+    sr = 22050
+    for freq, pitch_class in ((220.0, 9), (261.6255653005986, 0), (329.6275569128699, 4)):
+        tone = np.sin(2 * np.pi * freq * np.arange(sr // 2) / sr)
+        c = so.cqt_magnitude(tone, sr)
+        assert int(c[:, 10].argmax()) == int(round(36 * np.log2(freq / 32.70319566257483)))
+        assert int(so.chroma_cqt(tone, sr)[:, 10].argmax()) == pitch_class
+    rng = np.random.default_rng(0)
+    ch = np.abs(rng.standard_normal((12, 90)))
+    ch[:, 30:33] = 0
+    cens = so.cens_from_chroma(ch)
+    norms = np.sqrt((cens ** 2).sum(0))
+    assert np.all((np.abs(norms - 1) < 1e-12) | (norms == 0))
+    a, b = np.abs(rng.standard_normal(12)), np.abs(rng.standard_normal(12))
+    seq = np.stack([a if (t // 5) % 2 == 0 else b for t in range(60)], axis=1)
+    np.testing.assert_allclose(so.nn_filter_median(seq), seq, atol=1e-12)
