@@ -5,3 +5,4 @@ from .bend import *  # noqa: F401,F403
 from .latent import *  # noqa: F401,F403
 from .signal import *  # noqa: F401,F403
 from .signal import set_SMF  # noqa: F401
+from .util import *  # noqa: F401,F403

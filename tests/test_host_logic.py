@@ -205,3 +205,21 @@ def test_chroma_chain_oracle_properties():
     a, b = np.abs(rng.standard_normal(12)), np.abs(rng.standard_normal(12))
     seq = np.stack([a if (t // 5) % 2 == 0 else b for t in range(60)], axis=1)
     np.testing.assert_allclose(so.nn_filter_median(seq), seq, atol=1e-12)
+
+
+def test_ar_namespace_covers_the_shipped_example_plugins(tmp_path, monkeypatch):
+    """Every ``ar.<name>`` the reference's example plugins use (default / temper / kelp / tauceti: onsets, chroma, rms,
+    gaussian_filter, spline_loops, wrapping_slice, perlin_noise, AddNoise, plot_signals, ...) exists in the drop-in package;
+    the inspection helpers run headless (figures land in workspace/*.png)."""
+    import maua_stylegan2_amd.audioreactive as ar
+
+    used = ["gaussian_filter", "onsets", "chroma", "chroma_weight_latents", "wrapping_slice", "spline_loops", "rms",
+            "plot_signals", "perlin_noise", "normalize", "load_latents", "laplacian_segmentation", "expand", "AddNoise",
+            "info", "plot_spectra", "plot_audio", "plot_chroma_comparison", "raw_chroma", "percentile_clip", "compress",
+            "slerp_loops", "generate_latents", "save_latents", "NetworkBend", "Translate", "Zoom", "Rotate", "set_SMF"]
+    assert [n for n in used if not hasattr(ar, n)] == []
+    monkeypatch.chdir(tmp_path)
+    ar.info([np.ones(3), torch.zeros(2, 2)])
+    assert ar.plot_signals([np.sin(np.linspace(0, 6, 100)), torch.linspace(0, 1, 50)]).endswith("signals.png")
+    assert ar.plot_spectra([np.random.rand(40, 80), np.random.rand(30, 12)], chroma=True).endswith("spectra.png")
+    assert (tmp_path / "workspace" / "signals.png").stat().st_size > 0
