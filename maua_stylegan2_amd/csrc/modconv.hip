@@ -94,9 +94,10 @@ struct ConvPtrs {
 
 // UP = false : plain 3x3, pad 1.           per wave: TM x TN MFMA tiles.
 // UP = true  : stride-2 transposed 3x3.    per wave: TM x (TN position groups x 4 output parities).
-// FAST (Cin % 8 == 0 and the padded weight covers whole BM tiles — every layer of a real generator): loads are
-// unconditional (masked by multiplication at LDS-write time) and addressed as uniform base + 32-bit lane offset,
-// which removes the exec-mask / 64-bit-address scalar work that dominated the short-K (32/64-channel) layers.
+// FAST (Cin a multiple of the K chunk and the padded weight covers whole BM tiles — every layer of a real generator): both
+// operands come in by LDS DMA (or, on the register-staged patch path, by unconditional loads masked by multiplication at
+// LDS-write time), addressed as uniform base + 32-bit lane offset, which removes the exec-mask / 64-bit-address scalar work
+// that dominated the short-K (32/64-channel) layers.  Everything else (ragged channel counts) takes the generic path.
 // MODE 2 (WINO): plain 3x3 through Winograd F(2,3) along x — two adjacent output columns share four "frequency" products
 //   m0 = (d0-d2) g0, m1 = (d1+d2)(g0+g1+g2)/2, m2 = (d2-d1)(g0-g1+g2)/2, m3 = (d1-d3) g2;  y0 = m0+m1+m2, y1 = m1-m2-m3
 // so a pair of outputs costs 4 MFMA K-steps per (channel, ky) instead of 6: 1.5x fewer matrix-core cycles on the
@@ -104,6 +105,7 @@ struct ConvPtrs {
 // parities of the transposed mode (same accumulator layout), weights are pre-transformed (pack_weight_wino_kernel),
 // the B operand is formed from two 8-byte LDS reads of the ordinary patch, the epilogue undoes the transform in
 // registers and stores 8 bytes per lane.  fp32 F(2,3) has transform constants {1, 1/2}: error stays at the 1e-6 level.
+// MODE 3 / MODE 4: see the comments at their mfma_chunk branches (F(4,3) on output quads; transposed conv with F(2,2)).
 template <int BM, int BN, int WM, int MODE, bool MULTI, bool FAST, int MAXP>
 __global__ __launch_bounds__(256, ((MODE == 3 && BM >= 64) || MODE == 4) ? 2
                                             : ((BM / WM / 32) * (BN / (4 / WM) / 32) * (MODE ? 4 : 1) >= 8 || BM * BN > 8192 ? 2 : 3))
