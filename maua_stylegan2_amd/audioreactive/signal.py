@@ -261,9 +261,56 @@ def onset_strength(audio, sr, fmin=0.0, fmax=None, n_fft=2048, hop=512, n_mels=1
     return env[: db.shape[1]]
 
 
+def log_filterbank(sr, n_fft=2048, num_bands=24, fmin=20.0, fmax=8000.0, fref=440.0):
+    """Triangular filters on a logarithmic frequency grid, [n_filters, n_fft/2] float32 (host-built constant like
+    :func:`mel_filterbank`): ``num_bands`` centres per octave around ``fref`` inside [fmin, fmax], snapped to FFT bins
+    with duplicates dropped, each filter normalised to unit sum — the spectrogram filtering the reference gets from
+    madmom's LogarithmicFilterbank (signal.py:57)."""
+    n_bins = n_fft // 2
+    k = np.arange(math.floor(math.log2(fmin / fref) * num_bands), math.ceil(math.log2(fmax / fref) * num_bands) + 1)
+    f = fref * np.exp2(k / num_bands)
+    f = f[(f >= fmin) & (f <= fmax)]
+    c = np.unique(np.clip(np.rint(f * n_fft / sr).astype(np.int64), 0, n_bins - 1))
+    if c.size < 3:
+        raise ValueError(f"onsets: no log-spaced bands between {fmin} and {fmax} Hz at n_fft={n_fft}")
+    cols = np.arange(n_bins)[None, :]
+    lo, mid, hi = c[:-2, None], c[1:-1, None], c[2:, None]
+    rise = (cols - lo) / (mid - lo)
+    fall = (hi - cols) / (hi - mid)
+    fb = np.where((cols >= lo) & (cols < mid), rise, np.where((cols >= mid) & (cols < hi), fall, 0.0))
+    return (fb / fb.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
+def onset_functions_sum(filt):
+    """Sum of four onset detection functions of a filtered magnitude spectrogram ``filt`` [bands, frames] (any device):
+    squared and plain positive flux, flux against the 3-band maximum of the previous frame, and the mean log-ratio
+    between consecutive frames — the phase-free members of the sum at signal.py:58-67 (its complex-flux term needs the
+    phase spectrogram, which the power STFT kernel does not keep)."""
+    prev = th.cat([filt[:, :1], filt[:, :-1]], dim=1)
+    pos = (filt - prev).clamp(min=0)
+    widened = th.nn.functional.max_pool1d(prev.t()[None], 3, 1, 1)[0].t()
+    sup = (filt - widened).clamp(min=0)
+    ratio = th.log1p(filt.double() / (prev.double() + float(np.finfo(np.float64).eps))).float()
+    keep = th.ones(filt.shape[1], device=filt.device)
+    keep[0] = 0.0
+    return (pos * pos).sum(0) + pos.sum(0) + (sup.sum(0) + ratio.mean(0)) * keep
+
+
+def onset_strength_bands(audio, sr, fmin=20.0, fmax=8000.0, n_fft=2048, hop=441):
+    """type="mm" onset envelope: magnitude STFT (frame 2048, hop 441 — 50 frames/s at 22050 Hz) -> 24-per-octave
+    log filterbank -> :func:`onset_functions_sum`."""
+    mag = th.sqrt(stft_power(audio, n_fft, hop))[: n_fft // 2].contiguous()
+    return onset_functions_sum(project(log_filterbank(sr, n_fft, 24, fmin, fmax), mag))
+
+
 def onsets(audio, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, type="mm", device=None):
     y_perc = percussive(audio, margin=margin) if margin else audio  # reference :49 (margin=0/None skips the separation)
-    env = onset_strength(y_perc, sr, fmin=fmin, fmax=fmax)
+    if type == "rosa":
+        env = onset_strength(y_perc, sr, fmin=fmin, fmax=fmax)
+    elif type == "mm":
+        env = onset_strength_bands(y_perc, sr, fmin=fmin, fmax=fmax)
+    else:
+        raise ValueError(f"onsets: unknown type {type!r} (expected 'mm' or 'rosa')")
     onset = resample(env, n_frames).clamp(float(env.min()), float(env.max())).float()
     onset = gaussian_filter(onset, smooth, causal=0)
     onset = percentile_clip(onset, clip)

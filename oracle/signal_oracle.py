@@ -235,11 +235,63 @@ def hpss(y, margin=1.0, kernel_size=31, power=2.0):
     return istft(d * mask_h, len(y)), istft(d * mask_p, len(y))
 
 
-def onsets(y, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, smf=1.0):
-    """signal.py:31-73, type="rosa" branch (percussive separation at :49, then spectral-flux onset strength)."""
+def log_filterbank(sr, n_fft=2048, num_bands=24, fmin=20.0, fmax=8000.0, fref=440.0):
+    """Logarithmically spaced triangular filterbank in the style of madmom.audio.filters.LogarithmicFilterbank (the
+    FilteredSpectrogram of signal.py:57): centre frequencies fref * 2**(k/num_bands) inside [fmin, fmax] snapped to the
+    nearest FFT bin, duplicates removed; filter i rises from centre i-1 to centre i and falls to centre i+1; every filter
+    sums to one.  Returns [n_filters, n_fft/2] (the Nyquist bin is not used, as in madmom).  **parity unpinned.**"""
+    n_bins = n_fft // 2
+    bin_freqs = np.arange(n_bins) * (sr / n_fft)
+    lo = int(np.floor(np.log2(fmin / fref) * num_bands))
+    hi = int(np.ceil(np.log2(fmax / fref) * num_bands))
+    freqs = fref * 2.0 ** (np.arange(lo, hi + 1) / num_bands)
+    freqs = freqs[(freqs >= fmin) & (freqs <= fmax)]
+    centres = np.unique(np.clip(np.round(freqs / (sr / n_fft)).astype(np.int64), 0, n_bins - 1))
+    if len(centres) < 3:
+        raise ValueError("log_filterbank: fewer than three distinct FFT bins between fmin and fmax")
+    fb = np.zeros((len(centres) - 2, n_bins))
+    for i, (start, centre, stop) in enumerate(zip(centres[:-2], centres[1:-1], centres[2:])):
+        fb[i, start:centre] = np.linspace(0.0, 1.0, centre - start, endpoint=False)
+        fb[i, centre:stop] = np.linspace(1.0, 0.0, stop - centre, endpoint=False)
+        fb[i] /= fb[i].sum()
+    del bin_freqs
+    return fb
+
+
+def madmom_like_onset_functions(filt):
+    """The four phase-free onset detection functions signal.py:58-66 sums (madmom.features.onsets, frame lag 1), on a
+    filtered magnitude spectrogram ``filt`` [n_frames, n_bands]: spectral_diff = sum of squared positive differences,
+    spectral_flux = sum of positive differences, superflux = positive differences against the 3-bin frequency-maximum of the
+    previous frame, modified_kullback_leibler = mean log(1 + S[t] / (S[t-1] + eps)).  (complex_flux needs the local group
+    delay of the phase spectrogram and is not restated.)  Returns a dict of [n_frames] arrays."""
+    filt = np.asarray(filt, dtype=np.float64)
+    prev = np.concatenate([filt[:1], filt[:-1]], axis=0)
+    pos = np.maximum(filt - prev, 0.0)
+    padded = np.pad(prev, ((0, 0), (1, 1)), mode="edge")
+    prev_max = np.maximum(np.maximum(padded[:, :-2], padded[:, 1:-1]), padded[:, 2:])
+    sup = np.maximum(filt - prev_max, 0.0)
+    sup[0] = 0.0
+    mkl = np.log1p(filt / (prev + np.finfo(np.float64).eps)).mean(axis=1)
+    mkl[0] = 0.0
+    return {"spectral_diff": (pos ** 2).sum(axis=1), "spectral_flux": pos.sum(axis=1), "superflux": sup.sum(axis=1),
+            "modified_kullback_leibler": mkl}
+
+
+def madmom_like_onset_strength(y, sr, fmin=20.0, fmax=8000.0, n_fft=2048, hop=441):
+    """Sum of :func:`madmom_like_onset_functions` on the log-filtered magnitude spectrogram (frame 2048, hop 441 = 50 frames
+    per second at 22050 Hz, signal.py:54-57).  Frames are the centred, reflect-padded, periodic-Hann frames of
+    :func:`stft_power` (madmom zero-pads and uses a symmetric window: only the edge frames differ)."""
+    mag = np.sqrt(stft_power(y, n_fft, hop))[: n_fft // 2]  # [bins, frames]
+    filt = (log_filterbank(sr, n_fft, 24, fmin, fmax) @ mag).T
+    return sum(madmom_like_onset_functions(filt).values())
+
+
+def onsets(y, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, smf=1.0, type="rosa"):
+    """signal.py:31-73: percussive separation (:49), then the spectral-flux onset strength (type="rosa", :51) or the sum of
+    madmom-style onset functions on a log-filtered spectrogram (type="mm", :53-67), then resample / smooth / clip / power."""
     if margin:
         y = hpss(y, margin)[1]
-    env = onset_strength(y, sr, fmin=fmin, fmax=fmax)
+    env = onset_strength(y, sr, fmin=fmin, fmax=fmax) if type == "rosa" else madmom_like_onset_strength(y, sr, fmin, fmax)
     env = np.clip(resample(env, n_frames), env.min(), env.max())
     env = torch.from_numpy(env).float()
     env = gaussian_filter(env, smooth, causal=0, smf=smf)

@@ -100,6 +100,35 @@ def test_filterbanks_match_oracle(built_lib):
     np.testing.assert_allclose(sig.chroma_filterbank(22050), signal_oracle.chroma_filterbank(22050), atol=1e-6)
 
 
+def test_band_onset_functions_match_oracle(built_lib):
+    """type="mm" onsets: the log-spaced filterbank and the onset-function sum (both host/torch code around the STFT and
+    projection kernels) against the oracle's loop restatement."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    for kw in [dict(), dict(fmax=150), dict(fmin=500), dict(fmin=20, fmax=60), dict(num_bands=12, fmin=100.0, fmax=4000.0)]:
+        want = signal_oracle.log_filterbank(22050, **kw)
+        got = sig.log_filterbank(22050, **kw)
+        assert got.shape == want.shape and got.dtype == np.float32
+        np.testing.assert_allclose(got, want, atol=1e-7)
+        np.testing.assert_allclose(got.sum(1), 1.0, atol=1e-6)
+    with pytest.raises(ValueError):
+        sig.log_filterbank(22050, fmin=20, fmax=25)
+    rng = np.random.default_rng(3)
+    filt = (np.abs(rng.standard_normal((40, 97))) * rng.random((40, 1)) * 30).astype(np.float32)
+    filt[:, 50:53] = 0.0  # silent frames: the log-ratio term must stay finite
+    parts = signal_oracle.madmom_like_onset_functions(filt.T.astype(np.float64))
+    got = sig.onset_functions_sum(torch.from_numpy(filt)).numpy()
+    assert np.isfinite(got).all() and got[0] == 0.0
+    np.testing.assert_allclose(got, sum(parts.values()), rtol=1e-5, atol=1e-4)
+    # a step in every band is an onset for every function, a steady spectrogram for none but the log-ratio term (log 2)
+    steady = np.ones((5, 8))
+    steady[:, 4:] = 3.0
+    parts = signal_oracle.madmom_like_onset_functions(steady.T)
+    assert all(np.argmax(v) == 4 for v in parts.values())
+    np.testing.assert_allclose(parts["spectral_flux"], [0, 0, 0, 0, 10, 0, 0, 0])
+    np.testing.assert_allclose(parts["modified_kullback_leibler"][1:4], np.log(2.0))
+
+
 def test_envelope_postprocessing_matches_golden(built_lib, golden):
     from maua_stylegan2_amd.audioreactive import signal as sig
 

@@ -70,11 +70,18 @@ def test_onsets_and_chroma_features_vs_oracle(gpu):
     sr = 22050
     y = seeding.synthetic_audio(6.0, sr)
     n_frames = 180
-    for kw in [dict(fmax=150, smooth=5, clip=97, power=2), dict(fmin=500, smooth=5, clip=99, power=2)]:
-        want = signal_oracle.onsets(y, sr, n_frames, **kw).numpy()
-        got = sig.onsets(y, sr, n_frames, **kw)
-        assert got.device.type == "cpu" and got.shape == (n_frames,)
-        np.testing.assert_allclose(got.numpy(), want, atol=5e-3)
+    for kind in ("rosa", "mm"):  # "mm" (band-filtered onset-function sum) is the reference's default
+        for kw in [dict(fmax=150, smooth=5, clip=97, power=2), dict(fmin=500, smooth=5, clip=99, power=2)]:
+            want = signal_oracle.onsets(y, sr, n_frames, type=kind, **kw).numpy()
+            got = sig.onsets(y, sr, n_frames, type=kind, **kw)
+            assert got.device.type == "cpu" and got.shape == (n_frames,)
+            np.testing.assert_allclose(got.numpy(), want, atol=5e-3, err_msg=f"{kind} {kw}")
+    np.testing.assert_array_equal(sig.onsets(y, sr, n_frames, fmax=150).numpy(), sig.onsets(y, sr, n_frames, fmax=150, type="mm").numpy())
+    with pytest.raises(ValueError):
+        sig.onsets(y, sr, n_frames, type="flux")
+    env_w = signal_oracle.madmom_like_onset_strength(y, sr, 20.0, 8000.0)
+    env_g = sig.onset_strength_bands(y, sr).cpu().numpy()
+    np.testing.assert_allclose(env_g, env_w, rtol=2e-4, atol=2e-4 * env_w.max())
     for kind in ("stft", "cqt", "cens"):  # "cens" is the reference's default chroma type; all go through the nn median filter
         want = signal_oracle.chroma(y, sr, n_frames, type=kind, nearest_neighbor=True).numpy()
         got = sig.chroma(y, sr, n_frames, type=kind).numpy()
