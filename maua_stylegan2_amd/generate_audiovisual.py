@@ -162,8 +162,9 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
         selection = sharding.broadcast_tensor(selection.cuda()).cpu()
     if shuffle_latents:
         selection = selection[random.sample(range(len(selection)), len(selection))]
-    os.makedirs("workspace", exist_ok=True)
-    np.save("workspace/last-latents.npy", selection.numpy())
+    if sharding.rank_world()[0] == 0:  # one writer under torchrun
+        os.makedirs("workspace", exist_ok=True)
+        np.save("workspace/last-latents.npy", selection.numpy())
     latents = get_latents(selection=selection, args=args)
     print(f"{list(latents.shape)} amplitude={latents.std()}\n")
 
@@ -236,7 +237,8 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     os.makedirs(args.output_dir, exist_ok=True)
 
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not th.distributed.is_initialized():
+    own_group = int(os.environ.get("WORLD_SIZE", "1")) > 1 and not th.distributed.is_initialized()
+    if own_group:
         th.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         th.distributed.init_process_group("nccl")
@@ -256,7 +258,11 @@ def main(argv=None):
         settings[key] = value
         setattr(args, key, value)
     ckpt, audio_file = settings.pop("ckpt", None), settings.pop("audio_file", None)
-    generate(ckpt=ckpt, audio_file=audio_file, **callbacks, **settings, args=args)
+    try:
+        generate(ckpt=ckpt, audio_file=audio_file, **callbacks, **settings, args=args)
+    finally:
+        if own_group:
+            th.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

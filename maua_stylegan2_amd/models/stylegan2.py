@@ -153,11 +153,11 @@ class ModulatedConv2d(nn.Module):
     # plain 3x3 layers with at least this many output channels run through Winograd F(2,3) (MFMA-bound layers);
     # a huge value turns it off
     winograd_min_cout = 32
-
-    upconv_winograd = True
-    # ... and from this many output channels, on maps at least 64 wide, through F(4,3) (6 products per 4 outputs)
+    # ... and from this many output channels, on maps at least this wide, through F(4,3) (6 products per 4 outputs)
     winograd43_min_cout = 32
     winograd43_min_width = 32
+    # transposed layers: F(2,2) on the even x-phase (mode 4) where the launch is large enough, see conv_mode
+    upconv_winograd = True
 
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd F(2,3), 3 Winograd
@@ -166,8 +166,8 @@ class ModulatedConv2d(nn.Module):
             # F(2,2) on the even x-phase of the polyphase transposed conv (mode 4: -17 % MFMA work, but 2 instead of 3-4
             # workgroups per CU) once a batch of 8 frames yields at least ~4 rounds of workgroups; smaller grids lose more
             # to the partially filled last round than they gain and keep the plain polyphase kernel (mode 1)
-            pairs_per_tile = 128 if self.out_channel <= 32 else 64
-            tiles = -(-((h + 1) * (w // 2 + 1)) // pairs_per_tile) * -(-self.out_channel // (32 if self.out_channel <= 32 else 64))
+            pairs_per_tile, rows_per_tile = (128, 32) if self.out_channel <= 32 else (64, 64)
+            tiles = -(-((h + 1) * (w // 2 + 1)) // pairs_per_tile) * -(-self.out_channel // rows_per_tile)
             if self.upconv_winograd and w % 2 == 0 and tiles >= 256:
                 return 4
             return 1

@@ -155,62 +155,66 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
         lane_state.append({"stream": stream, "graph": None, "static": None, "u8": None})
         return lane_state[k]
 
-    k = 0
-    for n in range(lo, hi, batch_size):
-        m = min(n + batch_size, hi)
-        b = m - n
-        lane_id = k % n_lanes
-        lane = lane_for(lane_id)
-        with th.cuda.stream(lane["stream"]):
-            if capturable and b == batch_size:
-                if lane["graph"] is None:
-                    shapes = [None if nz is None else tuple(nz.shape[-2:]) for nz in noise]
-                    lane["graph"], lane["static"] = generator.capture_graph(batch_size, shapes, truncated=trunc_t is not None,
-                                                                            lane=lane_id)
-                static = lane["static"]
-                static["latents"].copy_(latents[n:m])
-                for dst, src in zip(static["noise"], noise):
-                    if src is not None:
-                        dst.copy_(src[n:m])
-                if trunc_t is not None:
-                    static["trunc"].copy_(trunc_t[n:m])
-                lane["graph"].replay()
-                images = static["image"]
-            else:
-                noise_batch = [None if nz is None else nz[n:m] for nz in noise]
-                bend_batch = []
-                for bend in bends:
-                    if "modulation" in bend:
-                        bend_batch.append({"layer": bend["layer"], "transform": bend["transform"](bend["modulation"][n:m])})
-                    else:
-                        bend_batch.append({"layer": bend["layer"], "transform": bend["transform"]})
-                for name, (rewrite, modulation) in rewrites.items():
-                    new_weight = rewrite(modulation[n:m])(original_weights[name]).to(dev, th.float32).contiguous()
-                    module = generator
-                    *path, leaf = name.split(".")
-                    for attr in path:
-                        module = getattr(module, attr)
-                    setattr(module, leaf, th.nn.Parameter(new_weight, requires_grad=False))
-                if n_lanes > 1:  # the eager tail batch shares lane 0's activation namespace: let the other lanes drain first
-                    for other in lane_state:
-                        lane["stream"].wait_stream(other["stream"])
-                images, _ = generator(styles=latents[n:m], noise=noise_batch,
-                                      truncation=truncation if trunc_t is None else trunc_t[n:m],
-                                      transform_dict_list=bend_batch, randomize_noise=randomize_noise, input_is_latent=True)
-            u8 = lane["u8"]
-            if u8 is None or u8.shape[0] != b or u8.shape[1:3] != images.shape[2:]:
-                u8 = lane["u8"] = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
-            frames_to_uint8(images, u8)
-            yield n, u8
-        k += 1
-    for name, w in original_weights.items():  # leave the generator as it was found
-        module = generator
-        *path, leaf = name.split(".")
-        for attr in path:
-            module = getattr(module, attr)
-        setattr(module, leaf, th.nn.Parameter(w, requires_grad=False))
-    for lane in lane_state:
-        caller_stream.wait_stream(lane["stream"])
+    try:
+        k = 0
+        for n in range(lo, hi, batch_size):
+            m = min(n + batch_size, hi)
+            b = m - n
+            lane_id = k % n_lanes
+            lane = lane_for(lane_id)
+            with th.cuda.stream(lane["stream"]):
+                if capturable and b == batch_size:
+                    if lane["graph"] is None:
+                        shapes = [None if nz is None else tuple(nz.shape[-2:]) for nz in noise]
+                        lane["graph"], lane["static"] = generator.capture_graph(
+                            batch_size, shapes, truncated=trunc_t is not None, lane=lane_id)
+                    static = lane["static"]
+                    static["latents"].copy_(latents[n:m])
+                    for dst, src in zip(static["noise"], noise):
+                        if src is not None:
+                            dst.copy_(src[n:m])
+                    if trunc_t is not None:
+                        static["trunc"].copy_(trunc_t[n:m])
+                    lane["graph"].replay()
+                    images = static["image"]
+                else:
+                    noise_batch = [None if nz is None else nz[n:m] for nz in noise]
+                    bend_batch = []
+                    for bend in bends:
+                        if "modulation" in bend:
+                            transform = bend["transform"](bend["modulation"][n:m])
+                            bend_batch.append({"layer": bend["layer"], "transform": transform})
+                        else:
+                            bend_batch.append({"layer": bend["layer"], "transform": bend["transform"]})
+                    for name, (rewrite, modulation) in rewrites.items():
+                        new_weight = rewrite(modulation[n:m])(original_weights[name]).to(dev, th.float32).contiguous()
+                        module = generator
+                        *path, leaf = name.split(".")
+                        for attr in path:
+                            module = getattr(module, attr)
+                        setattr(module, leaf, th.nn.Parameter(new_weight, requires_grad=False))
+                    if n_lanes > 1:  # the eager tail batch shares lane 0's activations: let the other lanes drain first
+                        for other in lane_state:
+                            lane["stream"].wait_stream(other["stream"])
+                    images, _ = generator(styles=latents[n:m], noise=noise_batch,
+                                          truncation=truncation if trunc_t is None else trunc_t[n:m],
+                                          transform_dict_list=bend_batch, randomize_noise=randomize_noise,
+                                          input_is_latent=True)
+                u8 = lane["u8"]
+                if u8 is None or u8.shape[0] != b or u8.shape[1:3] != images.shape[2:]:
+                    u8 = lane["u8"] = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
+                frames_to_uint8(images, u8)
+                yield n, u8
+            k += 1
+    finally:  # also when the consumer stops early (sink error, generator closed)
+        for name, w in original_weights.items():  # leave the generator as it was found
+            module = generator
+            *path, leaf = name.split(".")
+            for attr in path:
+                module = getattr(module, attr)
+            setattr(module, leaf, th.nn.Parameter(w, requires_grad=False))
+        for lane in lane_state:
+            caller_stream.wait_stream(lane["stream"])
 
 
 def render(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file=None,
@@ -226,55 +230,58 @@ def render(generator, latents, noise, offset, duration, batch_size, out_size, ou
     if rank == 0:
         sink = FrameSink(output_file, width, height, n_frames / duration, audio_file, offset, duration, ffmpeg_preset)
 
-    if world == 1:
-        # pinned staging ring, one slot per graph lane: the D2H of batch k overlaps the graph replays of the next batches
-        n_slots = 3
-        copy_stream = th.cuda.Stream(dev)
-        pinned, events, pending = [None] * n_slots, [None] * n_slots, []
+    try:
+        if world == 1:
+            # pinned staging ring, one slot per graph lane: the D2H of batch k overlaps the replays of the next batches
+            n_slots = 3
+            copy_stream = th.cuda.Stream(dev)
+            pinned, events, pending = [None] * n_slots, [None] * n_slots, []
 
-        def drain(slot_first):
-            slot, first, count = slot_first
-            events[slot].synchronize()
-            host = pinned[slot].numpy()
-            for i in range(count):
-                sink.write(host[i])
+            def drain(slot_first):
+                slot, first, count = slot_first
+                events[slot].synchronize()
+                host = pinned[slot].numpy()
+                for i in range(count):
+                    sink.write(host[i])
 
-        k = 0
-        for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites, randomize_noise,
-                                    lanes=n_slots):
-            slot = k % n_slots
-            if len(pending) == n_slots:
-                drain(pending.pop(0))
-            if pinned[slot] is None or pinned[slot].shape != u8.shape:
-                pinned[slot] = th.empty(u8.shape, dtype=th.uint8).pin_memory()
-            produced = th.cuda.Event()
-            produced.record(th.cuda.current_stream(dev))
-            with th.cuda.stream(copy_stream):
-                copy_stream.wait_event(produced)
-                pinned[slot].copy_(u8, non_blocking=True)
-                events[slot] = th.cuda.Event()
-                events[slot].record(copy_stream)
-            # the producer must not overwrite u8 before the copy has read it
-            th.cuda.current_stream(dev).wait_event(events[slot])
-            pending.append((slot, first, u8.shape[0]))
-            k += 1
-        for p in pending:
-            drain(p)
-    else:
-        shard = None
-        for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites, randomize_noise,
-                                    frame_range=(lo, hi)):
-            if shard is None:
-                shard = th.empty((sharding.max_shard(n_frames, world),) + tuple(u8.shape[1:]), dtype=th.uint8, device=dev)
-            shard[first - lo: first - lo + u8.shape[0]].copy_(u8)
-        if dev.type == "cuda":
-            th.cuda.synchronize(dev)
-        if shard is None:  # a rank whose block is empty (more ranks than frames) still takes part in the gather
-            shard = th.zeros((sharding.max_shard(n_frames, world), height, width, 3), dtype=th.uint8, device=dev)
-        gathered = sharding.gather_frames(shard, n_frames)
-        if rank == 0:
-            for frame in gathered:
-                sink.write(frame.numpy() if isinstance(frame, th.Tensor) else frame)
-    if sink is not None:
-        sink.close()
+            k = 0
+            for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
+                                        randomize_noise, lanes=n_slots):
+                slot = k % n_slots
+                if len(pending) == n_slots:
+                    drain(pending.pop(0))
+                if pinned[slot] is None or pinned[slot].shape != u8.shape:
+                    pinned[slot] = th.empty(u8.shape, dtype=th.uint8).pin_memory()
+                produced = th.cuda.Event()
+                produced.record(th.cuda.current_stream(dev))
+                with th.cuda.stream(copy_stream):
+                    copy_stream.wait_event(produced)
+                    pinned[slot].copy_(u8, non_blocking=True)
+                    events[slot] = th.cuda.Event()
+                    events[slot].record(copy_stream)
+                # the producer must not overwrite u8 before the copy has read it
+                th.cuda.current_stream(dev).wait_event(events[slot])
+                pending.append((slot, first, u8.shape[0]))
+                k += 1
+            for p in pending:
+                drain(p)
+        else:
+            shard = None
+            for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
+                                        randomize_noise, frame_range=(lo, hi)):
+                if shard is None:
+                    shard = th.empty((sharding.max_shard(n_frames, world),) + tuple(u8.shape[1:]), dtype=th.uint8,
+                                     device=dev)
+                shard[first - lo: first - lo + u8.shape[0]].copy_(u8)
+            if dev.type == "cuda":
+                th.cuda.synchronize(dev)
+            if shard is None:  # a rank whose block is empty (more ranks than frames) still takes part in the gather
+                shard = th.zeros((sharding.max_shard(n_frames, world), height, width, 3), dtype=th.uint8, device=dev)
+            gathered = sharding.gather_frames(shard, n_frames)
+            if rank == 0:
+                for frame in gathered:
+                    sink.write(frame.numpy() if isinstance(frame, th.Tensor) else frame)
+    finally:  # the encoder process / output file must not outlive a failed render
+        if sink is not None:
+            sink.close()
     return sink.count if sink is not None else 0

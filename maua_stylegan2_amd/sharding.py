@@ -49,19 +49,29 @@ def broadcast_tensor(t, src=0):
     return t
 
 
-def gather_frames(shard, n_frames, dst=0):
+def gather_frames(shard, n_frames, dst=0, chunk=64):
     """``shard``: uint8 [max_shard, H, W, 3] on every rank (rows beyond the rank's block are ignored).
-    Returns on ``dst`` the list of n_frames frames in order (CPU uint8 tensors), elsewhere None."""
+    Returns on ``dst`` an iterator over the n_frames frames in order (CPU uint8 tensors), elsewhere None.  The gathered
+    blocks stay on ``dst``'s device (3 MiB per 1024^2 frame) and are brought to the host ``chunk`` frames at a time while
+    the iterator is consumed, so host memory does not grow with the length of the video."""
     rank, world = rank_world()
     if world == 1:
-        return [f for f in shard[:n_frames].cpu()]
-    bufs = [th.empty_like(shard) for _ in range(world)] if rank == dst else None
-    dist.gather(shard, bufs, dst=dst)
-    if rank != dst:
-        return None
-    frames = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_frames, r, world)
-        host = bufs[r][: hi - lo].cpu()
-        frames.extend(host[i] for i in range(hi - lo))
-    return frames
+        blocks = [(shard, min(n_frames, shard.shape[0]))]
+    else:
+        bufs = [th.empty_like(shard) for _ in range(world)] if rank == dst else None
+        dist.gather(shard, bufs, dst=dst)
+        if rank != dst:
+            return None
+        blocks = []
+        for r in range(world):
+            lo, hi = shard_bounds(n_frames, r, world)
+            blocks.append((bufs[r], hi - lo))
+
+    def frames():
+        for block, count in blocks:
+            for c in range(0, count, chunk):
+                host = block[c: min(c + chunk, count)].cpu()
+                for i in range(host.shape[0]):
+                    yield host[i]
+
+    return frames()

@@ -51,8 +51,9 @@ def _worker(rank, world, port, n_frames, out_dir):
         shard = torch.zeros((sharding.max_shard(n_frames, world), 4, 5, 3), dtype=torch.uint8)
         for i in range(lo, hi):
             shard[i - lo] = i % 251
-        frames = sharding.gather_frames(shard, n_frames)
+        frames = sharding.gather_frames(shard, n_frames, chunk=3)
         if rank == 0:
+            frames = list(frames)
             assert len(frames) == n_frames
             for i, f in enumerate(frames):
                 assert f.shape == (4, 5, 3) and int(f[0, 0, 0]) == i % 251 and int(f.max()) == int(f.min())
