@@ -161,6 +161,10 @@ int maua_softmask_apply_f32(const float* re, const float* im, const float* x, co
 int maua_filterbank_f32(const float* fb, const float* p, float* out, int m, int k, int n, int to_db, float amin,
                         void* stream);
 
+/* Fourier-method resampling along time, y[num, features] from x[n, features] (row-major, fp64) — scipy.signal.resample
+ * as called at audioreactive/signal.py:68,152 — evaluated as a Dirichlet-kernel sum in the time domain. */
+int maua_resample_f64(const double* x, int n, int64_t features, double* y, int num, void* stream);
+
 /* |constant-Q transform| (librosa.cqt role inside chroma_cqt / chroma_cens, signal.py:115-117): out[k][t] for n_bins
  * geometrically spaced frequencies freqs[k] (Hz) with window lengths lengths[k] (samples), centred frames every `hop`
  * samples with reflect padding, periodic-Hann kernels of unit L1 norm, scaled by 1/sqrt(length). */

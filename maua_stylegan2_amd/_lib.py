@@ -61,6 +61,7 @@ _SIGNATURES = {
     "maua_istft_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int64, _P]),
     "maua_median_filter_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "maua_softmask_apply_f32": (c_int, [_P, _P, _P, _P, c_float, c_float, c_int, _P, _P, c_int64, _P]),
+    "maua_resample_f64": (c_int, [_P, c_int, c_int64, _P, c_int, _P]),
     "maua_cqt_mag_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_float, _P, c_int, _P]),
     "maua_chroma_cens_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "maua_nn_median_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -168,20 +168,17 @@ def harmonic(audio, margin=1.0):
 
 
 def resample(x, num):
-    """Fourier-method resampling along dim 0 (what scipy.signal.resample does at reference :68,152), on device."""
-    n = x.shape[0]
-    spec = th.fft.rfft(x.to(th.float64), dim=0)
-    m = min(n, num)
-    out = th.zeros((num // 2 + 1,) + tuple(x.shape[1:]), dtype=spec.dtype, device=x.device)
-    keep = m // 2 + 1
-    out[:keep] = spec[:keep]
-    if m % 2 == 0:  # the shared Nyquist bin of the shorter grid
-        if num < n:
-            out[m // 2] = out[m // 2] * 2.0  # fold +/- Nyquist of the source into the single real bin
-            out[m // 2] = out[m // 2].real.to(out.dtype)
-        elif num > n:
-            out[m // 2] = out[m // 2] * 0.5
-    return th.fft.irfft(out, n=num, dim=0) * (float(num) / float(n))
+    """Fourier-method resampling along dim 0 (what scipy.signal.resample does at reference :68,152) on device:
+    maua_resample_f64, float64 in and out like scipy."""
+    src = _to_dev(x, th.float64).contiguous()
+    n = src.shape[0]
+    num = int(num)
+    out = th.empty((num,) + tuple(src.shape[1:]), dtype=th.float64, device=src.device)
+    features = max(src.numel() // max(n, 1), 1)
+    with th.cuda.device(src.device):
+        _lib.check(_lib.load().maua_resample_f64(src.data_ptr(), n, features, out.data_ptr(), num,
+                                                 _lib.stream_ptr(src.device)), "maua_resample_f64")
+    return out
 
 
 def gaussian_filter(x, sigma, causal=None):

@@ -514,6 +514,61 @@ __global__ __launch_bounds__(256) void nn_median_kernel(const float* __restrict_
     }
 }
 
+
+// Fourier-method resampling along time (scipy.signal.resample as the reference calls it, signal.py:68,152) evaluated in
+// the time domain: y[i] = (1/n) sum_j R(i, j) x[j] with the Dirichlet kernel of the m = min(n, num) retained bins,
+//   R = sin((2K+1) pi th) / sin(pi th),  th = i/num - j/n,  K = (m-1)/2,
+// plus, for even m, the shared Nyquist bin: 2 (-1)^i cos(pi m j / n) when shortening (the +-m/2 bins of the source fold
+// into one real bin), (-1)^j cos(pi n i / num) when lengthening (the source's Nyquist bin is split in half).  Phases are
+// reduced in 64-bit integers before sinpi/cospi, all arithmetic is fp64: envelopes are O(n_frames) numbers, and an FFT
+// library would spend seconds planning the odd transform lengths (1293 -> 900 frames) that appear here.
+constexpr int RS_F = 16;  // feature columns per pass
+
+__global__ __launch_bounds__(256) void resample_kernel(const double* __restrict__ x, int n, int64_t features,
+                                                       double* __restrict__ y, int num) {
+    __shared__ double part[4][RS_F];
+    const int i = blockIdx.x;
+    const int64_t f0 = (int64_t)blockIdx.y * RS_F;
+    const int nf = (int)(features - f0 < RS_F ? features - f0 : RS_F);
+    const int m = n < num ? n : num, K = (m - 1) / 2;
+    const int64_t D = (int64_t)n * num;
+    const bool nyquist = (m % 2 == 0);
+    double acc[RS_F];
+#pragma unroll
+    for (int f = 0; f < RS_F; ++f) acc[f] = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        int64_t a = ((int64_t)i * n - (int64_t)j * num) % D;
+        if (a < 0) a += D;
+        double r = (double)(2 * K + 1);
+        if (a != 0) {
+            const int64_t q = ((int64_t)(2 * K + 1) * a) % (2 * D);
+            r = sinpi((double)q / (double)D) / sinpi((double)a / (double)D);
+        }
+        if (nyquist) {
+            if (num < n)
+                r += ((i & 1) ? -2.0 : 2.0) * cospi((double)(((int64_t)m * j) % (2 * (int64_t)n)) / (double)n);
+            else
+                r += ((j & 1) ? -1.0 : 1.0) * cospi((double)(((int64_t)n * i) % (2 * (int64_t)num)) / (double)num);
+        }
+        const double* xr = x + (int64_t)j * features + f0;
+#pragma unroll
+        for (int f = 0; f < RS_F; ++f)
+            if (f < nf) acc[f] = fma(r, xr[f], acc[f]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int f = 0; f < RS_F; ++f) {
+        double v = acc[f];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) part[wave][f] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nf) {
+        const int f = threadIdx.x;
+        y[(int64_t)i * features + f0 + f] = ((part[0][f] + part[1][f]) + (part[2][f] + part[3][f])) / (double)n;
+    }
+}
 }  // namespace
 
 extern "C" int maua_temporal_fir_f32(const float* x, const float* taps, float* y, int n_frames, int64_t features,
@@ -663,6 +718,21 @@ extern "C" int maua_cqt_mag_f32(const float* y, int64_t n_samples, const float* 
         return MAUA_EINVAL;
     hipLaunchKernelGGL(cqt_mag_kernel, dim3(n_frames, n_bins), dim3(256), 0, (hipStream_t)stream, y, n_samples, freqs,
                        lengths, hop, sr, out, n_frames);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_resample_f64(const double* x, int n, int64_t features, double* y, int num, void* stream) {
+    if (!x || !y || n <= 0 || num <= 0 || features <= 0) return MAUA_EINVAL;
+    if ((int64_t)n * num > (1ll << 40)) return MAUA_EINVAL;  // (2K+1) * phase must stay inside int64
+    hipStream_t st = (hipStream_t)stream;
+    if (n == num) {
+        hipError_t e = hipMemcpyAsync(y, x, (size_t)n * features * sizeof(double), hipMemcpyDeviceToDevice, st);
+        return e == hipSuccess ? 0 : (int)e;
+    }
+    const int64_t fy = ceil_div64(features, RS_F);
+    if (fy > 65535) return MAUA_EINVAL;
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)num, (unsigned)fy), dim3(256), 0, st, x, n, features, y, num);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

@@ -150,15 +150,6 @@ def test_latent_helpers_match_golden(built_lib, golden):
     np.testing.assert_allclose(latent.spline_loops(g["spline.sel"], 37, 2).numpy(), g["spline.y"], atol=1e-9)
 
 
-def test_resample_matches_scipy_on_cpu(built_lib):
-    from maua_stylegan2_amd.audioreactive.signal import resample
-
-    r = np.random.default_rng(0)
-    for n, num in [(431, 300), (300, 431), (128, 64), (64, 128), (87, 87), (100, 51), (51, 100)]:
-        x = r.standard_normal((n, 3))
-        np.testing.assert_allclose(resample(torch.from_numpy(x), num).numpy(), signal_oracle.resample(x, num), atol=1e-9)
-
-
 def test_wav_loading_and_cache(tmp_path, built_lib, monkeypatch):
     import scipy.io.wavfile
 

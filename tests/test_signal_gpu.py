@@ -92,11 +92,20 @@ def test_onsets_and_chroma_features_vs_oracle(gpu):
 
 
 def test_resample_on_device_matches_scipy(gpu):
+    """maua_resample_f64 (Dirichlet-kernel sum in fp64) against scipy.signal.resample: shortening / lengthening, odd and
+    even retained-bin counts (the shared Nyquist bin), equal lengths, 1-D and wide inputs."""
     from maua_stylegan2_amd.audioreactive.signal import resample
 
-    x = np.random.default_rng(1).standard_normal((431, 12))
-    got = resample(torch.from_numpy(x).to(gpu), 300).cpu().numpy()
-    np.testing.assert_allclose(got, signal_oracle.resample(x, 300), atol=1e-9)
+    r = np.random.default_rng(1)
+    cases = [(431, 300, 12), (300, 431, 3), (128, 64, 3), (64, 128, 3), (87, 87, 2), (100, 51, 1), (51, 100, 1), (1293, 900, 1),
+             (1292, 900, 20), (7, 2, 1), (2, 7, 1), (1, 3, 1), (3, 1, 1)]
+    for n, num, feat in cases:
+        x = r.standard_normal((n, feat))
+        got = resample(torch.from_numpy(x).to(gpu), num)
+        assert got.dtype == torch.float64 and tuple(got.shape) == (num, feat)
+        np.testing.assert_allclose(got.cpu().numpy(), signal_oracle.resample(x, num), atol=1e-9, err_msg=f"{n}->{num}")
+    x = r.standard_normal(517).astype(np.float32)  # 1-D float32 envelope, as onsets() passes it
+    np.testing.assert_allclose(resample(torch.from_numpy(x).to(gpu), 360).cpu().numpy(), signal_oracle.resample(x, 360), atol=1e-9)
 
 
 def test_perlin_noise_vs_oracle(gpu):

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--stage-times", action="store_true", help="print device-synchronised wall time per preprocessing stage")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="maua_e2e_")
     os.chdir(work)
@@ -52,10 +53,42 @@ def main():
             pass
 
     render.FrameSink = CountingSink
+    if args.stage_times:
+        from maua_stylegan2_amd import audioreactive as ar
+        from maua_stylegan2_amd.audioreactive import signal as sig
+
+        stages = {}
+
+        def timed(owner, name, label=None):
+            fn = getattr(owner, name)
+
+            def wrapper(*a, **k):
+                torch.cuda.synchronize()
+                t = time.time()
+                out = fn(*a, **k)
+                torch.cuda.synchronize()
+                acc = stages.setdefault(label or name, [0.0, 0])
+                acc[0] += time.time() - t
+                acc[1] += 1
+                return out
+
+            setattr(owner, name, wrapper)
+
+        for owner, name in ((ar, "load_audio"), (ar, "generate_latents"), (plugin, "initialize"), (plugin, "get_latents"),
+                            (plugin, "get_noise"), (gav, "load_generator"), (render, "render")):
+            timed(owner, name)
+        for name in ("hpss", "resample", "gaussian_filter", "cqt_magnitude", "nn_filter", "cens", "stft_power"):
+            timed(sig, name, "  signal." + name)
+            if hasattr(ar, name):
+                setattr(ar, name, getattr(sig, name))
+        timed(gav.gc, "collect", "  gc.collect")
     t0 = time.time()
     gav.generate(ckpt, wav, initialize=plugin.initialize, get_latents=plugin.get_latents, get_noise=plugin.get_noise,
                  G_res=args.size, out_size=args.size, fps=30, batch=args.batch, output_file=os.path.join(work, "out.mp4"))
     total = time.time() - t0
+    if args.stage_times:
+        for label, (sec, calls) in stages.items():
+            print(f"STAGE {label:28s} {sec:7.3f} s  ({calls} calls)")
     print(f"E2E frames={counted['frames']} bytes={counted['bytes']} checksum={counted['checksum']} total_wall_s={total:.2f}")
 
 
