@@ -5,16 +5,19 @@ Mirrors /root/reference/audioreactive/signal.py (names, arguments, return shapes
   percentile :257-268 · percentile_clip :271-292 · compress/expand :295-316 · gaussian_filter :319-368 ·
   load_audio :371-405.
 
-What runs where: the STFT (LDS radix-2 FFT), the mel / chroma / rms filterbank projections, and the temporal Gaussian
-FIR are HIP kernels (csrc/signal.hip) behind the C ABI; the O(n_frames) envelope post-processing (resample, clip,
-percentile, power) is a handful of torch ops on the same device.  Inputs may be numpy arrays or tensors on any device;
-results come back on the device the reference would have produced them on (envelopes: CPU tensors) unless
+What runs where: the STFT / inverse STFT (LDS radix-2 FFT), the median filters and soft masks of the harmonic /
+percussive separation, the mel / log-band / chroma / rms filterbank projections, the constant-Q transform, the CENS and
+nearest-neighbour chroma post-processing, the Fourier-method envelope resampling and the temporal Gaussian FIR are HIP
+kernels (csrc/signal.hip) behind the C ABI; the remaining O(n_frames) envelope post-processing (clip, percentile,
+power, the onset-function sum) is a handful of torch ops on the same device.  Inputs may be numpy arrays or tensors on
+any device; results come back on the device the reference would have produced them on (envelopes: CPU tensors) unless
 ``device=`` says otherwise, so existing plugins keep working while the heavy tensors can stay in HBM.
 
-Divergences from the reference, all stated in DESIGN.md ("parity unpinned" rows): librosa / madmom are not
-dependencies here.  ``onsets`` = median-filter percussive separation (``margin``) + the spectral-flux definition of the
-type="rosa" branch, for both ``type`` values (madmom's five onset functions are not built); ``chroma`` = harmonic
-separation + the type="stft" filterbank for every ``type`` (no CENS/CQT, no nn_filter) — SURVEY.md §8f rank 3.
+Divergences from the reference, all stated in DESIGN.md §7 ("parity unpinned" rows): librosa / madmom are not
+dependencies here.  ``onsets(type="mm")`` sums four of madmom's five onset functions on a log-filtered spectrogram
+built here (no phase-based complex flux), ``type="rosa"`` is the mel spectral flux; ``chroma`` runs harmonic
+separation -> constant-Q chromagram -> CENS -> nearest-neighbour median filter without librosa's tuning estimation,
+and madmom's "deep" / "clp" chroma models fall back to the constant-Q chromagram with a warning.
 """
 import math
 import os
