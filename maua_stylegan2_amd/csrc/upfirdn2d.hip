@@ -721,9 +721,9 @@ extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int 
     if (!x || !k || !y || major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 || up_x <= 0 ||
         up_y <= 0 || down_x <= 0 || down_y <= 0)
         return MAUA_EINVAL;
-    const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
-    const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
-    if (out_h <= 0 || out_w <= 0) return MAUA_EINVAL;
+    const int span_h = in_h * up_y + pad_y0 + pad_y1 - kh, span_w = in_w * up_x + pad_x0 + pad_x1 - kw;
+    if (span_h < 0 || span_w < 0) return MAUA_EINVAL;  // (C division would round a negative span toward one output row)
+    const int out_h = span_h / down_y + 1, out_w = span_w / down_x + 1;
     if (major == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == kw && kh >= 2 && kh <= 4) {

@@ -52,6 +52,10 @@ def test_rejects_bad_arguments_without_gpu(built_lib):
     assert conv(64, 63, 4) == -22           # mode 4 needs an even width
     assert conv(64, 64, 4, fuse=1) == -22   # mode 4 produces the raw transposed output only
     assert conv(4, 4, 4) == -22             # grid too small for flat pair runs: callers use mode 1
+    # upfirdn2d: a kernel larger than the padded input has no output (the reference's floor division gives <= 0 rows)
+    assert lib.maua_upfirdn2d_f32(fake, fake, fake, 1, 2, 2, 1, 4, 4, 1, 1, 2, 2, 0, 1, 0, 1, None) == -22
+    assert lib.maua_resample_f64(fake, 0, 1, fake, 4, None) == -22
+    assert lib.maua_resample_f64(fake, 1 << 21, 1, fake, 1 << 20, None) == -22  # phase arithmetic would leave int64
 
 
 def test_product_ops_refuse_cpu_tensors(built_lib):
