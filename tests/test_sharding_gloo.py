@@ -23,6 +23,17 @@ def test_shard_bounds_cover_every_frame_once():
     assert sharding.shard_bounds(1800, 3, 8) == (675, 900)  # config 4: 225 contiguous frames per GPU
 
 
+def test_gather_frames_single_process_streams_in_chunks():
+    """No process group: the shard itself is handed out frame by frame, fetched ``chunk`` frames at a time."""
+    shard = torch.arange(7, dtype=torch.uint8).reshape(7, 1, 1, 1).repeat(1, 2, 3, 3)
+    frames = sharding.gather_frames(shard, 5, chunk=2)
+    assert not isinstance(frames, (list, tuple))  # an iterator: host memory does not scale with the video length
+    got = list(frames)
+    assert len(got) == 5 and [int(f[0, 0, 0]) for f in got] == [0, 1, 2, 3, 4]
+    assert all(f.shape == (2, 3, 3) and f.dtype == torch.uint8 for f in got)
+    assert list(sharding.gather_frames(shard, 0)) == []
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
