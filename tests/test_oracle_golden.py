@@ -181,3 +181,69 @@ def test_c_restatement_matches_golden(golden):
     out = np.zeros(g["y"].shape, np.uint8)
     lib.ref_frames_to_u8(x.ctypes.data_as(fp), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 1, 4, 8)
     assert (out == g["y"]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent cross-checks of the "parity unpinned" audio restatements against third-party implementations that ARE
+# installed here (scipy, scikit-learn).  librosa itself is absent; these pin the building blocks it is made of.
+def test_oracle_stft_matches_scipy_stft():
+    """oracle.stft_complex (centred, reflect-padded, periodic Hann — librosa.stft's defaults) against scipy.signal.stft
+    on the same padded signal (scipy scales by 1 / sum(window))."""
+    import scipy.signal
+
+    sr = 22050
+    y = seeding.synthetic_audio(1.5, sr).astype(np.float64)
+    for n_fft, hop in [(2048, 512), (2048, 441), (1024, 256)]:
+        want_frames = 1 + len(y) // hop
+        ypad = np.pad(y, n_fft // 2, mode="reflect")
+        _, _, z = scipy.signal.stft(ypad, window="hann", nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary=None,
+                                    padded=False)
+        z = z * signal_oracle.hann_periodic(n_fft).sum()
+        got = signal_oracle.stft_complex(y, n_fft, hop)
+        assert got.shape == (n_fft // 2 + 1, want_frames) and z.shape[1] >= want_frames
+        np.testing.assert_allclose(got, z[:, :want_frames], atol=1e-9)
+        np.testing.assert_allclose(signal_oracle.stft_power(y, n_fft, hop), np.abs(z[:, :want_frames]) ** 2, atol=1e-8)
+
+
+def test_oracle_istft_inverts_stft():
+    y = seeding.synthetic_audio(1.0).astype(np.float64)
+    back = signal_oracle.istft(signal_oracle.stft_complex(y), len(y))
+    np.testing.assert_allclose(back, y, atol=1e-10)
+
+
+def test_oracle_nn_filter_matches_sklearn_neighbours():
+    """The neighbour selection of nn_filter_median against scikit-learn's cosine NearestNeighbors (the engine librosa's
+    recurrence matrix is built on): k + 2 width candidates, the |i - j| < width band removed, the k nearest kept."""
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(5)
+    for f, t, width in [(12, 60, 1), (12, 200, 1), (7, 90, 3)]:
+        ch = rng.random((f, t)) + 0.05
+        k = int(min(t - 1, 2 * np.ceil(np.sqrt(t - 2 * width + 1))))
+        knn = NearestNeighbors(n_neighbors=min(t, k + 2 * width), metric="cosine", algorithm="brute").fit(ch.T)
+        _, idx = knn.kneighbors(ch.T)
+        want = np.empty_like(ch)
+        for i in range(t):
+            nb = [j for j in idx[i] if abs(j - i) >= width][:k]
+            assert len(nb) == k
+            want[:, i] = np.median(ch[:, nb], axis=1)
+        np.testing.assert_allclose(signal_oracle.nn_filter_median(ch, width), want, atol=1e-12)
+
+
+def test_oracle_band_onset_envelope_peaks_on_the_beats():
+    """Property of the type="mm" onset envelope (50 frames per second): impulses every half second put its largest values
+    on frames 25, 50, 75, ... and nothing comparable in between."""
+    sr = 22050
+    y = np.zeros(4 * sr)
+    rng = np.random.default_rng(0)
+    for beat in range(1, 8):
+        start = beat * sr // 2
+        y[start:start + 400] += rng.standard_normal(400) * np.exp(-np.arange(400) / 80.0)
+    env = signal_oracle.madmom_like_onset_strength(y, sr)
+    assert env.shape == (1 + len(y) // 441,)
+    # frame t is centred on sample 441 t with a 2048-sample window: each burst lights up frames 25 beat - 1 and 25 beat
+    beats = [25 * b for b in range(1, 8)]
+    for t in beats:
+        assert int(np.argmax(env[t - 6:t + 7])) + t - 6 in (t - 1, t), (t, env[t - 6:t + 7])
+    off_beat = np.delete(env, np.concatenate([np.arange(t - 3, t + 4) for t in beats]))
+    assert off_beat.max() < 0.01 * min(env[t - 1:t + 1].max() for t in beats)
