@@ -6,14 +6,18 @@ PINNED against the imported reference (tests/golden/audioreactive_torch.npz):
   chroma_weight_latents <- /root/reference/audioreactive/latent.py:15-26
   noise_side_lengths    <- /root/reference/generate_audiovisual.py:22-34,147-151
   wrapping_slice        <- latent.py:110-133
+  perlin_noise          <- latent.py:188-246 (tests/golden/perlin.npz: the reference itself, run on the CPU by
+                           tests/golden/make_golden.py with Tensor.cuda replaced by the identity and numpy's global
+                           generator seeded; the oracle takes the gradient angles as inputs and agrees to 0.0)
 
-PARITY UNPINNED (stated in DESIGN.md): stft_power / mel_filterbank / onset_strength / chroma_filterbank /
-chroma_stft / hpss restate the *published* librosa algorithms that the reference calls at
-signal.py:49-51,115-119,150 (librosa is an un-pinned, un-vendored dependency, requirements.txt:4, and is not
-installed in this image, so no golden vector can be produced).  They define what the HIP STFT/mel path must
-reproduce; they are NOT claimed to be bit-identical to any librosa release.  perlin_noise restates
-latent.py:188-246, whose reference implementation hard-codes .cuda() and numpy global RNG and therefore
-cannot be run here; the oracle takes the gradient angles as inputs.
+PARITY UNPINNED (stated in DESIGN.md): stft_power / mel_filterbank / onset_strength / the band-filtered onset
+functions / chroma_filterbank / chroma_stft / constant-Q / CENS / nn_filter / hpss restate the *published* librosa and
+madmom algorithms that the reference calls at signal.py:49-67,115-131,150 (un-pinned, un-vendored dependencies,
+requirements.txt:4,6, not installed in this image, so no golden vector can be produced), and affine_reflect_warp
+restates the kornia composition of bend.py:60-102.  They define what the HIP kernels must reproduce; they are NOT claimed
+to be bit-identical to any librosa / madmom / kornia release.  Their building blocks are cross-checked against the
+third-party code that is installed (scipy.signal.stft, scipy.signal.resample, scipy.ndimage.median_filter,
+scikit-learn NearestNeighbors, torch grid_sample) in tests/test_oracle_golden.py.
 """
 import math
 

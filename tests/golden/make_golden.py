@@ -65,14 +65,52 @@ def check(name, mine, ref, tol=1e-5):
     return err
 
 
+def perlin_fixture(ref_latent, signal_oracle):
+    """perlin_noise (audioreactive/latent.py:188-246) hard-codes ``.cuda()`` (:207,219) and draws its gradient angles from
+    numpy's GLOBAL generator (:209-210).  Here Tensor.cuda is replaced by the identity for the duration of the call, so
+    the reference's own arithmetic runs on the CPU, and the global generator is seeded so the same two draws can be
+    repeated for the oracle.  Stored: the angles (inputs) and the reference's output."""
+    print("perlin_noise (reference run with Tensor.cuda -> identity, numpy global RNG seeded)")
+    out, cases = {}, []
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for name, shape, res, tileable, seed in [
+            ("time_tiled", (24, 8, 12), (4, 2, 3), (True, False, False), 7),      # the default: loops along time
+            ("no_tiling", (10, 6, 6), (2, 3, 1), (False, False, False), 8),
+            ("all_tiled", (12, 12, 8), (3, 4, 2), (True, True, True), 9),
+            ("one_period", (16, 4, 4), (1, 1, 1), (True, False, False), 10),
+        ]:
+            np.random.seed(seed)
+            y_ref = ref_latent.perlin_noise(shape, res, tileable)
+            np.random.seed(seed)
+            dims = (res[0] + 1, res[1] + 1, res[2] + 1)
+            theta = 2 * np.pi * np.random.rand(*dims)
+            phi = 2 * np.pi * np.random.rand(*dims)
+            y_mine = signal_oracle.perlin_noise(shape, res, theta.copy(), phi.copy(), tileable)
+            check("perlin_noise." + name, torch.from_numpy(np.asarray(y_mine)), y_ref.double(), tol=1e-12)
+            out[f"{name}.theta"], out[f"{name}.phi"], out[f"{name}.y"] = theta, phi, y_ref.numpy()
+            out[f"{name}.cfg"] = np.array(list(shape) + list(res) + [int(v) for v in tileable] + [seed], dtype=np.int64)
+            cases.append(name)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "perlin.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the 256^2 / 1024^2 generators (minutes on CPU)")
+    ap.add_argument("--only-perlin", action="store_true", help="(re)generate perlin.npz only")
     args = ap.parse_args()
 
     ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
     from maua_stylegan2_amd import seeding
     from oracle import ops_oracle, signal_oracle, stylegan2_oracle as so
+
+    if args.only_perlin:
+        perlin_fixture(ref_latent, signal_oracle)
+        return
 
     # ------------------------------------------------------------------ (1) upfirdn2d
     print("upfirdn2d")
@@ -313,6 +351,9 @@ def main():
     u8_ref = imgs.permute(0, 2, 3, 1).numpy().astype(np.uint8)
     assert (so.frames_to_uint8(t(vals)) == u8_ref).all()
     np.savez_compressed(os.path.join(HERE, "postprocess.npz"), x=vals, y=u8_ref)
+
+    # ------------------------------------------------------------------ (8) Perlin noise
+    perlin_fixture(ref_latent, signal_oracle)
     print("done")
 
 

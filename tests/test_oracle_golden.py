@@ -247,3 +247,49 @@ def test_oracle_band_onset_envelope_peaks_on_the_beats():
         assert int(np.argmax(env[t - 6:t + 7])) + t - 6 in (t - 1, t), (t, env[t - 6:t + 7])
     off_beat = np.delete(env, np.concatenate([np.arange(t - 3, t + 4) for t in beats]))
     assert off_beat.max() < 0.01 * min(env[t - 1:t + 1].max() for t in beats)
+
+
+def test_oracle_affine_warp_matches_torch_grid_sample():
+    """affine_reflect_warp (the bend transform of audioreactive/bend.py:60-102: ReflectionPad2d -> kornia affine warp ->
+    CenterCrop) against torch's own ReflectionPad2d + grid_sample(bilinear, zeros, align_corners=True) — the engine
+    kornia's warp_affine calls — for rotations, anisotropic scales and translations that leave the canvas."""
+    rng = np.random.default_rng(11)
+    b, c, h, w = 3, 2, 9, 13
+    x = rng.standard_normal((b, c, h, w))
+    for pads in [(4, 4, 4, 4), (3, 5, 2, 6), (0, 0, 0, 0)]:
+        pl, pr, pt, pb = pads
+        ch_, cw_ = h + pt + pb, w + pl + pr
+        maps = []
+        for i in range(b):
+            ang, sx, sy = rng.uniform(-1, 1), rng.uniform(0.6, 1.6), rng.uniform(0.6, 1.6)
+            cx0, cy0 = (cw_ - 1) / 2, (ch_ - 1) / 2
+            a = np.array([[np.cos(ang) * sx, -np.sin(ang) * sy], [np.sin(ang) * sx, np.cos(ang) * sy]])
+            t = np.array([cx0, cy0]) - a @ np.array([cx0, cy0]) + rng.uniform(-4, 4, 2)
+            maps.append([a[0, 0], a[0, 1], t[0], a[1, 0], a[1, 1], t[1]])
+        maps = np.array(maps)
+        noise = rng.standard_normal((ch_, cw_)) if pads[0] == 3 else None
+        got = signal_oracle.affine_reflect_warp(x, maps, pads, noise)
+
+        canvas = torch.nn.ReflectionPad2d(pads)(torch.from_numpy(x)) if any(pads) else torch.from_numpy(x)
+        if noise is not None:
+            canvas = canvas + torch.from_numpy(noise)[None, None]
+        oy, ox = np.meshgrid(np.arange(h) + (ch_ - h) // 2, np.arange(w) + (cw_ - w) // 2, indexing="ij")
+        grid = np.empty((b, h, w, 2))
+        for i in range(b):
+            m = maps[i]
+            grid[i, ..., 0] = 2 * (m[0] * ox + m[1] * oy + m[2]) / (cw_ - 1) - 1
+            grid[i, ..., 1] = 2 * (m[3] * ox + m[4] * oy + m[5]) / (ch_ - 1) - 1
+        want = torch.nn.functional.grid_sample(canvas, torch.from_numpy(grid), mode="bilinear", padding_mode="zeros",
+                                               align_corners=True).numpy()
+        np.testing.assert_allclose(got, want, atol=1e-10)
+
+
+def test_perlin_oracle_matches_reference_golden(golden):
+    """perlin.npz holds outputs of the reference's own perlin_noise (tests/golden/make_golden.py runs it on the CPU by
+    neutralising its hard-coded .cuda() calls) together with the gradient angles it drew."""
+    g = golden("perlin.npz")
+    for name in g["cases"]:
+        cfg = g[f"{name}.cfg"]
+        shape, res, tileable = tuple(cfg[:3]), tuple(cfg[3:6]), tuple(bool(v) for v in cfg[6:9])
+        got = signal_oracle.perlin_noise(shape, res, g[f"{name}.theta"].copy(), g[f"{name}.phi"].copy(), tileable)
+        np.testing.assert_allclose(got, g[f"{name}.y"], atol=1e-12, err_msg=str(name))

@@ -125,6 +125,22 @@ def test_perlin_noise_vs_oracle(gpu):
     assert out.is_cuda and out.shape == (16, 8, 8) and float(out.abs().max()) < 3
 
 
+def test_perlin_noise_vs_reference_golden(gpu, golden):
+    """The HIP Perlin kernel against outputs of the REFERENCE's perlin_noise (tests/golden/perlin.npz): with numpy's
+    global generator seeded as the fixture was, the drop-in draws the same gradient angles and must reproduce the
+    reference's tensor (fp32 kernel vs the reference's fp64 arithmetic)."""
+    from maua_stylegan2_amd.audioreactive import latent
+
+    g = golden("perlin.npz")
+    for name in g["cases"]:
+        cfg = [int(v) for v in g[f"{name}.cfg"]]
+        shape, res, tileable, seed = tuple(cfg[:3]), tuple(cfg[3:6]), tuple(bool(v) for v in cfg[6:9]), cfg[9]
+        np.random.seed(seed)
+        got = latent.perlin_noise(shape, res, tileable)
+        assert got.is_cuda and tuple(got.shape) == shape
+        np.testing.assert_allclose(got.cpu().numpy(), g[f"{name}.y"], atol=2e-5, err_msg=str(name))
+
+
 def test_bends_vs_oracle(gpu):
     from maua_stylegan2_amd.audioreactive import bend
 
