@@ -98,10 +98,90 @@ def perlin_fixture(ref_latent, signal_oracle):
     np.savez_compressed(os.path.join(HERE, "perlin.npz"), **out)
 
 
+RENDER_SUB = (slice(3, None, 8), slice(5, None, 8))  # stored pixels of every frame: rows 3::8, columns 5::8
+
+
+def render_fixture(ref_sg2, seeding, so):
+    """The reference's own render loop (render.py:14-192) on the CPU: ``ffmpeg`` is replaced by an object that records the
+    bytes written to its stdin, ``Tensor.cuda`` / ``Tensor.pin_memory`` by the identity, ``th.cuda.FloatTensor`` (the float
+    truncation branch, models/stylegan2.py:538) by ``th.FloatTensor``.  Two clips of 5 frames at 512^2 (the smallest size
+    render accepts), batch 2 (ragged tail): (a) checkpoint noise buffers + float truncation 1.0, (b) per-frame noise for
+    the scales <= 64 px, buffers above, per-frame truncation tensor.  Stored: seeds, the 64x64 pixel subsample RENDER_SUB of
+    every frame and per-frame byte sums."""
+    print("render.render (reference loop, frames captured from the ffmpeg pipe)")
+    captured = []
+
+    class _Pipe:
+        def write(self, data):
+            captured.append(np.frombuffer(data, dtype=np.uint8).copy())
+
+        def close(self):
+            pass
+
+    class _Chain:
+        stdin = _Pipe()
+
+        def output(self, *a, **k):
+            return self
+
+        def global_args(self, *a, **k):
+            return self
+
+        def overwrite_output(self):
+            return self
+
+        def run_async(self, **k):
+            return self
+
+        def wait(self):
+            return 0
+
+    ff = sys.modules["ffmpeg"]
+    ff.input = lambda *a, **k: _Chain()
+    import render as ref_render  # noqa  (/root/reference/render.py)
+
+    real = (torch.Tensor.cuda, torch.Tensor.pin_memory, torch.cuda.FloatTensor)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor
+    size, n, batch = 512, 5, 2
+    out = {"cfg": np.array([size, n, batch, 1, 2, 3], dtype=np.int64)}  # size, frames, batch, seeds: weights, latents, noise
+    try:
+        sd = seeding.seeded_state_dict(size, seed=1)
+        g = ref_sg2.Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+        g.load_state_dict(sd, strict=True)
+        g.eval()
+        lat = seeding.seeded_latents(n, g.n_latent, seed=2)
+        per_frame = seeding.seeded_noise(n, size, seed=3)
+        trunc = torch.linspace(0.6, 1.0, n)
+        tl = torch.from_numpy(seeding.seeded_array(5, "truncation_latent", (1, 512)))
+        for tag, noise, truncation in (("a", [None] * g.num_layers, 1.0),
+                                       ("b", [nz if nz.shape[-1] <= 64 else None for nz in per_frame], trunc)):
+            captured.clear()
+            g.truncation_latent = tl.clone()
+            ref_render.render(generator=g, latents=lat.clone(), noise=list(noise), offset=0, duration=n / 30,
+                              batch_size=batch, out_size=size, output_file="unused.mp4", truncation=truncation)
+            assert len(captured) == n, f"reference render delivered {len(captured)} of {n} frames"
+            frames = np.stack([c.reshape(size, size, 3) for c in captured])
+            mine = so.frames_to_uint8(so.generator_forward(
+                sd, lat, noise, truncation=None if isinstance(truncation, float) else truncation, truncation_latent=tl))
+            diff = np.abs(frames.astype(np.int16) - np.asarray(mine).astype(np.int16))
+            print(f"  render.{tag}: oracle-vs-reference frames max|diff| = {diff.max()} grey levels, "
+                  f"{(diff > 0).mean():.2e} of the bytes differ")
+            assert diff.max() <= 1 and (diff > 0).mean() < 1e-4
+            out[f"{tag}.sub"] = frames[:, RENDER_SUB[0], RENDER_SUB[1], :]
+            out[f"{tag}.sums"] = frames.reshape(n, -1).sum(1).astype(np.int64)
+        out["b.truncation"] = trunc.numpy()
+    finally:
+        torch.Tensor.cuda, torch.Tensor.pin_memory, torch.cuda.FloatTensor = real
+    np.savez_compressed(os.path.join(HERE, "render_512.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the 256^2 / 1024^2 generators (minutes on CPU)")
     ap.add_argument("--only-perlin", action="store_true", help="(re)generate perlin.npz only")
+    ap.add_argument("--only-render", action="store_true", help="(re)generate render_512.npz only")
     args = ap.parse_args()
 
     ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
@@ -110,6 +190,9 @@ def main():
 
     if args.only_perlin:
         perlin_fixture(ref_latent, signal_oracle)
+        return
+    if args.only_render:
+        render_fixture(ref_sg2, seeding, so)
         return
 
     # ------------------------------------------------------------------ (1) upfirdn2d
@@ -354,6 +437,9 @@ def main():
 
     # ------------------------------------------------------------------ (8) Perlin noise
     perlin_fixture(ref_latent, signal_oracle)
+
+    # ------------------------------------------------------------------ (9) render loop
+    render_fixture(ref_sg2, seeding, so)
     print("done")
 
 

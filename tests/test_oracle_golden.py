@@ -293,3 +293,24 @@ def test_perlin_oracle_matches_reference_golden(golden):
         shape, res, tileable = tuple(cfg[:3]), tuple(cfg[3:6]), tuple(bool(v) for v in cfg[6:9])
         got = signal_oracle.perlin_noise(shape, res, g[f"{name}.theta"].copy(), g[f"{name}.phi"].copy(), tileable)
         np.testing.assert_allclose(got, g[f"{name}.y"], atol=1e-12, err_msg=str(name))
+
+
+def test_oracle_frames_match_the_reference_render_loop(golden):
+    """render_512.npz holds frames the reference's own render() produced on the CPU (tests/golden/make_golden.py captures
+    them from its ffmpeg pipe): 5 frames of a seeded 512^2 generator, batch 2, (a) checkpoint noise buffers and float
+    truncation 1.0, (b) per-frame noise up to 64 px and a per-frame truncation tensor.  The oracle's generator + uint8
+    post-process reproduce the stored pixel subsample to within one grey level."""
+    g = golden("render_512.npz")
+    size, n, _, s_w, s_l, s_n = [int(v) for v in g["cfg"]]
+    sd = seeding.seeded_state_dict(size, seed=s_w)
+    n_latent = 2 * int(np.log2(size)) - 2
+    lat = seeding.seeded_latents(n, n_latent, seed=s_l)
+    per_frame = seeding.seeded_noise(n, size, seed=s_n)
+    tl = torch.from_numpy(seeding.seeded_array(5, "truncation_latent", (1, 512)))
+    for tag, noise, trunc in (("a", [None] * len(per_frame), None),
+                              ("b", [nz if nz.shape[-1] <= 64 else None for nz in per_frame], torch.from_numpy(g["b.truncation"]))):
+        frames = np.asarray(so.frames_to_uint8(so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=tl)))
+        assert frames.shape == (n, size, size, 3)
+        diff = np.abs(frames[:, 3::8, 5::8, :].astype(np.int16) - g[f"{tag}.sub"].astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, tag
+        assert np.abs(frames.reshape(n, -1).sum(1).astype(np.int64) - g[f"{tag}.sums"]).max() < 1e-4 * size * size * 3, tag

@@ -47,6 +47,31 @@ def test_synthesize_graph_equals_eager_and_oracle(gpu):
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
 
 
+def test_render_matches_reference_render_loop(gpu, tmp_path, monkeypatch, golden):
+    """render() against frames produced by the REFERENCE's own render loop (tests/golden/render_512.npz, captured from its
+    ffmpeg pipe on the CPU): seeded 512^2 generator, 5 frames, batch 2 — (a) checkpoint noise buffers, float truncation;
+    (b) per-frame noise up to 64 px, per-frame truncation tensor.  Compared on the stored pixel subsample, <= 1 grey level."""
+    from maua_stylegan2_amd import render
+
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)  # raw rgb24 sink
+    fx = golden("render_512.npz")
+    size, n, batch, s_w, s_l, s_n = [int(v) for v in fx["cfg"]]
+    g = build(size, gpu, s_w)
+    lat = seeding.seeded_latents(n, g.n_latent, seed=s_l)
+    per_frame = seeding.seeded_noise(n, size, seed=s_n)
+    g.truncation_latent = torch.from_numpy(seeding.seeded_array(5, "truncation_latent", (1, 512))).to(gpu)
+    scenarios = (("a", [None] * g.num_layers, 1.0),
+                 ("b", [nz if nz.shape[-1] <= 64 else None for nz in per_frame], torch.from_numpy(fx["b.truncation"])))
+    for tag, noise, truncation in scenarios:
+        out = str(tmp_path / f"clip_{tag}.mp4")
+        written = render.render(generator=g, latents=lat.clone(), noise=list(noise), offset=0, duration=n / 30,
+                                batch_size=batch, out_size=size, output_file=out, truncation=truncation)
+        assert written == n
+        raw = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(n, size, size, 3)
+        diff = np.abs(raw[:, 3::8, 5::8, :].astype(np.int16) - fx[f"{tag}.sub"].astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (tag, int(diff.max()), float((diff > 0).mean()))
+
+
 def test_render_writes_ordered_frames(gpu, tmp_path, monkeypatch):
     from maua_stylegan2_amd import render
 
