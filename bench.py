@@ -252,7 +252,6 @@ def main():
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        frames_u8 = lanes[0]["u8"]
         checksum = int(sum(int(lane["u8"].sum().item()) for lane in lanes))
 
         result = None

@@ -19,7 +19,6 @@ to be bit-identical to any librosa / madmom / kornia release.  Their building bl
 third-party code that is installed (scipy.signal.stft, scipy.signal.resample, scipy.ndimage.median_filter,
 scikit-learn NearestNeighbors, torch grid_sample) in tests/test_oracle_golden.py.
 """
-import math
 
 import numpy as np
 import scipy.signal
