@@ -40,6 +40,15 @@ def mapping_network(sd, z, n_mlp=8, lr_mlp=0.01):
     return w
 
 
+def latents_from_z(sd, zs, n_latent, inject_index=None):
+    """The ``input_is_latent=False`` branch of Generator.forward (:511-526): every z [N,512] goes through the mapping
+    network; one z fills all n_latent rows, two are mixed at ``inject_index`` (rows < index from the first)."""
+    ws = [mapping_network(sd, z) for z in zs]
+    if len(ws) < 2:
+        return ws[0][:, None, :].repeat(1, n_latent, 1)
+    return torch.cat([ws[0][:, None, :].repeat(1, inject_index, 1), ws[1][:, None, :].repeat(1, n_latent - inject_index, 1)], 1)
+
+
 def modulated_conv2d(x, style_vec, weight, mod_weight, mod_bias, demodulate=True, upsample=False, blur_kernel=None):
     """x [B,Cin,H,W], style_vec [B,512], weight [1,Cout,Cin,k,k]."""
     b, cin, h, w = x.shape

@@ -98,6 +98,34 @@ def perlin_fixture(ref_latent, signal_oracle):
     np.savez_compressed(os.path.join(HERE, "perlin.npz"), **out)
 
 
+def mapping_fixture(ref_sg2, seeding, so):
+    """The z-input side of the reference Generator (models/stylegan2.py:388-393,511-526): mapping network outputs and
+    one- / two-z forwards (style mixing at a fixed inject_index) of a seeded 32^2 generator."""
+    print("mapping network / input_is_latent=False")
+    size = 32
+    sd = seeding.seeded_state_dict(size, seed=3)
+    g = ref_sg2.Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(sd, strict=True)
+    g.eval()
+    g.truncation_latent = torch.zeros(1, 512)
+    z = torch.from_numpy(seeding.seeded_array(4, "z", (5, 512)))
+    w_ref = g.style(z)
+    check("mapping_network", so.mapping_network(sd, z), w_ref, tol=1e-5)
+    z1 = torch.from_numpy(seeding.seeded_array(4, "z1", (2, 512)))
+    z2 = torch.from_numpy(seeding.seeded_array(4, "z2", (2, 512)))
+    noise = seeding.seeded_noise(2, size, seed=9)
+    ones = torch.ones(2)
+    out = {"w": w_ref.numpy(), "inject_index": np.int64(3)}
+    for tag, zs, idx in (("one", [z1], None), ("mix", [z1, z2], 3)):
+        img_ref, lat_ref = g(list(zs), return_latents=True, inject_index=idx, truncation=ones, noise=list(noise),
+                             randomize_noise=False, input_is_latent=False)
+        lat_mine = so.latents_from_z(sd, zs, g.n_latent, idx)
+        check(f"latents_from_z.{tag}", lat_mine, lat_ref, tol=1e-5)
+        check(f"forward_from_z.{tag}", so.generator_forward(sd, lat_mine, noise), img_ref, tol=1e-4)
+        out[f"{tag}.latents"], out[f"{tag}.image"] = lat_ref.numpy(), img_ref.numpy()
+    np.savez_compressed(os.path.join(HERE, "mapping.npz"), **out)
+
+
 RENDER_SUB = (slice(3, None, 8), slice(5, None, 8))  # stored pixels of every frame: rows 3::8, columns 5::8
 
 
@@ -182,6 +210,7 @@ def main():
     ap.add_argument("--full", action="store_true", help="also run the 256^2 / 1024^2 generators (minutes on CPU)")
     ap.add_argument("--only-perlin", action="store_true", help="(re)generate perlin.npz only")
     ap.add_argument("--only-render", action="store_true", help="(re)generate render_512.npz only")
+    ap.add_argument("--only-mapping", action="store_true", help="(re)generate mapping.npz only")
     args = ap.parse_args()
 
     ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
@@ -193,6 +222,9 @@ def main():
         return
     if args.only_render:
         render_fixture(ref_sg2, seeding, so)
+        return
+    if args.only_mapping:
+        mapping_fixture(ref_sg2, seeding, so)
         return
 
     # ------------------------------------------------------------------ (1) upfirdn2d
@@ -438,7 +470,10 @@ def main():
     # ------------------------------------------------------------------ (8) Perlin noise
     perlin_fixture(ref_latent, signal_oracle)
 
-    # ------------------------------------------------------------------ (9) render loop
+    # ------------------------------------------------------------------ (9) mapping network, z inputs
+    mapping_fixture(ref_sg2, seeding, so)
+
+    # ------------------------------------------------------------------ (10) render loop
     render_fixture(ref_sg2, seeding, so)
     print("done")
 

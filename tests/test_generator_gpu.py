@@ -134,3 +134,26 @@ def test_generator_512_channel_multiplier_1_vs_oracle(gpu):
     want = so.generator_forward(sd, lat, noise)
     got, _ = g(styles=lat.to(gpu), noise=[n.to(gpu) for n in noise], truncation=1.0, randomize_noise=False, input_is_latent=True)
     assert float((got.cpu() - want).abs().max()) < TOL
+
+
+def test_generator_z_inputs_vs_reference_golden(gpu, golden):
+    """The input_is_latent=False side of Generator.forward (mapping network on the device, one z or two z mixed at
+    inject_index, return_latents) against outputs of the reference generator (tests/golden/mapping.npz)."""
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    fx = golden("mapping.npz")
+    g = Generator(32, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(32, seed=3), strict=True)
+    g = g.to(gpu).eval()
+    z = torch.from_numpy(seeding.seeded_array(4, "z", (5, 512))).to(gpu)
+    np.testing.assert_allclose(g.get_latent(z).cpu().numpy(), fx["w"], atol=2e-4, rtol=1e-3)
+    z1 = torch.from_numpy(seeding.seeded_array(4, "z1", (2, 512))).to(gpu)
+    z2 = torch.from_numpy(seeding.seeded_array(4, "z2", (2, 512))).to(gpu)
+    noise = [n.to(gpu) for n in seeding.seeded_noise(2, 32, seed=9)]
+    for tag, zs, idx in (("one", [z1], None), ("mix", [z1, z2], int(fx["inject_index"]))):
+        img, lat = g(list(zs), return_latents=True, inject_index=idx, truncation=1.0, noise=list(noise),
+                     randomize_noise=False, input_is_latent=False)
+        assert tuple(lat.shape) == (2, g.n_latent, 512)
+        np.testing.assert_allclose(lat.cpu().numpy(), fx[f"{tag}.latents"], atol=2e-4, rtol=1e-3, err_msg=tag)
+        # 2e-3: the mapping network's own fp32 rounding (device GEMM vs CPU) feeds into the generator here
+        np.testing.assert_allclose(img.cpu().numpy(), fx[f"{tag}.image"], atol=2e-3, err_msg=tag)

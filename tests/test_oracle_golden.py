@@ -314,3 +314,19 @@ def test_oracle_frames_match_the_reference_render_loop(golden):
         diff = np.abs(frames[:, 3::8, 5::8, :].astype(np.int16) - g[f"{tag}.sub"].astype(np.int16))
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, tag
         assert np.abs(frames.reshape(n, -1).sum(1).astype(np.int64) - g[f"{tag}.sums"]).max() < 1e-4 * size * size * 3, tag
+
+
+def test_oracle_z_inputs_match_reference_golden(golden):
+    """mapping.npz: the reference's mapping network and its one- / two-z forwards (style mixing at inject_index 3) of a
+    seeded 32^2 generator (models/stylegan2.py:388-393,511-526)."""
+    fx = golden("mapping.npz")
+    sd = seeding.seeded_state_dict(32, seed=3)
+    z = torch.from_numpy(seeding.seeded_array(4, "z", (5, 512)))
+    np.testing.assert_allclose(so.mapping_network(sd, z).numpy(), fx["w"], atol=1e-6)
+    z1 = torch.from_numpy(seeding.seeded_array(4, "z1", (2, 512)))
+    z2 = torch.from_numpy(seeding.seeded_array(4, "z2", (2, 512)))
+    noise = seeding.seeded_noise(2, 32, seed=9)
+    for tag, zs, idx in (("one", [z1], None), ("mix", [z1, z2], int(fx["inject_index"]))):
+        lat = so.latents_from_z(sd, zs, 8, idx)
+        np.testing.assert_allclose(lat.numpy(), fx[f"{tag}.latents"], atol=1e-6)
+        np.testing.assert_allclose(so.generator_forward(sd, lat, noise).numpy(), fx[f"{tag}.image"], atol=1e-5)
