@@ -126,6 +126,47 @@ def mapping_fixture(ref_sg2, seeding, so):
     np.savez_compressed(os.path.join(HERE, "mapping.npz"), **out)
 
 
+class FlipX(torch.nn.Module):
+    def forward(self, x):
+        return x.flip(-1)
+
+
+class Gain(torch.nn.Module):
+    def __init__(self, gain):
+        super().__init__()
+        self.gain = gain
+
+    def forward(self, x):
+        return x * self.gain
+
+
+def bends_fixture(ref_sg2, seeding, so):
+    """Where the reference's ManipulationLayers sit (models/stylegan2.py:297-307, ids :417-449) and its route to a 2:1 frame:
+    transform_dict_list with torch-only transforms (kornia is absent) on a seeded 32^2 generator — ReplicationPad2d widening
+    the constant at layer 0 (examples/tauceti.py:97-100), a horizontal flip after conv1 (id 1), a gain after the second and
+    the last StyledConv (ids 3 and 7).  Noise maps are 2:1 to match."""
+    print("network bends: layer ids / wide output")
+    size, batch = 32, 2
+    sd = seeding.seeded_state_dict(size, seed=12)
+    g = ref_sg2.Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(sd, strict=True)
+    g.eval()
+    g.truncation_latent = torch.zeros(1, 512)
+    lat = seeding.seeded_latents(batch, g.n_latent, seed=13)
+    noise = [torch.from_numpy(seeding.seeded_array(14, f"wn{i}", (batch, 1, r, 2 * r))) for i, r in enumerate(seeding.noise_sizes(size))]
+    transforms = {0: torch.nn.ReplicationPad2d((2, 2, 0, 0)), 1: FlipX(), 3: Gain(0.5), 7: Gain(-1.25)}
+    tdl = [{"layer": k, "transform": v} for k, v in transforms.items()]
+    img_ref, _ = g(lat, noise=list(noise), truncation=torch.ones(batch), transform_dict_list=tdl, randomize_noise=False,
+                   input_is_latent=True)
+    assert tuple(img_ref.shape) == (batch, 3, size, 2 * size)
+    img_mine = so.generator_forward(sd, lat, noise, bends=transforms)
+    check("generator_forward(bends)", img_mine, img_ref, tol=1e-4)
+    plain = so.generator_forward(sd, lat, [nz[..., : nz.shape[-2]].contiguous() for nz in noise])
+    assert plain.shape[-1] == size  # (and the bends really change the picture)
+    np.savez_compressed(os.path.join(HERE, "bends.npz"), image=img_ref.numpy(), layers=np.array(sorted(transforms)),
+                        seeds=np.array([12, 13, 14]))
+
+
 RENDER_SUB = (slice(3, None, 8), slice(5, None, 8))  # stored pixels of every frame: rows 3::8, columns 5::8
 
 
@@ -211,6 +252,7 @@ def main():
     ap.add_argument("--only-perlin", action="store_true", help="(re)generate perlin.npz only")
     ap.add_argument("--only-render", action="store_true", help="(re)generate render_512.npz only")
     ap.add_argument("--only-mapping", action="store_true", help="(re)generate mapping.npz only")
+    ap.add_argument("--only-bends", action="store_true", help="(re)generate bends.npz only")
     args = ap.parse_args()
 
     ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
@@ -225,6 +267,9 @@ def main():
         return
     if args.only_mapping:
         mapping_fixture(ref_sg2, seeding, so)
+        return
+    if args.only_bends:
+        bends_fixture(ref_sg2, seeding, so)
         return
 
     # ------------------------------------------------------------------ (1) upfirdn2d
@@ -473,7 +518,10 @@ def main():
     # ------------------------------------------------------------------ (9) mapping network, z inputs
     mapping_fixture(ref_sg2, seeding, so)
 
-    # ------------------------------------------------------------------ (10) render loop
+    # ------------------------------------------------------------------ (10) network bends
+    bends_fixture(ref_sg2, seeding, so)
+
+    # ------------------------------------------------------------------ (11) render loop
     render_fixture(ref_sg2, seeding, so)
     print("done")
 

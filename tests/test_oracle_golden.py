@@ -330,3 +330,26 @@ def test_oracle_z_inputs_match_reference_golden(golden):
         lat = so.latents_from_z(sd, zs, 8, idx)
         np.testing.assert_allclose(lat.numpy(), fx[f"{tag}.latents"], atol=1e-6)
         np.testing.assert_allclose(so.generator_forward(sd, lat, noise).numpy(), fx[f"{tag}.image"], atol=1e-5)
+
+
+class _FlipX(torch.nn.Module):
+    def forward(self, x):
+        return x.flip(-1)
+
+
+def test_oracle_bend_placement_matches_reference_golden(golden):
+    """bends.npz: the reference generator with transform_dict_list entries at layer ids 0 (ReplicationPad2d widening the
+    constant: the 2:1 output route), 1, 3 and 7 — pins where the oracle applies bends and its wide-noise handling."""
+    fx = golden("bends.npz")
+    s_w, s_l, s_n = [int(v) for v in fx["seeds"]]
+    size, batch = 32, 2
+    sd = seeding.seeded_state_dict(size, seed=s_w)
+    lat = seeding.seeded_latents(batch, 8, seed=s_l)
+    noise = [torch.from_numpy(seeding.seeded_array(s_n, f"wn{i}", (batch, 1, r, 2 * r))) for i, r in enumerate(seeding.noise_sizes(size))]
+    bends = {0: torch.nn.ReplicationPad2d((2, 2, 0, 0)), 1: _FlipX(), 3: lambda t: t * 0.5, 7: lambda t: t * -1.25}
+    assert sorted(bends) == list(fx["layers"])
+    got = so.generator_forward(sd, lat, noise, bends=bends)
+    assert tuple(got.shape) == (batch, 3, size, 2 * size)
+    np.testing.assert_allclose(got.numpy(), fx["image"], atol=1e-5)
+    moved = so.generator_forward(sd, lat, noise, bends={0: bends[0], 2: bends[1], 3: bends[3], 7: bends[7]})
+    assert float((moved - got).abs().max()) > 1e-2  # the layer id matters
