@@ -1,0 +1,106 @@
+"""CPU: the Winograd identities the modconv kernel modes are built on (maua_stylegan2_amd/csrc/modconv.hip), checked in
+numpy against direct convolution.  These are the formulas in the kernel's comments / pack kernels — F(2,3) (mode 2), F(4,3)
+with interpolation points 0, +-1, +-2, inf (mode 3), F(2,2) on the even phase of the stride-2 transposed conv (mode 4) —
+plus the two-axis form of the latter that DESIGN.md §8 lists as the next step for the transposed layers."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def test_f23_pair_identity():
+    rng = np.random.default_rng(0)
+    d, g = rng.standard_normal(4), rng.standard_normal(3)
+    m0 = (d[0] - d[2]) * g[0]
+    m1 = (d[1] + d[2]) * (g[0] + g[1] + g[2]) / 2
+    m2 = (d[2] - d[1]) * (g[0] - g[1] + g[2]) / 2
+    m3 = (d[1] - d[3]) * g[2]
+    want = [d[0] * g[0] + d[1] * g[1] + d[2] * g[2], d[1] * g[0] + d[2] * g[1] + d[3] * g[2]]
+    np.testing.assert_allclose([m0 + m1 + m2, m1 - m2 - m3], want, atol=1e-12)
+
+
+def test_f43_quad_identity():
+    """B^T d, G g, A^T m exactly as written in the mode-3 branch and pack_weight_wino43_kernel."""
+    rng = np.random.default_rng(1)
+    d, g = rng.standard_normal(6), rng.standard_normal(3)
+    t = [4 * d[0] - 5 * d[2] + d[4],
+         (d[4] - 4 * d[2]) + (d[3] - 4 * d[1]), (d[4] - 4 * d[2]) - (d[3] - 4 * d[1]),
+         (d[4] - d[2]) + 2 * (d[3] - d[1]), (d[4] - d[2]) - 2 * (d[3] - d[1]),
+         4 * d[1] - 5 * d[3] + d[5]]
+    u = [g[0] / 4, -(g[0] + g[1] + g[2]) / 6, -(g[0] - g[1] + g[2]) / 6,
+         (g[0] + 2 * g[1] + 4 * g[2]) / 24, (g[0] - 2 * g[1] + 4 * g[2]) / 24, g[2]]
+    m = [a * b for a, b in zip(t, u)]
+    y = [m[0] + m[1] + m[2] + m[3] + m[4], (m[1] - m[2]) + 2 * (m[3] - m[4]), (m[1] + m[2]) + 4 * (m[3] + m[4]),
+         (m[1] - m[2]) + 8 * (m[3] - m[4]) + m[5]]
+    want = [sum(d[i + k] * g[k] for k in range(3)) for i in range(4)]
+    np.testing.assert_allclose(y, want, atol=1e-12)
+
+
+def _upconv_direct(x, g):
+    return F.conv_transpose2d(torch.from_numpy(x)[None, None], torch.from_numpy(g)[None, None], stride=2)[0, 0].numpy()
+
+
+def _pad_get(x, i, j):
+    h, w = x.shape
+    return x[i, j] if 0 <= i < h and 0 <= j < w else 0.0
+
+
+def test_transposed_f22_even_phase_one_axis():
+    """Mode 4: per kernel row (g0, g1, g2) and position pair (p, p+1) with d0 = x[p-1], d1 = x[p], d2 = x[p+1]:
+    even outputs (m0 + m1, m1 + m2) from m0 = g2 (d0 - d1), m1 = (g0 + g2) d1, m2 = g0 (d2 - d1); odd outputs g1 d1, g1 d2.
+    5 products instead of 6 per pair."""
+    rng = np.random.default_rng(2)
+    x, g = rng.standard_normal((5, 6)), rng.standard_normal((3, 3))
+    want = _upconv_direct(x, g)
+    got = np.zeros_like(want)
+    h, w = x.shape
+    for i in range(h + 1):                     # position grid (H+1) x (W+2)/2 pairs, zero padded
+        for p in range(0, w + 2, 2):
+            for ky in range(3):
+                r = i - 1 if ky == 2 else i    # kernel row 2 reads the input row above
+                oy = 2 * i + (1 if ky == 1 else 0)
+                d0, d1, d2 = _pad_get(x, r, p - 1), _pad_get(x, r, p), _pad_get(x, r, p + 1)
+                g0, g1, g2 = g[ky]
+                m0, m1, m2 = g2 * (d0 - d1), (g0 + g2) * d1, g0 * (d2 - d1)
+                for ox, v in ((2 * p, m0 + m1), (2 * p + 1, g1 * d1), (2 * p + 2, m1 + m2), (2 * p + 3, g1 * d2)):
+                    if oy < want.shape[0] and ox < want.shape[1]:
+                        got[oy, ox] += v
+    np.testing.assert_allclose(got, want, atol=1e-12)
+
+
+def test_transposed_f22_both_axes_needs_25_products_per_block():
+    """The two-axis form: a 2x2 block of positions (rows i, i+1; columns p, p+1) reads the 3x3 input window around it and
+    produces its 4x4 outputs from 9 (even, even) + 6 (even, odd) + 6 (odd, even) + 4 (odd, odd) = 25 products — 6.25 per
+    input position against 9 for the plain polyphase form and 7.5 for mode 4."""
+    rng = np.random.default_rng(3)
+    x, g = rng.standard_normal((6, 8)), rng.standard_normal((3, 3))
+    want = _upconv_direct(x, g)
+    got = np.zeros((want.shape[0] + 3, want.shape[1] + 3))
+    tin = np.array([[1.0, -1.0, 0.0], [0.0, 1.0, 0.0], [0.0, -1.0, 1.0]])   # (d0 - d1, d1, d2 - d1)
+    tker = lambda k: np.array([k[2], k[0] + k[2], k[0]])                     # (g2, g0 + g2, g0)  # noqa: E731
+    tout = np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 1.0]])                      # (m0 + m1, m1 + m2)
+    products = 0
+    h, w = x.shape
+    for i in range(0, h + 2, 2):
+        for p in range(0, w + 2, 2):
+            d = np.array([[_pad_get(x, i - 1 + a, p - 1 + b) for b in range(3)] for a in range(3)])
+            # even rows x even columns: kernel taps {0,2} x {0,2}; transformed tap a of an axis collects taps sel[a]
+            sel = ([2], [0, 2], [0])
+            kee = np.array([[g[np.ix_(sel[a], sel[b])].sum() for b in range(3)] for a in range(3)])
+            ee = tout @ ((tin @ d @ tin.T) * kee) @ tout.T
+            # even rows x odd columns: taps {0,2} x {1}; the columns use d1, d2 directly
+            keo = tker(g[:, 1])
+            eo = tout @ ((tin @ d[:, 1:]) * keo[:, None])
+            # odd rows x even columns: taps {1} x {0,2}
+            koe = tker(g[1, :])
+            oe = ((d[1:, :] @ tin.T) * koe[None, :]) @ tout.T
+            oo = d[1:, 1:] * g[1, 1]
+            products += 9 + 6 + 6 + 4
+            for a in range(2):
+                for b in range(2):
+                    got[2 * (i + a), 2 * (p + b)] += ee[a, b]
+                    got[2 * (i + a), 2 * (p + b) + 1] += eo[a, b]
+                    got[2 * (i + a) + 1, 2 * (p + b)] += oe[a, b]
+                    got[2 * (i + a) + 1, 2 * (p + b) + 1] += oo[a, b]
+    np.testing.assert_allclose(got[: want.shape[0], : want.shape[1]], want, atol=1e-12)
+    blocks = ((h + 2) // 2) * ((w + 2) // 2)
+    assert products == 25 * blocks
