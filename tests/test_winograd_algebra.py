@@ -104,3 +104,25 @@ def test_transposed_f22_both_axes_needs_25_products_per_block():
     np.testing.assert_allclose(got[: want.shape[0], : want.shape[1]], want, atol=1e-12)
     blocks = ((h + 2) // 2) * ((w + 2) // 2)
     assert products == 25 * blocks
+
+
+def test_two_axis_f23_by_f43_is_24_products_per_8_outputs():
+    """F(2,3) along y nested with F(4,3) along x: Y = Ay^T [(Gy g Gx^T) * (By^T d Bx)] Ax on a
+    4 x 6 input window gives the 2 x 4 outputs of the 3x3 correlation from 4 x 6 = 24 products (3 per output; the
+    one-axis F(4,3) of mode 3 needs 4.5)."""
+    bt2 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    g2 = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]])
+    at2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    bt4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+    g4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                   [0, 0, 1]])
+    at4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+    rng = np.random.default_rng(4)
+    d, g = rng.standard_normal((4, 6)), rng.standard_normal((3, 3))
+    u = g2 @ g @ g4.T          # [4, 6] transformed kernel
+    v = bt2 @ d @ bt4.T        # [4, 6] transformed window
+    assert u.shape == v.shape == (4, 6)
+    y = at2 @ (u * v) @ at4.T  # [2, 4]
+    want = np.array([[(d[i:i + 3, j:j + 3] * g).sum() for j in range(4)] for i in range(2)])
+    np.testing.assert_allclose(y, want, atol=1e-11)
