@@ -126,6 +126,22 @@ def mapping_fixture(ref_sg2, seeding, so):
     np.savez_compressed(os.path.join(HERE, "mapping.npz"), **out)
 
 
+def meta_fixture(ref_sg2):
+    """Shape bookkeeping of the reference Generator constructor (models/stylegan2.py:395-470): n_latent, num_layers and
+    the noise-buffer shapes after the output_size / base_res_factor resize (:461-470) that load_generator relies on for
+    1920 / 1080 output (generate_audiovisual.py:37-56)."""
+    print("generator constructor bookkeeping")
+    rows = []
+    for size, output_size, factor in [(32, 32, 1), (32, 1920, 1), (32, 1080, 1), (64, 1024, 1), (64, 64, 2), (32, 1920, 0.5),
+                                      (128, 128, 1), (256, 1080, 1)]:
+        g = ref_sg2.Generator(size, 512, 2, channel_multiplier=2, constant_input=True, output_size=output_size,
+                              base_res_factor=factor)
+        shapes = [tuple(getattr(g.noises, f"noise_{i}").shape[-2:]) for i in range(g.num_layers)]
+        flat = [v for hw in shapes for v in hw]
+        rows.append([size, output_size, int(round(factor * 100)), g.n_latent, g.num_layers] + flat + [0] * (40 - len(flat)))
+    np.savez_compressed(os.path.join(HERE, "generator_meta.npz"), rows=np.array(rows, dtype=np.int64))
+
+
 class FlipX(torch.nn.Module):
     def forward(self, x):
         return x.flip(-1)
@@ -253,6 +269,7 @@ def main():
     ap.add_argument("--only-render", action="store_true", help="(re)generate render_512.npz only")
     ap.add_argument("--only-mapping", action="store_true", help="(re)generate mapping.npz only")
     ap.add_argument("--only-bends", action="store_true", help="(re)generate bends.npz only")
+    ap.add_argument("--only-meta", action="store_true", help="(re)generate generator_meta.npz only")
     args = ap.parse_args()
 
     ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
@@ -270,6 +287,9 @@ def main():
         return
     if args.only_bends:
         bends_fixture(ref_sg2, seeding, so)
+        return
+    if args.only_meta:
+        meta_fixture(ref_sg2)
         return
 
     # ------------------------------------------------------------------ (1) upfirdn2d
@@ -518,7 +538,10 @@ def main():
     # ------------------------------------------------------------------ (9) mapping network, z inputs
     mapping_fixture(ref_sg2, seeding, so)
 
-    # ------------------------------------------------------------------ (10) network bends
+    # ------------------------------------------------------------------ (10) constructor bookkeeping
+    meta_fixture(ref_sg2)
+
+    # ------------------------------------------------------------------ (10b) network bends
     bends_fixture(ref_sg2, seeding, so)
 
     # ------------------------------------------------------------------ (11) render loop

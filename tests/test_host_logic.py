@@ -243,3 +243,18 @@ def test_ar_namespace_covers_the_shipped_example_plugins(tmp_path, monkeypatch):
     assert ar.plot_signals([np.sin(np.linspace(0, 6, 100)), torch.linspace(0, 1, 50)]).endswith("signals.png")
     assert ar.plot_spectra([np.random.rand(40, 80), np.random.rand(30, 12)], chroma=True).endswith("spectra.png")
     assert (tmp_path / "workspace" / "signals.png").stat().st_size > 0
+
+
+def test_generator_constructor_bookkeeping_matches_reference(built_lib, golden):
+    """n_latent, num_layers and the noise-buffer shapes after the output_size / base_res_factor resize
+    (reference models/stylegan2.py:395-470) for square, 1920 (2:1), 1080 (1:2) and scaled configurations."""
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    for row in golden("generator_meta.npz")["rows"]:
+        size, output_size, factor100, n_latent, num_layers = [int(v) for v in row[:5]]
+        g = Generator(size, 512, 2, channel_multiplier=2, constant_input=True, output_size=output_size,
+                      base_res_factor=factor100 / 100)
+        assert (g.n_latent, g.num_layers) == (n_latent, num_layers)
+        want = [tuple(int(v) for v in row[5 + 2 * i: 7 + 2 * i]) for i in range(num_layers)]
+        got = [tuple(getattr(g.noises, f"noise_{i}").shape[-2:]) for i in range(num_layers)]
+        assert got == want, (size, output_size, factor100)
