@@ -126,6 +126,50 @@ def mapping_fixture(ref_sg2, seeding, so):
     np.savez_compressed(os.path.join(HERE, "mapping.npz"), **out)
 
 
+def signatures_fixture(ref_sg2, ref_op, ref_signal, ref_latent, ref_gav):
+    """Parameter names and (simple) defaults of the reference's public callables on the path, read with inspect from the
+    imported reference: the interface the drop-in mirrors.  Data only: {qualified name: [[param, default
+    repr or null], ...]}."""
+    import inspect
+    import json
+
+    import render as ref_render  # noqa
+
+    def describe(fn):
+        out = []
+        for name, prm in inspect.signature(fn).parameters.items():
+            if name == "self":
+                continue
+            d = prm.default
+            simple = d is None or isinstance(d, (bool, int, float, str, tuple, list, dict))
+            out.append([name, None if d is inspect.Parameter.empty else (repr(d) if simple else "<object>")])
+        return out
+
+    table = {
+        "generate_audiovisual.generate": describe(ref_gav.generate),
+        "generate_audiovisual.get_noise_range": describe(ref_gav.get_noise_range),
+        "generate_audiovisual.load_generator": describe(ref_gav.load_generator),
+        "render.render": describe(ref_render.render),
+        "op.upfirdn2d": describe(ref_op.upfirdn2d),
+        "op.fused_leaky_relu": describe(ref_op.fused_leaky_relu),
+        "op.FusedLeakyReLU.__init__": describe(ref_op.FusedLeakyReLU.__init__),
+    }
+    for cls in ("Generator", "ModulatedConv2d", "StyledConv", "ToRGB", "EqualLinear", "Blur", "Upsample", "NoiseInjection",
+                "ConstantInput", "ManipulationLayer"):
+        c = getattr(ref_sg2, cls)
+        table[f"models.stylegan2.{cls}.__init__"] = describe(c.__init__)
+        table[f"models.stylegan2.{cls}.forward"] = describe(c.forward)
+    for name in ("onsets", "rms", "raw_chroma", "chroma", "laplacian_segmentation", "normalize", "percentile", "percentile_clip",
+                 "compress", "expand", "gaussian_filter", "load_audio", "set_SMF"):
+        table[f"audioreactive.signal.{name}"] = describe(getattr(ref_signal, name))
+    for name in ("chroma_weight_latents", "slerp", "slerp_loops", "spline_loops", "wrapping_slice", "generate_latents",
+                 "save_latents", "load_latents", "perlin_noise"):
+        table[f"audioreactive.latent.{name}"] = describe(getattr(ref_latent, name))
+    with open(os.path.join(HERE, "signatures.json"), "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    print(f"signatures: {len(table)} callables")
+
+
 def meta_fixture(ref_sg2):
     """Shape bookkeeping of the reference Generator constructor (models/stylegan2.py:395-470): n_latent, num_layers and
     the noise-buffer shapes after the output_size / base_res_factor resize (:461-470) that load_generator relies on for
@@ -270,6 +314,7 @@ def main():
     ap.add_argument("--only-mapping", action="store_true", help="(re)generate mapping.npz only")
     ap.add_argument("--only-bends", action="store_true", help="(re)generate bends.npz only")
     ap.add_argument("--only-meta", action="store_true", help="(re)generate generator_meta.npz only")
+    ap.add_argument("--only-signatures", action="store_true", help="(re)generate signatures.json only")
     args = ap.parse_args()
 
     ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
@@ -290,6 +335,9 @@ def main():
         return
     if args.only_meta:
         meta_fixture(ref_sg2)
+        return
+    if args.only_signatures:
+        signatures_fixture(ref_sg2, ref_op, ref_signal, ref_latent, ref_gav)
         return
 
     # ------------------------------------------------------------------ (1) upfirdn2d
@@ -537,6 +585,9 @@ def main():
 
     # ------------------------------------------------------------------ (9) mapping network, z inputs
     mapping_fixture(ref_sg2, seeding, so)
+
+    # ------------------------------------------------------------------ (9b) interface signatures
+    signatures_fixture(ref_sg2, ref_op, ref_signal, ref_latent, ref_gav)
 
     # ------------------------------------------------------------------ (10) constructor bookkeeping
     meta_fixture(ref_sg2)

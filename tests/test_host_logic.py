@@ -258,3 +258,39 @@ def test_generator_constructor_bookkeeping_matches_reference(built_lib, golden):
         want = [tuple(int(v) for v in row[5 + 2 * i: 7 + 2 * i]) for i in range(num_layers)]
         got = [tuple(getattr(g.noises, f"noise_{i}").shape[-2:]) for i in range(num_layers)]
         assert got == want, (size, output_size, factor100)
+
+
+def test_interface_signatures_match_reference_fixture(built_lib):
+    """tests/golden/signatures.json records, with inspect from the imported reference, the parameter names and defaults of
+    49 callables on the path (generate, render, the ops, every generator module's __init__ / forward, the audioreactive
+    signal and latent functions).  The drop-in's mirrors must lead with exactly those parameters and defaults; the only
+    additions allowed are trailing keyword extensions (``device=`` on the envelope functions, ``gradients=`` on
+    perlin_noise)."""
+    import json
+
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import op, render
+    from maua_stylegan2_amd.audioreactive import latent, signal
+    from maua_stylegan2_amd.models import stylegan2
+
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "signatures.json")))
+    assert len(table) >= 49
+    roots = {"generate_audiovisual": gav, "render": render, "op": op, "models.stylegan2": stylegan2,
+             "audioreactive.signal": signal, "audioreactive.latent": latent}
+    extensions = {"audioreactive.signal.onsets": ["device"], "audioreactive.signal.rms": ["device"],
+                  "audioreactive.signal.chroma": ["device"], "audioreactive.latent.perlin_noise": ["gradients"]}
+    for qualified, ref_params in table.items():
+        root = max((r for r in roots if qualified.startswith(r + ".")), key=len)
+        obj = roots[root]
+        for part in qualified[len(root) + 1:].split("."):
+            obj = getattr(obj, part)
+        mine = [(n, p.default) for n, p in inspect.signature(obj).parameters.items() if n != "self"]
+        names = [n for n, _ in mine]
+        ref_names = [p[0] for p in ref_params]
+        assert names[: len(ref_names)] == ref_names, qualified
+        assert names[len(ref_names):] == extensions.get(qualified, []), qualified
+        for (name, default), (_, ref_default) in zip(mine, ref_params):
+            if ref_default == "<object>":
+                continue
+            have = None if default is inspect.Parameter.empty else repr(default)
+            assert have == ref_default, (qualified, name, have, ref_default)
