@@ -165,6 +165,10 @@ def signatures_fixture(ref_sg2, ref_op, ref_signal, ref_latent, ref_gav):
     for name in ("chroma_weight_latents", "slerp", "slerp_loops", "spline_loops", "wrapping_slice", "generate_latents",
                  "save_latents", "load_latents", "perlin_noise"):
         table[f"audioreactive.latent.{name}"] = describe(getattr(ref_latent, name))
+    import audioreactive.bend as ref_bend  # noqa  (kornia is a stub module: only the constructors' signatures are read)
+
+    for cls in ("NetworkBend", "AddNoise", "Translate", "Zoom", "Rotate"):
+        table[f"audioreactive.bend.{cls}.__init__"] = describe(getattr(ref_bend, cls).__init__)
     with open(os.path.join(HERE, "signatures.json"), "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     print(f"signatures: {len(table)} callables")

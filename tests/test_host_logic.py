@@ -262,21 +262,21 @@ def test_generator_constructor_bookkeeping_matches_reference(built_lib, golden):
 
 def test_interface_signatures_match_reference_fixture(built_lib):
     """tests/golden/signatures.json records, with inspect from the imported reference, the parameter names and defaults of
-    49 callables on the path (generate, render, the ops, every generator module's __init__ / forward, the audioreactive
-    signal and latent functions).  The drop-in's mirrors must lead with exactly those parameters and defaults; the only
+    54 callables on the path (generate, render, the ops, every generator module's __init__ / forward, the audioreactive
+    signal and latent functions, the bend constructors).  The drop-in's mirrors must lead with exactly those parameters and defaults; the only
     additions allowed are trailing keyword extensions (``device=`` on the envelope functions, ``gradients=`` on
     perlin_noise)."""
     import json
 
     from maua_stylegan2_amd import generate_audiovisual as gav
     from maua_stylegan2_amd import op, render
-    from maua_stylegan2_amd.audioreactive import latent, signal
+    from maua_stylegan2_amd.audioreactive import bend, latent, signal
     from maua_stylegan2_amd.models import stylegan2
 
     table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "signatures.json")))
-    assert len(table) >= 49
+    assert len(table) >= 54
     roots = {"generate_audiovisual": gav, "render": render, "op": op, "models.stylegan2": stylegan2,
-             "audioreactive.signal": signal, "audioreactive.latent": latent}
+             "audioreactive.signal": signal, "audioreactive.latent": latent, "audioreactive.bend": bend}
     extensions = {"audioreactive.signal.onsets": ["device"], "audioreactive.signal.rms": ["device"],
                   "audioreactive.signal.chroma": ["device"], "audioreactive.latent.perlin_noise": ["gradients"]}
     for qualified, ref_params in table.items():
