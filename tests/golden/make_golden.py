@@ -188,6 +188,15 @@ def meta_fixture(ref_sg2):
         flat = [v for hw in shapes for v in hw]
         rows.append([size, output_size, int(round(factor * 100)), g.n_latent, g.num_layers] + flat + [0] * (40 - len(flat)))
     np.savez_compressed(os.path.join(HERE, "generator_meta.npz"), rows=np.array(rows, dtype=np.int64))
+    import json
+
+    layout = {}
+    for size in (256, 1024):  # the two checkpoints of BASELINE.json's configs
+        g = ref_sg2.Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+        layout[str(size)] = [[k, list(v.shape)] for k, v in g.state_dict().items()]
+    with open(os.path.join(HERE, "state_dict_layout.json"), "w") as f:
+        json.dump(layout, f)
+    print("state dict layout:", {k: len(v) for k, v in layout.items()}, "tensors")
 
 
 class FlipX(torch.nn.Module):

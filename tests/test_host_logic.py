@@ -91,6 +91,22 @@ def test_state_dict_keys_equal_seeded_layout(built_lib):
         assert (g.n_latent, g.num_layers) == (2 * int(np.log2(size)) - 2, 2 * (int(np.log2(size)) - 2) + 1)
 
 
+def test_state_dict_layout_equals_reference_fixture(built_lib):
+    """tests/golden/state_dict_layout.json: keys (in order) and shapes of the reference Generator's state dict at 256^2
+    (135 tensors) and 1024^2 (171 tensors) — what th.load(ckpt)["g_ema"] holds (models/stylegan2.py:458-459)."""
+    import json
+
+    from maua_stylegan2_amd import seeding
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    layout = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_layout.json")))
+    for size, want in layout.items():
+        g = Generator(int(size), 512, 8, channel_multiplier=2, constant_input=True)
+        got = [[k, list(v.shape)] for k, v in g.state_dict().items()]
+        assert got == want, size
+        assert {k: list(v) for k, v in seeding.generator_tensor_shapes(int(size)).items()} == {k: v for k, v in want}, size
+
+
 def test_filterbanks_match_oracle(built_lib):
     from maua_stylegan2_amd.audioreactive import signal as sig
 
