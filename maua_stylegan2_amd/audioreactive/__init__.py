@@ -6,3 +6,4 @@ from .latent import *  # noqa: F401,F403
 from .signal import *  # noqa: F401,F403
 from .signal import set_SMF  # noqa: F401
 from .util import *  # noqa: F401,F403
+from ..models.stylegan2 import Generator  # noqa: F401,E402  (the reference's latent.py leaks it into ar.* through its star import)

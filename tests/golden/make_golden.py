@@ -169,6 +169,23 @@ def signatures_fixture(ref_sg2, ref_op, ref_signal, ref_latent, ref_gav):
 
     for cls in ("NetworkBend", "AddNoise", "Translate", "Zoom", "Rotate"):
         table[f"audioreactive.bend.{cls}.__init__"] = describe(getattr(ref_bend, cls).__init__)
+    # every ``ar.<name>`` / ``ar.<name>(...)`` attribute the reference's shipped plugins touch, and everything its
+    # audioreactive package star-exports: the namespace an unmodified plugin file expects to find
+    import ast
+
+    used = set()
+    ex_dir = os.path.join(REF, "audioreactive", "examples")
+    for fname in sorted(os.listdir(ex_dir)):
+        if fname.endswith(".py"):
+            for node in ast.walk(ast.parse(open(os.path.join(ex_dir, fname)).read())):
+                if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id == "ar":
+                    used.add(node.attr)
+    import audioreactive as ref_ar  # noqa
+
+    third_party = ("scipy", "numpy", "torch", "sklearn", "librosa", "madmom", "kornia", "matplotlib", "joblib", "builtins")
+    exported = sorted(n for n in dir(ref_ar) if not n.startswith("_") and callable(getattr(ref_ar, n))
+                      and not str(getattr(getattr(ref_ar, n), "__module__", "")).startswith(third_party))
+    table["__namespace__"] = {"used_by_example_plugins": sorted(used), "exported_callables": exported}
     with open(os.path.join(HERE, "signatures.json"), "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     print(f"signatures: {len(table)} callables")

@@ -295,6 +295,10 @@ def test_interface_signatures_match_reference_fixture(built_lib):
              "audioreactive.signal": signal, "audioreactive.latent": latent, "audioreactive.bend": bend}
     extensions = {"audioreactive.signal.onsets": ["device"], "audioreactive.signal.rms": ["device"],
                   "audioreactive.signal.chroma": ["device"], "audioreactive.latent.perlin_noise": ["gradients"]}
+    namespace = table.pop("__namespace__")
+    import maua_stylegan2_amd.audioreactive as ar
+
+    assert [n for n in namespace["used_by_example_plugins"] + namespace["exported_callables"] if not hasattr(ar, n)] == []
     for qualified, ref_params in table.items():
         root = max((r for r in roots if qualified.startswith(r + ".")), key=len)
         obj = roots[root]
