@@ -146,7 +146,13 @@ def cpu_baseline(size, max_seconds=25.0):
         if time.perf_counter() - t0 > max_seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), cpu_model)
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model, "kind": "port",
             "sample": f"{n} frames of {size}x{size}, batch 1, oracle/stylegan2_oracle.py (torch CPU fp32)"}
 
 
