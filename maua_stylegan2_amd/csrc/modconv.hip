@@ -336,6 +336,90 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             // B^T d for F(4,3) (interpolation points 0, +-1, +-2, inf) on six consecutive patch floats:
             //   t0 = 4 d0 - 5 d2 + d4          t1 = (d4 - 4 d2) + (d3 - 4 d1)     t2 = (d4 - 4 d2) - (d3 - 4 d1)
             //   t5 = 4 d1 - 5 d3 + d5          t3 = (d4 - d2) + 2 (d3 - d1)       t4 = (d4 - d2) - 2 (d3 - d1)
+#ifdef MAUA_W43_PIPE
+            // EXPERIMENT (not built by default; tools/build_exp.sh w43pipe -DMAUA_W43_PIPE): explicit software pipeline over
+            // the (ky, channel pair) groups of a chunk.  In the default schedule (tools/isa_mix.py, profiles/r01_isa_modconv.md)
+            // every group starts with "B reads -> wait -> 13 VALU -> first MFMA" and every frequency with "A read -> wait ->
+            // MFMA": two LDS round trips and ~80 VALU cycles with at most two MFMAs (128 cycles) in flight.  Here the raw
+            // window of group g+1 is read under the first MFMAs of group g, transformed under its middle ones, and the weight
+            // row of the next frequency is read one step ahead; sched_barrier(0) pins that order.
+            constexpr int NG = 3 * (CC / 2);
+            float bvp[2][TN][6];
+            f32x2 raw[TN][3];
+            auto read_raw = [&](int gq) {
+                const int ky = gq / (CC / 2), q = gq % (CC / 2);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const float* dp = Pc + 2 * q * g.PSTRIDE + boff[n] + ky * g.PWS;
+                    raw[n][0] = *reinterpret_cast<const f32x2*>(dp);
+                    raw[n][1] = *reinterpret_cast<const f32x2*>(dp + 2);
+                    raw[n][2] = *reinterpret_cast<const f32x2*>(dp + 4);
+                }
+            };
+            auto transform = [&](int gq, float (&bv)[TN][6]) {
+                const int q = gq % (CC / 2);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const f32x2 d01 = raw[n][0], d23 = raw[n][1], d45 = raw[n][2];
+                    float a_ = fmaf(-4.f, d23.x, d45.x);
+                    asm volatile("" : "+v"(a_));
+                    const float b_ = fmaf(-4.f, d01.y, d23.y);
+                    const float c_ = d45.x - d23.x, e_ = d23.y - d01.y;
+                    bv[n][0] = fmaf(4.f, d01.x, fmaf(-5.f, d23.x, d45.x));
+                    bv[n][1] = a_ + b_;
+                    bv[n][2] = a_ - b_;
+                    bv[n][3] = fmaf(2.f, e_, c_);
+                    bv[n][4] = fmaf(-2.f, e_, c_);
+                    bv[n][5] = fmaf(4.f, d01.y, fmaf(-5.f, d23.y, d45.y));
+                    if (Sc) {
+                        const float sc = Sc[2 * q + hi];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) bv[n][k] *= sc;
+                    }
+                }
+            };
+            auto read_a = [&](int step, float (&a)[TM]) {  // step = gq * 6 + xi
+                const int gq = step / 6, xi = step % 6;
+                const int ky = gq / (CC / 2), q = gq % (CC / 2);
+                if (TM == 2) {
+                    const f32x2 a2 = *reinterpret_cast<const f32x2*>(Ac + ((ky * 6 + xi) * CC + 2 * q) * BM + aoff2);
+                    a[0] = a2.x, a[TM - 1] = a2.y;
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 6 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
+                }
+            };
+            float a_cur[TM], a_nxt[TM];
+            read_raw(0);
+            read_a(0, a_cur);
+            transform(0, bvp[0]);
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                const int ky = gq / (CC / 2);
+                (void)ky;
+#pragma unroll
+                for (int xi = 0; xi < 6; ++xi) {
+                    const int step = gq * 6 + xi;
+                    if (step + 1 < NG * 6) read_a(step + 1, a_nxt);
+                    if (xi == 0 && gq + 1 < NG) read_raw(gq + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+                            acc[mt][n * NPH + xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], bvp[gq & 1][n][xi],
+                                                                                         acc[mt][n * NPH + xi], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (xi == 2 && gq + 1 < NG) {
+                        transform(gq + 1, bvp[(gq + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) a_cur[mt] = a_nxt[mt];
+                }
+            }
+            return;
+#endif
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
