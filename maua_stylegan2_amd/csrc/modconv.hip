@@ -36,6 +36,11 @@
 
 #include <type_traits>
 
+// (experiments, see profiles/r01_isa_modconv.md) the buffer-descriptor builtins only exist in the device pass
+#if defined(MAUA_DMA_BUFFER) && defined(__HIP_DEVICE_COMPILE__)
+#define MAUA_DMA_BUFFER_DEV 1
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -556,17 +561,31 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int tap = row / CC, c = row - tap * CC;
             a_goff[k] = row < NTAPS * CC ? (tap * g.Cin + c) * g.CoutPad + col : -1;  // -1: lane past the tile, masked off
         }
+#ifdef MAUA_DMA_BUFFER_DEV
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
+#endif
         auto issue_dma = [&](int chunk, int buf) {
             const char* wbase = reinterpret_cast<const char*>(p.wp + (size_t)chunk * CC * g.CoutPad + m0);  // uniform
+            (void)wbase;
             float* dst = As + buf * A_FLOATS;
 #pragma unroll
             for (int k = 0; k < A_PER_WAVE; ++k) {
                 const int i = wave + 4 * k;  // scalar
                 constexpr bool RAGGED = (NTAPS * CC) % RPI != 0;  // only then can lanes of the last instruction be masked
                 if (i < A_INSTR && (!RAGGED || a_goff[k] >= 0))
+#ifdef MAUA_DMA_BUFFER_DEV
+                    // EXPERIMENT (tools/build_exp.sh ... -DMAUA_DMA_BUFFER): the same DMA as a MUBUF `buffer_load ... lds`.
+                    // While a FLAT-encoded global_load_lds is in flight the compiler's wait insertion treats the LGKM counter
+                    // as out of order and turns EVERY LDS wait of the chunk into lgkmcnt(0) (profiles/r01_isa_modconv.md);
+                    // with the buffer form it emits partial counts again, which is what look-ahead LDS reads need.
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        w_rsrc, (__attribute__((address_space(3))) void*)(dst + i * 256), 16, a_goff[k] * 4,
+                        (int)(((size_t)chunk * CC * g.CoutPad + m0) * 4), 0, 0);
+#else
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(wbase + (unsigned)a_goff[k] * 4u),
                         (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+#endif
             }
         };
         auto load_patch = [&](int chunk) {
@@ -632,6 +651,11 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 rel_bytes[i] = pvalid[i] ? (unsigned)(src_off[i] - b0 * g.Cin * (int)plane_in) * 4u : 0u;
             const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * g.Cin * plane_in);
             const size_t plane_bytes = plane_in * sizeof(float);
+#ifdef MAUA_DMA_BUFFER_DEV
+            // one image's features (Cin planes, < 2 GiB: checked on the host) behind a raw buffer descriptor
+            const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
+#endif
             auto issue_patch = [&](int chunk, int buf) {
                 float* dst = Ps + buf * PBUF + wave * 64;
                 const char* xc = ximg + (size_t)(chunk * CC) * plane_bytes;  // uniform
@@ -640,9 +664,15 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                     for (int i = 0; i < MAX_POS; ++i)
                         if (pvalid[i])
+#ifdef MAUA_DMA_BUFFER_DEV
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                x_rsrc, (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE + i * 256), 4,
+                                (int)rel_bytes[i], (int)((size_t)(chunk * CC + c) * plane_bytes), 0, 0);
+#else
                             __builtin_amdgcn_global_load_lds(
                                 (const __attribute__((address_space(1))) void*)(xc + rel_bytes[i]),
                                 (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE + i * 256), 4, 0, 0);
+#endif
                     xc += plane_bytes;
                 }
             };

@@ -11,6 +11,14 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # kernel experiments: MAUA_TEST_LIB=tools/bin/libmaua_<name>.so (tools/build_exp.sh) runs the same suite against a variant
+    # build of the library; unset (the driver's runs), the in-tree csrc/libmaua_hip.so is what loads
+    alt = os.environ.get("MAUA_TEST_LIB")
+    if alt:
+        from maua_stylegan2_amd import _lib
+
+        _lib.LIB_PATH = os.path.abspath(alt)
+        print(f"[conftest] MAUA_TEST_LIB -> {_lib.LIB_PATH}")
 
 
 @pytest.fixture(scope="session")
