@@ -515,6 +515,55 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             }
             return;
         }
+#ifdef MAUA_TAP_PIPE
+        {
+            // EXPERIMENT (see MAUA_W43_PIPE above): one-step look-ahead of both operands over the 9 x CC/2 (tap, channel pair)
+            // steps of the direct / polyphase branch; the style multiply of the next B operand runs behind the current MFMAs.
+            constexpr int NS = 9 * (CC / 2);
+            float a_c[TM], b_c[TN], a_n[TM], b_n[TN];
+            auto fetch = [&](int st, float (&a)[TM], float (&b)[TN]) {
+                const int tap = st / (CC / 2), q = st % (CC / 2);
+                const int ky = tap / 3, kx = tap % 3;
+                const int dy = UP ? (ky == 2 ? 0 : 1) : ky;
+                const int dx = UP ? (kx == 2 ? 0 : 1) : kx;
+                const int tapoff = dy * g.PWS + dx;
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[(tap * CC + 2 * q) * BM + mt * 32 + aoff];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) b[n] = Pc[2 * q * g.PSTRIDE + boff[n] + tapoff];
+            };
+            auto scale = [&](int st, float (&b)[TN]) {
+                if (Sc) {
+                    const float sc = Sc[2 * (st % (CC / 2)) + hi];
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) b[n] *= sc;
+                }
+            };
+            fetch(0, a_c, b_c);
+            scale(0, b_c);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int tap = st / (CC / 2);
+                const int ky = tap / 3, kx = tap % 3;
+                const int ph = UP ? ((ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0)) : 0;
+                if (st + 1 < NS) fetch(st + 1, a_n, b_n);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[mt][n * NPH + ph] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[mt], b_c[n], acc[mt][n * NPH + ph], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NS) scale(st + 1, b_n);
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) a_c[mt] = a_n[mt];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) b_c[n] = b_n[n];
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
