@@ -186,6 +186,12 @@ int maua_perlin3d_f32(const float* grad, float* out, int n0, int n1, int n2, int
  * canvas (kornia warp_affine default padding_mode='zeros', align_corners as encoded by the host in m). */
 int maua_affine_reflect_warp_f32(const float* x, const float* m, float* y, int batch, int channels, int h, int w,
                                  int pad_l, int pad_r, int pad_t, int pad_b, const float* add_noise, void* stream);
+/* Same, for a canvas built by a CHAIN of ReflectionPad2d (audioreactive/bend.py:60-64 stacks three): pad_* are the total
+ * paddings, xmap[w+pad_l+pad_r] / ymap[h+pad_t+pad_b] (int32, device, either may be NULL = single fold) give the source
+ * column / row of every canvas column / row. */
+int maua_affine_reflect_warp_mapped_f32(const float* x, const float* m, float* y, int batch, int channels, int h, int w,
+                                        int pad_l, int pad_r, int pad_t, int pad_b, const float* add_noise,
+                                        const int* xmap, const int* ymap, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ hipGraph runtime
  * Capture everything launched on `stream` between begin/end into a hipGraph and replay it (per-frame generator

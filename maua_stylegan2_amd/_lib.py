@@ -68,6 +68,7 @@ _SIGNATURES = {
     "maua_filterbank_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_perlin3d_f32": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "maua_affine_reflect_warp_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P]),
+    "maua_affine_reflect_warp_mapped_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, _P, _P]),
     "maua_graph_begin_capture": (c_int, [_P]),
     "maua_graph_end_capture": (c_int, [_P, POINTER(c_void_p)]),
     "maua_graph_launch": (c_int, [_P, _P]),

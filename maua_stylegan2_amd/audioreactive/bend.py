@@ -39,14 +39,30 @@ class Print(th.nn.Module):
         return x
 
 
+def reflection_chain_index(n, pad_pairs):
+    """Source index of every element of an axis of length ``n`` after a CHAIN of reflection pads [(before, after), ...]
+    applied one after the other, as stacked ``ReflectionPad2d`` modules do: each pad mirrors the canvas built so far, so
+    the composition is in general not one triangular fold of the source (reference bend.py:60-64 stacks three)."""
+    idx = list(range(n))
+    for before, after in pad_pairs:
+        if before >= len(idx) or after >= len(idx):
+            raise ValueError(f"reflection pad ({before}, {after}) must be smaller than the axis ({len(idx)})")
+        idx = idx[before:0:-1] + idx + idx[-2:-2 - after:-1] if before or after else idx
+    return idx
+
+
 class AffineReflectWarp(th.nn.Module):
-    """y = CenterCrop(h, w)( Affine( ReflectionPad(x) [+ noise] ) ) with a per-sample inverse map ``m`` [B, 6]."""
+    """y = CenterCrop(h, w)( Affine( ReflectionPad(x) [+ noise] ) ) with a per-sample inverse map ``m`` [B, 6].
+    ``pads`` is one (left, right, top, bottom) tuple or a list of them (pads stacked in that order)."""
 
     def __init__(self, inv_maps, pads, noise=None):
         super().__init__()
         self.inv_maps = inv_maps
-        self.pads = pads  # (left, right, top, bottom)
+        chain = [tuple(pads)] if isinstance(pads[0], int) else [tuple(p) for p in pads]
+        self.chain = chain
+        self.pads = tuple(sum(p[i] for p in chain) for i in range(4))  # total (left, right, top, bottom)
         self.noise = noise
+        self._maps = None  # (h, w, device) -> int32 index tables, only for a real chain
 
     def forward(self, x):
         lib = _lib.load()
@@ -63,11 +79,19 @@ class AffineReflectWarp(th.nn.Module):
             pl, pr, pt, pb = self.pads
             if nz.numel() != (h + pt + pb) * (w + pl + pr):
                 raise RuntimeError("bend noise must have the size of one padded canvas plane")
+        xmap = ymap = None
+        if len(self.chain) > 1:
+            key = (h, w, str(x.device))
+            if self._maps is None or self._maps[0] != key:
+                xs = reflection_chain_index(w, [(p[0], p[1]) for p in self.chain])
+                ys = reflection_chain_index(h, [(p[2], p[3]) for p in self.chain])
+                self._maps = (key, th.tensor(xs, dtype=th.int32, device=x.device), th.tensor(ys, dtype=th.int32, device=x.device))
+            xmap, ymap = self._maps[1], self._maps[2]
         y = th.empty_like(x)
         with th.cuda.device(x.device):
-            _lib.check(lib.maua_affine_reflect_warp_f32(x.data_ptr(), m.data_ptr(), y.data_ptr(), b, c, h, w, self.pads[0],
-                                                        self.pads[1], self.pads[2], self.pads[3], _lib.ptr(nz),
-                                                        _lib.stream_ptr(x.device)), "maua_affine_reflect_warp_f32")
+            _lib.check(lib.maua_affine_reflect_warp_mapped_f32(
+                x.data_ptr(), m.data_ptr(), y.data_ptr(), b, c, h, w, self.pads[0], self.pads[1], self.pads[2], self.pads[3],
+                _lib.ptr(nz), _lib.ptr(xmap), _lib.ptr(ymap), _lib.stream_ptr(x.device)), "maua_affine_reflect_warp_mapped_f32")
         return y
 
 
@@ -110,10 +134,12 @@ def _inverse_maps_rotate(angle_deg, cw, ch):
 
 
 class Translate(NetworkBend):
-    """Horizontal scrolling (reference :52-72): reflect-pad 2.5 w left / 1.5 w right, add noise, translate, crop."""
+    """Horizontal scrolling (reference :52-72): three STACKED reflection pads (w/2 | w/2, then w | w, then w | 0 — each
+    mirrors the canvas built so far, which is what makes a scroll of w pixels land on the same features), add noise,
+    translate, centre crop."""
 
     def __init__(self, modulation, h, w, noise):
-        pads = (int(w / 2) + w + w, int(w / 2) + w, 0, 0)
+        pads = [(int(w / 2), int(w / 2), 0, 0), (w, w, 0, 0), (w, 0, 0, 0)]
         sequential_fn = lambda b: AffineReflectWarp(_inverse_maps_translate(b), pads, noise)  # noqa: E731
         super().__init__(sequential_fn, modulation)
 

@@ -6,8 +6,6 @@ perlin_noise :188-246.  perlin_noise runs as one HIP kernel (csrc/signal.hip per
 gradient angles the reference draws; generate_latents maps z through the mapping network of the MI355X generator
 (the evident intent — the reference's map_latents branch normalises over a singleton axis).
 """
-import gc
-
 import numpy as np
 import torch as th
 from scipy import interpolate
@@ -22,31 +20,37 @@ def chroma_weight_latents(chroma, latents):
 
 
 def slerp(val, low, high):
-    omega = np.arccos(np.clip(np.dot(low / np.linalg.norm(low), high / np.linalg.norm(high)), -1, 1))
-    so = np.sin(omega)
-    if so == 0:
-        return (1.0 - val) * low + val * high
-    return np.sin((1.0 - val) * omega) / so * low + np.sin(val * omega) / so * high
+    """Great-circle interpolation between two vectors (reference :29-45).  ``val`` may be a scalar or an array of
+    fractions: all of them are evaluated at once, one row per fraction."""
+    low, high = np.asarray(low), np.asarray(high)
+    frac = np.asarray(val, dtype=np.float64)
+    if frac.ndim:
+        frac = frac.reshape(frac.shape + (1,) * low.ndim)
+    cosine = np.dot(low.ravel() / np.linalg.norm(low), high.ravel() / np.linalg.norm(high))
+    angle = np.arccos(np.clip(cosine, -1.0, 1.0))
+    sine = np.sin(angle)
+    if sine == 0:  # parallel vectors: the geodesic degenerates to the straight line
+        return low + frac * (high - low)
+    return (np.sin((1.0 - frac) * angle) * low + np.sin(frac * angle) * high) / sine
 
 
 def slerp_loops(latent_selection, n_frames, n_loops, smoothing=1, loop=True):
-    """Reference :48-83, with the float64 -> float32 cast it needs to get through gaussian_filter."""
-    latent_selection = np.asarray(latent_selection)
-    n_lat = latent_selection.shape[1]
+    """Looping latent sequence along great circles between consecutive selection entries (reference :48-83): every key
+    gets n_frames // n_loops // n_keys frames, the loop is Gaussian-smoothed along time and tiled to ``n_frames``.
+    Differences from the reference, both needed for it to run at all or off 1024 px: the float64 interpolant is cast to
+    float32 before the filter (the reference's conv1d rejects it) and the layer axis is
+    the selection's own instead of a hard-coded 18."""
+    keys = np.asarray(latent_selection)
+    n_layers = keys.shape[1]
     if loop:
-        latent_selection = np.concatenate([latent_selection, latent_selection[[0]]])
-    base = []
-    for n in range(len(latent_selection)):
-        for val in np.linspace(0.0, 1.0, int(n_frames // max(1, n_loops) // len(latent_selection))):
-            base.append(th.from_numpy(slerp(val, latent_selection[n % len(latent_selection)][0],
-                                            latent_selection[(n + 1) % len(latent_selection)][0])))
-    base = th.stack(base).float()
-    base = gaussian_filter(base, smoothing)
-    base = th.cat([base] * int(n_frames / len(base)), axis=0)
-    base = th.cat([base[:, None, :]] * n_lat, axis=1)
-    if n_frames - len(base) != 0:
-        base = th.cat([base, base[0: n_frames - len(base)]])
-    return base
+        keys = np.concatenate([keys, keys[:1]])
+    fractions = np.linspace(0.0, 1.0, int(n_frames // max(1, n_loops) // len(keys)))
+    legs = [slerp(fractions, keys[k][0], keys[(k + 1) % len(keys)][0]) for k in range(len(keys))]
+    cycle = gaussian_filter(th.from_numpy(np.concatenate(legs)).float(), smoothing)
+    frames = cycle.repeat(int(n_frames / len(cycle)), 1)
+    if len(frames) != n_frames:
+        frames = th.cat([frames, frames[: n_frames - len(frames)]])
+    return frames[:, None, :].repeat(1, n_layers, 1)
 
 
 def spline_loops(latent_selection, n_frames, n_loops, loop=True):
@@ -67,32 +71,39 @@ def spline_loops(latent_selection, n_frames, n_loops, loop=True):
 
 
 def wrapping_slice(tensor, start, length, return_indices=False):
-    if start + length <= tensor.shape[0]:
-        indices = th.arange(start, start + length)
-    else:
-        indices = th.cat((th.arange(start, tensor.shape[0]), th.arange(0, (start + length) % tensor.shape[0])))
-    if tensor.shape[0] == 1:
-        indices = th.zeros(1, dtype=th.int64)
-    if return_indices:
-        return indices
-    return tensor[indices]
+    """``length`` entries of ``tensor`` from ``start``, continuing at the beginning when the end is reached (reference
+    :110-133).  Like the reference the slice wraps at most once: a request that would lap the tensor again ends at
+    (start + length) mod n."""
+    n = tensor.shape[0]
+    indices = th.arange(start, start + length) % n
+    if start + length > n:
+        indices = indices[: max(n - start, 0) + (start + length) % n]
+    if n == 1:
+        indices = indices.new_zeros(1)
+    return indices if return_indices else tensor[indices]
 
 
 def generate_latents(n_latents, ckpt, G_res, noconst=False, latent_dim=512, n_mlp=8, channel_multiplier=2):
-    from ..models.stylegan2 import Generator
+    """``n_latents`` random w vectors, each repeated over the generator's layers: [n_latents, n_latent, latent_dim] on the
+    CPU (reference :136-159).  Only the mapping network is needed for that, so only its ``style.*`` tensors are read from
+    the checkpoint and put on the device (the reference builds and uploads a second full generator).  z is mapped on
+    [N, latent_dim] — the evident intent; the reference's map_latents branch normalises over a singleton axis."""
+    from ..models.stylegan2 import EqualLinear, PixelNorm
 
-    generator = Generator(G_res, latent_dim, n_mlp, channel_multiplier=channel_multiplier, constant_input=not noconst,
-                          checkpoint=ckpt).cuda()
-    zs = th.randn((n_latents, latent_dim), device="cuda")
-    latent_selection = generator(zs, map_latents=True).cpu()
-    del generator, zs
-    gc.collect()
-    th.cuda.empty_cache()
-    return latent_selection
+    mapping = th.nn.Sequential(PixelNorm(), *[EqualLinear(latent_dim, latent_dim, lr_mul=0.01, activation="fused_lrelu")
+                                              for _ in range(n_mlp)])
+    if ckpt is not None:
+        weights = th.load(ckpt, map_location="cpu")["g_ema"]
+        mapping.load_state_dict({k[len("style."):]: v for k, v in weights.items() if k.startswith("style.")})
+        del weights
+    mapping = mapping.cuda()
+    w = mapping(th.randn((n_latents, latent_dim), device="cuda"))
+    n_layers = 2 * int(np.log2(G_res)) - 2
+    return w[:, None, :].repeat(1, n_layers, 1).cpu()
 
 
 def save_latents(latents, filename):
-    np.save(filename, latents)
+    np.save(filename, latents.numpy() if isinstance(latents, th.Tensor) else np.asarray(latents))
 
 
 def load_latents(filename):

@@ -215,36 +215,39 @@ def gaussian_filter(x, sigma, causal=None):
 
 # ------------------------------------------------------------------------------------------------ envelope post-processing
 def normalize(signal):
-    signal -= signal.min()
-    signal /= signal.max()
+    """Rescale to [0, 1] IN PLACE and return the same object (reference :243-254 mutates its argument too)."""
+    low = signal.min()
+    span = signal.max() - low
+    signal -= low
+    signal /= span
     return signal
 
 
 def percentile(signal, p):
-    k = 1 + round(0.01 * float(p) * (signal.numel() - 1))
-    return signal.view(-1).kthvalue(k).values.item()
+    """Value at the p-th percentile by rank (no interpolation): the (1 + round(p% of n-1))-th smallest (reference :257-268)."""
+    ordered = signal.reshape(-1).sort().values
+    return ordered[round(0.01 * float(p) * (ordered.numel() - 1))].item()
 
 
 def percentile_clip(signal, p):
-    locs = th.arange(0, signal.shape[0], device=signal.device)
-    plus = signal.take((locs + 1).clamp(0, signal.shape[0] - 1))
-    minus = signal.take((locs - 1).clamp(0, signal.shape[0] - 1))
-    peaks = th.gt(signal, plus) & th.gt(signal, minus)
-    signal = signal.clamp(0, percentile(signal[peaks], p))
-    signal /= signal.max()
-    return signal
+    """Clamp to [0, p-th percentile of the strict local maxima], then scale the maximum to 1 (reference :271-292).  The two
+    end points are never maxima (each is compared with itself there)."""
+    is_peak = th.zeros(signal.shape[0], dtype=th.bool, device=signal.device)
+    middle = signal[1:-1]
+    is_peak[1:-1] = (middle > signal[2:]) & (middle > signal[:-2])
+    clipped = signal.clamp(0, percentile(signal[is_peak], p))
+    return clipped.div_(clipped.max())
 
 
 def compress(signal, threshold, ratio, invert=False):
-    if invert:
-        signal[signal < threshold] *= ratio
-    else:
-        signal[signal > threshold] *= ratio
+    """Multiply everything above (``invert``: below) ``threshold`` by ``ratio`` in place, then :func:`normalize`
+    (reference :295-311)."""
+    selected = (signal < threshold) if invert else (signal > threshold)
+    signal *= th.where(selected, float(ratio), 1.0).to(signal.dtype)
     return normalize(signal)
 
 
-def expand(signal, threshold, ratio, invert=False):
-    return compress(signal, threshold, ratio, invert)
+expand = compress  # same operation; which one it is depends on threshold / ratio (reference :314-316)
 
 
 # ------------------------------------------------------------------------------------------------ features

@@ -324,7 +324,9 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {  // ReflectionPad2d s
 __global__ __launch_bounds__(256) void affine_reflect_warp_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                                   float* __restrict__ y, int channels, int h, int w,
                                                                   int pad_l, int pad_r, int pad_t, int pad_b,
-                                                                  const float* __restrict__ add_noise) {
+                                                                  const float* __restrict__ add_noise,
+                                                                  const int* __restrict__ xmap,
+                                                                  const int* __restrict__ ymap) {
     const int b = blockIdx.z;
     const int ch = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -347,7 +349,11 @@ __global__ __launch_bounds__(256) void affine_reflect_warp_kernel(const float* _
             const int yy = y0 + dy, xx = x0 + dx;
             if (yy < 0 || yy >= ch_h || xx < 0 || xx >= cw) continue;
             const float wgt = (dy ? fy : 1.f - fy) * (dx ? fx : 1.f - fx);
-            float v = xp[reflect_idx(yy - pad_t, h) * w + reflect_idx(xx - pad_l, w)];
+            // canvas pixel -> source pixel: one reflection fold, or the host's table when the canvas was built by SEVERAL
+            // stacked ReflectionPad2d (each re-reflects the already padded canvas: not a single triangular fold)
+            const int srow = ymap ? ymap[yy] : reflect_idx(yy - pad_t, h);
+            const int scol = xmap ? xmap[xx] : reflect_idx(xx - pad_l, w);
+            float v = xp[srow * w + scol];
             if (add_noise) v += add_noise[(size_t)yy * cw + xx];
             acc = fmaf(wgt, v, acc);
         }
@@ -624,7 +630,20 @@ extern "C" int maua_affine_reflect_warp_f32(const float* x, const float* m, floa
     if (!x || !m || !y || batch <= 0 || channels <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || channels > 65535 || batch > 65535) return MAUA_EINVAL;
     hipLaunchKernelGGL(affine_reflect_warp_kernel, dim3(ceil_div(h * w, 256), channels, batch), dim3(256), 0,
-                       (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise);
+                       (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise,
+                       (const int*)nullptr, (const int*)nullptr);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_affine_reflect_warp_mapped_f32(const float* x, const float* m, float* y, int batch, int channels, int h,
+                                                   int w, int pad_l, int pad_r, int pad_t, int pad_b,
+                                                   const float* add_noise, const int* xmap, const int* ymap,
+                                                   void* stream) {
+    if (!x || !m || !y || batch <= 0 || channels <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
+    if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || channels > 65535 || batch > 65535) return MAUA_EINVAL;
+    hipLaunchKernelGGL(affine_reflect_warp_kernel, dim3(ceil_div(h * w, 256), channels, batch), dim3(256), 0,
+                       (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise, xmap, ymap);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

@@ -280,6 +280,49 @@ class ConstantInput(nn.Module):
         return self.input.repeat(inputs.shape[0], 1, 1, 1)
 
 
+class LatentInput(nn.Module):
+    """reference :281-294 (``--noconst`` checkpoints): the 4x4 input is an affine function of the first latent row,
+    ``activate(fused_lrelu(EqualLinear(latent[:, 0])))`` reshaped to [B, C, 4, 4].  State-dict keys as the reference:
+    input.linear.{weight,bias}, input.activate.bias, input.input (an unused scalar Parameter that only carries the device)."""
+
+    def __init__(self, latent_dim, channel, size=4):
+        super().__init__()
+        self.channel = channel
+        self.size = size
+        self.linear = EqualLinear(latent_dim, channel * size * size, activation="fused_lrelu")
+        self.activate = FusedLeakyReLU(channel * size * size)
+        self.input = nn.Parameter(th.randn(1))
+
+    def forward(self, inputs):
+        out = self.activate(self.linear(inputs[:, 0]))
+        return out.reshape((inputs.shape[0], self.channel, self.size, self.size))
+
+    def run(self, latent, trunc, tl, out):
+        """Device path on static buffers (capturable): the table-driven affine kernel (truncation lerp included) writes
+        W x / sqrt(dim) + b into ``out`` [B, C*16]; two in-place bias-act launches apply lrelu*sqrt2 and the second
+        bias + lrelu*sqrt2."""
+        lib = _lib.load()
+        dev = latent.device
+        n_out = self.channel * self.size * self.size
+        batch = latent.shape[0]
+        key = (self.linear.weight.data_ptr(), self.linear.bias.data_ptr(), str(dev))
+        if getattr(self, "_table", None) is None or self._table[0] != key:
+            entry = dict(mod_w=self.linear.weight, mod_b=self.linear.bias, wsq=None, cin=n_out, cout=0, lat_idx=0, s_off=0,
+                         d_off=0, wscale=1.0)
+            self._table = (key, _style_table([entry], dev))
+        st = _lib.stream_ptr(dev)
+        flat = out.view(batch, n_out)
+        _lib.check(lib.maua_style_affine_f32(latent.data_ptr(), batch, latent.shape[1], latent.shape[2], _lib.ptr(trunc),
+                                             _lib.ptr(tl), self._table[1].data_ptr(), 1, n_out, flat.data_ptr(), n_out, st),
+                   "maua_style_affine_f32")
+        _lib.check(lib.maua_fused_bias_act_f32(flat.data_ptr(), None, None, flat.data_ptr(), flat.numel(), 0, 1, 3, 0, 0.2,
+                                               2 ** 0.5, st), "maua_fused_bias_act_f32")
+        _lib.check(lib.maua_fused_bias_act_f32(flat.data_ptr(), self.activate.bias.data_ptr(), None, flat.data_ptr(),
+                                               flat.numel(), n_out, 1, 3, 0, self.activate.negative_slope,
+                                               self.activate.scale, st), "maua_fused_bias_act_f32")
+        return out
+
+
 class ManipulationLayer(nn.Module):
     """reference :297-307 — applies every transform whose "layer" id matches."""
 
@@ -320,6 +363,13 @@ class StyledConv(nn.Module):
         ws = bufs(tag + ".ws", (n_ws,)) if n_ws else None
         if noise is not None:
             noise = _lib.require_cuda(noise, "noise")
+            # the kernels read oh*ow floats per sample (b samples unless the map is shared): a wrongly sized map would be
+            # a silent out-of-bounds read where the reference raises a broadcast error (models/stylegan2.py:266)
+            oh, ow = (2 * h, 2 * w) if conv.upsample else (h, w)
+            if noise.dim() != 4 or noise.shape[1] != 1 or tuple(noise.shape[-2:]) != (oh, ow) or noise.shape[0] not in (1, b):
+                raise RuntimeError(f"noise {tuple(noise.shape)} does not match feature map [{b}, 1, {oh}, {ow}] "
+                                   f"(batch must be 1 or {b})")
+            noise = noise.contiguous()
         if not conv.upsample:
             out = bufs(tag, (b, conv.out_channel, h, w))
             if rgb is not None and conv.out_channel <= 64 and n_ws == 0:
@@ -351,8 +401,6 @@ class StyledConv(nn.Module):
         pad0, pad1 = conv.blur.pad
         oh, ow = raw.shape[2] + pad0 + pad1 - k.shape[0] + 1, raw.shape[3] + pad0 + pad1 - k.shape[1] + 1
         out = bufs(tag, (b, conv.out_channel, oh, ow))
-        if noise is not None and tuple(noise.shape[-2:]) != (oh, ow):
-            raise RuntimeError(f"noise {tuple(noise.shape)} does not match feature map {oh}x{ow}")
         nstride = 0 if noise is None or noise.shape[0] == 1 else oh * ow
         rc = lib.maua_blur_noise_act_f32(raw.data_ptr(), k.data_ptr(), out.data_ptr(), b, conv.out_channel, raw.shape[2],
                                          raw.shape[3], k.shape[0], k.shape[1], pad0, pad1, None, _lib.ptr(noise), nstride,
@@ -430,15 +478,12 @@ class ToRGB(nn.Module):
 
 
 class Generator(nn.Module):
-    """reference :368-576 (ConstantInput generators only — load_generator passes constant_input=not noconst,
-    generate_audiovisual.py:49; the LatentInput variant is outside the hot path)."""
+    """reference :368-576.  ``constant_input=True`` is what load_generator passes by default
+    (generate_audiovisual.py:49); ``--noconst`` checkpoints use LatentInput (:281-294,409-412)."""
 
     def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01,
                  constant_input=False, checkpoint=None, output_size=None, min_rgb_size=4, base_res_factor=1):
         super().__init__()
-        if not constant_input:
-            raise NotImplementedError("only constant_input=True generators are built (the default of the "
-                                      "generate_audiovisual path); pass constant_input=True")
         self.size = size
         self.style_dim = style_dim
         layers = [PixelNorm()]
@@ -451,7 +496,7 @@ class Generator(nn.Module):
         self.num_layers = (self.log_size - 2) * 2 + 1
         self.n_latent = self.log_size * 2 - 2
         self.min_rgb_size = min_rgb_size
-        self.input = ConstantInput(self.channels[4])
+        self.input = ConstantInput(self.channels[4]) if constant_input else LatentInput(style_dim, self.channels[4])
         self.const_manipulation = ManipulationLayer(0)
         layerID = 1
         self.conv1 = StyledConv(self.channels[4], self.channels[4], 3, style_dim, blur_kernel=blur_kernel, layerID=layerID)
@@ -596,8 +641,12 @@ class Generator(nn.Module):
         with th.cuda.device(dev):
             image, acts, lat_out = self._forward_device(latent, noise, trunc, tl, transform_dict_list,
                                                         return_activation_maps, return_latents)
+        # the device forward writes into static per-(batch, layer, lane) buffers that the next call overwrites; the public
+        # call hands out private copies, like the reference's freshly allocated outputs (render / hipGraph replay read the
+        # static buffers directly and never pass through here)
+        image = image.clone() if image is not None else None  # None: min_rgb_size above the output size (reference :553-568)
         if return_activation_maps:
-            return image, acts
+            return image, [a.clone() for a in acts]
         if return_latents:
             return image, lat_out
         return image, None
@@ -630,15 +679,22 @@ class Generator(nn.Module):
             return nz.to(dev)
 
         acts = []
-        x = bufs("const", (batch,) + tuple(self.input.input.shape[1:]))
-        x.copy_(self.input.input.expand(batch, -1, -1, -1))
+        if isinstance(self.input, LatentInput):
+            x = self.input.run(latent, trunc, tl, bufs("const", (batch, self.input.channel, self.input.size, self.input.size)))
+        else:
+            x = bufs("const", (batch,) + tuple(self.input.input.shape[1:]))
+            x.copy_(self.input.input.expand(batch, -1, -1, -1))
         x = self.const_manipulation(x, bends)
         li = 0
         out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1")
         out = self.conv1.manipulation(out, bends)
         acts.append(out)
         li += 1
-        image = self.to_rgb1.run(out, s, ent[li]["s_off"], None, bufs("rgb1", (batch, 3) + tuple(out.shape[2:])))
+        # min_rgb_size (reference :553,567): resolutions below it contribute no ToRGB, the skip chain starts later
+        current_size = 4
+        image = None
+        if self.min_rgb_size <= current_size:
+            image = self.to_rgb1.run(out, s, ent[li]["s_off"], None, bufs("rgb1", (batch, 3) + tuple(out.shape[2:])))
         li += 1
         for n in range(self.log_size - 2):
             up, plain, rgb = self.convs[2 * n], self.convs[2 * n + 1], self.to_rgbs[n]
@@ -647,13 +703,15 @@ class Generator(nn.Module):
             out = up.manipulation(out, bends)
             acts.append(out)
             li += 1
+            current_size *= 2
             # fold ToRGB into the conv epilogue where the layer qualifies (<= 64 channels) and nothing needs the feature
             # map in between (a bend on this layer id would); the last layer then never writes its feature map at all
             layer_id = 2 * n + 3
             bent = any(bd["layer"] == layer_id for bd in bends)
             rgb_buf = bufs(f"rgbs.{n}", (batch, 3, out.shape[2], out.shape[3]))
             fuse = None
-            if not bent and not getattr(self, "disable_rgb_fusion", False):
+            wants_rgb = self.min_rgb_size <= current_size
+            if wants_rgb and not bent and not getattr(self, "disable_rgb_fusion", False):
                 is_last = n == self.log_size - 3
                 fuse = dict(module=rgb, s_off=ent[li + 1]["s_off"], skip=image, out=rgb_buf,
                             store=(not is_last) or want_acts)
@@ -664,7 +722,7 @@ class Generator(nn.Module):
             li += 1
             if fuse is not None and fuse.get("done"):
                 image = rgb_buf
-            else:
+            elif wants_rgb:
                 image = rgb.run(out, s, ent[li]["s_off"], image, rgb_buf)
             li += 1
         lat_out = None

@@ -123,7 +123,15 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
     lo, hi = frame_range if frame_range is not None else (0, n_total)
     latents = latents.to(dev, th.float32).contiguous()  # resident in HBM for the whole render
     noise = [None if nz is None else nz.to(dev, th.float32).contiguous() for nz in noise]
-    trunc_t = None if isinstance(truncation, float) else truncation.to(dev, th.float32).contiguous()
+    if isinstance(truncation, (int, float)):
+        truncation = float(truncation)
+        # a float != 1 (or a generator that carries a truncation latent) must reach the captured graph as well: the
+        # graph is captured with a per-frame truncation input, filled with the constant (reference
+        # models/stylegan2.py:537-543 lerps every batch); 1.0 without a truncation latent is the exact identity
+        needs_lerp = truncation != 1.0 or getattr(generator, "truncation_latent", None) is not None
+        trunc_t = th.full((n_total,), truncation, dtype=th.float32, device=dev) if needs_lerp else None
+    else:
+        trunc_t = truncation.to(dev, th.float32).contiguous()
     bends = list(bends or [])
     for bend in bends:
         if "modulation" in bend:

@@ -36,7 +36,6 @@ def fir_kernel_2d(taps=(1, 3, 3, 1), gain=1.0):
 
 def generator_tensor_shapes(size, style_dim=512, n_mlp=8, channel_multiplier=2, constant_input=True):
     """Ordered {state_dict key: shape} of the reference ``Generator`` (g_ema) for ``size``."""
-    assert constant_input, "only the ConstantInput generator is on the hot path (SURVEY.md §8a quirks)"
     ch = channels_for(channel_multiplier)
     log_size = int(math.log2(size))
     num_layers = (log_size - 2) * 2 + 1
@@ -44,7 +43,13 @@ def generator_tensor_shapes(size, style_dim=512, n_mlp=8, channel_multiplier=2, 
     for i in range(1, n_mlp + 1):
         shapes[f"style.{i}.weight"] = (style_dim, style_dim)
         shapes[f"style.{i}.bias"] = (style_dim,)
-    shapes["input.input"] = (1, ch[4], 4, 4)
+    if constant_input:
+        shapes["input.input"] = (1, ch[4], 4, 4)
+    else:  # LatentInput (reference models/stylegan2.py:281-294), the --noconst checkpoints
+        shapes["input.input"] = (1,)
+        shapes["input.linear.weight"] = (ch[4] * 16, style_dim)
+        shapes["input.linear.bias"] = (ch[4] * 16,)
+        shapes["input.activate.bias"] = (ch[4] * 16,)
 
     def styled(prefix, cin, cout, up):
         shapes[f"{prefix}.conv.weight"] = (1, cout, cin, 3, 3)
@@ -93,7 +98,7 @@ def seeded_array(seed, name, shape, std=1.0, mean=0.0):
     return a
 
 
-def seeded_state_dict(size, seed=0, style_dim=512, n_mlp=8, channel_multiplier=2):
+def seeded_state_dict(size, seed=0, style_dim=512, n_mlp=8, channel_multiplier=2, constant_input=True):
     """Random-init-like checkpoint with *non-trivial* noise strengths and biases.
 
     The reference's random init has noise.weight = activate.bias = ToRGB.bias = 0
@@ -101,7 +106,7 @@ def seeded_state_dict(size, seed=0, style_dim=512, n_mlp=8, channel_multiplier=2
     (SURVEY.md §7 "Hard parts"); here they are N(0, 0.1) around their init value.
     """
     sd = OrderedDict()
-    for key, shape in generator_tensor_shapes(size, style_dim, n_mlp, channel_multiplier).items():
+    for key, shape in generator_tensor_shapes(size, style_dim, n_mlp, channel_multiplier, constant_input).items():
         if key.endswith("blur.kernel") or key.endswith("upsample.kernel"):
             arr = fir_kernel_2d((1, 3, 3, 1), gain=4.0)
         elif key.endswith("modulation.bias"):
@@ -110,7 +115,7 @@ def seeded_state_dict(size, seed=0, style_dim=512, n_mlp=8, channel_multiplier=2
             arr = seeded_array(seed, key, shape, std=0.1)
         elif key.endswith("activate.bias") or (key.startswith("to_rgb") and key.endswith(".bias") and len(shape) == 4):
             arr = seeded_array(seed, key, shape, std=0.1)
-        elif key.startswith("style.") and key.endswith(".bias"):
+        elif (key.startswith("style.") and key.endswith(".bias")) or key in ("input.linear.bias", "input.activate.bias"):
             arr = seeded_array(seed, key, shape, std=0.1)
         else:
             arr = seeded_array(seed, key, shape)

@@ -456,8 +456,13 @@ def affine_reflect_warp(x, inv_maps, pads, add_noise=None):
     (bilinear, zeros outside the canvas, pixel-unit maps).  x [B,C,h,w] numpy, inv_maps [B,6], pads (l,r,t,b)."""
     x = np.asarray(x, dtype=np.float64)
     b, c, h, w = x.shape
-    pl, pr, pt, pb = pads
-    canvas = np.pad(x, ((0, 0), (0, 0), (pt, pb), (pl, pr)), mode="reflect")
+    # ``pads`` may be a list of (l,r,t,b): stacked ReflectionPad2d modules (bend.py:60-64), each padding the canvas built so
+    # far — pinned against real stacked torch.nn.ReflectionPad2d in tests/test_oracle_golden.py
+    chain = [tuple(pads)] if isinstance(pads[0], (int, np.integer)) else [tuple(p) for p in pads]
+    canvas = x
+    for cl, cr, ct, cb in chain:
+        canvas = np.pad(canvas, ((0, 0), (0, 0), (ct, cb), (cl, cr)), mode="reflect")
+    pl, pr, pt, pb = (sum(p[i] for p in chain) for i in range(4))
     if add_noise is not None:
         canvas = canvas + np.asarray(add_noise, dtype=np.float64).reshape(1, 1, h + pt + pb, w + pl + pr)
     ch, cw = canvas.shape[-2:]

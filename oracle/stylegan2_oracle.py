@@ -101,7 +101,8 @@ def to_rgb(sd, prefix, x, style_vec, skip=None):
     return y
 
 
-def generator_forward(sd, latents, noise=None, truncation=None, truncation_latent=None, bends=None, return_activations=False):
+def generator_forward(sd, latents, noise=None, truncation=None, truncation_latent=None, bends=None, return_activations=False,
+                      min_rgb_size=4):
     """latents [B,n_latent,512] (or [B,512]); noise: list of [B,1,r,r] / None (None -> checkpoint buffer
     ``noises.noise_i``, i.e. randomize_noise=False, :531-535); truncation: None | float | [B] tensor.
     ``bends``: optional {layer_id: callable} applied where ManipulationLayer sits (:297-307, ids :417-449)."""
@@ -126,17 +127,26 @@ def generator_forward(sd, latents, noise=None, truncation=None, truncation_laten
         return bends[layer_id](t) if layer_id in bends else t
 
     acts = []
-    out = bend(0, sd["input.input"].repeat(b, 1, 1, 1))
+    if "input.linear.weight" in sd:  # LatentInput (:281-294): activate(fused_lrelu(EqualLinear(latent[:, 0]))) -> [B,C,4,4]
+        w_in = sd["input.linear.weight"]
+        first = F.linear(latents[:, 0], w_in * (1 / math.sqrt(w_in.shape[1])))
+        first = ops.fused_leaky_relu(ops.fused_leaky_relu(first, sd["input.linear.bias"]), sd["input.activate.bias"])
+        out = bend(0, first.reshape(b, -1, 4, 4))
+    else:
+        out = bend(0, sd["input.input"].repeat(b, 1, 1, 1))
     out = bend(1, styled_conv(sd, "conv1", out, latents[:, 0], noise[0], False))
     acts.append(out)
-    image = to_rgb(sd, "to_rgb1", out, latents[:, 1])
+    current = 4
+    image = to_rgb(sd, "to_rgb1", out, latents[:, 1]) if min_rgb_size <= current else None  # (:553-556)
     i = 1
     for n in range(log_size - 2):
+        current *= 2
         out = bend(2 * n + 2, styled_conv(sd, f"convs.{2 * n}", out, latents[:, i], noise[2 * n + 1], True))
         acts.append(out)
         out = bend(2 * n + 3, styled_conv(sd, f"convs.{2 * n + 1}", out, latents[:, i + 1], noise[2 * n + 2], False))
         acts.append(out)
-        image = to_rgb(sd, f"to_rgbs.{n}", out, latents[:, i + 2], image)
+        if min_rgb_size <= current:  # (:567-568)
+            image = to_rgb(sd, f"to_rgbs.{n}", out, latents[:, i + 2], image)
         i += 2
     if return_activations:
         return image, acts

@@ -336,6 +336,208 @@ def render_fixture(ref_sg2, seeding, so):
     np.savez_compressed(os.path.join(HERE, "render_512.npz"), **out)
 
 
+def variants_fixture(ref_sg2, seeding, so):
+    """Generator variants off the default path: LatentInput (``--noconst``, models/stylegan2.py:281-294,409-412) and
+    ``min_rgb_size`` above 4 (:553-568, no ToRGB below that resolution).  Seeded 32^2 generators, reference images."""
+    print("generator variants: LatentInput (--noconst), min_rgb_size")
+    size, batch = 32, 2
+    out = {"seeds": np.array([21, 22, 23, 24], dtype=np.int64)}
+    lat = seeding.seeded_latents(batch, 8, seed=22)
+    noise = seeding.seeded_noise(batch, size, seed=23)
+    trunc = torch.tensor([0.8, 1.0])
+    tl = torch.from_numpy(seeding.seeded_array(24, "truncation_latent", (1, 512)))
+    # (a) LatentInput
+    sd = seeding.seeded_state_dict(size, seed=21, constant_input=False)
+    g = ref_sg2.Generator(size, 512, 8, channel_multiplier=2, constant_input=False)
+    g.load_state_dict(sd, strict=True)
+    g.eval()
+    g.truncation_latent = tl.clone()
+    img_ref, _ = g(lat, noise=list(noise), truncation=trunc, randomize_noise=False, input_is_latent=True)
+    check("generator(noconst)", so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=tl), img_ref, tol=1e-4)
+    out["noconst.image"] = img_ref.numpy()
+    # (b) min_rgb_size 16
+    sd = seeding.seeded_state_dict(size, seed=21)
+    g = ref_sg2.Generator(size, 512, 8, channel_multiplier=2, constant_input=True, min_rgb_size=16)
+    g.load_state_dict(sd, strict=True)
+    g.eval()
+    g.truncation_latent = tl.clone()
+    img_ref, _ = g(lat, noise=list(noise), truncation=trunc, randomize_noise=False, input_is_latent=True)
+    check("generator(min_rgb_size=16)", so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=tl,
+                                                            min_rgb_size=16), img_ref, tol=1e-4)
+    out["min_rgb16.image"] = img_ref.numpy()
+    np.savez_compressed(os.path.join(HERE, "generator_variants.npz"), **out)
+
+
+def plugin_fixtures(ref_sg2, ref_gav, seeding):
+    """The reference's own glue around the (unavailable) audio features: its default plugin
+    (audioreactive/examples/default.py:6-45) and ``generate()`` (generate_audiovisual.py:59-231) run here on the CPU with
+    ``ar.onsets`` / ``ar.chroma`` / ``ar.load_audio`` replaced by the seeded stand-ins of tests/golden/plugin_stubs.py,
+    ``torch.randn`` by its shape-keyed seeded generator, ``Tensor.cuda`` / ``Module.cuda`` / ``pin_memory`` by the identity,
+    ``th.cuda.FloatTensor`` by ``th.FloatTensor`` and ffmpeg by a byte recorder.  Stored: what the reference produced
+    (latents / noise summaries, frame subsamples); the stand-ins regenerate the inputs on the GPU box."""
+    import argparse as _argparse
+    import queue as _queue
+    import tempfile
+
+    sys.path.insert(0, HERE)
+    import plugin_stubs as stubs
+
+    import audioreactive as ref_ar  # noqa  (the reference package: /root/reference is first on sys.path)
+    from audioreactive.examples import default as ref_plugin  # noqa
+    import render as ref_render  # noqa
+
+    real = dict(cuda=torch.Tensor.cuda, mcuda=torch.nn.Module.cuda, pin=torch.Tensor.pin_memory, ft=torch.cuda.FloatTensor,
+                randn=torch.randn, onsets=ref_ar.onsets, chroma=ref_ar.chroma, load=ref_ar.load_audio, q=ref_render.queue)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor
+
+    class PatientQueue(_queue.Queue):  # render.py:37,97 give up after 5 s without a batch: a CPU forward can take longer
+        def get(self, block=True, timeout=None):
+            return super().get(block, None if timeout is None else 30)
+
+    ref_render.queue = types.SimpleNamespace(Queue=PatientQueue, Empty=_queue.Empty)
+    cwd = os.getcwd()
+    try:
+        # ------------------------------------------------------------ (A) the plugin callbacks on their own, long clip
+        print("default plugin (reference callbacks, stubbed features)")
+        n_frames = 600
+        feats = stubs.Features(n_frames)
+        ref_ar.onsets, ref_ar.chroma = feats.onsets, feats.chroma
+        ref_ar.set_SMF(1)
+        torch.randn = stubs.SeededRandn(41)
+        args = _argparse.Namespace(audio=np.zeros(8, np.float32), sr=22050, n_frames=n_frames, fps=30)
+        args = ref_plugin.initialize(args)
+        assert [c[0] for c in feats.calls] == ["onsets", "onsets"], feats.calls
+        out = {"n_frames": np.int64(n_frames), "onset_calls": np.array([list(c[1:]) for c in feats.calls], dtype=np.float64)}
+        selection = torch.from_numpy(seeding.seeded_array(42, "selection", (12, 16, 512)))
+        lat = ref_plugin.get_latents(selection, args)
+        assert tuple(lat.shape) == (n_frames, 16, 512)
+        for k, v in stubs.summary(lat).items():
+            out[f"latents.{k}"] = v
+        sizes = [(4, 4), (8, 8), (16, 32), (32, 32), (64, 64), (128, 128), (512, 512)]
+        for h, w in sizes:
+            nz = ref_plugin.get_noise(h, w, 0, len(sizes), args)
+            if nz is None:
+                out[f"noise_{h}x{w}.none"] = np.int64(1)
+                continue
+            assert tuple(nz.shape) == (n_frames, 1, h, w)
+            for k, v in stubs.summary(nz).items():
+                out[f"noise_{h}x{w}.{k}"] = v
+            print(f"  noise {h}x{w}: std {float(nz.std()):.4f}")
+        out["noise_sizes"] = np.array(sizes, dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, "default_plugin.npz"), **out)
+
+        # ------------------------------------------------------------ (B) generate() end to end, 512^2, 10 frames
+        print("generate() end to end (reference orchestrator + plugin + render loop, stubbed features)")
+        captured = []
+
+        class _Pipe:
+            def write(self, data):
+                captured.append(np.frombuffer(data, dtype=np.uint8).copy())
+
+            def close(self):
+                pass
+
+        class _Chain:
+            stdin = _Pipe()
+
+            def output(self, *a, **k):
+                return self
+
+            def global_args(self, *a, **k):
+                return self
+
+            def overwrite_output(self):
+                return self
+
+            def run_async(self, **k):
+                return self
+
+            def wait(self):
+                return 0
+
+        sys.modules["ffmpeg"].input = lambda *a, **k: _Chain()
+        size, n, batch, fps = 512, 10, 4, 30
+        out = {"cfg": np.array([size, n, batch, fps, 43, 42], dtype=np.int64)}  # ..., weight seed, selection seed
+        tmp = tempfile.mkdtemp(prefix="maua_golden_")
+        os.chdir(tmp)
+        os.makedirs("workspace")
+        torch.save({"g_ema": seeding.seeded_state_dict(size, seed=43)}, "seeded512.pt")
+        np.save("selection.npy", seeding.seeded_array(42, "selection", (12, 16, 512)))
+        for tag, truncation in (("a", 1.0), ("b", 0.7)):
+            feats = stubs.Features(n, fps)
+            ref_ar.onsets, ref_ar.chroma, ref_ar.load_audio = feats.onsets, feats.chroma, feats.load_audio
+            torch.randn = stubs.SeededRandn(44)
+            seen = {}
+
+            def get_latents(selection, args):
+                seen["latents"] = ref_plugin.get_latents(selection, args)
+                return seen["latents"]
+
+            def get_noise(height, width, scale, num_scales, args):
+                nz = ref_plugin.get_noise(height, width, scale, num_scales, args)
+                seen.setdefault("noise", []).append(nz)
+                return nz
+
+            captured.clear()
+            ref_gav.generate(ckpt="seeded512.pt", audio_file="clip.wav", initialize=ref_plugin.initialize,
+                             get_latents=get_latents, get_noise=get_noise, latent_file="selection.npy", G_res=size,
+                             out_size=size, fps=fps, batch=batch, truncation=truncation, output_file="unused.mp4")
+            assert len(captured) == n, f"reference generate() delivered {len(captured)} of {n} frames"
+            frames = np.stack([c.reshape(size, size, 3) for c in captured])
+            out[f"{tag}.sub"] = frames[:, RENDER_SUB[0], RENDER_SUB[1], :]
+            out[f"{tag}.sums"] = frames.reshape(n, -1).sum(1).astype(np.int64)
+            for k, v in stubs.summary(seen["latents"]).items():
+                out[f"{tag}.latents.{k}"] = v
+            out[f"{tag}.noise_is_none"] = np.array([nz is None for nz in seen["noise"]])
+            for i, nz in enumerate(seen["noise"]):
+                if nz is not None:
+                    out[f"{tag}.noise_{i}.stats"] = stubs.summary(nz)["stats"]
+            assert np.array_equal(np.load("workspace/last-latents.npy"), np.load("selection.npy"))
+            print(f"  generate.{tag}: truncation {truncation}, frames mean {frames.mean():.2f} std {frames.std():.2f}")
+        np.savez_compressed(os.path.join(HERE, "generate_e2e.npz"), **out)
+    finally:
+        os.chdir(cwd)
+        torch.Tensor.cuda, torch.nn.Module.cuda, torch.Tensor.pin_memory = real["cuda"], real["mcuda"], real["pin"]
+        torch.cuda.FloatTensor, torch.randn = real["ft"], real["randn"]
+        ref_ar.onsets, ref_ar.chroma, ref_ar.load_audio = real["onsets"], real["chroma"], real["load"]
+        ref_render.queue = real["q"]
+
+
+def latent_utils_fixture(ref_latent, ref_signal):
+    """Host-side latent sequencing helpers (audioreactive/latent.py:29-133): slerp values, wrapping_slice index sets incl.
+    its single-wrap quirk, and slerp_loops — which in the reference dies in gaussian_filter's float32 conv1d because its
+    interpolant is float64; it is run here with that one cast added in front of the filter."""
+    print("latent helpers: slerp / wrapping_slice / slerp_loops")
+    r = rng(104)
+    out = {}
+    a, b = r.standard_normal(16), r.standard_normal(16)
+    vals = np.array([0.0, 0.1, 0.5, 0.77, 1.0])
+    out["slerp.a"], out["slerp.b"], out["slerp.vals"] = a, b, vals
+    out["slerp.y"] = np.stack([ref_latent.slerp(v, a, b) for v in vals])
+    out["slerp.parallel"] = np.stack([ref_latent.slerp(v, a, 2.0 * a) for v in vals])
+    cases = [(10, 0, 10), (10, 7, 6), (10, 9, 10), (10, 3, 4), (1, 0, 1), (1, 0, 5), (7, 5, 16), (6, 0, 13)]
+    out["wrap.cases"] = np.array(cases, dtype=np.int64)
+    for n, start, length in cases:
+        out[f"wrap.{n}_{start}_{length}"] = ref_latent.wrapping_slice(torch.arange(n), start, length, return_indices=True).numpy()
+    sel = r.standard_normal((4, 18, 16)).astype(np.float32)
+    real_gf = ref_latent.gaussian_filter
+    ref_latent.gaussian_filter = lambda x, sigma, causal=None: ref_signal.gaussian_filter(x.float(), sigma, causal)
+    try:
+        ref_signal.set_SMF(1)
+        out["slerp_loops.sel"] = sel
+        for tag, (n_frames, n_loops, smoothing, loop) in {"a": (120, 2, 1, True), "b": (100, 1, 3, False), "c": (53, 2, 1, True)}.items():
+            y = ref_latent.slerp_loops(sel, n_frames, n_loops, smoothing, loop)
+            out[f"slerp_loops.{tag}.cfg"] = np.array([n_frames, n_loops, smoothing, int(loop)], dtype=np.int64)
+            out[f"slerp_loops.{tag}.y"] = y.numpy()[:, ::6, :]  # the layer axis is a plain repeat: keep 3 of 18
+            out[f"slerp_loops.{tag}.shape"] = np.array(y.shape, dtype=np.int64)
+    finally:
+        ref_latent.gaussian_filter = real_gf
+    np.savez_compressed(os.path.join(HERE, "latent_utils.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the 256^2 / 1024^2 generators (minutes on CPU)")
@@ -345,6 +547,9 @@ def main():
     ap.add_argument("--only-bends", action="store_true", help="(re)generate bends.npz only")
     ap.add_argument("--only-meta", action="store_true", help="(re)generate generator_meta.npz only")
     ap.add_argument("--only-signatures", action="store_true", help="(re)generate signatures.json only")
+    ap.add_argument("--only-variants", action="store_true", help="(re)generate generator_variants.npz only")
+    ap.add_argument("--only-latent-utils", action="store_true", help="(re)generate latent_utils.npz only")
+    ap.add_argument("--only-plugin", action="store_true", help="(re)generate default_plugin.npz / generate_e2e.npz only")
     args = ap.parse_args()
 
     ref_sg2, ref_op, ref_signal, ref_latent, ref_gav = import_reference()
@@ -368,6 +573,15 @@ def main():
         return
     if args.only_signatures:
         signatures_fixture(ref_sg2, ref_op, ref_signal, ref_latent, ref_gav)
+        return
+    if args.only_variants:
+        variants_fixture(ref_sg2, seeding, so)
+        return
+    if args.only_latent_utils:
+        latent_utils_fixture(ref_latent, ref_signal)
+        return
+    if args.only_plugin:
+        plugin_fixtures(ref_sg2, ref_gav, seeding)
         return
 
     # ------------------------------------------------------------------ (1) upfirdn2d
@@ -627,6 +841,15 @@ def main():
 
     # ------------------------------------------------------------------ (11) render loop
     render_fixture(ref_sg2, seeding, so)
+
+    # ------------------------------------------------------------------ (12) generator variants
+    variants_fixture(ref_sg2, seeding, so)
+
+    # ------------------------------------------------------------------ (12b) latent sequencing helpers
+    latent_utils_fixture(ref_latent, ref_signal)
+
+    # ------------------------------------------------------------------ (13) default plugin + generate() end to end
+    plugin_fixtures(ref_sg2, ref_gav, seeding)
     print("done")
 
 

@@ -157,3 +157,61 @@ def test_generator_z_inputs_vs_reference_golden(gpu, golden):
         np.testing.assert_allclose(lat.cpu().numpy(), fx[f"{tag}.latents"], atol=2e-4, rtol=1e-3, err_msg=tag)
         # 2e-3: the mapping network's own fp32 rounding (device GEMM vs CPU) feeds into the generator here
         np.testing.assert_allclose(img.cpu().numpy(), fx[f"{tag}.image"], atol=2e-3, err_msg=tag)
+
+
+def test_forward_outputs_are_private_copies_and_noise_is_validated(gpu):
+    """Reference-style use of the public call: results of successive calls are kept side by side (the reference returns
+    freshly allocated tensors), and a noise map that does not match the feature map raises (the reference fails with a
+    broadcast error, models/stylegan2.py:266) instead of being read out of bounds."""
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    size = 16
+    g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
+    g = g.to(gpu).eval()
+    lat = seeding.seeded_latents(2, g.n_latent, seed=1).to(gpu)
+    noise = [n.to(gpu) for n in seeding.seeded_noise(1, size, seed=2)]
+    a, acts_a = g(styles=lat[:1], noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True,
+                  return_activation_maps=True)
+    keep, keep_act = a.clone(), acts_a[-1].clone()
+    b, _ = g(styles=lat[1:], noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    assert torch.equal(a, keep) and torch.equal(acts_a[-1], keep_act) and not torch.equal(a, b)
+    for bad in (torch.zeros(1, 1, 8, 4, device=gpu), torch.zeros(3, 1, 8, 8, device=gpu), torch.zeros(1, 2, 8, 8, device=gpu)):
+        wrong = list(noise)
+        wrong[1] = bad  # first 8x8 layer (the up-sampling StyledConv)
+        with pytest.raises(RuntimeError, match="noise"):
+            g(styles=lat[:1], noise=wrong, truncation=1.0, randomize_noise=False, input_is_latent=True)
+        wrong = list(noise)
+        wrong[2] = bad  # plain StyledConv
+        with pytest.raises(RuntimeError, match="noise"):
+            g(styles=lat[:1], noise=wrong, truncation=1.0, randomize_noise=False, input_is_latent=True)
+
+
+def test_generator_variants_match_reference_golden(gpu, golden):
+    """LatentInput generators (``--noconst``, reference models/stylegan2.py:281-294) and ``min_rgb_size`` (:553-568) against
+    images of the reference classes (tests/golden/generator_variants.npz), eager and through a captured hipGraph."""
+    from maua_stylegan2_amd.models.stylegan2 import Generator
+
+    fx = golden("generator_variants.npz")
+    s_w, s_lat, s_noise, s_tl = (int(v) for v in fx["seeds"])
+    size, batch = 32, 2
+    lat = seeding.seeded_latents(batch, 8, seed=s_lat).to(gpu)
+    noise = [n.to(gpu) for n in seeding.seeded_noise(batch, size, seed=s_noise)]
+    trunc = torch.tensor([0.8, 1.0], device=gpu)
+    tl = torch.from_numpy(seeding.seeded_array(s_tl, "truncation_latent", (1, 512))).to(gpu)
+    for key, kwargs in (("noconst", dict(constant_input=False)), ("min_rgb16", dict(constant_input=True, min_rgb_size=16))):
+        g = Generator(size, 512, 8, channel_multiplier=2, **kwargs)
+        g.load_state_dict(seeding.seeded_state_dict(size, seed=s_w, constant_input=kwargs["constant_input"]), strict=True)
+        g = g.to(gpu).eval()
+        g.truncation_latent = tl
+        img, _ = g(styles=lat, noise=noise, truncation=trunc, randomize_noise=False, input_is_latent=True)
+        err = float((img.cpu() - torch.from_numpy(fx[f"{key}.image"])).abs().max())
+        assert err < TOL, (key, err)
+        graph, static = g.capture_graph(batch, [tuple(n.shape[-2:]) for n in noise], truncated=True)
+        static["latents"].copy_(lat)
+        static["trunc"].copy_(trunc)
+        for dst, src in zip(static["noise"], noise):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static["image"], img), key

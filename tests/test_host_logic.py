@@ -314,3 +314,21 @@ def test_interface_signatures_match_reference_fixture(built_lib):
                 continue
             have = None if default is inspect.Parameter.empty else repr(default)
             assert have == ref_default, (qualified, name, have, ref_default)
+
+
+def test_latent_helpers_match_reference_golden(golden):
+    """slerp (scalar and vectorised fractions, parallel vectors) and wrapping_slice (incl. n == 1 and the reference's
+    single-wrap behaviour for over-long requests) against values of the reference functions (latent_utils.npz)."""
+    from maua_stylegan2_amd.audioreactive import latent
+
+    g = golden("latent_utils.npz")
+    a, b, vals = g["slerp.a"], g["slerp.b"], g["slerp.vals"]
+    for i, v in enumerate(vals):
+        np.testing.assert_allclose(latent.slerp(float(v), a, b), g["slerp.y"][i], atol=1e-12)
+    np.testing.assert_allclose(latent.slerp(vals, a, b), g["slerp.y"], atol=1e-12)
+    np.testing.assert_allclose(latent.slerp(vals, a, 2.0 * a), g["slerp.parallel"], atol=1e-12)
+    for n, start, length in g["wrap.cases"]:
+        want = g[f"wrap.{n}_{start}_{length}"]
+        got = latent.wrapping_slice(torch.arange(int(n)), int(start), int(length), return_indices=True)
+        assert got.dtype == torch.int64 and got.tolist() == want.tolist(), (n, start, length)
+        assert latent.wrapping_slice(torch.arange(int(n)) * 3, int(start), int(length)).tolist() == (want * 3).tolist()

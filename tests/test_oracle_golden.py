@@ -284,6 +284,45 @@ def test_oracle_affine_warp_matches_torch_grid_sample():
         np.testing.assert_allclose(got, want, atol=1e-10)
 
 
+def test_oracle_stacked_reflection_pads_match_torch():
+    """Translate (audioreactive/bend.py:60-64) stacks THREE ReflectionPad2d modules; each mirrors the canvas built so far, so
+    the result is not one reflection fold of the source.  The oracle's pad chain and the host's index tables
+    (bend.reflection_chain_index, what the HIP warp kernel reads) against really stacked torch.nn.ReflectionPad2d."""
+    from maua_stylegan2_amd.audioreactive.bend import reflection_chain_index
+
+    rng = np.random.default_rng(12)
+    for h, w in [(6, 8), (5, 9), (4, 16)]:
+        x = rng.standard_normal((2, 3, h, w))
+        chain = [(int(w / 2), int(w / 2), 0, 0), (w, w, 0, 0), (w, 0, 0, 0)]
+        canvas = torch.from_numpy(x)
+        for p in chain:
+            canvas = torch.nn.ReflectionPad2d(p)(canvas)
+        cw = canvas.shape[-1]
+        assert cw == w + 2 * int(w / 2) + 3 * w
+        cols = reflection_chain_index(w, [(p[0], p[1]) for p in chain])
+        np.testing.assert_array_equal(canvas.numpy(), x[..., cols])
+        # identity map + centre crop through the oracle == the centre columns of the stacked canvas; a shift of w columns
+        # lands on the same features (the seamless scroll of examples/tauceti.py:142-144) when w is even
+        ident = np.tile(np.array([1.0, 0, 0, 0, 1.0, 0]), (2, 1))
+        got = signal_oracle.affine_reflect_warp(x, ident, chain)
+        lo = (cw - w) // 2
+        np.testing.assert_allclose(got, canvas.numpy()[..., lo: lo + w], atol=1e-12)
+        shifted = ident.copy()
+        shifted[:, 2] = -w
+        if w % 2 == 0:
+            np.testing.assert_allclose(signal_oracle.affine_reflect_warp(x, shifted, chain), got, atol=1e-12)
+        # a single fold of the total padding is NOT the same canvas (what round 1 implemented)
+        single = np.pad(x, ((0, 0), (0, 0), (0, 0), (int(w / 2) + 2 * w, int(w / 2) + w)), mode="reflect")
+        assert np.abs(single - canvas.numpy()).max() > 0.1
+    # mixed vertical / horizontal chain
+    x = rng.standard_normal((1, 2, 7, 6))
+    chain = [(2, 1, 3, 0), (4, 5, 2, 6)]
+    canvas = torch.nn.ReflectionPad2d(chain[1])(torch.nn.ReflectionPad2d(chain[0])(torch.from_numpy(x))).numpy()
+    rows = reflection_chain_index(7, [(p[2], p[3]) for p in chain])
+    cols = reflection_chain_index(6, [(p[0], p[1]) for p in chain])
+    np.testing.assert_array_equal(canvas, x[..., rows, :][..., cols])
+
+
 def test_perlin_oracle_matches_reference_golden(golden):
     """perlin.npz holds outputs of the reference's own perlin_noise (tests/golden/make_golden.py runs it on the CPU by
     neutralising its hard-coded .cuda() calls) together with the gradient angles it drew."""
@@ -353,3 +392,46 @@ def test_oracle_bend_placement_matches_reference_golden(golden):
     np.testing.assert_allclose(got.numpy(), fx["image"], atol=1e-5)
     moved = so.generator_forward(sd, lat, noise, bends={0: bends[0], 2: bends[1], 3: bends[3], 7: bends[7]})
     assert float((moved - got).abs().max()) > 1e-2  # the layer id matters
+
+
+def test_oracle_generator_variants_match_reference_golden(golden):
+    """LatentInput (--noconst) and min_rgb_size generators: the oracle against images of the reference classes."""
+    from maua_stylegan2_amd import seeding
+    from oracle import stylegan2_oracle as so
+
+    fx = golden("generator_variants.npz")
+    s_w, s_lat, s_noise, s_tl = (int(v) for v in fx["seeds"])
+    lat = seeding.seeded_latents(2, 8, seed=s_lat)
+    noise = seeding.seeded_noise(2, 32, seed=s_noise)
+    trunc = torch.tensor([0.8, 1.0])
+    tl = torch.from_numpy(seeding.seeded_array(s_tl, "truncation_latent", (1, 512)))
+    sd = seeding.seeded_state_dict(32, seed=s_w, constant_input=False)
+    got = so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=tl)
+    np.testing.assert_allclose(got.numpy(), fx["noconst.image"], atol=1e-4)
+    sd = seeding.seeded_state_dict(32, seed=s_w)
+    got = so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=tl, min_rgb_size=16)
+    np.testing.assert_allclose(got.numpy(), fx["min_rgb16.image"], atol=1e-4)
+    assert np.abs(so.generator_forward(sd, lat, noise, truncation=trunc, truncation_latent=tl).numpy()
+                  - fx["min_rgb16.image"]).max() > 1e-2  # the skipped low-resolution ToRGBs matter
+
+
+def test_plugin_stand_ins_are_deterministic():
+    """tests/golden/plugin_stubs.py regenerates the inputs the reference was run on (make_golden.py --only-plugin): the
+    envelopes and the shape-keyed randn must not depend on call order or on the process."""
+    import sys
+
+    from conftest import GOLDEN
+
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import plugin_stubs as stubs
+
+    lo, hi, ch = stubs.envelopes(600)
+    lo2, hi2, ch2 = stubs.envelopes(600)
+    assert np.array_equal(lo, lo2) and np.array_equal(ch, ch2) and 0 <= lo.min() and hi.max() <= 1
+    np.testing.assert_allclose(ch.sum(1), 1.0, atol=1e-6)
+    r1, r2 = stubs.SeededRandn(7), stubs.SeededRandn(7)
+    a = r1(4, 1, 8, 8)
+    r2(3, 3)  # an unrelated draw in between changes nothing
+    assert torch.equal(a, r2((4, 1, 8, 8))) and not torch.equal(a, r1(4, 1, 8, 8))
+    assert lo.std() > 0.05 and hi.std() > 0.05  # peaky envelopes, not constants

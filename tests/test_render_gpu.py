@@ -47,6 +47,36 @@ def test_synthesize_graph_equals_eager_and_oracle(gpu):
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
 
 
+def test_float_truncation_reaches_the_captured_graph(gpu):
+    """A float truncation != 1 (CLI ``--truncation 0.7``) must truncate the hipGraph batches exactly like the eager tail
+    batch and like the oracle (reference models/stylegan2.py:537-543 lerps every batch): round 1 captured the graph without
+    the lerp, so full batches came out untruncated and the ragged tail truncated."""
+    from maua_stylegan2_amd import render
+    from oracle import stylegan2_oracle as so
+
+    size, n = 32, 10
+    sd = seeding.seeded_state_dict(size, seed=4)
+    g = build(size, gpu, 4)
+    lat = seeding.seeded_latents(n, g.n_latent, seed=6)
+    noise = seeding.seeded_noise(n, size, seed=7)
+    tl = torch.from_numpy(seeding.seeded_array(5, "tl", (1, 512)))
+    g.truncation_latent = tl.to(gpu)
+
+    def run(truncation, use_graph):
+        frames = np.zeros((n, size, size, 3), np.uint8)
+        for first, u8 in render.synthesize(g, lat, noise, 4, truncation=truncation, use_graph=use_graph):
+            frames[first: first + u8.shape[0]] = u8.cpu().numpy()
+        return frames
+
+    graphed, eager = run(0.7, True), run(0.7, False)
+    assert np.array_equal(graphed, eager)
+    want = so.frames_to_uint8(so.generator_forward(sd, lat, noise, truncation=torch.full((n,), 0.7), truncation_latent=tl))
+    diff = np.abs(graphed.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+    untruncated = run(torch.ones(n), True)
+    assert np.abs(graphed.astype(np.int16) - untruncated.astype(np.int16)).mean() > 1.0  # 0.7 is really applied
+
+
 def test_render_matches_reference_render_loop(gpu, tmp_path, monkeypatch, golden):
     """render() against frames produced by the REFERENCE's own render loop (tests/golden/render_512.npz, captured from its
     ffmpeg pipe on the CPU): seeded 512^2 generator, 5 frames, batch 2 — (a) checkpoint noise buffers, float truncation;
@@ -120,6 +150,110 @@ def test_generate_end_to_end_default_plugin(gpu, tmp_path, monkeypatch):
     assert os.path.exists("workspace/last-latents.npy")
 
 
+def _stubs():
+    import sys
+
+    from conftest import GOLDEN
+
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import plugin_stubs
+
+    return plugin_stubs
+
+
+def _assert_summary(got, fx, prefix, atol):
+    for key in ("stats", "frame_mean", "sub"):
+        np.testing.assert_allclose(got[key], fx[f"{prefix}.{key}"], atol=atol, rtol=0, err_msg=f"{prefix}.{key}")
+
+
+def test_default_plugin_matches_reference_plugin(gpu, golden, monkeypatch):
+    """The default plugin's callbacks against the REFERENCE's audioreactive/examples/default.py:6-45 run on the same
+    stand-in features and the same seeded ``randn`` draws (tests/golden/default_plugin.npz, written by make_golden.py from
+    the imported reference): 600 frames, latents [600,16,512] and reactive noise for 4..128 px (incl. a 2:1 map),
+    ``None`` above 256 px.  Everything between the feature calls and the returned tensors is pinned: which onset bands are
+    asked for, chroma weighting, both Gaussian filters (sigma 128 on the normal, non-shortened path), the onset
+    cross-fades, the order of the two random fields and the std normalisation."""
+    import argparse
+
+    import maua_stylegan2_amd.audioreactive as ar
+    from maua_stylegan2_amd.audioreactive.examples import default as plugin
+
+    stubs = _stubs()
+    fx = golden("default_plugin.npz")
+    n_frames = int(fx["n_frames"])
+    feats = stubs.Features(n_frames)
+    monkeypatch.setattr(ar, "onsets", feats.onsets)
+    monkeypatch.setattr(ar, "chroma", feats.chroma)
+    monkeypatch.setattr(torch, "randn", stubs.SeededRandn(41))
+    ar.set_SMF(1)
+    args = plugin.initialize(argparse.Namespace(audio=np.zeros(8, np.float32), sr=22050, n_frames=n_frames, fps=30))
+    np.testing.assert_array_equal(np.array([list(c[1:]) for c in feats.calls], dtype=np.float64), fx["onset_calls"])
+    selection = torch.from_numpy(seeding.seeded_array(42, "selection", (12, 16, 512)))
+    lat = plugin.get_latents(selection, args)
+    assert tuple(lat.shape) == (n_frames, 16, 512)
+    _assert_summary(stubs.summary(lat), fx, "latents", 2e-5)
+    sizes = [tuple(int(v) for v in hw) for hw in fx["noise_sizes"]]
+    for h, w in sizes:
+        nz = plugin.get_noise(h, w, 0, len(sizes), args)
+        if f"noise_{h}x{w}.none" in fx.files:
+            assert nz is None
+            continue
+        assert tuple(nz.shape) == (n_frames, 1, h, w)
+        _assert_summary(stubs.summary(nz), fx, f"noise_{h}x{w}", 2e-5)
+
+
+@pytest.mark.parametrize("tag,truncation", [("a", 1.0), ("b", 0.7)])
+def test_generate_matches_reference_generate(gpu, golden, tmp_path, monkeypatch, tag, truncation):
+    """``generate()`` end to end against the REFERENCE's generate_audiovisual.generate (:59-231) + default plugin + render
+    loop run on the CPU with the same stand-ins (tests/golden/generate_e2e.npz): seeded 512^2 checkpoint file, latent file,
+    10 frames at batch 4 (two hipGraph batches + a ragged eager tail), (a) truncation 1.0, (b) float truncation 0.7 with the
+    lazily drawn ``mean_latent(2**14)`` truncation latent.  Latents within 2e-5, noise statistics within 2e-5, delivered
+    frames within one grey level on the stored pixel subsample."""
+    import maua_stylegan2_amd.audioreactive as ar
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.audioreactive.examples import default as plugin
+
+    stubs = _stubs()
+    fx = golden("generate_e2e.npz")
+    size, n, batch, fps, s_w, s_sel = [int(v) for v in fx["cfg"]]
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)  # raw rgb24 sink
+    torch.save({"g_ema": seeding.seeded_state_dict(size, seed=s_w)}, "seeded512.pt")
+    np.save("selection.npy", seeding.seeded_array(s_sel, "selection", (12, 16, 512)))
+    feats = stubs.Features(n, fps)
+    monkeypatch.setattr(ar, "onsets", feats.onsets)
+    monkeypatch.setattr(ar, "chroma", feats.chroma)
+    monkeypatch.setattr(ar, "load_audio", feats.load_audio)
+    monkeypatch.setattr(torch, "randn", stubs.SeededRandn(44))
+    seen = {}
+
+    def get_latents(selection, args):
+        seen["latents"] = plugin.get_latents(selection, args)
+        return seen["latents"]
+
+    def get_noise(height, width, scale, num_scales, args):
+        nz = plugin.get_noise(height, width, scale, num_scales, args)
+        seen.setdefault("noise", []).append(nz)
+        return nz
+
+    out = gav.generate(ckpt="seeded512.pt", audio_file="clip.wav", initialize=plugin.initialize, get_latents=get_latents,
+                       get_noise=get_noise, latent_file="selection.npy", G_res=size, out_size=size, fps=fps, batch=batch,
+                       truncation=truncation, output_file=str(tmp_path / "o.mp4"))
+    _assert_summary(stubs.summary(seen["latents"]), fx, f"{tag}.latents", 2e-5)
+    assert [nz is None for nz in seen["noise"]] == [bool(v) for v in fx[f"{tag}.noise_is_none"]]
+    for i, nz in enumerate(seen["noise"]):
+        if nz is not None:
+            np.testing.assert_allclose(stubs.summary(nz)["stats"], fx[f"{tag}.noise_{i}.stats"], atol=2e-5, rtol=0)
+    np.testing.assert_array_equal(np.load("workspace/last-latents.npy"), np.load("selection.npy"))
+    frames = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(n, size, size, 3)
+    diff = np.abs(frames[:, 3::8, 5::8, :].astype(np.int16) - fx[f"{tag}.sub"].astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (tag, int(diff.max()), float((diff > 0).mean()))
+    sums = frames.reshape(n, -1).sum(1).astype(np.int64)
+    assert np.abs(sums - fx[f"{tag}.sums"]).max() < 2e-3 * size * size * 3  # whole frames, not just the subsample
+
+
 def test_generator_with_bends_and_wide_output_vs_oracle(gpu):
     """Config-5 style network bending through the whole generator: a layer-0 bend that widens the constant (the
     reference's route to 2:1 output, tauceti.py:97-100) plus a per-frame modulated Translate at layer 4 and a Zoom at
@@ -149,7 +283,7 @@ def test_generator_with_bends_and_wide_output_vs_oracle(gpu):
         frames[first: first + u8.shape[0]] = u8.cpu().numpy()
 
     def o_translate(t):
-        pads = (int(w / 2) + 2 * w, int(w / 2) + w, 0, 0)
+        pads = [(int(w / 2), int(w / 2), 0, 0), (w, w, 0, 0), (w, 0, 0, 0)]  # the reference's three stacked pads
         m = bend._inverse_maps_translate(shift).numpy()
         return torch.from_numpy(signal_oracle.affine_reflect_warp(t.numpy(), m, pads, bnoise.numpy())).float()
 

@@ -152,9 +152,15 @@ def test_bends_vs_oracle(gpu):
     noise = (0.1 * rng.standard_normal((1, 1, h, 5 * w))).astype(np.float32)
     t = torch.tensor([[0.0, 0.0], [3.5, 0.0], [-7.25, 0.0]])
     mod = bend.Translate(t, h, w, torch.from_numpy(noise))
-    pads = (int(w / 2) + 2 * w, int(w / 2) + w, 0, 0)
+    pads = [(int(w / 2), int(w / 2), 0, 0), (w, w, 0, 0), (w, 0, 0, 0)]  # three STACKED pads (reference bend.py:60-64)
     want = signal_oracle.affine_reflect_warp(x, bend._inverse_maps_translate(t).numpy(), pads, noise)
     np.testing.assert_allclose(mod(xd).cpu().numpy(), want, atol=1e-5)
+    # the point of the stacked pads (examples/tauceti.py:142-144): scrolling by a whole width w shows the same features
+    # as scrolling by 0, so the saw-tooth modulation loops seamlessly
+    zero = torch.zeros(1, 1, h, 5 * w)
+    scroll = lambda dx: bend.Translate(torch.tensor([[dx, 0.0]] * b), h, w, zero)(xd).cpu().numpy()  # noqa: E731
+    np.testing.assert_allclose(scroll(float(w)), scroll(0.0), atol=1e-6)
+    assert np.abs(scroll(w / 2.0) - scroll(0.0)).max() > 0.1
     # zero translation: the asymmetric reference padding (2.5 w left, 1.5 w right) + centre crop shows source columns
     # [-w/2, w/2) -> the reflected left half followed by the left half
     got0 = mod(xd).cpu().numpy()[0] - noise[0, 0][:, 2 * w: 3 * w][None]
@@ -280,3 +286,18 @@ def test_constant_q_transform_vs_oracle(gpu):
         np.testing.assert_allclose(got, want, atol=1e-6 + 1e-5 * want.max())
         np.testing.assert_allclose(sig.raw_chroma(y, sr, type="cqt", nearest_neighbor=False), signal_oracle.chroma_cqt(y, sr),
                                    atol=2e-4)
+
+
+def test_slerp_loops_matches_reference_golden(gpu, golden):
+    """slerp_loops against the reference function (latent_utils.npz; run there with the float32 cast its own
+    gaussian_filter needs): key spacing, Gaussian smoothing on the HIP FIR kernel, tiling and the ragged tail."""
+    from maua_stylegan2_amd.audioreactive import latent, signal as sig
+
+    g = golden("latent_utils.npz")
+    sig.set_SMF(1)
+    sel = g["slerp_loops.sel"]
+    for tag in "abc":
+        n_frames, n_loops, smoothing, loop = (int(v) for v in g[f"slerp_loops.{tag}.cfg"])
+        y = latent.slerp_loops(sel, n_frames, n_loops, smoothing, bool(loop))
+        assert list(y.shape) == g[f"slerp_loops.{tag}.shape"].tolist() and y.dtype == torch.float32
+        np.testing.assert_allclose(y.cpu().numpy()[:, ::6, :], g[f"slerp_loops.{tag}.y"], atol=1e-5, err_msg=tag)
