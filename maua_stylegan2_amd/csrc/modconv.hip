@@ -36,9 +36,9 @@
 
 #include <type_traits>
 
-// (experiments, see profiles/r01_isa_modconv.md) the buffer-descriptor builtins only exist in the device pass
-#if defined(MAUA_DMA_BUFFER) && defined(__HIP_DEVICE_COMPILE__)
-#define MAUA_DMA_BUFFER_DEV 1
+// the buffer-descriptor builtins (MUBUF `buffer_load ... lds`) only exist in the device pass
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAUA_DEVICE_PASS 1
 #endif
 
 namespace {
@@ -341,13 +341,12 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             // B^T d for F(4,3) (interpolation points 0, +-1, +-2, inf) on six consecutive patch floats:
             //   t0 = 4 d0 - 5 d2 + d4          t1 = (d4 - 4 d2) + (d3 - 4 d1)     t2 = (d4 - 4 d2) - (d3 - 4 d1)
             //   t5 = 4 d1 - 5 d3 + d5          t3 = (d4 - d2) + 2 (d3 - d1)       t4 = (d4 - d2) - 2 (d3 - d1)
-#ifdef MAUA_W43_PIPE
-            // EXPERIMENT (not built by default; tools/build_exp.sh w43pipe -DMAUA_W43_PIPE): explicit software pipeline over
-            // the (ky, channel pair) groups of a chunk.  In the default schedule (tools/isa_mix.py, profiles/r01_isa_modconv.md)
-            // every group starts with "B reads -> wait -> 13 VALU -> first MFMA" and every frequency with "A read -> wait ->
-            // MFMA": two LDS round trips and ~80 VALU cycles with at most two MFMAs (128 cycles) in flight.  Here the raw
-            // window of group g+1 is read under the first MFMAs of group g, transformed under its middle ones, and the weight
-            // row of the next frequency is read one step ahead; sched_barrier(0) pins that order.
+            // Explicit software pipeline over the (ky, channel pair) groups of a chunk.  A naive schedule starts every group
+            // with "B reads -> wait -> 13 VALU -> first MFMA" and every frequency with "A read -> wait -> MFMA": two LDS round
+            // trips and ~80 VALU cycles with at most two MFMAs (128 cycles) in flight (profiles/r01_isa_modconv.md).  Here the
+            // raw window of group g+1 is read under the first MFMAs of group g, transformed under its middle ones, and the
+            // weight row of the next frequency is read one step ahead; sched_barrier(0) pins that order.  Measured against the
+            // naive schedule (profiles/r02_ab_variants.md): -5..8 % per launch on the 64..512-channel layers.
             constexpr int NG = 3 * (CC / 2);
             float bvp[2][TN][6];
             f32x2 raw[TN][3];
@@ -424,54 +423,6 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 }
             }
             return;
-#endif
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                for (int q = 0; q < CC / 2; ++q) {
-                    float bv[TN][6];
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) {
-                        const float* dp = Pc + 2 * q * g.PSTRIDE + boff[n] + ky * g.PWS;  // offset is a multiple of 4 floats
-                        const f32x2 d01 = *reinterpret_cast<const f32x2*>(dp);
-                        const f32x2 d23 = *reinterpret_cast<const f32x2*>(dp + 2);
-                        const f32x2 d45 = *reinterpret_cast<const f32x2*>(dp + 4);
-                        float a_ = fmaf(-4.f, d23.x, d45.x);
-                        asm volatile("" : "+v"(a_));  // keeps the compiler from pairing a_/b_ into v_pk_fma_f32 behind 4 v_movs
-                        const float b_ = fmaf(-4.f, d01.y, d23.y);
-                        const float c_ = d45.x - d23.x, e_ = d23.y - d01.y;
-                        bv[n][0] = fmaf(4.f, d01.x, fmaf(-5.f, d23.x, d45.x));
-                        bv[n][1] = a_ + b_;
-                        bv[n][2] = a_ - b_;
-                        bv[n][3] = fmaf(2.f, e_, c_);
-                        bv[n][4] = fmaf(-2.f, e_, c_);
-                        bv[n][5] = fmaf(4.f, d01.y, fmaf(-5.f, d23.y, d45.y));
-                        if (Sc) {
-                            const float sc = Sc[2 * q + hi];
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) bv[n][k] *= sc;
-                        }
-                    }
-#pragma unroll
-                    for (int xi = 0; xi < 6; ++xi) {
-                        float a[TM];
-                        if (TM == 2) {  // weight rows are packed [lane][mt] per 64 output channels: one 8-byte read, immediate offset
-                            const f32x2 a2 = *reinterpret_cast<const f32x2*>(Ac + ((ky * 6 + xi) * CC + 2 * q) * BM + aoff2);
-                            a[0] = a2.x, a[TM - 1] = a2.y;
-                        } else {
-#pragma unroll
-                            for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[((ky * 6 + xi) * CC + 2 * q) * BM + mt * 32 + aoff];
-                        }
-#pragma unroll
-                        for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-                            for (int n = 0; n < TN; ++n)
-                                acc[mt][n * NPH + xi] =
-                                    __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bv[n][xi], acc[mt][n * NPH + xi], 0, 0, 0);
-                    }
-                }
-            }
-            return;
         }
         if (W23) {
 #pragma unroll
@@ -515,10 +466,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             }
             return;
         }
-#ifdef MAUA_TAP_PIPE
         {
-            // EXPERIMENT (see MAUA_W43_PIPE above): one-step look-ahead of both operands over the 9 x CC/2 (tap, channel pair)
-            // steps of the direct / polyphase branch; the style multiply of the next B operand runs behind the current MFMAs.
+            // direct / polyphase branch: one-step look-ahead of both operands over the 9 x CC/2 (tap, channel pair) steps; the
+            // style multiply of the next B operand runs behind the current MFMAs (-5..7 % on the 512-channel layers).
             constexpr int NS = 9 * (CC / 2);
             float a_c[TM], b_c[TN], a_n[TM], b_n[TN];
             auto fetch = [&](int st, float (&a)[TM], float (&b)[TN]) {
@@ -563,35 +513,6 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             }
             return;
         }
-#endif
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            // plain: window rows ky, cols kx.  up: output parity (ky&1, kx&1); tap 2 reads the previous row/col.
-            const int dy = UP ? (ky == 2 ? 0 : 1) : ky;
-            const int dx = UP ? (kx == 2 ? 0 : 1) : kx;
-            const int ph = UP ? ((ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0)) : 0;
-            const int tapoff = dy * g.PWS + dx;
-#pragma unroll
-            for (int q = 0; q < CC / 2; ++q) {
-                float a[TM], bv[TN];
-#pragma unroll
-                for (int mt = 0; mt < TM; ++mt) a[mt] = Ac[(tap * CC + 2 * q) * BM + mt * 32 + aoff];
-#pragma unroll
-                for (int n = 0; n < TN; ++n) bv[n] = Pc[2 * q * g.PSTRIDE + boff[n] + tapoff];
-                if (Sc) {
-                    const float sc = Sc[2 * q + hi];
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) bv[n] *= sc;
-                }
-#pragma unroll
-                for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[mt][n * NPH + ph] =
-                            __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bv[n], acc[mt][n * NPH + ph], 0, 0, 0);
-            }
-        }
     };
 
     if (FAST) {
@@ -610,30 +531,27 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             const int tap = row / CC, c = row - tap * CC;
             a_goff[k] = row < NTAPS * CC ? (tap * g.Cin + c) * g.CoutPad + col : -1;  // -1: lane past the tile, masked off
         }
-#ifdef MAUA_DMA_BUFFER_DEV
+        // Both DMAs are MUBUF `buffer_load ... lds` through raw buffer descriptors: while a FLAT-encoded global_load_lds is
+        // in flight the compiler's wait insertion treats the LGKM counter as out of order and turns EVERY LDS wait of the
+        // chunk into lgkmcnt(0) (profiles/r01_isa_modconv.md); with the buffer form it emits partial counts, which is what
+        // the look-ahead LDS reads of the pipelined MFMA phases need.
+#ifdef MAUA_DEVICE_PASS
         const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, 0x7fffffff, 0x00020000);
 #endif
         auto issue_dma = [&](int chunk, int buf) {
-            const char* wbase = reinterpret_cast<const char*>(p.wp + (size_t)chunk * CC * g.CoutPad + m0);  // uniform
-            (void)wbase;
             float* dst = As + buf * A_FLOATS;
+            (void)dst;
 #pragma unroll
             for (int k = 0; k < A_PER_WAVE; ++k) {
                 const int i = wave + 4 * k;  // scalar
                 constexpr bool RAGGED = (NTAPS * CC) % RPI != 0;  // only then can lanes of the last instruction be masked
                 if (i < A_INSTR && (!RAGGED || a_goff[k] >= 0))
-#ifdef MAUA_DMA_BUFFER_DEV
-                    // EXPERIMENT (tools/build_exp.sh ... -DMAUA_DMA_BUFFER): the same DMA as a MUBUF `buffer_load ... lds`.
-                    // While a FLAT-encoded global_load_lds is in flight the compiler's wait insertion treats the LGKM counter
-                    // as out of order and turns EVERY LDS wait of the chunk into lgkmcnt(0) (profiles/r01_isa_modconv.md);
-                    // with the buffer form it emits partial counts again, which is what look-ahead LDS reads need.
+#ifdef MAUA_DEVICE_PASS
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         w_rsrc, (__attribute__((address_space(3))) void*)(dst + i * 256), 16, a_goff[k] * 4,
                         (int)(((size_t)chunk * CC * g.CoutPad + m0) * 4), 0, 0);
 #else
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void*)(wbase + (unsigned)a_goff[k] * 4u),
-                        (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+                    (void)a_goff[k];
 #endif
             }
         };
@@ -700,29 +618,26 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                 rel_bytes[i] = pvalid[i] ? (unsigned)(src_off[i] - b0 * g.Cin * (int)plane_in) * 4u : 0u;
             const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * g.Cin * plane_in);
             const size_t plane_bytes = plane_in * sizeof(float);
-#ifdef MAUA_DMA_BUFFER_DEV
+            (void)ximg, (void)plane_bytes;  // (only the device pass builds the descriptor)
+#ifdef MAUA_DEVICE_PASS
             // one image's features (Cin planes, < 2 GiB: checked on the host) behind a raw buffer descriptor
             const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
 #endif
             auto issue_patch = [&](int chunk, int buf) {
                 float* dst = Ps + buf * PBUF + wave * 64;
-                const char* xc = ximg + (size_t)(chunk * CC) * plane_bytes;  // uniform
+                (void)dst;
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
 #pragma unroll
                     for (int i = 0; i < MAX_POS; ++i)
-                        if (pvalid[i])
-#ifdef MAUA_DMA_BUFFER_DEV
+                        if (pvalid[i]) {
+#ifdef MAUA_DEVICE_PASS
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                 x_rsrc, (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE + i * 256), 4,
                                 (int)rel_bytes[i], (int)((size_t)(chunk * CC + c) * plane_bytes), 0, 0);
-#else
-                            __builtin_amdgcn_global_load_lds(
-                                (const __attribute__((address_space(1))) void*)(xc + rel_bytes[i]),
-                                (__attribute__((address_space(3))) void*)(dst + c * g.PSTRIDE + i * 256), 4, 0, 0);
 #endif
-                    xc += plane_bytes;
+                        }
                 }
             };
             if (chunk_begin < chunk_end) {

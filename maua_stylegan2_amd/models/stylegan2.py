@@ -737,6 +737,9 @@ class Generator(nn.Module):
         checkpoint noise buffers) and ``static["image"]`` is the output buffer.  Bends are not capturable.
         Graphs captured under different ``lane`` ids share the weights but no activation / input buffer, so they can
         be replayed concurrently on different streams."""
+        if th.cuda.current_stream(self.input.input.device).cuda_stream == 0:
+            raise RuntimeError("capture_graph must run on a non-default stream (with torch.cuda.stream(s): ...): HIP cannot "
+                               "capture the legacy default stream")
         self._lane = lane
         self._captured = True
         try:

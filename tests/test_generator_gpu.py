@@ -207,11 +207,16 @@ def test_generator_variants_match_reference_golden(gpu, golden):
         img, _ = g(styles=lat, noise=noise, truncation=trunc, randomize_noise=False, input_is_latent=True)
         err = float((img.cpu() - torch.from_numpy(fx[f"{key}.image"])).abs().max())
         assert err < TOL, (key, err)
-        graph, static = g.capture_graph(batch, [tuple(n.shape[-2:]) for n in noise], truncated=True)
-        static["latents"].copy_(lat)
-        static["trunc"].copy_(trunc)
-        for dst, src in zip(static["noise"], noise):
-            dst.copy_(src)
-        graph.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(static["image"], img), key
+        with pytest.raises(RuntimeError, match="non-default stream"):
+            g.capture_graph(batch, [tuple(n.shape[-2:]) for n in noise], truncated=True)
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            graph, static = g.capture_graph(batch, [tuple(n.shape[-2:]) for n in noise], truncated=True)
+            static["latents"].copy_(lat)
+            static["trunc"].copy_(trunc)
+            for dst, src in zip(static["noise"], noise):
+                dst.copy_(src)
+            graph.replay()
+            stream.synchronize()
+            assert torch.equal(static["image"], img), key

@@ -10,7 +10,9 @@
 #        Results under gpurun_out/ab/.
 set -u
 cd "$(dirname "$0")/.."
-VARIANTS="buf:-DMAUA_DMA_BUFFER pipebuf:-DMAUA_DMA_BUFFER,-DMAUA_W43_PIPE tappipebuf:-DMAUA_DMA_BUFFER,-DMAUA_W43_PIPE,-DMAUA_TAP_PIPE"
+# name:flag,flag ... — round 1's three switches (buffer-form DMA, F(4,3) pipeline, tap look-ahead) were timed with this script
+# (profiles/r02_ab_variants.md) and became the default schedule; list new experiment macros here or in $VARIANTS.
+VARIANTS="${VARIANTS:-}"
 case "${1:-}" in
 build)
     for v in $VARIANTS; do
