@@ -31,6 +31,18 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
 
+def pmc_traffic_table():
+    """Newest profiles/r*_pmc_traffic.json (written by tools/make_profiles.py from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of THIS bench command): {kernel instance: {read_bytes, write_bytes, dispatches, avg_us, batch}} or None."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    if not paths:
+        return None, None
+    with open(paths[-1]) as f:
+        return json.load(f), os.path.relpath(paths[-1], REPO)
+
+
 def conv_flops_per_frame(size):
     """2*Cin*Cout*k^2*H_in*W_in per modulated conv."""
     from maua_stylegan2_amd.seeding import channels_for
@@ -58,6 +70,9 @@ def time_calls(fn, iters, stream_ptr):
         fn()
     e1.record(stream_ptr)
     return e0.elapsed_ms(e1) / iters
+
+
+INSTANCES = {}  # bench row name -> rocprofv3 kernel instance name (filled by layer_breakdown)
 
 
 def layer_breakdown(g, batch, static, stream):
@@ -100,6 +115,7 @@ def layer_breakdown(g, batch, static, stream):
         ws = g._buf(batch, "bench.ws", (max(n_ws, 1),)) if n_ws else None
         t_up = time_calls(lambda: up.conv.run(xin, s, e_up["s_off"], demod_of(e_up), raw, ws), 10, sp)
         rows.append((f"convs.{2*n}.upconv", "modconv_up", t_up, 2 * cin * cout * 9 * h * h * batch, 0))
+        INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
         t_all = time_calls(lambda: up.run(xin, s, e_up["s_off"], demod_of(e_up), nz1, bufs, f"u{n}"), 10, sp)
         blur_bytes = 4 * batch * cout * ((2 * h + 1) ** 2 + (2 * h) ** 2)
         rows.append((f"convs.{2*n}.blur+noise+act", "upfirdn2d_tail", max(t_all - t_up, 1e-6), 16 * 2 * batch * cout * (2 * h) ** 2, blur_bytes))
@@ -118,6 +134,7 @@ def layer_breakdown(g, batch, static, stream):
         else:
             t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}"), 10, sp)
             rows.append((f"convs.{2*n+1}", "modconv", t_pl, conv_flops, 0))
+        INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
         out = g._buf(batch, f"convs.{2*n+1}", (batch, cout, 2 * h, 2 * h))
         o2 = out
         if not fused:
@@ -159,8 +176,8 @@ def cpu_baseline(size, max_seconds=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: ~2.5 s of device time at 8 frames/step)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="frames per rank per step (reference default --batch 8)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--lanes", type=int, default=3,
@@ -201,7 +218,8 @@ def main():
     # synthetic inputs resident in HBM: a pool of latents for every step of this rank; noise maps for scales <= 256
     # are per-frame (audio-reactive in the default plugin), 512/1024 use the checkpoint buffers (get_noise -> None).
     n_steps = args.steps + args.warmup
-    lat_pool = seeding.seeded_latents(n_steps * B, g.n_latent, seed=100 + rank).to(dev)
+    POOL = 64  # distinct latent batches resident in HBM, cycled through (every step still refreshes the graph's inputs)
+    lat_pool = seeding.seeded_latents(POOL * B, g.n_latent, seed=100 + rank).to(dev)
     sizes = seeding.noise_sizes(size)
     noise_shapes = [(r, r) if r <= 256 else None for r in sizes]
     noise_pool = [torch.from_numpy(seeding.seeded_array(200 + rank, f"n{i}", (B, 1, r, r))).to(dev) if r <= 256 else None
@@ -229,7 +247,8 @@ def main():
             lane = lanes[i % n_lanes]
             with torch.cuda.stream(lane["stream"]):
                 sp_ = lane["stream"].cuda_stream
-                lane["static"]["latents"].copy_(lat_pool[i * B:(i + 1) * B], non_blocking=True)
+                j = i % POOL
+                lane["static"]["latents"].copy_(lat_pool[j * B:(j + 1) * B], non_blocking=True)
                 for dst, src in zip(lane["static"]["noise"], noise_pool):
                     if src is not None:
                         dst.copy_(src, non_blocking=True)
@@ -241,23 +260,73 @@ def main():
             for lane in lanes:
                 lane["stream"].synchronize()
 
+        def run_region(first_step, count, mode):
+            """Time ``count`` steps.  mode "synth": replay + uint8 epilogue only.  "gathered" (N > 1): every step's frames
+            also travel to rank 0 through sharding.FrameStream (one asynchronous RCCL gather per step, as render() issues
+            them); the clock stops when the last round has landed in rank 0's HBM — SURVEY.md 8d's definition of the metric
+            ("uint8 frames gathered to rank 0").  "pcie": every step's frames also go to the host through the pinned
+            staging ring on a copy stream exactly as render() does (null sink)."""
+            fs = None
+            if mode == "gathered":
+                from maua_stylegan2_amd import sharding
+
+                fs = sharding.FrameStream(world * count * B, B, (size, size, 3), dev)
+            n_slots = 3
+            pinned = [torch.empty((B, size, size, 3), dtype=torch.uint8).pin_memory() for _ in range(n_slots)] if mode == "pcie" else None
+            copy_stream = torch.cuda.Stream(dev) if mode == "pcie" else None
+            copied = [None] * n_slots
+            sync_lanes()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k in range(count):
+                i = first_step + k
+                step(i)
+                lane = lanes[i % n_lanes]
+                if fs is not None:
+                    with torch.cuda.stream(lane["stream"]):
+                        fs.push(k, lane["u8"])
+                if mode == "pcie":
+                    slot = k % n_slots
+                    if copied[slot] is not None:
+                        copied[slot].synchronize()  # the host consumed this slot (null sink) before it is overwritten
+                    produced = torch.cuda.Event()
+                    produced.record(lane["stream"])
+                    with torch.cuda.stream(copy_stream):
+                        copy_stream.wait_event(produced)
+                        pinned[slot].copy_(lane["u8"], non_blocking=True)
+                        copied[slot] = torch.cuda.Event()
+                        copied[slot].record(copy_stream)
+                    lane["stream"].wait_event(copied[slot])  # the producer must not overwrite u8 before the copy read it
+            if fs is not None:
+                fs.wait_all()
+            if copy_stream is not None:
+                copy_stream.synchronize()
+            sync_lanes()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            if use_dist:
+                dist.barrier()
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt
+
         for i in range(args.warmup):
             step(i)
         sync_lanes()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(args.warmup, n_steps):
-            step(i)
-        sync_lanes()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-        if use_dist:
-            dist.barrier()
-            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        # the headline region: EXACTLY --steps steps.  One GPU: synthesis with the frames left in HBM (the PCIe-inclusive rate
+        # is reported next to it).  Several GPUs: the frames of every step are gathered to rank 0 inside the timed region.
+        elapsed = run_region(args.warmup, args.steps, "gathered" if world > 1 else "synth")
+        extra = {}
+        side = max(3, min(args.steps, 120))
+        if world > 1:
+            extra["frames_per_sec_synth_only"] = world * side * B / run_region(n_steps, side, "synth")
+        else:
+            extra["frames_per_sec_pcie_inclusive"] = side * B / run_region(n_steps, side, "pcie")
+            extra["pcie_inclusive_note"] = (f"{side} steps; uint8 frames copied to pinned host memory through a 3-slot staging "
+                                            "ring on a copy stream, as render() does; null sink (no encoder)")
         checksum = int(sum(int(lane["u8"].sum().item()) for lane in lanes))
 
         result = None
@@ -274,6 +343,11 @@ def main():
                                        f"per-frame noise <=256^2, uint8 NHWC epilogue",
                            "frames_per_step_per_gpu": B, "lanes": n_lanes, "parallelism": f"frame-shard x{world}"},
                 "frames_per_sec_per_gpu": fps / world,
+                "timed_region_s": elapsed,
+                "value_definition": ("uint8 frames of every step gathered to rank 0's HBM (one async RCCL gather per step, "
+                                     "sharding.FrameStream) inside the timed region" if world > 1 else
+                                     "uint8 frames left in HBM (see frames_per_sec_pcie_inclusive for the host-inclusive rate)"),
+                **extra,
                 "conv_tflops_sustained": conv_flops_per_frame(size) * fps / world / 1e12,
                 "frame_checksum": checksum,
                 "device": _lib.device_info(),
@@ -288,7 +362,10 @@ def main():
                     fam[family][0] += ms
                     fam[family][1] += flops
                     fam[family][2] += byts
-                result["kernel_families"] = {k: {"ms_per_step": v[0], "share": v[0] / total_ms,
+                result["kernel_families_note"] = (
+                    "isolated eager launches on one stream (HIP events), summed per family; `share` is the share of THAT sum "
+                    f"({total_ms:.3f} ms) — the timed steps overlap {n_lanes} graph lanes, so the sum exceeds ms_per_step")
+                result["kernel_families"] = {k: {"ms_isolated": v[0], "share": v[0] / total_ms,
                                                  "tflops": v[1] / v[0] / 1e9, "gbs": v[2] / v[0] / 1e6}
                                              for k, v in fam.items()}
                 result["layers"] = [{"name": n, "ms": ms, "tflops": fl / ms / 1e9, "gbs": by / ms / 1e6} for n, _, ms, fl, by in rows]
@@ -315,12 +392,20 @@ def main():
                                 "direct-conv flops as SURVEY 8d defines them and can therefore exceed 1)")
                             result["roofline"]["executed"] = ach * ratio
                             result["roofline"]["executed_frac"] = ach * ratio / MFMA_F32_PEAK_TFLOPS
-                    if size == 1024 and B == 8 and dom[0].startswith("convs.15"):
-                        # HBM bytes of this launch from the PMC passes (FETCH_SIZE x2 correction, WRITE_SIZE exact):
-                        # 2 x 555,601 KB read + 131,072 KB written; algorithmic 1,077,252 KB + 98,304 KB
-                        result["roofline"]["traffic"] = (2 * 555601.4 + 131072.0) * 1024
-                        result["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_traffic.md"
-                        result["roofline"]["algorithmic_bytes"] = (1077252 + 98304) * 1024
+                    inst = INSTANCES.get(dom[0])
+                    result["roofline"]["kernel_instance"] = inst
+                    table, table_path = pmc_traffic_table()
+                    rec = (table or {}).get("kernels", {}).get(inst) if inst else None
+                    if rec is not None and table.get("batch") == B and table.get("size") == size and rec.get("dispatches_per_step") == 1:
+                        # HBM bytes of this launch from the PMC passes of the SAME bench command (tools/profile_round.sh ->
+                        # tools/make_profiles.py): FETCH_SIZE x2 (guide's gfx950 correction, calibrated on a known-size copy) +
+                        # WRITE_SIZE.  Only used when that instance is launched once per step, i.e. the average IS this launch.
+                        result["roofline"]["traffic"] = rec["read_bytes"] + rec["write_bytes"]
+                        result["roofline"]["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}"
+                    if size == 1024 and dom[0].startswith("convs.15"):
+                        # input + skip image + noise map + packed weights, read once; RGB image written once
+                        result["roofline"]["algorithmic_bytes"] = (B * 32 * size * size * 4 + B * 3 * (size // 2) ** 2 * 4
+                                                                   + size * size * 4 + 18 * 32 * 32 * 4 + B * 3 * size * size * 4)
                 else:
                     ach = dom[4] / dom[2] / 1e6
                     result["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -341,10 +426,14 @@ def main():
             ach = byts / ms / 1e6
             # HBM bytes per launch from the PMC passes of profiles/r01_pmc_upfirdn2d.md (FETCH_SIZE x2 correction,
             # WRITE_SIZE exact), scaled to this launch's plane count; measured at 256 planes.
-            traffic = (2 * 537346.9 + 1048576.0) * 1024.0 * major / 256.0 if size == 1024 else None
+            table, table_path = pmc_traffic_table()
+            rec = (table or {}).get("kernels", {}).get("fir_strip_kernel<4, 4, 4, false, false>")
+            traffic = None
+            if rec is not None and table.get("size") == size and rec.get("planes"):
+                traffic = (rec["read_bytes"] + rec["write_bytes"]) * major / rec["planes"]  # scaled to this launch's planes
             result["roofline_upfirdn2d"] = {"kernel": "fir_strip_kernel<4,4,4,false,false>", "bound": "hbm", "achieved": ach,
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                            "traffic": traffic, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_upfirdn2d.md", "launch_ms": ms, "algorithmic_bytes": byts,
+                                            "traffic": traffic, "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}" if traffic else None), "launch_ms": ms, "algorithmic_bytes": byts,
                                             "shape": f"[{xin.shape[0]},{xin.shape[1]},{r_out+1},{r_out+1}] -> {r_out}^2"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -107,6 +107,9 @@ int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, vo
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
  * floats used for split-K partial sums on small feature maps (may be NULL when that returns 0). */
 int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up);
+/* Name of the kernel template instance launched by the last modconv call of this process, as rocprofv3 prints it
+ * ("modconv_mfma_kernel<BM, BN, WM, MODE, MULTI, FAST, MAXP>") — the key of the per-instance PMC tables in profiles/. */
+int maua_modconv_last_instance(char* buf, int buf_len);
 int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                         float* y, int batch, int cin, int cout, int h, int w, int up, float wscale, int fuse_act,
                         const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,

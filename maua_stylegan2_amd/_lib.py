@@ -50,6 +50,7 @@ _SIGNATURES = {
     "maua_pack_weight_wino43_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "maua_pack_weight_upwino_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "maua_modconv_ws_floats": (c_int64, [c_int] * 6),
+    "maua_modconv_last_instance": (c_int, [c_char_p, c_int]),
     "maua_modconv3x3_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, _P, c_int64, _P, _P, _P, _P]),
     "maua_styledconv_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
                                           _P, _P, _P, _P, c_int, _P]),
@@ -138,6 +139,13 @@ def device_info():
     buf = ctypes.create_string_buffer(256)
     check(lib.maua_device_info(ctypes.byref(cu), ctypes.byref(lds), buf, 256), "maua_device_info")
     return {"cu_count": cu.value, "lds_bytes": lds.value, "name": buf.value.decode()}
+
+
+def last_modconv_instance():
+    """rocprofv3 name of the kernel instance the last modulated-conv call launched (key of profiles/*_pmc_traffic.json)."""
+    buf = ctypes.create_string_buffer(128)
+    check(load().maua_modconv_last_instance(buf, 128), "maua_modconv_last_instance")
+    return buf.value.decode()
 
 
 class HipEvent:

@@ -34,6 +34,7 @@
 // MFMAs per output (Winograd) and fewer non-MFMA instructions are what pay, not occupancy or prefetch depth.
 #include "common.h"
 
+#include <cstdio>
 #include <type_traits>
 
 // the buffer-descriptor builtins (MUBUF `buffer_load ... lds`) only exist in the device pass
@@ -1181,9 +1182,13 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
     return pl;
 }
 
+char g_last_instance[96] = "";
+
 template <int BM, int BN, int WM, int UP, bool MULTI, bool FAST, int MAXP>
 int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI, FAST, MAXP>;
+    snprintf(g_last_instance, sizeof(g_last_instance), "modconv_mfma_kernel<%d, %d, %d, %d, %s, %s, %d>", BM, BN, WM, UP,
+             MULTI ? "true" : "false", FAST ? "true" : "false", MAXP);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1263,6 +1268,15 @@ extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, i
     if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     return pl.g.splits > 1 ? pl.g.ws_slab * pl.g.splits : 0;
+}
+
+// Name of the kernel template instance the LAST maua_modconv3x3_f32 / maua_styledconv_torgb_f32 call of this process
+// launched, as rocprofv3 prints it ("modconv_mfma_kernel<BM, BN, WM, MODE, MULTI, FAST, MAXP>"): lets bench.py join its live
+// timings with the per-instance PMC tables under profiles/ without re-implementing the plan.
+extern "C" int maua_modconv_last_instance(char* buf, int buf_len) {
+    if (!buf || buf_len <= 0) return MAUA_EINVAL;
+    snprintf(buf, (size_t)buf_len, "%s", g_last_instance);
+    return 0;
 }
 
 namespace {

@@ -114,18 +114,28 @@ def _collect_noise(get_noise, args, out_size, G_res, stylegan1):
     return maps
 
 
-def _share_from_rank0(latents, noise, truncation, bends):
-    """One process per GPU: every rank ran the callbacks (they may draw random numbers); rank 0's results win."""
-    def bc(t):
-        return sharding.broadcast_tensor(t.cuda().float().contiguous())
-
-    latents = bc(latents)
-    noise = [None if nz is None else bc(nz) for nz in noise]
-    if not isinstance(truncation, float):
-        truncation = bc(truncation)
+def _scatter_from_rank0(latents, noise, truncation, bends, rewrites, n_frames):
+    """One process per GPU: rank 0 ran the audio front end and the callbacks; every rank receives only its contiguous
+    block of the per-frame inputs (sharding.scatter_frames).  Bend modulations are broadcast (they are [n_frames, k]
+    vectors) and cut to the block here, because the transforms that consume them are closures every rank built itself."""
+    rank, world = sharding.rank_world()
+    dev = th.device("cuda", th.cuda.current_device()) if th.cuda.is_available() else th.device("cpu")
+    on_dev = lambda t: None if t is None else t.to(dev, th.float32).contiguous()  # noqa: E731
+    latents = sharding.scatter_frames(on_dev(latents), n_frames, device=dev)
+    n_noise = sharding.broadcast_object(len(noise) if rank == 0 else None)
+    noise = [sharding.scatter_frames(on_dev(noise[i]) if rank == 0 else None, n_frames, device=dev) for i in range(n_noise)]
+    is_float = sharding.broadcast_object(isinstance(truncation, float) if rank == 0 else None)
+    if is_float:
+        truncation = float(sharding.broadcast_object(truncation if rank == 0 else None))
+    else:
+        truncation = sharding.scatter_frames(on_dev(truncation) if rank == 0 else None, n_frames, device=dev)
+    lo, hi = sharding.shard_bounds(n_frames, rank, world)
     for bend in bends:
         if "modulation" in bend:
-            bend["modulation"] = bc(bend["modulation"])
+            bend["modulation"] = sharding.broadcast_tensor(on_dev(bend["modulation"]))[lo:hi]
+    for name in sorted(rewrites):
+        rewrite, modulation = rewrites[name]
+        rewrites[name] = [rewrite, sharding.broadcast_tensor(on_dev(modulation))[lo:hi]]
     return latents, noise, truncation
 
 
@@ -143,55 +153,76 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
     th.set_grad_enabled(False)
     ar.set_SMF(args.fps / 30)  # temporal smoothing independent of the frame rate
 
-    args.audio, args.sr, duration = ar.load_audio(audio_file, offset, duration)
-    args.duration = duration
-    args.n_frames = n_frames = int(round(duration * fps))
-    if initialize is not None:
-        args = initialize(args)
+    rank, world = sharding.rank_world()
+    # One process per GPU: the audio front end and the latent / noise / truncation callbacks run on rank 0 only and their
+    # per-frame results are scattered.  Bends and rewrites are closures, so a plugin that defines them is run on every rank
+    # (from one broadcast seed, so that random draws inside it agree).
+    everywhere = world > 1 and (get_bends is not None or get_rewrites is not None)
+    front_end = rank == 0 or everywhere
+    if world > 1:
+        seed = int(sharding.broadcast_object(random.randrange(2 ** 31) if rank == 0 else None))
+        if everywhere:
+            th.manual_seed(seed), np.random.seed(seed), random.seed(seed)
 
     from .audioreactive.examples import default as default_plugin
 
     get_latents = get_latents or default_plugin.get_latents
     get_noise = get_noise or default_plugin.get_noise
+    latents, noise, bends, rewrites = None, [], [], {}
+    if front_end:
+        args.audio, args.sr, duration = ar.load_audio(audio_file, offset, duration)
+    duration = float(sharding.broadcast_object(duration if rank == 0 else None))
+    args.duration = duration
+    args.n_frames = n_frames = int(round(duration * fps))
+    if front_end:
+        if initialize is not None:
+            args = initialize(args)
 
-    print("\ngenerating latents...")
-    if latent_file is not None:
-        selection = ar.load_latents(latent_file)
-    else:
-        selection = ar.generate_latents(args.latent_count, ckpt, G_res, noconst, latent_dim, n_mlp, channel_multiplier)
-        selection = sharding.broadcast_tensor(selection.cuda()).cpu()
-    if shuffle_latents:
-        selection = selection[random.sample(range(len(selection)), len(selection))]
-    if sharding.rank_world()[0] == 0:  # one writer under torchrun
+    if rank == 0:
+        print("\ngenerating latents...")
+        if latent_file is not None:
+            selection = ar.load_latents(latent_file)
+        else:
+            selection = ar.generate_latents(args.latent_count, ckpt, G_res, noconst, latent_dim, n_mlp, channel_multiplier)
+        if shuffle_latents:
+            selection = selection[random.sample(range(len(selection)), len(selection))]
         os.makedirs("workspace", exist_ok=True)
         np.save("workspace/last-latents.npy", selection.numpy())
-    latents = get_latents(selection=selection, args=args)
-    print(f"{list(latents.shape)} amplitude={latents.std()}\n")
+        latents = get_latents(selection=selection, args=args)
+        print(f"{list(latents.shape)} amplitude={latents.std()}\n")
 
-    print("generating noise...")
-    noise = _collect_noise(get_noise, args, out_size, G_res, stylegan1)
-    print()
+        print("generating noise...")
+        noise = _collect_noise(get_noise, args, out_size, G_res, stylegan1)
+        print()
 
-    bends, rewrites = [], {}
-    if get_bends is not None:
+    if front_end and get_bends is not None:
         print("generating network bends...")
         bends = get_bends(args=args)
-    if get_rewrites is not None:
+    if front_end and get_rewrites is not None:
         print("generating model rewrites...")
         rewrites = get_rewrites(args=args)
-    if get_truncation is not None:
-        print("generating truncation...")
-        truncation = get_truncation(args=args)
-    else:
-        truncation = float(truncation)
+    if rank == 0:
+        if get_truncation is not None:
+            print("generating truncation...")
+            truncation = get_truncation(args=args)
+        else:
+            truncation = float(truncation)
 
-    if sharding.rank_world()[1] > 1:
-        latents, noise, truncation = _share_from_rank0(latents, noise, truncation, bends)
+    shard = None
+    if world > 1:
+        latents, noise, truncation = _scatter_from_rank0(latents, noise, truncation, bends, rewrites, n_frames)
+        lo, hi = sharding.shard_bounds(n_frames, rank, world)
+        shard = (lo, hi, n_frames)
 
     gc.collect()
     generator = load_generator(ckpt=ckpt, is_stylegan1=stylegan1, G_res=G_res, out_size=out_size, noconst=noconst,
                                latent_dim=latent_dim, n_mlp=n_mlp, channel_multiplier=channel_multiplier,
                                dataparallel=dataparallel, base_res_factor=base_res_factor)
+    if world > 1 and not (isinstance(truncation, float) and truncation == 1.0):
+        # the truncation centre is a random draw (mean_latent(2**14), reference models/stylegan2.py:539-540): one draw, on rank
+        # 0, for every shard — otherwise neighbouring shards are truncated toward slightly different centres
+        centre = generator.mean_latent(2 ** 14) if rank == 0 else th.empty(1, latent_dim, device=generator.input.input.device)
+        generator.truncation_latent = sharding.broadcast_tensor(centre.contiguous())
     print(f"\npreprocessing took {time.time() - started:.2f}s\n")
 
     print(f"rendering {n_frames} frames...")
@@ -202,7 +233,7 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
     written = render.render(generator=generator, latents=latents, noise=noise, audio_file=audio_file, offset=offset,
                             duration=duration, batch_size=batch, truncation=truncation, bends=bends, rewrites=rewrites,
                             out_size=out_size, output_file=output_file, randomize_noise=randomize_noise,
-                            ffmpeg_preset=ffmpeg_preset)
+                            ffmpeg_preset=ffmpeg_preset, **({"_shard": shard} if shard is not None else {}))
     dt = max(time.time() - t0, 1e-9)
     print(f"\nrendered {written} frames in {dt:.2f}s ({written / dt:.1f} frames/s)")
     print(f"total time taken: {(time.time() - started) / 60:.2f} minutes")

@@ -226,13 +226,20 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
 
 
 def render(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file=None,
-           truncation=1.0, bends=[], rewrites={}, randomize_noise=False, ffmpeg_preset="slow"):
+           truncation=1.0, bends=[], rewrites={}, randomize_noise=False, ffmpeg_preset="slow", _shard=None):
     """Drop-in for reference render.render (render.py:14-29).  With torch.distributed initialised (one process per
-    GPU) every rank renders a contiguous shard of the frames and rank 0 receives them in order over RCCL."""
+    GPU) every rank renders a contiguous shard of the frames and streams them, batch by batch, to rank 0's ordered sink
+    (sharding.FrameStream).  ``_shard = (lo, hi, n_frames)`` (set by generate() after sharding.scatter_frames) says that
+    ``latents`` / ``noise`` / ``truncation`` / bend modulations already hold only this rank's block."""
     width, height = _output_dims(out_size)
-    n_frames = len(latents)
     rank, world = sharding.rank_world()
-    lo, hi = sharding.shard_bounds(n_frames, rank, world)
+    if _shard is None:
+        n_frames = len(latents)
+        lo, hi = sharding.shard_bounds(n_frames, rank, world)
+        frame_range = (lo, hi)
+    else:
+        lo, hi, n_frames = _shard
+        frame_range = (0, hi - lo)
     dev = generator.input.input.device
     sink = None
     if rank == 0:
@@ -274,22 +281,40 @@ def render(generator, latents, noise, offset, duration, batch_size, out_size, ou
             for p in pending:
                 drain(p)
         else:
-            shard = None
+            # One asynchronous gather per batch-round, issued as soon as the round's frames exist: the transfer of round k
+            # runs under the compute of rounds k+1.., rank 0 writes frames to the sink as their rounds land (its own block
+            # first — the blocks are contiguous — while the peers' frames accumulate in its HBM store).
+            stream = None
+            k = 0
             for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
-                                        randomize_noise, frame_range=(lo, hi)):
-                if shard is None:
-                    shard = th.empty((sharding.max_shard(n_frames, world),) + tuple(u8.shape[1:]), dtype=th.uint8,
-                                     device=dev)
-                shard[first - lo: first - lo + u8.shape[0]].copy_(u8)
-            if dev.type == "cuda":
-                th.cuda.synchronize(dev)
-            if shard is None:  # a rank whose block is empty (more ranks than frames) still takes part in the gather
-                shard = th.zeros((sharding.max_shard(n_frames, world), height, width, 3), dtype=th.uint8, device=dev)
-            gathered = sharding.gather_frames(shard, n_frames)
+                                        randomize_noise, frame_range=frame_range):
+                if stream is None:  # the frame shape is whatever the generator (and its layer-0 bends) produce
+                    stream = sharding.FrameStream(n_frames, batch_size, tuple(u8.shape[1:]), dev)
+                stream.push(k, u8)
+                k += 1
+                if rank == 0:
+                    for _, frame in stream.drain(block=False):
+                        sink.write(frame.numpy())
+            if stream is None:  # a rank whose block is empty (more ranks than frames) still takes part in every round
+                stream = sharding.FrameStream(n_frames, batch_size, _stream_frame_shape(generator, out_size), dev)
+            stream.finish()
             if rank == 0:
-                for frame in gathered:
-                    sink.write(frame.numpy() if isinstance(frame, th.Tensor) else frame)
+                for _, frame in stream.drain(block=True):
+                    sink.write(frame.numpy())
+            else:
+                stream.wait_all()
     finally:  # the encoder process / output file must not outlive a failed render
         if sink is not None:
             sink.close()
     return sink.count if sink is not None else 0
+
+
+def _stream_frame_shape(generator, out_size):
+    """[H, W, 3] of the frames the generator produces for ``out_size`` (1920 / 1080 render 2048-px-wide / -high frames
+    that the sink crops and resizes, render.py:98-105)."""
+    side = int(getattr(generator, "size", 0)) or _output_dims(out_size)[0]
+    if out_size == 1920:
+        return (side, 2 * side, 3)
+    if out_size == 1080:
+        return (2 * side, side, 3)
+    return (side, side, 3)

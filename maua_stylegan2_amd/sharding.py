@@ -3,13 +3,17 @@
 every forward.
 
 Frames are independent units: one process per GPU (torchrun), rank r renders the contiguous block
-``shard_bounds(n_frames, r, world)``, with NO collective on the data path.  Collectives (RCCL over xGMI through
-``torch.distributed``; ``gloo`` in the CPU tests) appear exactly twice per render:
-  * ``broadcast_module``: weights + buffers from rank 0, once (only rank 0 needs the checkpoint);
-  * ``gather_frames``: finished uint8 NHWC frames to rank 0 (3 MiB/frame at 1024^2 — 4x less than the fp32 images
-    DataParallel gathers), each peer over its own direct xGMI link.
-``truncation_latent`` is random in the reference (models/stylegan2.py:539-540); ``broadcast_tensor`` keeps it identical
-on every rank.
+``shard_bounds(n_frames, r, world)``.  Collectives (RCCL over xGMI through ``torch.distributed``; ``gloo`` in the CPU
+tests):
+  * ``broadcast_module``: weights + buffers from rank 0, once (only rank 0 reads the checkpoint);
+  * ``scatter_frames``: rank 0 ran the audio front end and the plugin callbacks; every rank receives only ITS block of the
+    per-frame inputs (latents, reactive noise maps, truncation) — 1/world of what a broadcast would move;
+  * ``FrameStream``: finished uint8 NHWC frames (3 MiB/frame at 1024^2 — 4x less than the fp32 images DataParallel gathers)
+    travel to rank 0 one batch-round at a time, as asynchronous gathers that overlap the next batches' compute; each peer
+    writes over its own direct xGMI link into its slot of rank 0's HBM store, and rank 0's ordered sink consumes frames
+    while the shards are still rendering.  No all-reduce anywhere on the path.
+``truncation_latent`` is random in the reference (models/stylegan2.py:539-540); generate() draws it on rank 0 and
+``broadcast_tensor`` makes it identical on every rank.
 """
 import torch as th
 import torch.distributed as dist
@@ -75,3 +79,128 @@ def gather_frames(shard, n_frames, dst=0, chunk=64):
                     yield host[i]
 
     return frames()
+
+
+def broadcast_object(obj, src=0):
+    """Small picklable metadata (shapes, which noise scales are None) from ``src`` to every rank."""
+    rank, world = rank_world()
+    if world == 1:
+        return obj
+    box = [obj if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def scatter_frames(t, n_frames, src=0, device=None):
+    """``t`` [n_frames, ...] exists on ``src`` (others pass None): every rank gets its contiguous block
+    ``t[shard_bounds(n_frames, rank, world)]`` on ``device`` and nothing else.  ``None`` on ``src`` stays ``None`` everywhere
+    (a noise scale served by the checkpoint's buffer)."""
+    rank, world = rank_world()
+    if world == 1:
+        return t if t is None or device is None else t.to(device)
+    meta = broadcast_object(None if t is None else (tuple(t.shape[1:]), str(t.dtype).replace("torch.", "")), src)
+    if meta is None:
+        return None
+    shape, dtype = meta[0], getattr(th, meta[1])
+    per = max_shard(n_frames, world)
+    if device is None:
+        device = t.device if t is not None else th.device("cpu")
+    mine = th.empty((per,) + shape, dtype=dtype, device=device)
+    chunks = None
+    if rank == src:
+        if t.shape[0] != n_frames:
+            raise RuntimeError(f"per-frame tensor has {t.shape[0]} entries for {n_frames} frames")
+        padded = th.zeros((world * per,) + shape, dtype=dtype, device=device)
+        padded[:n_frames].copy_(t)
+        chunks = list(padded.view((world, per) + shape).unbind(0))
+    dist.scatter(mine, chunks, src=src)
+    lo, hi = shard_bounds(n_frames, rank, world)
+    return mine[: hi - lo]
+
+
+class FrameStream:
+    """Ordered multi-rank frame sink transport: every rank calls ``push(k, u8)`` once per batch-round k = 0, 1, ... with the
+    frames it produced in that round ([b <= batch, H, W, 3] uint8, or None when its block is exhausted); each push starts
+    one asynchronous ``gather`` of that round straight into ``dst``'s store [world, rounds * batch, H, W, 3] (device memory:
+    675 MiB per peer at 1800 frames / 8 GPUs), so transfers overlap the following rounds' compute.  On ``dst``,
+    ``drain()`` yields the frames whose round has landed, in global frame order (rank-major: the blocks are contiguous),
+    fetched to the host one round at a time — reference render.py:94-113 semantics (an ordered writer that consumes while
+    the generator runs) without its per-frame D2H."""
+
+    def __init__(self, n_frames, batch_size, frame_shape, device, dst=0):
+        self.rank, self.world = rank_world()
+        self.n_frames, self.batch, self.dst = int(n_frames), int(batch_size), dst
+        self.per = max_shard(n_frames, self.world)
+        self.rounds = (self.per + self.batch - 1) // self.batch
+        self.lo, self.hi = shard_bounds(n_frames, self.rank, self.world)
+        self.shape = tuple(frame_shape)
+        slots = max(self.rounds, 1) * self.batch
+        # this rank's frames, kept until the gather has read them (the producer recycles its batch buffers)
+        self.mine = th.zeros((slots,) + self.shape, dtype=th.uint8, device=device)
+        self.store = th.empty((self.world, slots) + self.shape, dtype=th.uint8, device=device) if self.rank == dst else None
+        self.works = []
+        self.pushed = 0
+        self._cursor = (0, 0)  # (rank, round) of the next frames to hand out on dst
+
+    def push(self, k, u8):
+        if k != self.pushed:
+            raise RuntimeError(f"FrameStream.push: round {k} out of order (expected {self.pushed})")
+        slot = self.mine[k * self.batch: (k + 1) * self.batch]
+        if u8 is not None:
+            slot[: u8.shape[0]].copy_(u8)
+        if self.world > 1:
+            into = [self.store[p, k * self.batch: (k + 1) * self.batch] for p in range(self.world)] if self.rank == self.dst else None
+            self.works.append(dist.gather(slot, into, dst=self.dst, async_op=True))
+        elif self.store is not None:
+            self.store[0, k * self.batch: (k + 1) * self.batch].copy_(slot)
+            self.works.append(None)
+        self.pushed += 1
+
+    def finish(self):
+        """Keep taking part in the remaining rounds (ranks whose block was short or empty) — every rank must issue the
+        same sequence of collectives."""
+        while self.pushed < self.rounds:
+            self.push(self.pushed, None)
+
+    def wait_all(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+
+    def _landed(self, k, block):
+        if k >= len(self.works):
+            return False
+        w = self.works[k]
+        if w is None:
+            return True
+        if block:
+            w.wait()
+            return True
+        return w.is_completed()
+
+    def drain(self, block=False):
+        """dst only: yield (global_frame_index, uint8 CPU tensor [H, W, 3]) for every frame that is next in order and whose
+        round has arrived; with ``block=True`` wait for rounds that were pushed but have not landed yet."""
+        if self.rank != self.dst:
+            return
+        p, k = self._cursor
+        while p < self.world:
+            lo, hi = shard_bounds(self.n_frames, p, self.world)
+            first = lo + k * self.batch
+            if first >= hi:  # this rank's block is done (or empty): next rank
+                p, k = p + 1, 0
+                self._cursor = (p, k)
+                continue
+            count = min(self.batch, hi - first)
+            if p == self.rank:  # dst's own frames never wait for a transfer: they are local as soon as they are pushed
+                if k >= self.pushed:
+                    break
+                host = self.mine[k * self.batch: k * self.batch + count].cpu()
+            else:
+                if not self._landed(k, block):
+                    break
+                host = self.store[p, k * self.batch: k * self.batch + count].cpu()
+            k += 1
+            self._cursor = (p, k)
+            for i in range(count):
+                yield first + i, host[i]

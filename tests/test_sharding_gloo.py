@@ -128,3 +128,91 @@ def test_render_two_ranks_ordered_sink(tmp_path):
     n_frames = 11
     mp.spawn(_render_worker, args=(2, _free_port(), n_frames, str(tmp_path)), nprocs=2, join=True)
     assert int(np.load(tmp_path / "render_ok.npy")[0]) == n_frames
+
+
+def _stream_worker(rank, world, port, n_frames, batch, out_dir):
+    import time
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ---- scatter_frames: rank 0 owns the per-frame inputs, every rank gets exactly its block; None stays None
+        full = torch.arange(n_frames * 6, dtype=torch.float32).reshape(n_frames, 3, 2) if rank == 0 else None
+        lo, hi = sharding.shard_bounds(n_frames, rank, world)
+        mine = sharding.scatter_frames(full, n_frames)
+        want = torch.arange(n_frames * 6, dtype=torch.float32).reshape(n_frames, 3, 2)[lo:hi]
+        assert mine.shape == want.shape and torch.equal(mine, want)
+        assert sharding.scatter_frames(None, n_frames) is None
+        assert sharding.broadcast_object({"a": rank} if rank == 0 else None) == {"a": 0}
+
+        # ---- generate()'s hand-over: rank 0 ran the callbacks, the others hold nothing before the scatter
+        from maua_stylegan2_amd import generate_audiovisual as gav
+
+        lat_full = torch.arange(n_frames * 8, dtype=torch.float32).reshape(n_frames, 2, 4)
+        nz_full = torch.arange(n_frames * 4, dtype=torch.float32).reshape(n_frames, 1, 2, 2)
+        tr_full = torch.linspace(0.5, 1.0, n_frames)
+        mod_full = torch.arange(n_frames * 2, dtype=torch.float32).reshape(n_frames, 2)
+        bends = [{"layer": 3, "modulation": mod_full.clone() if rank == 0 else torch.zeros_like(mod_full), "transform": None},
+                 {"layer": 0, "transform": None}]
+        rewrites = {"conv1.conv.weight": [None, mod_full[:, 0].clone() if rank == 0 else torch.zeros(n_frames)]}
+        if rank == 0:
+            lat_s, nz_s, tr_s = gav._scatter_from_rank0(lat_full, [nz_full, None], tr_full, bends, rewrites, n_frames)
+        else:
+            lat_s, nz_s, tr_s = gav._scatter_from_rank0(None, [], 1.0, bends, rewrites, n_frames)
+        assert torch.equal(lat_s, lat_full[lo:hi]) and torch.equal(nz_s[0], nz_full[lo:hi]) and nz_s[1] is None
+        assert torch.allclose(tr_s, tr_full[lo:hi]) and torch.equal(bends[0]["modulation"], mod_full[lo:hi])
+        assert torch.equal(rewrites["conv1.conv.weight"][1], mod_full[lo:hi, 0])
+        lat_s, nz_s, tr_s = gav._scatter_from_rank0(lat_full if rank == 0 else None, [None] if rank == 0 else [], 0.7, [], {},
+                                                    n_frames)
+        assert tr_s == 0.7 and nz_s == [None]
+
+        # ---- FrameStream: batch-rounds travel while the shards are still being produced
+        stream = sharding.FrameStream(n_frames, batch, (4, 5, 3), torch.device("cpu"))
+        assert stream.rounds == -(-sharding.max_shard(n_frames, world) // batch)
+        got, first_peer_frame_at = [], None
+        k = 0
+        for first in range(lo, hi, batch):
+            if rank == 1:
+                time.sleep(0.25)  # rank 1 is the slow producer: its block takes >= rounds * 0.25 s
+            count = min(batch, hi - first)
+            u8 = torch.zeros((count, 4, 5, 3), dtype=torch.uint8)
+            for i in range(count):
+                u8[i] = (first + i) % 251
+            stream.push(k, u8)
+            k += 1
+            if rank == 0:
+                got += list(stream.drain(block=False))
+        if rank == 0:
+            # rank 0's own block is already on its way to the sink although no later round of the slow peer exists yet
+            assert [i for i, _ in got] == list(range(lo, hi))
+        stream.finish()
+        finished_at = time.monotonic()
+        if rank == 0:
+            for item in stream.drain(block=True):
+                if first_peer_frame_at is None and item[0] >= sharding.shard_bounds(n_frames, 1, world)[0]:
+                    first_peer_frame_at = time.monotonic()  # = the moment the peer's FIRST round was on rank 0's host
+                got.append(item)
+            assert [i for i, _ in got] == list(range(n_frames))
+            for i, f in got:
+                assert f.shape == (4, 5, 3) and int(f.min()) == int(f.max()) == i % 251
+        else:
+            stream.wait_all()
+        # rank 0 had rank 1's FIRST round on its host before rank 1 finished producing its block
+        stamps = [torch.zeros(2, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+        dist.gather(torch.tensor([finished_at, first_peer_frame_at or 0.0], dtype=torch.float64), stamps, dst=0)
+        if rank == 0:
+            if stream.rounds >= 3:
+                assert first_peer_frame_at is not None and first_peer_frame_at < float(stamps[1][0]), (
+                    first_peer_frame_at, float(stamps[1][0]))
+            np.save(os.path.join(out_dir, "stream_ok.npy"), np.array([n_frames]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch", [(23, 3), (8, 4), (5, 8)])
+def test_two_rank_scatter_and_streamed_ordered_frames(tmp_path, n_frames, batch):
+    """world_size 2 over gloo: scatter_frames hands every rank only its block; FrameStream delivers the frames to rank 0 in
+    global order, and (23 frames, batch 3: 4 rounds) rank 0 holds the slow rank's first round before that rank has finished
+    its block — the transfer overlaps production instead of waiting for the end of the shard."""
+    mp.spawn(_stream_worker, args=(2, _free_port(), n_frames, batch, str(tmp_path)), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "stream_ok.npy")[0]) == n_frames

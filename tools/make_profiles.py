@@ -103,6 +103,25 @@ MULTI, FAST, MAXP>.
         w = wr.get(n, {})
         tr.append(f"| `{n}` | {t['n']} | {t['FETCH_SIZE']:.0f} | {2 * t['FETCH_SIZE']:.0f} | {w.get('WRITE_SIZE', float('nan')):.0f} | {t['us']:.0f} |")
     open(f"/tmp/{TAG}_pmc_traffic_table.md", "w").write("\n".join(tr) + "\n")
+    # machine-readable twin, read by bench.py for roofline.traffic (no literals in bench.py): bytes per dispatch, averaged over
+    # the dispatches of an instance in `bench.py --steps 2 --warmup 1 --lanes 1 --no-breakdown` (3 steps + 2 capture passes)
+    steps_in_run = 2 + 1 + 2  # timed + warm-up + (warm-up forward, captured forward) of the single lane
+    kernels = {}
+    for n, t in fe.items():
+        w = wr.get(n, {})
+        if "WRITE_SIZE" not in w:
+            continue
+        rec = {"read_bytes": 2.0 * t["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0, "dispatches": t["n"],
+               "avg_us": t["us"], "dispatches_per_step": t["n"] / steps_in_run if t["n"] % steps_in_run == 0 else None}
+        if n.startswith("fir_strip_kernel"):
+            rec["planes"] = 256  # bench.py's standalone upfirdn2d leg: [8, 32, 1025, 1025]
+        kernels[n] = rec
+    bench = last_json(f"{O}/bench_default.json")
+    with open(f"profiles/{TAG}_pmc_traffic.json", "w") as f:
+        json.dump({"source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python bench.py "
+                             "--steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown",
+                   "correction": "FETCH_SIZE x2 (reports 1/2 of the bytes read on gfx950, calibrated on a known-size copy), WRITE_SIZE exact",
+                   "batch": bench["config"]["frames_per_step_per_gpu"], "size": 1024, "kernels": kernels}, f, indent=1)
     print("wrote profiles/*; tables in /tmp for the hand-annotated files")
 
 
