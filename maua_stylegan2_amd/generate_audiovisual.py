@@ -230,10 +230,14 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
         stem = lambda path: str(path).split("/")[-1].split(".")[0].lower()  # noqa: E731
         output_file = f"{output_dir}/{stem(audio_file)}_{stem(ckpt)}_{uuid.uuid4().hex[:8]}.mp4"
     t0 = time.time()
-    written = render.render(generator=generator, latents=latents, noise=noise, audio_file=audio_file, offset=offset,
-                            duration=duration, batch_size=batch, truncation=truncation, bends=bends, rewrites=rewrites,
-                            out_size=out_size, output_file=output_file, randomize_noise=randomize_noise,
-                            ffmpeg_preset=ffmpeg_preset, **({"_shard": shard} if shard is not None else {}))
+    if shard is None:
+        written = render.render(generator=generator, latents=latents, noise=noise, audio_file=audio_file, offset=offset,
+                                duration=duration, batch_size=batch, truncation=truncation, bends=bends, rewrites=rewrites,
+                                out_size=out_size, output_file=output_file, randomize_noise=randomize_noise,
+                                ffmpeg_preset=ffmpeg_preset)
+    else:  # one process per GPU: the per-frame inputs were scattered, this rank holds frames [lo, hi) only
+        written = render.render_shard(generator, latents, noise, offset, duration, batch, out_size, output_file, audio_file,
+                                      truncation, bends, rewrites, randomize_noise, ffmpeg_preset, shard)
     dt = max(time.time() - t0, 1e-9)
     print(f"\nrendered {written} frames in {dt:.2f}s ({written / dt:.1f} frames/s)")
     print(f"total time taken: {(time.time() - started) / 60:.2f} minutes")

@@ -226,11 +226,18 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
 
 
 def render(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file=None,
-           truncation=1.0, bends=[], rewrites={}, randomize_noise=False, ffmpeg_preset="slow", _shard=None):
+           truncation=1.0, bends=[], rewrites={}, randomize_noise=False, ffmpeg_preset="slow"):
     """Drop-in for reference render.render (render.py:14-29).  With torch.distributed initialised (one process per
     GPU) every rank renders a contiguous shard of the frames and streams them, batch by batch, to rank 0's ordered sink
-    (sharding.FrameStream).  ``_shard = (lo, hi, n_frames)`` (set by generate() after sharding.scatter_frames) says that
-    ``latents`` / ``noise`` / ``truncation`` / bend modulations already hold only this rank's block."""
+    (sharding.FrameStream)."""
+    return render_shard(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file,
+                        truncation, bends, rewrites, randomize_noise, ffmpeg_preset, None)
+
+
+def render_shard(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file, truncation,
+                 bends, rewrites, randomize_noise, ffmpeg_preset, _shard):
+    """``render`` with an optional ``_shard = (lo, hi, n_frames)``: set by generate() after sharding.scatter_frames, it says
+    that ``latents`` / ``noise`` / ``truncation`` / bend modulations already hold only this rank's block of the frames."""
     width, height = _output_dims(out_size)
     rank, world = sharding.rank_world()
     if _shard is None:
