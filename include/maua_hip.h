@@ -92,6 +92,13 @@ int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, vo
  * wq[(ky*4+j)][i][o_pad] with j 0: g2, 1: g0+g2, 2: g0, 3: g1. */
 int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, void* stream);
 
+/* 2-D Winograd F(2x4, 3x3) form for mode 5 (F(2,3) along ky on top of F(4,3) along kx: 24 values per (cout, cin) pair),
+ * stored as the LDS tile image the kernel DMAs linearly: wq[cout/BM][cin/4][fy 4][xf 6][cin%4][BM columns] (BM = 64, or 32 for
+ * a 32-channel layer; m-tile pairs interleaved inside a row).  Needs 24*cin*cout floats.  maua_modconv_w2d_ok() says whether a
+ * layer shape qualifies (cin % 4 == 0, cout == 32 or cout % 64 == 0, w % 32 == 0, h % 8 (16 for cout 32) == 0). */
+int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream);
+int maua_modconv_w2d_ok(int cin, int cout, int h, int w);
+
 /* ModulatedConv2d 3x3 (models/stylegan2.py:217-254) as input-scale -> shared-weight implicit GEMM on MFMA ->
  * output-demod, with the StyledConv tail (noise + bias + leaky ReLU, :338-343) fused when `fuse_act`:
  *   plain   : x[B,cin,H,W] -> y[B,cout,H,W]        (pad 1)
@@ -103,6 +110,8 @@ int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, vo
  *             of 6 MFMA K-steps per position pair and kernel row; wp from maua_pack_weight_upwino_f32.
  *   up == 3 : the same through Winograd F(4,3) (W % 4 == 0): 2x fewer MFMA cycles than direct, |error| ~2e-5 of
  *             the output scale; wp from maua_pack_weight_wino43_f32.
+ *   up == 5 : the plain convolution through 2-D Winograd F(2x4, 3x3) (shapes accepted by maua_modconv_w2d_ok): 3x fewer
+ *             MFMA cycles than direct, 1.5x fewer than up == 3; wp from maua_pack_weight_wino2d_f32.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
  * floats used for split-K partial sums on small feature maps (may be NULL when that returns 0). */
@@ -119,7 +128,7 @@ int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_s
  * activated feature map is reduced to RGB while it is still in registers (all channels of a pixel sit in one wave).
  * Only for layers whose channels fit one weight tile in a single wave row (cout <= 64); returns MAUA_ENOSYS otherwise
  * (the caller then runs maua_modconv3x3_f32 + maua_torgb_f32).  rgb_s = the ToRGB layer's styles [B, s_stride] (same
- * stride as s).  mode = 0 (direct), 2 or 3 (Winograd F(2,3) / F(4,3), wp from the matching pack function).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
+ * stride as s).  mode = 0 (direct), 2, 3 or 5 (Winograd F(2,3) / F(4,3) / 2-D F(2x4,3x3), wp from the matching pack function).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
 int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                               float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
                               const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,

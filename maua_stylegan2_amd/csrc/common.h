@@ -26,3 +26,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 }
 
 __device__ __forceinline__ float lrelu_gain(float v) { return (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f; }
+
+// modconv_w2d.hip (mode 5 of maua_modconv3x3_f32 / maua_styledconv_torgb_f32): 2-D Winograd F(2x4, 3x3) plain convolution
+int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn);
+const char* maua_w2d_last_instance();
+int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
+                    int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
+                    const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
+                    const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, int rgb_mode,
+                    void* stream);

@@ -1265,7 +1265,7 @@ extern "C" int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, 
 }
 
 extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
-    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || up == 5) return 0;
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     return pl.g.splits > 1 ? pl.g.ws_slab * pl.g.splits : 0;
 }
@@ -1291,6 +1291,14 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
                  void* stream) {
     if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     if (noise && !noise_w) return MAUA_EINVAL;
+    if (up == 5) {  // 2-D Winograd F(2x4, 3x3), modconv_w2d.hip
+        const int rc = maua_w2d_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, fuse_act, noise, noise_batch_stride,
+                                       noise_w, bias, rgb ? rgb->w : nullptr, rgb ? rgb->s : nullptr, rgb ? rgb->wscale : 0.f,
+                                       rgb ? rgb->bias : nullptr, rgb ? rgb->skip : nullptr, rgb ? rgb->k4 : nullptr,
+                                       rgb ? rgb->out : nullptr, rgb ? (rgb->store_features ? 1 : 2) : 0, stream);
+        if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
+        return rc;
+    }
     if ((int64_t)batch * cin * h * w > 0x7fffffffLL) return MAUA_EINVAL;  // 32-bit patch offsets
     if (up < 0 || up > 4 || ((up == 2 || up == 4) && (w & 1)) || (up == 3 && (w & 3))) return MAUA_EINVAL;
     if (up == 4 && (fuse_act || rgb)) return MAUA_EINVAL;  // raw output only: the blur kernel applies the tail

@@ -1,0 +1,494 @@
+// Plain 3x3 modulated convolution through 2-D Winograd F(2x4, 3x3) on the fp32 matrix cores (mode 5 of
+// maua_modconv3x3_f32 / maua_styledconv_torgb_f32).
+//
+// Behavioural contract: /root/reference/models/stylegan2.py:217-254 (plain branch :248-252) + StyledConv tail :338-343
+// (+ ToRGB :356-365 when fused) — the same input-scale -> shared-weight contraction -> output-demod formulation as
+// modconv.hip.  What changes is the contraction: F(2,3) along y on top of F(4,3) along x,
+//
+//     Y(2x4 outputs) = A_y^T [ sum_c (G_y g_c G_x^T) .* (B_y^T d_c B_x) ] A_x          d_c = 4x6 input window of channel c
+//
+// 24 products per 8 outputs per (cin, cout) pair = 3 MAC per output instead of 9 (direct) or 4.5 (F(4,3) along x only):
+// a third fewer matrix-core cycles than mode 3 on layers that are MFMA-bound.  fp32 error: F(2,3) only adds {1, 1/2}
+// constants on top of F(4,3)'s, measured ~3e-5 of the output scale (tests/test_layers_gpu.py).
+//
+// Work decomposition (what makes 24 accumulator tiles fit): a workgroup owns BM = 16 TM output channels x 16 TN positions
+// (a position = one 2x4 output block; an n-tile = 8 x 2 positions = 32 x 4 pixels; n-tiles stack along y), and its FOUR WAVES
+// SPLIT THE FOUR y-FREQUENCIES: wave fy accumulates the six x-frequencies of its own y-frequency for the whole BM x 16 TN
+// tile on v_mfma_f32_16x16x4_f32 (K = 4 input channels per step, 6 TM TN accumulator tiles of 4 registers).  Consequences:
+//   * the B operand (B_y^T d B_x of the staged raw patch) is never formed twice inside a workgroup: wave fy needs only row
+//     combination fy of the window (one fused multiply-add per column), then the 6-point x transform — 24 VALU per
+//     (position, channel) per wave for 24 TM MFMAs;
+//   * every wave streams its own quarter of the weight tile from LDS, the patch is shared;
+//   * the inverse y transform crosses waves: after the main loop every wave applies A_x to its accumulators and the four
+//     partial 1x4 rows meet in LDS (16 channels per pass), where the tail (demod, noise, bias, leaky ReLU), the fused ToRGB
+//     reduction and the 16-byte stores are done by all 256 threads.
+// Operands reach LDS by MUBUF `buffer_load ... lds` DMA, double buffered, one barrier per 4-channel K step; the packed weight
+// (maua_pack_weight_wino2d_f32) is laid out in HBM exactly as the LDS tile image, so its DMA is a linear copy.
+#include "common.h"
+
+#include <cstdio>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAUA_DEVICE_PASS 1
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int W2D_PW = 34;    // staged patch columns: 32 outputs + 1 halo on each side
+// LDS row stride (floats).  The window reads are 8-byte reads at a 16-byte lane stride (8 positions along x) over two position
+// rows (2 patch rows apart): 2 * 48 floats = 32 banks puts the second position row on the other half of the 64 banks.
+constexpr int W2D_PWS = 48;
+constexpr int W2D_CC = 4;     // input channels per K step = K of v_mfma_f32_16x16x4_f32
+
+struct W2dArgs {
+    const float* x;
+    const float* wq;
+    const float* s;
+    const float* d;
+    const float* noise;
+    const float* noise_w;
+    const float* bias;
+    float* y;
+    const float* rgb_w;
+    const float* rgb_s;
+    const float* rgb_bias;
+    const float* rgb_skip;
+    const float* rgb_k4;
+    float* rgb_out;
+    int B, Cin, Cout, H, W;
+    int s_stride;
+    float wscale;
+    int fuse_act;
+    int64_t noise_batch_stride;
+    int tiles_x, tiles_y, m_tiles, n_chunks;
+    int rgb;  // 0 off, 1 on, 2 on and the feature map itself is not stored
+    float rgb_wscale;
+};
+
+__host__ __device__ constexpr int w2d_pstride(int tn) {
+    // floats per channel of the staged patch, padded to 2 (mod 64): an 8-byte read by 16 lanes of one channel touches banks
+    // {4 jx, 4 jx + 1} (+32 for the second position row); the next channel (the other K lane group of the same half-wave)
+    // then lands on {4 jx + 2, 4 jx + 3}
+    const int raw = (4 * tn + 2) * W2D_PWS;
+    return raw + ((2 - raw % 64) + 64) % 64;
+}
+
+// physical column of (m-tile mt, row i16) inside a weight row of BM = 16 TM floats: m-tile pairs interleaved so that one
+// 8-byte LDS read feeds two MFMAs; for BM = 64 odd K lanes are rotated by half a row (their 256-byte row stride would put
+// them on the banks of the even ones)
+__host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
+    const int col = (mt >> 1) * 32 + i16 * 2 + (mt & 1);
+    return tm == 4 ? ((col + 32 * (kq & 1)) & 63) : col;
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
+    constexpr int BM = 16 * TM;
+    constexpr int NPOS = 16 * TN;
+    constexpr int TH = 4 * TN;  // output rows per tile
+    constexpr int PH = TH + 2;
+    constexpr int PSTRIDE = w2d_pstride(TN);
+    constexpr int PUSED = PH * W2D_PWS;
+    constexpr int MAXP = (PUSED + 255) / 256;
+    constexpr int A_FLOATS = 24 * W2D_CC * BM;
+    constexpr int A_INSTR = A_FLOATS / 256;  // 1-KiB DMA instructions per weight tile
+    constexpr int A_PER_WAVE = A_INSTR / 4;
+    constexpr int PBUF = W2D_CC * PSTRIDE;
+    static_assert(A_INSTR % 4 == 0, "weight tile must split evenly over the four waves");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                      // [2][A_FLOATS]
+    float* Ps = lds + 2 * A_FLOATS;       // [2][PBUF]
+    float* Ss = Ps + 2 * PBUF;            // [Cin] styles of this image
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int fy = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's y-frequency
+    const int j = lane & 15, kq = lane >> 4;
+    const int jx = j & 7, jy = j >> 3;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt_id = t % p.m_tiles;
+    t /= p.m_tiles;
+    const int tile_x = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tile_y = t % p.tiles_y;
+    const int b0 = t / p.tiles_y;
+    const int ty0 = tile_y * TH, tx0 = tile_x * 32;
+    const int m0 = mt_id * BM;
+    const size_t plane = (size_t)p.H * p.W;
+
+    // ---- patch elements of this thread (decoded once): LDS slot e = tid + i * 256 of every channel plane
+    bool pvalid[MAXP];
+    unsigned rel_bytes[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int e = tid + i * 256;
+        const int pr = e / W2D_PWS, pc = e - pr * W2D_PWS;
+        const int yy = ty0 + pr - 1, xx = tx0 + pc - 1;
+        pvalid[i] = e < PUSED && pc < W2D_PW && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        rel_bytes[i] = pvalid[i] ? (unsigned)(yy * p.W + xx) * 4u : 0u;
+        if (!pvalid[i] && e < PSTRIDE) {  // border / padding slot: zero in both buffers, for good
+#pragma unroll
+            for (int c = 0; c < W2D_CC; ++c) Ps[c * PSTRIDE + e] = 0.f, Ps[PBUF + c * PSTRIDE + e] = 0.f;
+        }
+    }
+    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+
+    const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
+    const size_t plane_bytes = plane * sizeof(float);
+    (void)ximg, (void)plane_bytes;
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wq), 0, 0x7fffffff, 0x00020000);
+#endif
+    auto issue = [&](int chunk, int buf) {
+#ifdef MAUA_DEVICE_PASS
+        // weight tile: linear copy of A_FLOATS floats, 1 KiB per wave instruction
+        const int wbase = (int)(((size_t)mt_id * p.n_chunks + chunk) * A_FLOATS * sizeof(float));
+#pragma unroll
+        for (int k = 0; k < A_PER_WAVE; ++k) {
+            const int i = fy + 4 * k;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(As + buf * A_FLOATS + i * 256),
+                                                     16, (i * 256 + lane * 4) * 4, wbase, 0, 0);
+        }
+        float* dst = Ps + buf * PBUF + fy * 64;
+#pragma unroll
+        for (int c = 0; c < W2D_CC; ++c) {
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i)
+                if (pvalid[i])
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(dst + c * PSTRIDE + i * 256), 4,
+                                                             (int)rel_bytes[i], (int)((size_t)(chunk * W2D_CC + c) * plane_bytes), 0, 0);
+        }
+#else
+        (void)chunk, (void)buf;
+#endif
+    };
+
+    // ---- accumulators: [x-frequency][m-tile][n-tile]
+    f32x4 acc[6][TM][TN];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[a][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // window rows combined by y-frequency fy (F(2,3) B^T): fy 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int ra = fy == 0 ? 0 : (fy == 2 ? 2 : 1);
+    const int rb = fy == 0 ? 2 : (fy == 1 ? 2 : (fy == 2 ? 1 : 3));
+    const float sgn = fy == 1 ? 1.f : -1.f;
+    int boff[TN];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) boff[n] = kq * PSTRIDE + (2 * (2 * n + jy)) * W2D_PWS + 4 * jx;
+    // weight rows of this wave: ((fy * 6 + xf) * 4 + kq) * BM + physical column of (m-tile pair, row j)
+    int aoff[TM / 2];
+#pragma unroll
+    for (int h = 0; h < TM / 2; ++h) aoff[h] = (fy * 24 + kq) * BM + w2d_col(TM, 2 * h, j, kq);
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+        if (chunk + 1 < p.n_chunks) issue(chunk + 1, cur ^ 1);
+        const float* __restrict__ Ac = As + cur * A_FLOATS;
+        const float* __restrict__ Pc = Ps + cur * PBUF;
+        const float sc = Ss[chunk * W2D_CC + kq];
+        float bv[TN][6];
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const float* da = Pc + boff[n] + ra * W2D_PWS;
+            const float* db = Pc + boff[n] + rb * W2D_PWS;
+            const f32x2 a01 = *reinterpret_cast<const f32x2*>(da), a23 = *reinterpret_cast<const f32x2*>(da + 2);
+            const f32x2 a45 = *reinterpret_cast<const f32x2*>(da + 4);
+            const f32x2 b01 = *reinterpret_cast<const f32x2*>(db), b23 = *reinterpret_cast<const f32x2*>(db + 2);
+            const f32x2 b45 = *reinterpret_cast<const f32x2*>(db + 4);
+            const float d0 = fmaf(sgn, b01.x, a01.x), d1 = fmaf(sgn, b01.y, a01.y), d2 = fmaf(sgn, b23.x, a23.x);
+            const float d3 = fmaf(sgn, b23.y, a23.y), d4 = fmaf(sgn, b45.x, a45.x), d5 = fmaf(sgn, b45.y, a45.y);
+            // B_x^T for F(4,3) (interpolation points 0, +-1, +-2, inf), as in modconv.hip's mode 3
+            const float a_ = fmaf(-4.f, d2, d4), b_ = fmaf(-4.f, d1, d3);
+            const float c_ = d4 - d2, e_ = d3 - d1;
+            bv[n][0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4)) * sc;
+            bv[n][1] = (a_ + b_) * sc;
+            bv[n][2] = (a_ - b_) * sc;
+            bv[n][3] = fmaf(2.f, e_, c_) * sc;
+            bv[n][4] = fmaf(-2.f, e_, c_) * sc;
+            bv[n][5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5)) * sc;
+        }
+#pragma unroll
+        for (int xf = 0; xf < 6; ++xf) {
+#pragma unroll
+            for (int h = 0; h < TM / 2; ++h) {
+                const f32x2 a2 = *reinterpret_cast<const f32x2*>(Ac + xf * (W2D_CC * BM) + aoff[h]);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    acc[xf][2 * h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bv[n][xf], acc[xf][2 * h][n], 0, 0, 0);
+                    acc[xf][2 * h + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bv[n][xf], acc[xf][2 * h + 1][n], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue
+    // A_x^T m in registers: y0 = m0+m1+m2+m3+m4, y1 = (m1-m2) + 2(m3-m4), y2 = (m1+m2) + 4(m3+m4), y3 = (m1-m2) + 8(m3-m4) + m5
+    // then, 16 output channels (one m-tile) per pass, the four waves' 1x4 partial rows meet in LDS:
+    //   output row 0 = Z0 + Z1 + Z2,  row 1 = Z1 - Z2 - Z3     (A_y^T of F(2,3))
+    float* Z = lds;                               // [4 fy][16 ch][NPOS][4]
+    float* Eg = lds + 4 * 16 * NPOS * 4;          // [BM] gain
+    float* Eb = Eg + BM;                          // [BM] bias
+    float* Er = Eb + BM;                          // [3][BM] modulated ToRGB weights
+    float* Rr = Er + 3 * BM;                      // [CG][2 * NPOS][12] ToRGB partial sums
+    const bool act = p.fuse_act != 0;
+    const float act_gain = act ? 1.41421356237309515f : 1.f;
+    for (int i = tid; i < BM; i += 256) {
+        const int o = m0 + i;
+        float gain = p.wscale * act_gain;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
+        Eg[i] = gain;
+        Eb[i] = (act && p.bias) ? p.bias[o] * act_gain : 0.f;
+        if (p.rgb) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Er[c * BM + i] = p.rgb_wscale * p.rgb_w[c * p.Cout + o] * p.rgb_s[(size_t)b0 * p.s_stride + o];
+        }
+    }
+    // combine-phase role of this thread: position cp, output row cr of the 2-row block, channel group cg of every pass
+    constexpr int CG = 256 / (2 * NPOS);        // channel groups (4 for TN = 2, 2 for TN = 4)
+    constexpr int CPG = 16 / CG;                // channels per thread per pass
+    const int cp = tid % NPOS, cr = (tid / NPOS) & 1, cg = tid / (2 * NPOS);
+    const int cjx = cp & 7, cpy = cp >> 3;      // position column / position row inside the tile (cpy = 2 nt + jy)
+    const int oy = ty0 + 2 * cpy + cr, ox = tx0 + 4 * cjx;
+    const float nw = (act && p.noise) ? p.noise_w[0] * act_gain : 0.f;
+    f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nw != 0.f) {
+        nz = *reinterpret_cast<const f32x4*>(p.noise + (size_t)b0 * p.noise_batch_stride + (size_t)oy * p.W + ox);
+        nz = nz * nw;
+    }
+    float rgbp[4][3];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) rgbp[px][0] = rgbp[px][1] = rgbp[px][2] = 0.f;
+    const bool store_feat = p.rgb != 2;
+    float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane;
+    const unsigned pix_off = (unsigned)oy * (unsigned)p.W + (unsigned)ox;
+
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        __syncthreads();  // previous pass's reads (or the main loop's LDS use) are done
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float m0_ = acc[0][mt][n][v], m1_ = acc[1][mt][n][v], m2_ = acc[2][mt][n][v];
+                const float m3_ = acc[3][mt][n][v], m4_ = acc[4][mt][n][v], m5_ = acc[5][mt][n][v];
+                const float s12 = m1_ + m2_, d12 = m1_ - m2_, s34 = m3_ + m4_, d34 = m3_ - m4_;
+                const f32x4 o4 = f32x4{(m0_ + s12) + s34, fmaf(2.f, d34, d12), fmaf(4.f, s34, s12), fmaf(8.f, d34, d12) + m5_};
+                const int ch16 = 4 * kq + v;  // row of the 16x16 result tile held in register v
+                *reinterpret_cast<f32x4*>(Z + (((fy * 16 + ch16) * NPOS) + n * 16 + j) * 4) = o4;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CPG; ++q) {
+            const int ch16 = cg * CPG + q;
+            const int ol = mt * 16 + ch16;
+            const float* zp = Z + ((ch16 * NPOS) + cp) * 4;
+            const f32x4 z1 = *reinterpret_cast<const f32x4*>(zp + 1 * 16 * NPOS * 4);
+            const f32x4 z2 = *reinterpret_cast<const f32x4*>(zp + 2 * 16 * NPOS * 4);
+            const f32x4 zo = *reinterpret_cast<const f32x4*>(zp + (cr ? 3 : 0) * 16 * NPOS * 4);
+            const f32x4 raw = cr ? (z1 - z2) - zo : (zo + z1) + z2;
+            const float gain = Eg[ol], bias = Eb[ol];
+            f32x4 v4;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float tt = fmaf(raw[px], gain, nz[px] + bias);
+                v4[px] = act ? fmaxf(tt, 0.2f * tt) : tt;
+            }
+            if (p.rgb) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float rw = Er[c * BM + ol];
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) rgbp[px][c] = fmaf(rw, v4[px], rgbp[px][c]);
+                }
+            }
+            if (store_feat) *reinterpret_cast<f32x4*>(yimg + (size_t)ol * plane + pix_off) = v4;
+        }
+    }
+    if (!p.rgb) return;
+    // ---- fused ToRGB: sum the channel groups through LDS, add bias and the 2x FIR-upsampled skip image, store
+    __syncthreads();
+    {
+        float* rp = Rr + ((cg * 2 + cr) * NPOS + cp) * 12;
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rp[px * 3 + c] = rgbp[px][c];
+    }
+    __syncthreads();
+    if (cg != 0) return;
+#pragma unroll
+    for (int g2 = 1; g2 < CG; ++g2) {
+        const float* rp = Rr + ((g2 * 2 + cr) * NPOS + cp) * 12;
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgbp[px][c] += rp[px * 3 + c];
+    }
+    // upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, x): two live source rows / columns, iy0 = floor((oy-1)/2), iy0+1 with taps
+    // k4[3]/k4[1] for even oy and k4[2]/k4[0] for odd (models/stylegan2.py:34-52, op/upfirdn2d.py:159-200)
+    const int sh = p.H >> 1, sw = p.W >> 1;
+    const size_t rgb_plane = plane;
+    float* rgb_img = p.rgb_out + (size_t)b0 * 3 * rgb_plane;
+    f32x4 outc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) outc[c][px] = rgbp[px][c] + p.rgb_bias[c];
+    if (p.rgb_skip) {
+        const float* skip_img = p.rgb_skip + (size_t)b0 * 3 * sh * sw;
+        const int iy0 = (oy - 1) >> 1;
+        const int ty_ = (oy & 1) ? 2 : 3;
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy) {
+            const int yy = iy0 + qy;
+            if (yy < 0 || yy >= sh) continue;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const int xo = ox + px;
+                const int ix0 = (xo - 1) >> 1;
+                const int tx_ = (xo & 1) ? 2 : 3;
+#pragma unroll
+                for (int qx = 0; qx < 2; ++qx) {
+                    const int xx = ix0 + qx;
+                    if (xx < 0 || xx >= sw) continue;
+                    const float wgt = p.rgb_k4[(ty_ - 2 * qy) * 4 + (tx_ - 2 * qx)];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) outc[c][px] = fmaf(wgt, skip_img[((size_t)c * sh + yy) * sw + xx], outc[c][px]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(rgb_img + (size_t)c * rgb_plane + pix_off) = outc[c];
+}
+
+// wq (the LDS tile image): [m_tile][chunk][fy 4][xf 6][kq 4][BM physical column]
+__global__ __launch_bounds__(256) void pack_weight_wino2d_kernel(const float* __restrict__ w, float* __restrict__ wq, int cout,
+                                                                 int cin, int tm) {
+    const int bm = 16 * tm;
+    const int n_chunks = cin / W2D_CC;
+    const int64_t total = (int64_t)(cout / bm) * n_chunks * W2D_CC * bm;  // one thread per (m_tile, chunk, kq, logical column)
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx;
+        const int ol = (int)(r % bm);
+        r /= bm;
+        const int kq = (int)(r % W2D_CC);
+        r /= W2D_CC;
+        const int chunk = (int)(r % n_chunks);
+        const int mtile = (int)(r / n_chunks);
+        const int o = mtile * bm + ol, i = chunk * W2D_CC + kq;
+        const float* g = w + ((size_t)o * cin + i) * 9;
+        // G_y (F(2,3)): rows {g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2};  G_x (F(4,3)): {g0/4, -(g0+g1+g2)/6, -(g0-g1+g2)/6,
+        // (g0+2g1+4g2)/24, (g0-2g1+4g2)/24, g2} — the constants of maua_pack_weight_wino_f32 / _wino43_f32
+        float gy[4][3];
+        for (int kx = 0; kx < 3; ++kx) {
+            const float g0 = g[0 * 3 + kx], g1 = g[1 * 3 + kx], g2 = g[2 * 3 + kx];
+            gy[0][kx] = g0, gy[1][kx] = 0.5f * (g0 + g1 + g2), gy[2][kx] = 0.5f * (g0 - g1 + g2), gy[3][kx] = g2;
+        }
+        const int col = w2d_col(tm, ol / 16, ol % 16, kq);
+        float* dst = wq + ((size_t)mtile * n_chunks + chunk) * (24 * W2D_CC * bm);
+        for (int f = 0; f < 4; ++f) {
+            const float g0 = gy[f][0], g1 = gy[f][1], g2 = gy[f][2];
+            const float u[6] = {g0 * 0.25f,
+                                -(g0 + g1 + g2) * (1.f / 6.f),
+                                -(g0 - g1 + g2) * (1.f / 6.f),
+                                (g0 + 2.f * g1 + 4.f * g2) * (1.f / 24.f),
+                                (g0 - 2.f * g1 + 4.f * g2) * (1.f / 24.f),
+                                g2};
+            for (int xf = 0; xf < 6; ++xf) dst[((f * 6 + xf) * W2D_CC + kq) * bm + col] = u[xf];
+        }
+    }
+}
+
+size_t w2d_lds_bytes(int tm, int tn, int cin) {
+    const int bm = 16 * tm, npos = 16 * tn;
+    const size_t main_loop = (size_t)2 * 24 * W2D_CC * bm + (size_t)2 * W2D_CC * w2d_pstride(tn) + (size_t)cin;
+    const int cg = 256 / (2 * npos);
+    const size_t epilogue = (size_t)4 * 16 * npos * 4 + (size_t)5 * bm + (size_t)cg * 2 * npos * 12;
+    return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
+}
+
+char g_w2d_instance[64] = "";
+
+template <int TM, int TN>
+int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
+    auto kern = modconv_w2d_kernel<TM, TN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d>", TM, TN);
+    const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), w2d_lds_bytes(TM, TN, a.Cin), st, a);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// Tile shape for a layer: TM (16-channel m-tiles per workgroup) and TN (16-position n-tiles); 0 = the layer does not qualify.
+int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
+    if (cin % W2D_CC || w % 32 || cin <= 0 || cout <= 0) return 0;
+    int m, n;
+    if (cout % 64 == 0) m = 4, n = 2;
+    else if (cout == 32) m = 2, n = 4;
+    else return 0;
+    if (h % (4 * n)) return 0;
+    if (tm) *tm = m;
+    if (tn) *tn = n;
+    return 1;
+}
+
+const char* maua_w2d_last_instance() { return g_w2d_instance; }
+
+int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
+                    int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
+                    const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
+                    const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, int rgb_mode,
+                    void* stream) {
+    int tm = 0, tn = 0;
+    if (!maua_w2d_tiles(cin, cout, h, w, &tm, &tn)) return MAUA_EINVAL;
+    if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)24 * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
+    W2dArgs a{};
+    a.x = x, a.wq = wq, a.s = s, a.d = d, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.y = y;
+    a.rgb_w = rgb_w, a.rgb_s = rgb_s, a.rgb_bias = rgb_bias, a.rgb_skip = rgb_skip, a.rgb_k4 = rgb_k4, a.rgb_out = rgb_out;
+    a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale, a.fuse_act = fuse_act;
+    a.noise_batch_stride = noise_batch_stride;
+    a.tiles_x = w / 32, a.tiles_y = h / (4 * tn), a.m_tiles = cout / (16 * tm), a.n_chunks = cin / W2D_CC;
+    a.rgb = rgb_mode, a.rgb_wscale = rgb_wscale;
+    if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || !rgb_out || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
+        return MAUA_ENOSYS;
+    hipStream_t st = (hipStream_t)stream;
+    if (tm == 4) return w2d_launch_t<4, 2>(a, st);
+    return w2d_launch_t<2, 4>(a, st);
+}
+
+extern "C" int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {
+    if (!w || !wq || cout <= 0 || cin <= 0) return MAUA_EINVAL;
+    int tm = 0, tn = 0;
+    if (!maua_w2d_tiles(cin, cout, 32, 32, &tm, &tn)) return MAUA_EINVAL;
+    const int64_t total = (int64_t)cout * cin;
+    const int64_t blocks = ceil_div64(total, 256);
+    hipLaunchKernelGGL(pack_weight_wino2d_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       w, wq, cout, cin, tm);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_modconv_w2d_ok(int cin, int cout, int h, int w) { return maua_w2d_tiles(cin, cout, h, w, nullptr, nullptr); }

@@ -158,10 +158,13 @@ class ModulatedConv2d(nn.Module):
     winograd43_min_width = 32
     # transposed layers: F(2,2) on the even x-phase (mode 4) where the launch is large enough, see conv_mode
     upconv_winograd = True
+    # plain layers whose shape the 2-D Winograd kernel accepts (csrc/modconv_w2d.hip, mode 5: F(2,3) along y on top of
+    # F(4,3) along x, 3 instead of 4.5 MFMA products per output) with at least this many output channels
+    winograd2d_min_cout = 32
 
     def conv_mode(self, h, w):
-        """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 transposed, 2 Winograd F(2,3), 3 Winograd
-        F(4,3), 0 direct."""
+        """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 / 4 transposed, 2 Winograd F(2,3), 3 Winograd
+        F(4,3), 5 2-D Winograd F(2x4,3x3), 0 direct."""
         if self.upsample:
             # F(2,2) on the even x-phase of the polyphase transposed conv (mode 4: -17 % MFMA work, but 2 instead of 3-4
             # workgroups per CU) once a batch of 8 frames yields at least ~4 rounds of workgroups; smaller grids lose more
@@ -173,6 +176,9 @@ class ModulatedConv2d(nn.Module):
             return 1
         # (the Winograd kernels want at least one full 128-position tile per image; shorter maps would pack several images
         # into a tile, which only the direct mode implements)
+        if (self.out_channel >= self.winograd2d_min_cout
+                and _lib.load().maua_modconv_w2d_ok(self.in_channel, self.out_channel, h, w)):
+            return 5
         if (self.out_channel >= self.winograd43_min_cout and w % 4 == 0 and w >= self.winograd43_min_width
                 and h * (w // 4) >= 128):
             return 3
@@ -186,6 +192,15 @@ class ModulatedConv2d(nn.Module):
         self.packed()  # refreshes / invalidates on weight change
         if self._packed_wino is None:
             self._packed_wino = {}
+        if mode == 5 and mode not in self._packed_wino:
+            w = self.weight
+            wd = _lib.require_cuda(w.detach(), "weight")
+            wq = th.empty(24 * self.in_channel * self.out_channel, dtype=th.float32, device=w.device)
+            with th.cuda.device(w.device):
+                _lib.check(_lib.load().maua_pack_weight_wino2d_f32(wd.data_ptr(), wq.data_ptr(), self.out_channel,
+                                                                   self.in_channel, _lib.stream_ptr(w.device)),
+                           "maua_pack_weight_wino2d_f32")
+            self._packed_wino[mode] = wq
         if mode not in self._packed_wino:
             w = self.weight
             wd = _lib.require_cuda(w.detach(), "weight")

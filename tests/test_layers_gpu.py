@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from maua_stylegan2_amd import _lib, seeding
+
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 TOL = 1e-4  # fp32 MFMA sums over K <= 16*9; north_star budget 1e-3
@@ -145,7 +147,7 @@ def test_modconv_winograd_vs_oracle(gpu, cin, cout, h, w, batch):
 
     r = np.random.default_rng(cin + 3 * cout + h + w)
     m = StyledConv(cin, cout, 3, 512, upsample=False)
-    m.conv.winograd43_min_cout = 1 << 30  # this test pins the F(2,3) mode
+    m.conv.winograd43_min_cout = m.conv.winograd2d_min_cout = 1 << 30  # this test pins the F(2,3) mode
     assert m.conv.conv_mode(h, w) == 2
     sd = {
         "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
@@ -186,6 +188,7 @@ def test_modconv_winograd43_vs_oracle(gpu, cin, cout, h, w, batch):
 
     r = np.random.default_rng(2 * cin + cout + h + w)
     m = StyledConv(cin, cout, 3, 512, upsample=False)
+    m.conv.winograd2d_min_cout = 1 << 30  # this test pins the 1-D F(4,3) mode
     assert m.conv.conv_mode(h, w) == 3
     sd = {
         "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
@@ -205,6 +208,118 @@ def test_modconv_winograd43_vs_oracle(gpu, cin, cout, h, w, batch):
     m.conv.winograd_min_cout = m.conv.winograd43_min_cout = 1 << 30
     direct = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
     np.testing.assert_allclose(got, direct, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [
+    (64, 64, 32, 32, 2),      # one m-tile group (BM 64), 1 x 4 tiles per image
+    (128, 128, 16, 64, 1),    # two weight tiles per position tile, 2 x 2 tiles
+    (32, 32, 32, 64, 2),      # 32-channel layer: BM 32, 64-position tiles (16 rows)
+    (512, 256, 8, 32, 1),     # deep K (128 chunks), a single 8-row tile
+    (64, 192, 24, 96, 1),     # three weight tiles, 3 x 3 position tiles
+    (36, 64, 40, 32, 3),      # Cin = 9 chunks, ragged nothing: H % 8 == 0, three images
+])
+def test_modconv_winograd2d_vs_oracle(gpu, cin, cout, h, w, batch):
+    """Plain 3x3 layers whose shape qualifies run 2-D Winograd F(2x4, 3x3) (mode 5, csrc/modconv_w2d.hip: F(2,3) along y
+    on top of F(4,3) along x, the four waves of a workgroup splitting the y-frequencies).  Same tolerances as the 1-D
+    F(4,3) mode: 5e-4 against the oracle (north_star budget 1e-3), 2e-4 against the direct kernel; also without the fused
+    tail (ModulatedConv2d.forward) and with a shared [1,1,H,W] noise map."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(5 * cin + cout + h + w)
+    m = StyledConv(cin, cout, 3, 512, upsample=False)
+    assert m.conv.conv_mode(h, w) == 5
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.31]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((batch, 1, h, w)).astype(np.float32))
+    want = so.styled_conv(sd, "L", x, s, nz, False).numpy()
+    got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-4, rtol=1e-4)
+    shared = m(x.to(gpu), s.to(gpu), noise=nz[:1].to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(shared, so.styled_conv(sd, "L", x, s, nz[:1], False).numpy(), atol=5e-4, rtol=1e-4)
+    raw = m.conv(x.to(gpu), s.to(gpu)).cpu().numpy()  # no tail: demodulated convolution only
+    want_raw = so.modulated_conv2d(x, s, sd["L.conv.weight"], sd["L.conv.modulation.weight"], sd["L.conv.modulation.bias"]).numpy()
+    np.testing.assert_allclose(raw, want_raw, atol=5e-4, rtol=1e-4)
+    m.conv.winograd_min_cout = m.conv.winograd43_min_cout = m.conv.winograd2d_min_cout = 1 << 30
+    assert m.conv.conv_mode(h, w) == 0
+    direct = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, direct, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,with_skip", [(64, 64, 32, 64, True), (32, 32, 32, 32, True), (128, 64, 16, 32, False),
+                                                     (32, 32, 48, 64, True)])
+def test_fused_torgb_epilogue_equals_separate_launches(gpu, cin, cout, h, w, with_skip):
+    """StyledConv + ToRGB folded into one launch (maua_styledconv_torgb_f32: <= 64-channel plain layers, every kernel mode that
+    the layer shape selects — 2-D Winograd here) against the same two layers run as separate launches and against the oracle;
+    with ``store`` off the feature map is not written at all."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv, ToRGB
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(cin + cout + h + w)
+    b = 2
+    conv, rgb = StyledConv(cin, cout, 3, 512), ToRGB(cout, 512)
+    sd = {
+        "C.conv.weight": r.standard_normal((1, cout, cin, 3, 3)), "C.conv.modulation.weight": r.standard_normal((cin, 512)),
+        "C.conv.modulation.bias": 1 + 0.1 * r.standard_normal(cin), "C.noise.weight": np.array([0.23]),
+        "C.activate.bias": 0.3 * r.standard_normal(cout),
+        "T.bias": 0.3 * r.standard_normal((1, 3, 1, 1)), "T.upsample.kernel": seeding.fir_kernel_2d((1, 3, 3, 1), 4.0),
+        "T.conv.weight": r.standard_normal((1, 3, cout, 1, 1)), "T.conv.modulation.weight": r.standard_normal((cout, 512)),
+        "T.conv.modulation.bias": 1 + 0.1 * r.standard_normal(cout),
+    }
+    sd = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in sd.items()}
+    conv.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("C.")}, strict=True)
+    rgb.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("T.")}, strict=True)
+    conv, rgb = conv.to(gpu), rgb.to(gpu)
+    assert conv.conv.conv_mode(h, w) == 5
+    x = torch.from_numpy(r.standard_normal((b, cin, h, w)).astype(np.float32))
+    s1 = torch.from_numpy(r.standard_normal((b, 512)).astype(np.float32))
+    s2 = torch.from_numpy(r.standard_normal((b, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((b, 1, h, w)).astype(np.float32))
+    skip = torch.from_numpy(r.standard_normal((b, 3, h // 2, w // 2)).astype(np.float32)) if with_skip else None
+    feat_want = so.styled_conv(sd, "C", x, s1, nz, False)
+    img_want = so.to_rgb(sd, "T", feat_want, s2, skip).numpy()
+    # separate launches (the public modules)
+    feat = conv(x.to(gpu), s1.to(gpu), noise=nz.to(gpu))
+    img_sep = rgb(feat, s2.to(gpu), skip.to(gpu) if with_skip else None).cpu().numpy()
+    np.testing.assert_allclose(img_sep, img_want, atol=2e-3, rtol=1e-4)
+    # fused launch through StyledConv.run on precomputed styles
+    lib = _lib.load()
+    from maua_stylegan2_amd.models.stylegan2 import _style_table
+
+    entries = [conv.conv.table_entry(0, 0, 0), rgb.conv.table_entry(1, cin, b * cout)]
+    table = _style_table(entries, gpu)
+    lat = torch.stack([s1, s2], 1).to(gpu).contiguous()
+    styles = torch.empty(b, cin + cout, device=gpu)
+    demod = torch.empty(b * cout, device=gpu)
+    st = _lib.stream_ptr(gpu)
+    _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 2, 512, None, None, table.data_ptr(), 2, max(cin, cout),
+                                         styles.data_ptr(), cin + cout, st), "affine")
+    _lib.check(lib.maua_demod_f32(table.data_ptr(), 2, cout, styles.data_ptr(), cin + cout, demod.data_ptr(), b, st), "demod")
+    for store in (True, False):
+        out_img = torch.full((b, 3, h, w), float("nan"), device=gpu)
+        feat_buf = {}
+
+        def bufs(name, shape):
+            feat_buf[name] = torch.full(shape, float("nan"), device=gpu)
+            return feat_buf[name]
+
+        fuse = dict(module=rgb, s_off=cin, skip=skip.to(gpu) if with_skip else None, out=out_img, store=store)
+        conv.run(x.to(gpu), styles, 0, demod.view(b, cout), nz.to(gpu), bufs, "f", rgb=fuse)
+        assert fuse.get("done"), "the layer was expected to take the fused path"
+        np.testing.assert_allclose(out_img.cpu().numpy(), img_want, atol=2e-3, rtol=1e-4)
+        if store:
+            np.testing.assert_allclose(feat_buf["f"].cpu().numpy(), feat_want.numpy(), atol=5e-4, rtol=1e-4)
+        else:
+            assert torch.isnan(feat_buf["f"]).all()  # never written
 
 
 @pytest.mark.parametrize("cin,cout,h,w,batch", [

@@ -409,9 +409,10 @@ def test_synthesize_graph_lanes_match_eager_256_batch8(gpu, lanes):
 
 
 def test_render_rank_shards_on_device_equal_single_rank(gpu, tmp_path, monkeypatch):
-    """The multi-rank branch of render() (device shard buffer filled from the graph lanes, then gathered) on ONE GPU:
-    rank_world / gather are stubbed so that this process plays rank 0 and rank 1 of a 2-rank job in turn; the two shards
-    concatenated must equal the single-rank render, frame for frame."""
+    """The multi-rank branch of render() (every batch-round pushed into a sharding.FrameStream from the graph lanes) on ONE
+    GPU: rank_world and the gather collective are stubbed so that this process plays rank 0 and rank 1 of a 2-rank job in
+    turn; the two blocks concatenated must equal the single-rank render, frame for frame, and rank 0's sink must have
+    written its own block in order."""
     from maua_stylegan2_amd import render, sharding
 
     monkeypatch.setattr(render.shutil, "which", lambda name: None)
@@ -423,16 +424,42 @@ def test_render_rank_shards_on_device_equal_single_rank(gpu, tmp_path, monkeypat
     assert render.render(g, lat, noise, 0, n / 30, 2, 512, single) == n
     want = np.fromfile(single + ".rgb24", dtype=np.uint8).reshape(n, 512, 512, 3)
 
-    shards = {}
+    class _Done:
+        def wait(self):
+            return True
+
+        def is_completed(self):
+            return True
+
+    def fake_gather(tensor, gather_list=None, dst=0, group=None, async_op=False):
+        if gather_list is not None:  # "rank 0": its own slot arrives, the peer's slot stays as allocated
+            gather_list[0].copy_(tensor)
+        return _Done()
+
+    monkeypatch.setattr(sharding.dist, "gather", fake_gather)
+    shards, streams = {}, []
+    real_stream = sharding.FrameStream
+
+    class Recording(real_stream):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            streams.append(self)
+
+    monkeypatch.setattr(sharding, "FrameStream", Recording)
     for rank in (0, 1):
         monkeypatch.setattr(sharding, "rank_world", lambda r=rank: (r, 2))
         lo, hi = sharding.shard_bounds(n, rank, 2)
-
-        def fake_gather(shard, n_frames, dst=0, r=rank, lo=lo, hi=hi):
-            shards[r] = shard[: hi - lo].cpu().numpy()
-            return [] if r == 0 else None  # rank 0 "receives" nothing here: the comparison below does the ordering
-
-        monkeypatch.setattr(sharding, "gather_frames", fake_gather)
-        render.render(g, lat, noise, 0, n / 30, 2, 512, str(tmp_path / f"rank{rank}.mp4"))
+        out = str(tmp_path / f"rank{rank}.mp4")
+        written = render.render(g, lat, noise, 0, n / 30, 2, 512, out)
+        torch.cuda.synchronize()
+        stream = streams[-1]
+        assert stream.rounds == 3 and stream.pushed == 3 and (stream.lo, stream.hi) == (lo, hi)
+        shards[rank] = stream.mine[: hi - lo].cpu().numpy()
+        if rank == 0:  # rank 0's sink consumed every frame slot in order; its own block holds real frames
+            assert written == n
+            raw = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(n, 512, 512, 3)
+            assert np.array_equal(raw[: hi - lo], want[: hi - lo])
+        else:
+            assert written == 0
     got = np.concatenate([shards[0], shards[1]])
     assert got.shape == want.shape and np.array_equal(got, want)

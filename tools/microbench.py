@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--wino-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd_min_cout")
     ap.add_argument("--no-up-wino", action="store_true", help="transposed layers use the plain polyphase kernel (mode 1)")
     ap.add_argument("--wino43-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd43_min_cout")
+    ap.add_argument("--wino2d-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd2d_min_cout (huge = mode 3)")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     if args.lib:
@@ -97,6 +98,8 @@ def main():
                 ModulatedConv2d.upconv_winograd = False
             if args.wino43_min_cout is not None:
                 ModulatedConv2d.winograd43_min_cout = args.wino43_min_cout
+            if args.wino2d_min_cout is not None:
+                ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
             for name, cin, cout, h, up in [("plain32@1024", 32, 32, 1024, 0), ("plain64@512", 64, 64, 512, 0),
                                            ("plain128@256", 128, 128, 256, 0), ("plain256@128", 256, 256, 128, 0),
                                            ("plain512@64", 512, 512, 64, 0), ("up64-32@512", 64, 32, 512, 1),
@@ -121,7 +124,7 @@ def main():
                 e1.record(sp)
                 ms = e0.elapsed_ms(e1) / args.iters
                 fl = 2.0 * cin * cout * 9 * h * h * B
-                out[name] = {"ms": ms, "tflops": fl / ms / 1e9}
+                out[name] = {"ms": ms, "tflops": fl / ms / 1e9, "mode": m.conv_mode(h, h), "kernel": _lib.last_modconv_instance()}
         stream.synchronize()
     print(json.dumps(out))
 
