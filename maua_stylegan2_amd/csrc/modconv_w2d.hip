@@ -27,6 +27,8 @@
 #include "common.h"
 
 #include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAUA_DEVICE_PASS 1
@@ -37,11 +39,53 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int W2D_PW = 34;    // staged patch columns: 32 outputs + 1 halo on each side
-// LDS row stride (floats).  The window reads are 8-byte reads at a 16-byte lane stride (8 positions along x) over two position
-// rows (2 patch rows apart): 2 * 48 floats = 32 banks puts the second position row on the other half of the 64 banks.
+// Staged patch: rows of ten 16-byte segments = image columns tx0-4 .. tx0+35 (16-byte aligned in HBM, so that every segment
+// lies wholly inside or wholly outside the image and the zero padding comes from the DMA's out-of-range rule); a position's
+// 6-float window starts at row float 4 jx + 3.  LDS row stride 48 floats = 12 segment slots: two position rows (2 patch rows
+// apart = 96 floats = 32 banks) land on opposite halves of the 64 banks for the 8-byte window reads.
+constexpr int W2D_SEGS = 10;
 constexpr int W2D_PWS = 48;
+constexpr int W2D_ROWS_PER_DMA = 5;  // 64 lanes x 16 bytes = 5 1/3 LDS rows: a DMA instruction covers 5 rows (+ 4 slots of the 6th)
 constexpr int W2D_CC = 4;     // input channels per K step = K of v_mfma_f32_16x16x4_f32
+
+// LDS reads of the main loop are issued as single `ds_read_b64` instructions through inline assembly: left to itself the
+// compiler pairs neighbouring 8-byte reads into ds_read2_b64 / ds_read2st64_b64, which are serviced in 16-lane groups on a
+// 32-bank modulus at half the bytes per clock (MI355X_MICROARCH.md, LDS table) — measured 30 % of the LDS-active cycles of this
+// kernel as bank conflicts for a layout that is conflict-free under ds_read_b64's rule (32-lane groups, 64 banks).  The
+// compiler does not count inline-assembly LDS operations, so the waits are explicit as well; a wait "produces" the values it
+// guards (tied operands), which keeps their consumers behind it.
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_read64(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ float lds_read32o(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ float lds_read32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 struct W2dArgs {
     const float* x;
@@ -66,14 +110,15 @@ struct W2dArgs {
     int tiles_x, tiles_y, m_tiles, n_chunks;
     int rgb;  // 0 off, 1 on, 2 on and the feature map itself is not stored
     float rgb_wscale;
+    int debug;  // ablation switches (maua_tuning_set key 3): 1 skip MFMA, 2 skip the DMA of every chunk after the first, 4 skip stores
 };
 
+__host__ __device__ constexpr int w2d_dma_per_channel(int tn) { return (4 * tn + 2 + W2D_ROWS_PER_DMA - 1) / W2D_ROWS_PER_DMA; }
 __host__ __device__ constexpr int w2d_pstride(int tn) {
-    // floats per channel of the staged patch, padded to 2 (mod 64): an 8-byte read by 16 lanes of one channel touches banks
-    // {4 jx, 4 jx + 1} (+32 for the second position row); the next channel (the other K lane group of the same half-wave)
-    // then lands on {4 jx + 2, 4 jx + 3}
-    const int raw = (4 * tn + 2) * W2D_PWS;
-    return raw + ((2 - raw % 64) + 64) % 64;
+    // floats per channel of the staged patch: whole DMA instructions (the last one runs 16 floats past its fifth row).  Planes
+    // stay 16-byte aligned for the DMA, which leaves the 8-byte window reads of the two K lane groups of a half-wave on the
+    // same banks (2-way) and the 4-byte edge reads 4-way: ~100 LDS cycles per wave and K step next to 1536 MFMA cycles.
+    return w2d_dma_per_channel(tn) * W2D_ROWS_PER_DMA * W2D_PWS + 16;
 }
 
 // physical column of (m-tile mt, row i16) inside a weight row of BM = 16 TM floats: m-tile pairs interleaved so that one
@@ -91,15 +136,16 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     constexpr int TH = 4 * TN;  // output rows per tile
     constexpr int PH = TH + 2;
     constexpr int PSTRIDE = w2d_pstride(TN);
-    constexpr int PUSED = PH * W2D_PWS;
-    constexpr int MAXP = (PUSED + 255) / 256;
+    constexpr int NQ = w2d_dma_per_channel(TN);  // patch DMA instructions per channel
     constexpr int A_FLOATS = 24 * W2D_CC * BM;
     constexpr int A_INSTR = A_FLOATS / 256;  // 1-KiB DMA instructions per weight tile
     constexpr int A_PER_WAVE = A_INSTR / 4;
     constexpr int PBUF = W2D_CC * PSTRIDE;
     static_assert(A_INSTR % 4 == 0, "weight tile must split evenly over the four waves");
+    (void)A_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                      // [2][A_FLOATS]
+    (void)As;
     float* Ps = lds + 2 * A_FLOATS;       // [2][PBUF]
     float* Ss = Ps + 2 * PBUF;            // [Cin] styles of this image
 
@@ -120,20 +166,21 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     const int m0 = mt_id * BM;
     const size_t plane = (size_t)p.H * p.W;
 
-    // ---- patch elements of this thread (decoded once): LDS slot e = tid + i * 256 of every channel plane
-    bool pvalid[MAXP];
-    unsigned rel_bytes[MAXP];
+    // ---- patch DMA of this lane (decoded once).  The 4 NQ instructions of a chunk (channel c, row group q) are dealt to the
+    // waves round-robin; NQ divides 4 or is a multiple of it, so a wave always draws the same q: one source offset per lane.
+    // Lane l of instruction (c, q) fills 16-byte slot l of the group = patch row 5 q + l / 12, segment l % 12 (slots 60..63 are
+    // the first four of the next row: the same bytes the next instruction writes there).  Segments 10, 11, rows past the patch
+    // and everything outside the image get an offset beyond the buffer descriptor's range, for which a raw buffer load returns
+    // 0: the DMA itself writes the convolution's zero padding — no exec masks, no pre-zeroing.
+    static_assert(NQ == 1 || NQ == 2 || NQ % 4 == 0, "a wave must keep one row group");
+    unsigned rel_bytes[(NQ + 3) / 4];
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int e = tid + i * 256;
-        const int pr = e / W2D_PWS, pc = e - pr * W2D_PWS;
-        const int yy = ty0 + pr - 1, xx = tx0 + pc - 1;
-        pvalid[i] = e < PUSED && pc < W2D_PW && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        rel_bytes[i] = pvalid[i] ? (unsigned)(yy * p.W + xx) * 4u : 0u;
-        if (!pvalid[i] && e < PSTRIDE) {  // border / padding slot: zero in both buffers, for good
-#pragma unroll
-            for (int c = 0; c < W2D_CC; ++c) Ps[c * PSTRIDE + e] = 0.f, Ps[PBUF + c * PSTRIDE + e] = 0.f;
-        }
+    for (int g = 0; g < (NQ + 3) / 4; ++g) {
+        const int q = (fy + 4 * g) % NQ;
+        const int pr = W2D_ROWS_PER_DMA * q + lane / 12, sg = lane % 12;
+        const int yy = ty0 + pr - 1, xx = tx0 - 4 + 4 * sg;
+        const bool ok = sg < W2D_SEGS && pr < PH && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        rel_bytes[g] = ok ? (unsigned)(yy * p.W + xx) * 4u : 0x80000000u;
     }
     for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
 
@@ -154,14 +201,16 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(As + buf * A_FLOATS + i * 256),
                                                      16, (i * 256 + lane * 4) * 4, wbase, 0, 0);
         }
-        float* dst = Ps + buf * PBUF + fy * 64;
 #pragma unroll
-        for (int c = 0; c < W2D_CC; ++c) {
-#pragma unroll
-            for (int i = 0; i < MAXP; ++i)
-                if (pvalid[i])
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(dst + c * PSTRIDE + i * 256), 4,
-                                                             (int)rel_bytes[i], (int)((size_t)(chunk * W2D_CC + c) * plane_bytes), 0, 0);
+        for (int k = 0; k < (4 * NQ + 3) / 4; ++k) {
+            const int id = fy + 4 * k;  // (scalar) instruction id = channel * NQ + row group
+            if (id < W2D_CC * NQ) {
+                const int c = id / NQ, q = id % NQ;
+                float* dst = Ps + buf * PBUF + c * PSTRIDE + q * (W2D_ROWS_PER_DMA * W2D_PWS);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
+                                                         (int)rel_bytes[(NQ % 4 == 0) ? (k % (NQ / 4 > 0 ? NQ / 4 : 1)) : 0],
+                                                         (int)((size_t)(chunk * W2D_CC + c) * plane_bytes), 0, 0);
+            }
         }
 #else
         (void)chunk, (void)buf;
@@ -181,34 +230,57 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     const int ra = fy == 0 ? 0 : (fy == 2 ? 2 : 1);
     const int rb = fy == 0 ? 2 : (fy == 1 ? 2 : (fy == 2 ? 1 : 3));
     const float sgn = fy == 1 ? 1.f : -1.f;
-    int boff[TN];
+    // LDS byte addresses (buffer 0) of this lane's operands; the second buffer is a constant distance away
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    // window rows ra / rb of n-tile 0, channel kq; n-tile n lies a constant 4 patch rows further (immediate offset)
+    unsigned b_addr[2];
+    {
+        const int top = kq * PSTRIDE + (2 * jy) * W2D_PWS + 4 * jx + 3;  // the window starts one column left of the position
+        b_addr[0] = lds0 + (unsigned)(2 * A_FLOATS + top + ra * W2D_PWS) * 4u;
+        b_addr[1] = lds0 + (unsigned)(2 * A_FLOATS + top + rb * W2D_PWS) * 4u;
+    }
+    constexpr int NT_BYTES = 4 * W2D_PWS * 4;
+    // weight rows of this wave: ((fy * 6 + xf) * 4 + kq) * BM + physical column of (m-tile pair h, row j)
+    unsigned a_addr[TM / 2];
 #pragma unroll
-    for (int n = 0; n < TN; ++n) boff[n] = kq * PSTRIDE + (2 * (2 * n + jy)) * W2D_PWS + 4 * jx;
-    // weight rows of this wave: ((fy * 6 + xf) * 4 + kq) * BM + physical column of (m-tile pair, row j)
-    int aoff[TM / 2];
-#pragma unroll
-    for (int h = 0; h < TM / 2; ++h) aoff[h] = (fy * 24 + kq) * BM + w2d_col(TM, 2 * h, j, kq);
+    for (int h = 0; h < TM / 2; ++h) a_addr[h] = lds0 + (unsigned)((fy * 24 + kq) * BM + w2d_col(TM, 2 * h, j, kq)) * 4u;
+    unsigned s_addr = lds0 + (unsigned)(2 * A_FLOATS + 2 * PBUF + kq) * 4u;
+    constexpr unsigned A_BUF_BYTES = A_FLOATS * 4u, P_BUF_BYTES = PBUF * 4u;
+    constexpr int XF_BYTES = W2D_CC * BM * 4;  // distance between x-frequencies in the weight tile
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-        if (chunk + 1 < p.n_chunks) issue(chunk + 1, cur ^ 1);
-        const float* __restrict__ Ac = As + cur * A_FLOATS;
-        const float* __restrict__ Pc = Ps + cur * PBUF;
-        const float sc = Ss[chunk * W2D_CC + kq];
-        float bv[TN][6];
+        if (chunk + 1 < p.n_chunks && !(p.debug & 2)) issue(chunk + 1, cur ^ 1);
+        // ---- operand reads of this chunk: style, raw window rows, first weight row
+        const unsigned a_off = cur ? A_BUF_BYTES : 0u, p_off = cur ? P_BUF_BYTES : 0u;
+        float sc = lds_read32(s_addr);
+        s_addr += W2D_CC * 4u;
+        unsigned ap[TM / 2];
 #pragma unroll
-        for (int n = 0; n < TN; ++n) {
-            const float* da = Pc + boff[n] + ra * W2D_PWS;
-            const float* db = Pc + boff[n] + rb * W2D_PWS;
-            const f32x2 a01 = *reinterpret_cast<const f32x2*>(da), a23 = *reinterpret_cast<const f32x2*>(da + 2);
-            const f32x2 a45 = *reinterpret_cast<const f32x2*>(da + 4);
-            const f32x2 b01 = *reinterpret_cast<const f32x2*>(db), b23 = *reinterpret_cast<const f32x2*>(db + 2);
-            const f32x2 b45 = *reinterpret_cast<const f32x2*>(db + 4);
-            const float d0 = fmaf(sgn, b01.x, a01.x), d1 = fmaf(sgn, b01.y, a01.y), d2 = fmaf(sgn, b23.x, a23.x);
-            const float d3 = fmaf(sgn, b23.y, a23.y), d4 = fmaf(sgn, b45.x, a45.x), d5 = fmaf(sgn, b45.y, a45.y);
+        for (int h = 0; h < TM / 2; ++h) ap[h] = a_addr[h] + a_off;
+        f32x2 a2[2][TM / 2];
+        float bv[TN][6];
+        // windows are read two n-tiles ahead of their transform (12 registers each: at most two are live), the first weight row
+        // goes out behind the last window; LDS returns in order, so "at most k operations outstanding" identifies what landed
+        // (with four n-tiles per wave the register file only has room for one window in flight)
+        constexpr int WSLOTS = TN > 2 ? 1 : 2;
+        float wa0[WSLOTS], wa5[WSLOTS], wb0[WSLOTS], wb5[WSLOTS];  // window columns 0 and 5 (4-byte reads: odd float index)
+        f32x2 wa[WSLOTS][2], wb[WSLOTS][2];                         // columns 1-2 and 3-4 (8-byte aligned)
+        const unsigned pa = b_addr[0] + p_off, pb = b_addr[1] + p_off;
+        auto read_window = [&](auto n_c, int slot) {
+            constexpr int o = decltype(n_c)::value * NT_BYTES;
+            wa0[slot] = lds_read32o<o>(pa), wa[slot][0] = lds_read64<o + 4>(pa), wa[slot][1] = lds_read64<o + 12>(pa);
+            wa5[slot] = lds_read32o<o + 20>(pa);
+            wb0[slot] = lds_read32o<o>(pb), wb[slot][0] = lds_read64<o + 4>(pb), wb[slot][1] = lds_read64<o + 12>(pb);
+            wb5[slot] = lds_read32o<o + 20>(pb);
+        };
+        auto transform = [&](int n, int slot) {
+            const float d0 = fmaf(sgn, wb0[slot], wa0[slot]), d1 = fmaf(sgn, wb[slot][0].x, wa[slot][0].x);
+            const float d2 = fmaf(sgn, wb[slot][0].y, wa[slot][0].y), d3 = fmaf(sgn, wb[slot][1].x, wa[slot][1].x);
+            const float d4 = fmaf(sgn, wb[slot][1].y, wa[slot][1].y), d5 = fmaf(sgn, wb5[slot], wa5[slot]);
             // B_x^T for F(4,3) (interpolation points 0, +-1, +-2, inf), as in modconv.hip's mode 3
             const float a_ = fmaf(-4.f, d2, d4), b_ = fmaf(-4.f, d1, d3);
             const float c_ = d4 - d2, e_ = d3 - d1;
@@ -218,19 +290,46 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             bv[n][3] = fmaf(2.f, e_, c_) * sc;
             bv[n][4] = fmaf(-2.f, e_, c_) * sc;
             bv[n][5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5)) * sc;
-        }
+        };
+        read_window(std::integral_constant<int, 0>{}, 0);
+        if constexpr (TN > 1 && WSLOTS > 1) read_window(std::integral_constant<int, 1>{}, 1);
+        static_for<0, TN>([&](auto n_c) {
+            constexpr int n = decltype(n_c)::value;
+            constexpr int slot = n % WSLOTS;
+            if constexpr (n == TN - 1) {  // behind the last window: the first weight row
 #pragma unroll
-        for (int xf = 0; xf < 6; ++xf) {
-#pragma unroll
-            for (int h = 0; h < TM / 2; ++h) {
-                const f32x2 a2 = *reinterpret_cast<const f32x2*>(Ac + xf * (W2D_CC * BM) + aoff[h]);
-#pragma unroll
-                for (int n = 0; n < TN; ++n) {
-                    acc[xf][2 * h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bv[n][xf], acc[xf][2 * h][n], 0, 0, 0);
-                    acc[xf][2 * h + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bv[n][xf], acc[xf][2 * h + 1][n], 0, 0, 0);
-                }
+                for (int h = 0; h < TM / 2; ++h) a2[0][h] = lds_read64<0>(ap[h]);
             }
-        }
+            // outstanding behind window n: window n+1 (8 reads) unless n is the last, plus the weight reads when they are out
+            constexpr int behind = ((n + 1 < TN && WSLOTS > 1) ? 8 : 0) + (n == TN - 1 ? TM / 2 : 0);
+            asm volatile("s_waitcnt lgkmcnt(%9)"
+                         : "+v"(sc), "+v"(wa[slot][0]), "+v"(wa[slot][1]), "+v"(wb[slot][0]), "+v"(wb[slot][1]), "+v"(wa0[slot]),
+                           "+v"(wa5[slot]), "+v"(wb0[slot]), "+v"(wb5[slot])
+                         : "n"(behind));
+            transform(n, slot);
+            if constexpr (n + WSLOTS < TN) read_window(std::integral_constant<int, n + WSLOTS>{}, slot);
+        });
+        // ---- MFMA phase: the weight row of the next x-frequency is read one step ahead
+        static_for<0, 6>([&](auto xf_c) {
+            constexpr int xf = decltype(xf_c)::value;
+            if constexpr (xf < 5) {
+#pragma unroll
+                for (int h = 0; h < TM / 2; ++h) a2[(xf + 1) & 1][h] = lds_read64<(xf + 1) * XF_BYTES>(ap[h]);
+            }
+            constexpr int pending = xf < 5 ? TM / 2 : 0;
+            if constexpr (TM == 4) lds_wait<pending>(a2[xf & 1][0], a2[xf & 1][1]);
+            else lds_wait<pending>(a2[xf & 1][0]);
+            if (!(p.debug & 1)) {
+#pragma unroll
+                for (int h = 0; h < TM / 2; ++h)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        acc[xf][2 * h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[xf & 1][h].x, bv[n][xf], acc[xf][2 * h][n], 0, 0, 0);
+                        acc[xf][2 * h + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[xf & 1][h].y, bv[n][xf], acc[xf][2 * h + 1][n], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
@@ -273,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     float rgbp[4][3];
 #pragma unroll
     for (int px = 0; px < 4; ++px) rgbp[px][0] = rgbp[px][1] = rgbp[px][2] = 0.f;
-    const bool store_feat = p.rgb != 2;
+    const bool store_feat = p.rgb != 2 && !(p.debug & 4);
     float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane;
     const unsigned pix_off = (unsigned)oy * (unsigned)p.W + (unsigned)ox;
 
@@ -424,6 +523,7 @@ size_t w2d_lds_bytes(int tm, int tn, int cin) {
 }
 
 char g_w2d_instance[64] = "";
+int g_w2d_debug = 0;
 
 template <int TM, int TN>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
@@ -446,8 +546,9 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
 int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
     if (cin % W2D_CC || w % 32 || cin <= 0 || cout <= 0) return 0;
     int m, n;
-    if (cout % 64 == 0) m = 4, n = 2;
-    else if (cout == 32) m = 2, n = 4;
+    static const bool force_tm2 = getenv("MAUA_W2D_TM2") != nullptr;  // experiment switch: 32-row tiles for every layer
+    if (cout % 64 == 0 && !(force_tm2 && h % 16 == 0)) m = 4, n = 2;
+    else if (cout % 32 == 0 && (cout == 32 || force_tm2)) m = 2, n = 4;
     else return 0;
     if (h % (4 * n)) return 0;
     if (tm) *tm = m;
@@ -456,6 +557,7 @@ int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
 }
 
 const char* maua_w2d_last_instance() { return g_w2d_instance; }
+int maua_w2d_debug_set(int v) { g_w2d_debug = v; return 0; }
 
 int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
@@ -472,6 +574,7 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     a.noise_batch_stride = noise_batch_stride;
     a.tiles_x = w / 32, a.tiles_y = h / (4 * tn), a.m_tiles = cout / (16 * tm), a.n_chunks = cin / W2D_CC;
     a.rgb = rgb_mode, a.rgb_wscale = rgb_wscale;
+    a.debug = g_w2d_debug;
     if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || !rgb_out || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;

@@ -108,15 +108,22 @@ def test_fused_torgb_and_winograd_match_separate_direct_kernels(gpu):
     noise = [n.to(gpu) for n in seeding.seeded_noise(1, 1024, seed=7)]
     fast, _ = g(styles=lat, noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
     fast = fast.clone()
-    keep, keep43 = ModulatedConv2d.winograd_min_cout, ModulatedConv2d.winograd43_min_cout
+    keep = (ModulatedConv2d.winograd_min_cout, ModulatedConv2d.winograd43_min_cout, ModulatedConv2d.winograd2d_min_cout)
     try:
-        ModulatedConv2d.winograd_min_cout = ModulatedConv2d.winograd43_min_cout = 1 << 30
+        ModulatedConv2d.winograd_min_cout = ModulatedConv2d.winograd43_min_cout = ModulatedConv2d.winograd2d_min_cout = 1 << 30
         g.disable_rgb_fusion = True
         plain, _ = g(styles=lat, noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
+        plain = plain.clone()
+        # ... and with the 2-D Winograd kernel on EVERY qualifying layer (incl. the fused-ToRGB 32/64-channel ones)
+        ModulatedConv2d.winograd_min_cout, ModulatedConv2d.winograd43_min_cout = keep[0], keep[1]
+        ModulatedConv2d.winograd2d_min_cout = 32
+        g.disable_rgb_fusion = False
+        all2d, _ = g(styles=lat, noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
     finally:
-        ModulatedConv2d.winograd_min_cout, ModulatedConv2d.winograd43_min_cout = keep, keep43
+        ModulatedConv2d.winograd_min_cout, ModulatedConv2d.winograd43_min_cout, ModulatedConv2d.winograd2d_min_cout = keep
         g.disable_rgb_fusion = False
     assert float((fast - plain).abs().max()) < 5e-4
+    assert float((all2d - plain).abs().max()) < 5e-4
 
 
 def test_generator_512_channel_multiplier_1_vs_oracle(gpu):

@@ -228,6 +228,7 @@ def test_modconv_winograd2d_vs_oracle(gpu, cin, cout, h, w, batch):
 
     r = np.random.default_rng(5 * cin + cout + h + w)
     m = StyledConv(cin, cout, 3, 512, upsample=False)
+    m.conv.winograd2d_min_cout = 32  # (the generator itself uses mode 5 from 128 channels up)
     assert m.conv.conv_mode(h, w) == 5
     sd = {
         "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
@@ -279,6 +280,7 @@ def test_fused_torgb_epilogue_equals_separate_launches(gpu, cin, cout, h, w, wit
     conv.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("C.")}, strict=True)
     rgb.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("T.")}, strict=True)
     conv, rgb = conv.to(gpu), rgb.to(gpu)
+    conv.conv.winograd2d_min_cout = 32
     assert conv.conv.conv_mode(h, w) == 5
     x = torch.from_numpy(r.standard_normal((b, cin, h, w)).astype(np.float32))
     s1 = torch.from_numpy(r.standard_normal((b, 512)).astype(np.float32))
