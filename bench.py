@@ -7,7 +7,7 @@
 
 A "step" = one pass of the hot path over one batch of B synthetic frames on every rank: copy the batch's latents
 (already resident in HBM) into the graph's static inputs, replay the hipGraph-captured generator forward
-(style affines, demod, 17 StyledConv, 9 ToRGB), convert to uint8 NHWC frames (render.py:40-43 epilogue).  Frames
+(style affines, demod, 17 StyledConv, 9 ToRGB; the last ToRGB writes uint8 NHWC frames, render.py:40-43 epilogue).  Frames
 are independent, so ranks shard them with no data-path collective (weak scaling: B frames per rank per step).
 Weights are random-init (seeded numpy streams) of the real 1024^2 architecture; arithmetic is fp32 end to end.
 
@@ -230,13 +230,13 @@ def main():
     for lane_id in range(n_lanes):
         lane_stream = torch.cuda.Stream(dev)
         with torch.cuda.stream(lane_stream):
-            lane_graph, lane_static = g.capture_graph(B, noise_shapes, lane=lane_id)
+            lane_graph, lane_static = g.capture_graph(B, noise_shapes, lane=lane_id, frames_u8=True)
             for dst, src in zip(lane_static["noise"], noise_pool):
                 if src is not None:
                     dst.copy_(src)
         lane_stream.synchronize()
-        lanes.append({"stream": lane_stream, "graph": lane_graph, "static": lane_static,
-                      "u8": torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev)})
+        # (the uint8 NHWC frame epilogue of render.py:40-43 is part of the captured forward: fused into the last ToRGB)
+        lanes.append({"stream": lane_stream, "graph": lane_graph, "static": lane_static, "u8": lane_static["u8"]})
     stream, graph, static = lanes[0]["stream"], lanes[0]["graph"], lanes[0]["static"]
     with torch.cuda.stream(stream):
         sp = stream.cuda_stream
@@ -253,8 +253,6 @@ def main():
                     if src is not None:
                         dst.copy_(src, non_blocking=True)
                 lane["graph"].replay(sp_)
-                _lib.check(lib.maua_frames_to_u8(lane["static"]["image"].data_ptr(), lane["u8"].data_ptr(), B, size, size,
-                                                 sp_), "u8")
 
         def sync_lanes():
             for lane in lanes:
@@ -340,7 +338,7 @@ def main():
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"StyleGAN2-{size} generator (config 3 shape: random-init, channel_multiplier 2), "
                                        f"{B} frames/step/GPU, hipGraph per batch ({n_lanes} graphs round-robin on {n_lanes} streams), "
-                                       f"per-frame noise <=256^2, uint8 NHWC epilogue",
+                                       f"per-frame noise <=256^2, uint8 NHWC frames written by the last layer",
                            "frames_per_step_per_gpu": B, "lanes": n_lanes, "parallelism": f"frame-shard x{world}"},
                 "frames_per_sec_per_gpu": fps / world,
                 "timed_region_s": elapsed,

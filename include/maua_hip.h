@@ -128,13 +128,15 @@ int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_s
  * activated feature map is reduced to RGB while it is still in registers (all channels of a pixel sit in one wave).
  * Only for layers whose channels fit one weight tile in a single wave row (cout <= 64); returns MAUA_ENOSYS otherwise
  * (the caller then runs maua_modconv3x3_f32 + maua_torgb_f32).  rgb_s = the ToRGB layer's styles [B, s_stride] (same
- * stride as s).  mode = 0 (direct), 2, 3 or 5 (Winograd F(2,3) / F(4,3) / 2-D F(2x4,3x3), wp from the matching pack function).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
+ * stride as s).  frames_u8 != NULL (last layer): the image is not written as fp32 planes at all but leaves as uint8 NHWC frames
+ * [B,H,W,3] = clamp(-1,1), (x+1)*127.5, truncating cast (the frame epilogue of render.py:40-43 folded in; rgb_out may be NULL).
+ * mode = 0 (direct), 2, 3 or 5 (Winograd F(2,3) / F(4,3) / 2-D F(2x4,3x3), wp from the matching pack function).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
 int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                               float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
                               const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                               const float* rgb_w, const float* rgb_s, float rgb_wscale, const float* rgb_bias,
                               const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,
-                              void* stream);
+                              uint8_t* frames_u8, void* stream);
 
 /* ToRGB (models/stylegan2.py:356-365): 1x1 modulated conv without demod + bias + 2x FIR-upsampled skip
  * (Upsample :34-52, kernel k4 = 4x4 taps in device memory, pad (2,1)).  skip == NULL: no skip.
@@ -186,9 +188,12 @@ int maua_cqt_mag_f32(const float* y, int64_t n_samples, const float* freqs, cons
 /* Chroma post-processing for audioreactive/signal.py:102-133 (ch / out are [n_bins <= 32, n_frames], fp32):
  * CENS = per-frame L1 normalisation, 4-level quantisation, Hann smoothing over win_len (odd) frames, L2 normalisation;
  * nn_median = per-frame median over the k frames of highest cosine similarity outside |i-j| < width (the
- * aggregate=np.median, metric="cosine" nearest-neighbour filter at :131).  n_frames * 8 + k * (4 + 4 n_bins) bytes of LDS. */
+ * aggregate=np.median, metric="cosine" nearest-neighbour filter at :131).  The fp64 similarity row of a frame lives in LDS
+ * while n_frames * 8 + k * (4 + 4 n_bins) bytes fit (~16k frames); longer tracks need a caller-owned workspace `ws` of
+ * maua_nn_median_ws_doubles() doubles (0 = not needed, ws may be NULL). */
 int maua_chroma_cens_f32(const float* ch, float* out, int n_bins, int n_frames, int win_len, void* stream);
-int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, void* stream);
+int64_t maua_nn_median_ws_doubles(int n_bins, int n_frames, int k);
+int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, double* ws, void* stream);
 
 /* 3-D tileable Perlin noise (audioreactive/latent.py:188-246): grad [r0+1,r1+1,r2+1,3] -> out [n0,n1,n2]. */
 int maua_perlin3d_f32(const float* grad, float* out, int n0, int n1, int n2, int r0, int r1, int r2, void* stream);

@@ -55,7 +55,7 @@ _SIGNATURES = {
     "maua_modconv_last_instance": (c_int, [c_char_p, c_int]),
     "maua_modconv3x3_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, _P, c_int64, _P, _P, _P, _P]),
     "maua_styledconv_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
-                                          _P, _P, _P, _P, c_int, _P]),
+                                          _P, _P, _P, _P, c_int, _P, _P]),
     "maua_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_frames_to_u8": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "maua_temporal_fir_f32": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P]),
@@ -67,7 +67,8 @@ _SIGNATURES = {
     "maua_resample_f64": (c_int, [_P, c_int, c_int64, _P, c_int, _P]),
     "maua_cqt_mag_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_float, _P, c_int, _P]),
     "maua_chroma_cens_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
-    "maua_nn_median_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "maua_nn_median_ws_doubles": (c_int64, [c_int] * 3),
+    "maua_nn_median_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "maua_filterbank_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_perlin3d_f32": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "maua_affine_reflect_warp_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P]),

@@ -14,8 +14,8 @@ any device; results come back on the device the reference would have produced th
 ``device=`` says otherwise, so existing plugins keep working while the heavy tensors can stay in HBM.
 
 Divergences from the reference, all stated in DESIGN.md §7 ("parity unpinned" rows): librosa / madmom are not
-dependencies here.  ``onsets(type="mm")`` sums four of madmom's five onset functions on a log-filtered spectrogram
-built here (no phase-based complex flux), ``type="rosa"`` is the mel spectral flux; ``chroma`` runs harmonic
+dependencies here.  ``onsets(type="mm")`` sums madmom's five onset functions (incl. the phase-based complex flux) on a
+log-filtered spectrogram built here, ``type="rosa"`` is the mel spectral flux; ``chroma`` runs harmonic
 separation -> constant-Q chromagram -> CENS -> nearest-neighbour median filter without librosa's tuning estimation,
 and madmom's "deep" / "clp" chroma models fall back to the constant-Q chromagram with a warning.
 """
@@ -287,8 +287,7 @@ def log_filterbank(sr, n_fft=2048, num_bands=24, fmin=20.0, fmax=8000.0, fref=44
 def onset_functions_sum(filt):
     """Sum of four onset detection functions of a filtered magnitude spectrogram ``filt`` [bands, frames] (any device):
     squared and plain positive flux, flux against the 3-band maximum of the previous frame, and the mean log-ratio
-    between consecutive frames — the phase-free members of the sum at signal.py:58-67 (its complex-flux term needs the
-    phase spectrogram, which the power STFT kernel does not keep)."""
+    between consecutive frames — the phase-free members of the sum at signal.py:58-67 (the fifth is :func:`complex_flux`)."""
     prev = th.cat([filt[:, :1], filt[:, :-1]], dim=1)
     pos = (filt - prev).clamp(min=0)
     widened = th.nn.functional.max_pool1d(prev.t()[None], 3, 1, 1)[0].t()
@@ -299,11 +298,68 @@ def onset_functions_sum(filt):
     return (pos * pos).sum(0) + pos.sum(0) + (sup.sum(0) + ratio.mean(0)) * keep
 
 
+def stft_complex(audio, n_fft=2048, hop=512):
+    """Complex STFT on device as (re, im), each [n_fft/2+1, 1 + len/hop] float32 (centred, reflect-padded, periodic Hann)."""
+    lib = _lib.load()
+    y = _to_dev(audio)
+    n = y.numel()
+    n_frames = 1 + n // hop
+    win = _hann(n_fft, y.device)
+    re = th.empty((n_fft // 2 + 1, n_frames), dtype=th.float32, device=y.device)
+    im = th.empty_like(re)
+    with th.cuda.device(y.device):
+        _lib.check(lib.maua_stft_complex_f32(y.data_ptr(), n, win.data_ptr(), n_fft, hop, re.data_ptr(), im.data_ptr(), n_frames,
+                                             _lib.stream_ptr(y.device)), "maua_stft_complex_f32")
+    return re, im
+
+
+def local_group_delay(re, im):
+    """|local group delay| / pi of a complex STFT [bins, frames] measured against the frame centre (madmom's
+    circular_shift=True, reference signal.py:55): (-1)^k on bin k, phase differenced along frequency with the jumps wrapped to
+    (-pi, pi] — the difference of the unwrapped phase IS the wrapped difference of the phase — last bin 0."""
+    sign = 1.0 - 2.0 * (th.arange(re.shape[0], device=re.device) % 2).float()
+    phase = th.atan2(im * sign[:, None], re * sign[:, None]).double()
+    jump = phase[1:] - phase[:-1]
+    wrapped = th.remainder(jump + math.pi, 2 * math.pi) - math.pi
+    wrapped = th.where((wrapped == -math.pi) & (jump > 0), th.full_like(wrapped, math.pi), wrapped)  # numpy.unwrap's tie rule
+    lgd = th.zeros_like(phase)
+    lgd[:-1] = -wrapped
+    return (lgd.abs() / math.pi).float()
+
+
+def complex_flux(re, im, fb, filt):
+    """madmom's complex_flux (reference signal.py:63) on device tensors: the SuperFlux difference of the filtered
+    spectrogram ``filt`` [bands, frames], weighted per band by the minimum — over the FFT bins the band's filter spans, widened
+    by one bin on each side — of the 3-frame temporal maximum of the local group delay.  ``fb`` [bands, bins] numpy."""
+    lgd = local_group_delay(re, im)
+    lgd = th.nn.functional.max_pool1d(th.nn.functional.pad(lgd[None], (1, 1), mode="replicate"), 3, 1)[0]
+    support = np.asarray(fb) != 0
+    first = support.argmax(axis=1)
+    last = support.shape[1] - 1 - support[:, ::-1].argmax(axis=1)
+    n_bins = lgd.shape[0]
+    width = int((last - first).max()) + 3
+    rows = np.clip(first[:, None] - 1 + np.arange(width)[None, :], 0, n_bins - 1)  # [bands, width] bin indices
+    keep = (np.arange(width)[None, :] <= (last - first + 2)[:, None])              # beyond a band's span: ignored (inf)
+    idx = th.from_numpy(rows).to(lgd.device)
+    gathered = lgd[idx.reshape(-1)].reshape(rows.shape[0], width, -1)
+    gathered = th.where(th.from_numpy(keep).to(lgd.device)[:, :, None], gathered, th.full_like(gathered, float("inf")))
+    mask = gathered.min(dim=1).values                                              # [bands, frames]
+    prev = th.cat([filt[:, :1], filt[:, :-1]], dim=1)
+    widened = th.nn.functional.max_pool1d(th.nn.functional.pad(prev.t()[None], (1, 1), mode="replicate"), 3, 1)[0].t()
+    diff = (filt - widened).clamp(min=0)
+    diff[:, 0] = 0.0
+    return (diff * mask).sum(0)
+
+
 def onset_strength_bands(audio, sr, fmin=20.0, fmax=8000.0, n_fft=2048, hop=441):
-    """type="mm" onset envelope: magnitude STFT (frame 2048, hop 441 — 50 frames/s at 22050 Hz) -> 24-per-octave
-    log filterbank -> :func:`onset_functions_sum`."""
-    mag = th.sqrt(stft_power(audio, n_fft, hop))[: n_fft // 2].contiguous()
-    return onset_functions_sum(project(log_filterbank(sr, n_fft, 24, fmin, fmax), mag))
+    """type="mm" onset envelope: complex STFT (frame 2048, hop 441 — 50 frames/s at 22050 Hz) -> magnitudes through the
+    24-per-octave log filterbank -> the five onset functions of reference signal.py:58-67: :func:`onset_functions_sum` (spectral
+    difference, spectral flux, SuperFlux, modified Kullback-Leibler) + :func:`complex_flux`."""
+    re, im = stft_complex(audio, n_fft, hop)
+    re, im = re[: n_fft // 2].contiguous(), im[: n_fft // 2].contiguous()
+    fb = log_filterbank(sr, n_fft, 24, fmin, fmax)
+    filt = project(fb, th.sqrt(re * re + im * im))
+    return onset_functions_sum(filt) + complex_flux(re, im, fb, filt)
 
 
 def onsets(audio, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, type="mm", device=None):
@@ -348,21 +404,20 @@ def cens(ch, win_len=41):
 
 def nn_filter(ch, width=1):
     """Nearest-neighbour median filter of a [n_bins, T] sequence on the device (maua_nn_median_f32): per frame, the median
-    over the k = 2 ceil(sqrt(T - 2 width + 1)) most cosine-similar frames (reference signal.py:131).  Tracks too long for
-    the kernel's LDS budget (> ~16k frames) are returned unfiltered with a warning."""
+    over the k = 2 ceil(sqrt(T - 2 width + 1)) most cosine-similar frames (reference signal.py:131).  Tracks whose similarity
+    rows no longer fit LDS (> ~16k frames, 6 min of audio) run the same kernel on a device workspace."""
     ch = _to_dev(ch).float().contiguous()
     t = ch.shape[1]
     k = int(min(t - 1, 2 * math.ceil(math.sqrt(max(t - 2 * width + 1, 1)))))
     if k < 1:
         return ch
     out = th.empty_like(ch)
+    lib = _lib.load()
+    n_ws = lib.maua_nn_median_ws_doubles(ch.shape[0], t, k)
+    ws = th.empty(n_ws, dtype=th.float64, device=ch.device) if n_ws else None
     with th.cuda.device(ch.device):
-        rc = _lib.load().maua_nn_median_f32(ch.data_ptr(), out.data_ptr(), ch.shape[0], t, k, width, _lib.stream_ptr(ch.device))
-    if rc == -22:
-        warnings.warn(f"nn_filter: {t} frames exceed the nearest-neighbour kernel's LDS budget; chromagram left unfiltered",
-                      stacklevel=2)
-        return ch
-    _lib.check(rc, "maua_nn_median_f32")
+        _lib.check(lib.maua_nn_median_f32(ch.data_ptr(), out.data_ptr(), ch.shape[0], t, k, width, _lib.ptr(ws),
+                                          _lib.stream_ptr(ch.device)), "maua_nn_median_f32")
     return out
 
 

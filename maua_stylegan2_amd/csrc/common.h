@@ -33,5 +33,5 @@ const char* maua_w2d_last_instance();
 int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
                     const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
-                    const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, int rgb_mode,
-                    void* stream);
+                    const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, uint8_t* rgb_u8,
+                    int rgb_mode, void* stream);

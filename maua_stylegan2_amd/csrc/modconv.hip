@@ -96,6 +96,7 @@ struct ConvPtrs {
     const float* rgb_skip;  // [B, 3, H/2, W/2] or null
     const float* rgb_k4;    // 4x4 upsample taps
     float* rgb_out;         // [B, 3, H, W]
+    uint8_t* rgb_u8;        // when set: the image leaves as uint8 NHWC frames [B, H, W, 3] (render.py:40-43) instead of rgb_out
 };
 
 // UP = false : plain 3x3, pad 1.           per wave: TM x TN MFMA tiles.
@@ -924,6 +925,9 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
                     }
                     float* __restrict__ rgb_img = p.rgb_out + (size_t)b0 * 3 * plane_out;
                     const unsigned rgb_off = (unsigned)(oy * g.OW + ox);
+                    uint32_t pix[PXN];  // packed frame bytes (R | G << 8 | B << 16) when the frame epilogue is fused
+#pragma unroll
+                    for (int px = 0; px < PXN; ++px) pix[px] = 0u;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         float val[PXN];
@@ -935,10 +939,29 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                                 for (int qx = 0; qx < 2; ++qx) val[px] = fmaf(wgt[px][qy][qx], sv[px][c][qy][qx], val[px]);
                         }
+                        if (p.rgb_u8) {  // render.py:40-43: clamp(-1, 1), (x + 1) * 127.5, truncating cast
+#pragma unroll
+                            for (int px = 0; px < PXN; ++px)
+                                pix[px] |= (uint32_t)((fminf(fmaxf(val[px], -1.f), 1.f) + 1.f) * 127.5f) << (8 * c);
+                            continue;
+                        }
                         float* ro = rgb_img + (size_t)c * plane_out + rgb_off;
                         if (PXN == 4 && ok1) *reinterpret_cast<f32x4u*>(ro) = f32x4{val[0], val[1 % PXN], val[2 % PXN], val[3 % PXN]};
                         else if (PXN == 2 && ok1) *reinterpret_cast<f32x2u*>(ro) = f32x2{val[0], val[PXN - 1]};
                         else ro[0] = val[0];
+                    }
+                    if (p.rgb_u8) {
+                        uint8_t* fo = p.rgb_u8 + ((size_t)b0 * plane_out + rgb_off) * 3;
+                        if (PXN == 4 && ok1) {  // 12 bytes at a 12-byte multiple: three dword stores
+                            uint32_t* fw = reinterpret_cast<uint32_t*>(fo);
+                            fw[0] = pix[0] | (pix[1 % PXN] << 24);
+                            fw[1] = (pix[1 % PXN] >> 8) | (pix[2 % PXN] << 16);
+                            fw[2] = (pix[2 % PXN] >> 16) | (pix[3 % PXN] << 8);
+                        } else {
+#pragma unroll
+                            for (int px = 0; px < PXN; ++px)
+                                if (px == 0 || ok1) fo[3 * px] = (uint8_t)pix[px], fo[3 * px + 1] = (uint8_t)(pix[px] >> 8), fo[3 * px + 2] = (uint8_t)(pix[px] >> 16);
+                        }
                     }
                 }
             }
@@ -1282,7 +1305,7 @@ extern "C" int maua_modconv_last_instance(char* buf, int buf_len) {
 namespace {
 struct RgbArgs {
     const float* w; const float* s; const float* bias; const float* skip; const float* k4; float* out;
-    float wscale; int store_features;
+    float wscale; int store_features; uint8_t* u8;
 };
 
 int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, int batch,
@@ -1295,7 +1318,8 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
         const int rc = maua_w2d_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, fuse_act, noise, noise_batch_stride,
                                        noise_w, bias, rgb ? rgb->w : nullptr, rgb ? rgb->s : nullptr, rgb ? rgb->wscale : 0.f,
                                        rgb ? rgb->bias : nullptr, rgb ? rgb->skip : nullptr, rgb ? rgb->k4 : nullptr,
-                                       rgb ? rgb->out : nullptr, rgb ? (rgb->store_features ? 1 : 2) : 0, stream);
+                                       rgb ? rgb->out : nullptr, rgb ? rgb->u8 : nullptr, rgb ? (rgb->store_features ? 1 : 2) : 0,
+                                       stream);
         if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
         return rc;
     }
@@ -1311,17 +1335,17 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     pl.g.debug = g_conv_debug;
     pl.g.rgb = 0;
     pl.g.rgb_wscale = 0.f;
-    ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (rgb) {
         // fusable only when one workgroup holds every channel of its pixels in a single wave row (BM >= Cout, WM == 1),
         // no split-K, one image per tile, the tail fused
         const bool ok = up != 1 && up != 4 && fuse_act && pl.wm == 1 && pl.g.m_tiles == 1 && pl.g.splits == 1 && pl.g.lni == 0 &&
-                        rgb->w && rgb->s && rgb->bias && rgb->out && (!rgb->skip || (rgb->k4 && !(h & 1) && !(w & 1)));
+                        rgb->w && rgb->s && rgb->bias && (rgb->out || rgb->u8) && (!rgb->skip || (rgb->k4 && !(h & 1) && !(w & 1)));
         if (!ok) return MAUA_ENOSYS;
         pl.g.rgb = rgb->store_features ? 1 : 2;
         pl.g.rgb_wscale = rgb->wscale;
         ptrs.rgb_w = rgb->w, ptrs.rgb_s = rgb->s, ptrs.rgb_bias = rgb->bias, ptrs.rgb_skip = rgb->skip;
-        ptrs.rgb_k4 = rgb->k4, ptrs.rgb_out = rgb->out;
+        ptrs.rgb_k4 = rgb->k4, ptrs.rgb_out = rgb->out, ptrs.rgb_u8 = rgb->u8;
     }
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -1374,8 +1398,8 @@ extern "C" int maua_styledconv_torgb_f32(const float* x, const float* wp, const 
                                          const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                          const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                                          const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out,
-                                         int store_features, void* stream) {
-    RgbArgs rgb{rgb_w, rgb_s, rgb_bias, rgb_skip, rgb_k4, rgb_out, rgb_wscale, store_features};
+                                         int store_features, uint8_t* frames_u8, void* stream) {
+    RgbArgs rgb{rgb_w, rgb_s, rgb_bias, rgb_skip, rgb_k4, rgb_out, rgb_wscale, store_features, frames_u8};
     if (mode == 1) return MAUA_ENOSYS;
     return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, mode, wscale, 1, noise, noise_batch_stride, noise_w,
                         bias, nullptr, &rgb, stream);

@@ -102,6 +102,7 @@ struct W2dArgs {
     const float* rgb_skip;
     const float* rgb_k4;
     float* rgb_out;
+    uint8_t* rgb_u8;  // when set: uint8 NHWC frames [B, H, W, 3] (render.py:40-43) instead of rgb_out
     int B, Cin, Cout, H, W;
     int s_stride;
     float wscale;
@@ -472,6 +473,20 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             }
         }
     }
+    if (p.rgb_u8) {  // fused frame epilogue: clamp(-1, 1), (x + 1) * 127.5, truncating cast; 12 bytes = three dword stores
+        uint32_t pix[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            pix[px] = 0u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pix[px] |= (uint32_t)((fminf(fmaxf(outc[c][px], -1.f), 1.f) + 1.f) * 127.5f) << (8 * c);
+        }
+        uint32_t* fw = reinterpret_cast<uint32_t*>(p.rgb_u8 + ((size_t)b0 * rgb_plane + pix_off) * 3);
+        fw[0] = pix[0] | (pix[1] << 24);
+        fw[1] = (pix[1] >> 8) | (pix[2] << 16);
+        fw[2] = (pix[2] >> 16) | (pix[3] << 8);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(rgb_img + (size_t)c * rgb_plane + pix_off) = outc[c];
 }
@@ -562,20 +577,21 @@ int maua_w2d_debug_set(int v) { g_w2d_debug = v; return 0; }
 int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
                     const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
-                    const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, int rgb_mode,
-                    void* stream) {
+                    const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, uint8_t* rgb_u8,
+                    int rgb_mode, void* stream) {
     int tm = 0, tn = 0;
     if (!maua_w2d_tiles(cin, cout, h, w, &tm, &tn)) return MAUA_EINVAL;
     if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)24 * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
     W2dArgs a{};
     a.x = x, a.wq = wq, a.s = s, a.d = d, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.y = y;
     a.rgb_w = rgb_w, a.rgb_s = rgb_s, a.rgb_bias = rgb_bias, a.rgb_skip = rgb_skip, a.rgb_k4 = rgb_k4, a.rgb_out = rgb_out;
+    a.rgb_u8 = rgb_u8;
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale, a.fuse_act = fuse_act;
     a.noise_batch_stride = noise_batch_stride;
     a.tiles_x = w / 32, a.tiles_y = h / (4 * tn), a.m_tiles = cout / (16 * tm), a.n_chunks = cin / W2D_CC;
     a.rgb = rgb_mode, a.rgb_wscale = rgb_wscale;
     a.debug = g_w2d_debug;
-    if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || !rgb_out || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
+    if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
     if (tm == 4) return w2d_launch_t<4, 2>(a, st);

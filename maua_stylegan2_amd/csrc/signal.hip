@@ -449,15 +449,21 @@ __global__ __launch_bounds__(256) void chroma_cens_kernel(const float* __restric
 // signal.py:131).  One workgroup per frame i: cosine similarity to every frame in fp64 (the neighbour ORDER has to match
 // the float64 oracle), the k best frames outside |i-j| < width by k rounds of block-wide arg-max (ties -> lower index,
 // i.e. a stable descending sort), then a per-feature median over those k frames.
+// SIMS_IN_LDS: the similarity row of the frame lives in LDS (tracks up to ~16k frames = 6 min at hop 512); otherwise every
+// workgroup owns one row of a caller-provided fp64 workspace [gridDim.x][n_frames] and walks frames i = blockIdx.x,
+// blockIdx.x + gridDim.x, ... — full-length songs keep the reference's semantics instead of skipping the filter.
+template <bool SIMS_IN_LDS>
 __global__ __launch_bounds__(256) void nn_median_kernel(const float* __restrict__ ch, float* __restrict__ out, int n_bins,
-                                                        int n_frames, int k, int width) {
+                                                        int n_frames, int k, int width, double* __restrict__ sims_ws) {
     extern __shared__ __attribute__((aligned(8))) unsigned char nn_lds[];
-    double* sims = reinterpret_cast<double*>(nn_lds);                      // [n_frames]
-    int* picked = reinterpret_cast<int*>(sims + n_frames);                 // [k]
+    double* sims = SIMS_IN_LDS ? reinterpret_cast<double*>(nn_lds) : sims_ws + (size_t)blockIdx.x * n_frames;  // [n_frames]
+    int* picked = reinterpret_cast<int*>(nn_lds + (SIMS_IN_LDS ? (size_t)n_frames * sizeof(double) : 0));     // [k]
     float* vals = reinterpret_cast<float*>(picked + k);                    // [n_bins][k]
     __shared__ double red_v[256];
     __shared__ int red_i[256];
-    const int i = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = blockIdx.x; i < n_frames; i += gridDim.x) {
+    __syncthreads();  // (the previous frame's vals / picked are no longer read)
     double ui[CENS_MAX_BINS];
     {
         double ni = 0.0;
@@ -517,6 +523,7 @@ __global__ __launch_bounds__(256) void nn_median_kernel(const float* __restrict_
             v[c + 1] = x;
         }
         out[(size_t)tid * n_frames + i] = (k & 1) ? v[k / 2] : (float)(0.5 * ((double)v[k / 2 - 1] + (double)v[k / 2]));
+    }
     }
 }
 
@@ -713,19 +720,38 @@ extern "C" int maua_chroma_cens_f32(const float* ch, float* out, int n_bins, int
     return 0;
 }
 
-extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, void* stream) {
-    if (!ch || !out || n_bins <= 0 || n_bins > CENS_MAX_BINS || n_frames <= 1 || k <= 0 || k >= n_frames || k > 512 || width < 1)
-        return MAUA_EINVAL;
+static int g_nn_force_ws = 0;  // maua_tuning_set key 4: 1 = take the workspace path at every size (tests)
+int maua_nn_force_ws_set(int v) { g_nn_force_ws = v; return 0; }
+
+extern "C" int64_t maua_nn_median_ws_doubles(int n_bins, int n_frames, int k) {
     const size_t lds = (size_t)n_frames * sizeof(double) + (size_t)k * sizeof(int) + (size_t)n_bins * k * sizeof(float);
-    if (lds > 150 * 1024) return MAUA_EINVAL;  // ~16k frames (6 min of audio at hop 512): longer tracks skip the filter
+    if (lds <= 150 * 1024 && !g_nn_force_ws) return 0;  // the similarity row fits LDS
+    const int rows = g_nn_force_ws > 1 ? (g_nn_force_ws < n_frames ? g_nn_force_ws : n_frames) : (n_frames < 1024 ? n_frames : 1024);
+    return (int64_t)rows * n_frames;
+}
+
+extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, double* ws, void* stream) {
+    if (!ch || !out || n_bins <= 0 || n_bins > CENS_MAX_BINS || n_frames <= 1 || k <= 0 || k >= n_frames || k > 2048 || width < 1)
+        return MAUA_EINVAL;
+    const size_t small = (size_t)k * sizeof(int) + (size_t)n_bins * k * sizeof(float);
+    const size_t lds = (size_t)n_frames * sizeof(double) + small;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(nn_median_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, ch, out, n_bins, n_frames, k,
-                       width);
+    if (lds <= 150 * 1024 && !g_nn_force_ws) {
+        hipLaunchKernelGGL(nn_median_kernel<true>, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, ch, out, n_bins, n_frames, k,
+                           width, (double*)nullptr);
+    } else {  // long track: similarity rows in the caller's workspace (maua_nn_median_ws_doubles), frames strided over the grid
+        if (!ws || small > 150 * 1024) return MAUA_EINVAL;
+        const int rows = g_nn_force_ws > 1 ? (g_nn_force_ws < n_frames ? g_nn_force_ws : n_frames) : (n_frames < 1024 ? n_frames : 1024);
+        hipLaunchKernelGGL(nn_median_kernel<false>, dim3(rows), dim3(256), small, (hipStream_t)stream, ch, out, n_bins, n_frames, k,
+                           width, ws);
+    }
     MAUA_LAUNCH_CHECK();
     return 0;
 }

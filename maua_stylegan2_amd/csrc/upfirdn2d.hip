@@ -709,11 +709,13 @@ int dispatch_fir_tile(const float* x, const float* k, float* y, int planes, int 
 int maua_conv_debug_set(int v);
 int maua_conv_cfg_set(int v);
 int maua_w2d_debug_set(int v);
+int maua_nn_force_ws_set(int v);
 extern "C" int maua_tuning_set(int key, int value) {
     if (key == 0) { g_fir_path = value; return 0; }
     if (key == 1) return maua_conv_debug_set(value);
     if (key == 2) return maua_conv_cfg_set(value);
     if (key == 3) return maua_w2d_debug_set(value);
+    if (key == 4) return maua_nn_force_ws_set(value);
     return MAUA_EINVAL;
 }
 

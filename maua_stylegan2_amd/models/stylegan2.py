@@ -404,7 +404,7 @@ class StyledConv(nn.Module):
                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
                         s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), t.bias.data_ptr(), _lib.ptr(skip),
                         _lib.ptr(t.upsample.kernel) if skip is not None else None, rgb["out"].data_ptr(),
-                        int(rgb.get("store", True)), _lib.stream_ptr(x.device))
+                        int(rgb.get("store", True)), _lib.ptr(rgb.get("u8")), _lib.stream_ptr(x.device))
                     if rc == 0:
                         rgb["done"] = True
                         return out
@@ -668,7 +668,10 @@ class Generator(nn.Module):
             return image, lat_out
         return image, None
 
-    def _forward_device(self, latent, noise, trunc, tl, bends, want_acts=False, want_latents=False):
+    def _forward_device(self, latent, noise, trunc, tl, bends, want_acts=False, want_latents=False, frames_u8=None):
+        """``frames_u8`` ([B, H, W, 3] uint8): the frame epilogue of render.py:40-43 (clamp, scale, NHWC, uint8) is folded into
+        the last layer's fused ToRGB epilogue — the fp32 image of the last resolution is then never written (``image`` returned
+        is None) — or, when that layer cannot take the fused path, applied by maua_frames_to_u8 right behind it."""
         lib = _lib.load()
         dev = latent.device
         batch = latent.shape[0]
@@ -728,10 +731,10 @@ class Generator(nn.Module):
             rgb_buf = bufs(f"rgbs.{n}", (batch, 3, out.shape[2], out.shape[3]))
             fuse = None
             wants_rgb = self.min_rgb_size <= current_size
+            is_last = n == self.log_size - 3
             if wants_rgb and not bent and not getattr(self, "disable_rgb_fusion", False):
-                is_last = n == self.log_size - 3
                 fuse = dict(module=rgb, s_off=ent[li + 1]["s_off"], skip=image, out=rgb_buf,
-                            store=(not is_last) or want_acts)
+                            store=(not is_last) or want_acts, u8=frames_u8 if is_last else None)
             out = plain.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 2, out.shape[2], out.shape[3]),
                             bufs, f"convs.{2 * n + 1}", rgb=fuse)
             out = plain.manipulation(out, bends)
@@ -739,16 +742,21 @@ class Generator(nn.Module):
             li += 1
             if fuse is not None and fuse.get("done"):
                 image = rgb_buf
+                if is_last and frames_u8 is not None:
+                    image = None  # left the device path as uint8 frames
             elif wants_rgb:
                 image = rgb.run(out, s, ent[li]["s_off"], image, rgb_buf)
             li += 1
+        if frames_u8 is not None and image is not None:  # last layer not fusable (bend on it, > 64 channels, ...)
+            _lib.check(lib.maua_frames_to_u8(image.data_ptr(), frames_u8.data_ptr(), batch, image.shape[2], image.shape[3], st),
+                       "maua_frames_to_u8")
         lat_out = None
         if want_latents:
             lat_out = latent if trunc is None else tl[None, None, :] + trunc[:, None, None] * (latent - tl[None, None, :])
         return image, acts, lat_out
 
     # ------------------------------------------------------------------ hipGraph
-    def capture_graph(self, batch, noise_static, truncated=False, lane=0):
+    def capture_graph(self, batch, noise_static, truncated=False, lane=0, frames_u8=False):
         """Capture one forward of ``batch`` frames into a hipGraph.  Returns (graph, static) where static holds the
         input buffers to overwrite before each ``graph.replay()`` (latents, truncation, per-layer noise or None for
         checkpoint noise buffers) and ``static["image"]`` is the output buffer.  Bends are not capturable.
@@ -760,11 +768,11 @@ class Generator(nn.Module):
         self._lane = lane
         self._captured = True
         try:
-            return self._capture_graph(batch, noise_static, truncated)
+            return self._capture_graph(batch, noise_static, truncated, frames_u8)
         finally:
             self._lane = 0
 
-    def _capture_graph(self, batch, noise_static, truncated):
+    def _capture_graph(self, batch, noise_static, truncated, frames_u8=False):
         dev = self.input.input.device
         with th.cuda.device(dev):
             static = {
@@ -789,11 +797,16 @@ class Generator(nn.Module):
                     self.truncation_latent = self.mean_latent(2 ** 14)
                 tl = self.truncation_latent.to(dev).reshape(-1).contiguous()
             static["trunc_latent"] = tl
+            # ``frames_u8``: the graph's output is static["u8"] ([B, H, W, 3] uint8 frames); static["image"] is then None
+            u8 = None
+            if frames_u8:
+                hw = static["noise"][-1].shape[-2:]
+                u8 = static["u8"] = self._buf(batch, "g.frames_u8", (batch, int(hw[0]), int(hw[1]), 3), dtype=th.uint8)
             # warm-up (allocates every static buffer, packs weights), then capture
-            self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [])
+            self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [], frames_u8=u8)
             th.cuda.synchronize(dev)
             graph = _lib.HipGraph()
             with graph:
-                image, _, _ = self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [])
+                image, _, _ = self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [], frames_u8=u8)
             static["image"] = image
         return graph, static

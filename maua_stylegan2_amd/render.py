@@ -8,7 +8,7 @@ with ``input_is_latent=True``), different machinery:
   pin + H2D of latents and up to 17 noise maps / batch    inputs are uploaded ONCE and stay resident in HBM (288 GB)
   eager generator call, ~200 launches per batch           hipGraph replay per batch (eager only when bends / rewrites /
                                                           randomize_noise make the batch non-capturable, or a tail batch)
-  clamp/scale/permute on device, per-FRAME .cpu()         one fused fp32->uint8 NHWC kernel, one async D2H per BATCH into
+  clamp/scale/permute on device, per-FRAME .cpu()         uint8 NHWC written by the last layer's epilogue, one async D2H per BATCH into
   .numpy().astype(uint8), two Python threads + queues     pinned double buffers on a copy stream, ordered sink
   DataParallel replicate/scatter/gather per forward       one process per GPU, contiguous frame shards, RCCL gather of
                                                           uint8 frames to rank 0 (maua_stylegan2_amd/sharding.py)
@@ -175,7 +175,7 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
                     if lane["graph"] is None:
                         shapes = [None if nz is None else tuple(nz.shape[-2:]) for nz in noise]
                         lane["graph"], lane["static"] = generator.capture_graph(
-                            batch_size, shapes, truncated=trunc_t is not None, lane=lane_id)
+                            batch_size, shapes, truncated=trunc_t is not None, lane=lane_id, frames_u8=True)
                     static = lane["static"]
                     static["latents"].copy_(latents[n:m])
                     for dst, src in zip(static["noise"], noise):
@@ -184,7 +184,9 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
                     if trunc_t is not None:
                         static["trunc"].copy_(trunc_t[n:m])
                     lane["graph"].replay()
-                    images = static["image"]
+                    yield n, static["u8"]  # the frame epilogue is part of the captured forward (fused into the last ToRGB)
+                    k += 1
+                    continue
                 else:
                     noise_batch = [None if nz is None else nz[n:m] for nz in noise]
                     bend_batch = []

@@ -265,8 +265,8 @@ def madmom_like_onset_functions(filt):
     """The four phase-free onset detection functions signal.py:58-66 sums (madmom.features.onsets, frame lag 1), on a
     filtered magnitude spectrogram ``filt`` [n_frames, n_bands]: spectral_diff = sum of squared positive differences,
     spectral_flux = sum of positive differences, superflux = positive differences against the 3-bin frequency-maximum of the
-    previous frame, modified_kullback_leibler = mean log(1 + S[t] / (S[t-1] + eps)).  (complex_flux needs the local group
-    delay of the phase spectrogram and is not restated.)  Returns a dict of [n_frames] arrays."""
+    previous frame, modified_kullback_leibler = mean log(1 + S[t] / (S[t-1] + eps)).  (The fifth, complex_flux, needs the phase
+    spectrogram: :func:`complex_flux`.)  Returns a dict of [n_frames] arrays."""
     filt = np.asarray(filt, dtype=np.float64)
     prev = np.concatenate([filt[:1], filt[:-1]], axis=0)
     pos = np.maximum(filt - prev, 0.0)
@@ -280,13 +280,54 @@ def madmom_like_onset_functions(filt):
             "modified_kullback_leibler": mkl}
 
 
+def local_group_delay(spec):
+    """|local group delay| / pi of a complex STFT ``spec`` [bins, frames] whose frames were circularly shifted by half a
+    window (madmom ShortTimeFourierTransform(circular_shift=True), signal.py:55: the phase is then measured against the frame
+    centre): bin k of the un-shifted transform is multiplied by (-1)^k, the phase unwrapped along frequency, differenced
+    (phase[k] - phase[k+1], last bin 0 — madmom.audio.stft.Phase.local_group_delay), absolute value, / pi."""
+    spec = np.asarray(spec)
+    sign = np.where(np.arange(spec.shape[0]) % 2 == 0, 1.0, -1.0)[:, None]
+    phase = np.unwrap(np.angle(spec * sign), axis=0)
+    lgd = np.zeros_like(phase)
+    lgd[:-1] = phase[:-1] - phase[1:]
+    return np.abs(lgd) / np.pi
+
+
+def complex_flux(spec, fb, filt, temporal_filter=3):
+    """madmom.features.onsets.complex_flux (Boeck & Widmer 2013, "Local group delay based vibrato and tremolo suppression for
+    onset detection"), the fifth member of the sum at signal.py:58-67: the SuperFlux difference (positive difference against
+    the 3-bin frequency maximum of the previous frame) of the filtered spectrogram ``filt`` [frames, bands], weighted per band
+    by the MINIMUM local group delay over the FFT bins the band's filter covers (widened by one bin on each side), after a
+    3-frame temporal maximum filter of the local group delay.  ``spec`` [bins, frames] complex STFT, ``fb`` [bands, bins]."""
+    import scipy.ndimage
+
+    lgd = local_group_delay(spec).T  # [frames, bins]
+    if temporal_filter > 0:
+        lgd = scipy.ndimage.maximum_filter(lgd, size=[temporal_filter, 1])
+    filt = np.asarray(filt, dtype=np.float64)
+    mask = np.zeros_like(filt)
+    n_bins = lgd.shape[1]
+    for b in range(mask.shape[1]):
+        corner = np.nonzero(fb[b])[0]
+        start, stop = max(corner[0] - 1, 0), min(corner[-1] + 2, n_bins)
+        mask[:, b] = lgd[:, start:stop].min(axis=1)
+    prev = np.concatenate([filt[:1], filt[:-1]], axis=0)
+    padded = np.pad(prev, ((0, 0), (1, 1)), mode="edge")
+    prev_max = np.maximum(np.maximum(padded[:, :-2], padded[:, 1:-1]), padded[:, 2:])
+    diff = np.maximum(filt - prev_max, 0.0)
+    diff[0] = 0.0
+    return (diff * mask).sum(axis=1)
+
+
 def madmom_like_onset_strength(y, sr, fmin=20.0, fmax=8000.0, n_fft=2048, hop=441):
-    """Sum of :func:`madmom_like_onset_functions` on the log-filtered magnitude spectrogram (frame 2048, hop 441 = 50 frames
-    per second at 22050 Hz, signal.py:54-57).  Frames are the centred, reflect-padded, periodic-Hann frames of
-    :func:`stft_power` (madmom zero-pads and uses a symmetric window: only the edge frames differ)."""
-    mag = np.sqrt(stft_power(y, n_fft, hop))[: n_fft // 2]  # [bins, frames]
-    filt = (log_filterbank(sr, n_fft, 24, fmin, fmax) @ mag).T
-    return sum(madmom_like_onset_functions(filt).values())
+    """Sum of :func:`madmom_like_onset_functions` and :func:`complex_flux` — all five members of signal.py:58-67 — on the
+    log-filtered magnitude spectrogram (frame 2048, hop 441 = 50 frames per second at 22050 Hz, signal.py:54-57).  Frames are the
+    centred, reflect-padded, periodic-Hann frames of :func:`stft_complex` (madmom zero-pads and uses a symmetric window: only the
+    edge frames differ)."""
+    spec = stft_complex(y, n_fft, hop)[: n_fft // 2]  # [bins, frames]
+    fb = log_filterbank(sr, n_fft, 24, fmin, fmax)
+    filt = (fb @ np.abs(spec)).T
+    return sum(madmom_like_onset_functions(filt).values()) + complex_flux(spec, fb, filt)
 
 
 def onsets(y, sr, n_frames, margin=8, fmin=20, fmax=8000, smooth=1, clip=100, power=1, smf=1.0, type="rosa"):

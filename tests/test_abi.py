@@ -42,11 +42,15 @@ def test_rejects_bad_arguments_without_gpu(built_lib):
     assert lib.maua_torgb_f32(None, None, None, 0, None, None, None, None, 1, 8, 4, 4, 1.0, None) == -22
     assert lib.maua_modconv_ws_floats(1, 512, 512, 4, 4, 0) > 0  # 4x4 layers are split-K
     assert lib.maua_modconv_ws_floats(1, 32, 32, 1024, 1024, 0) == 0
-    # kernel modes of maua_modconv3x3_f32: 0 direct, 1 transposed, 2 / 3 Winograd F(2,3) / F(4,3), 4 transposed + F(2,2)
+    # kernel modes of maua_modconv3x3_f32: 0 direct, 1 transposed, 2 / 3 Winograd F(2,3) / F(4,3), 4 transposed + F(2,2), 5 2-D Winograd
     fake = 0x1000  # never dereferenced: these calls are rejected during validation / planning
     conv = lambda h, w, mode, fuse=0: lib.maua_modconv3x3_f32(fake, fake, fake, 64, None, fake, 1, 64, 64, h, w, mode, 1.0, fuse,  # noqa: E731
                                                               None, 0, None, None, fake, None)
-    assert conv(64, 64, 5) == -22           # unknown mode
+    assert conv(64, 64, 6) == -22           # unknown mode
+    assert conv(64, 48, 5) == -22           # 2-D Winograd (mode 5) needs W % 32 == 0 ...
+    assert conv(12, 64, 5) == -22           # ... and H % 8 == 0
+    assert lib.maua_modconv_w2d_ok(64, 64, 64, 64) == 1 and lib.maua_modconv_w2d_ok(64, 48, 64, 64) == 0
+    assert lib.maua_modconv_w2d_ok(32, 32, 24, 64) == 0 and lib.maua_modconv_w2d_ok(32, 32, 32, 64) == 1  # 32 channels: H % 16
     assert conv(64, 63, 2) == -22           # F(2,3) needs an even width
     assert conv(64, 66, 3) == -22           # F(4,3) needs W % 4 == 0
     assert conv(64, 63, 4) == -22           # mode 4 needs an even width

@@ -332,3 +332,33 @@ def test_latent_helpers_match_reference_golden(golden):
         got = latent.wrapping_slice(torch.arange(int(n)), int(start), int(length), return_indices=True)
         assert got.dtype == torch.int64 and got.tolist() == want.tolist(), (n, start, length)
         assert latent.wrapping_slice(torch.arange(int(n)) * 3, int(start), int(length)).tolist() == (want * 3).tolist()
+
+
+def test_complex_flux_and_local_group_delay():
+    """The fifth madmom onset function of the reference's default onset envelope (signal.py:63).  (a) The oracle's local group
+    delay restates madmom's definition: an impulse d samples after the frame centre has phase -2 pi k d / N against the centre,
+    i.e. |lgd| / pi = 2 d / N in every bin, 0 for d = 0.  (b) The device-side torch implementation (run here on CPU tensors)
+    equals the oracle on a noisy two-tone signal: same wrapped phase differences, band masks, SuperFlux difference."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    n_fft, hop = 256, 64
+    for d in (0, 3, 17):
+        y = np.zeros(4 * n_fft)
+        centre = 5 * hop
+        y[centre + d] = 1.0
+        spec = signal_oracle.stft_complex(y, n_fft, hop)[: n_fft // 2]
+        lgd = signal_oracle.local_group_delay(spec)[:-1, 5]  # frame 5 is centred on sample 5 * hop
+        np.testing.assert_allclose(lgd, 2.0 * d / n_fft, atol=1e-9)
+    rng = np.random.default_rng(3)
+    sr, n_fft, hop = 22050, 2048, 441
+    t = np.arange(2 * sr) / sr
+    y = np.sin(2 * np.pi * 440 * t) * (t > 0.7) + 0.5 * np.sin(2 * np.pi * (900 + 40 * np.sin(2 * np.pi * 6 * t)) * t) + 0.05 * rng.standard_normal(t.size)
+    spec = signal_oracle.stft_complex(y, n_fft, hop)[: n_fft // 2]
+    fb = signal_oracle.log_filterbank(sr, n_fft, 24, 20.0, 8000.0)
+    filt = fb @ np.abs(spec)
+    want = signal_oracle.complex_flux(spec, fb, filt.T)
+    re, im = torch.from_numpy(spec.real.astype(np.float32)), torch.from_numpy(spec.imag.astype(np.float32))
+    got = sig.complex_flux(re, im, fb.astype(np.float32), torch.from_numpy(filt.astype(np.float32))).numpy()
+    assert abs(int(np.argmax(want[2:])) + 2 - round(0.7 * sr / hop)) <= 2  # the tone onset at 0.7 s is the envelope's peak
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * want.max())
+    np.testing.assert_allclose(sig.local_group_delay(re, im).numpy(), signal_oracle.local_group_delay(spec), atol=2e-4)

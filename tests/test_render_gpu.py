@@ -150,6 +150,38 @@ def test_generate_end_to_end_default_plugin(gpu, tmp_path, monkeypatch):
     assert os.path.exists("workspace/last-latents.npy")
 
 
+@pytest.mark.parametrize("size,all2d", [(1024, False), (512, True), (64, False)])
+def test_frame_epilogue_fused_into_last_torgb(gpu, size, all2d):
+    """capture_graph(frames_u8=True): the uint8 NHWC frames written by the last layer's fused ToRGB epilogue (1024^2: F(4,3)
+    kernel; 512^2 with the 2-D Winograd kernel forced; 64^2: 512-channel last layer, not fusable -> maua_frames_to_u8 behind
+    it) equal render.py:40-43 applied to the eager fp32 image, bit for bit; the fp32 image is not produced in the fused case."""
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+
+    keep = ModulatedConv2d.winograd2d_min_cout
+    try:
+        if all2d:
+            ModulatedConv2d.winograd2d_min_cout = 32
+        g = build(size, gpu, 3)
+        b = 2
+        lat = seeding.seeded_latents(b, g.n_latent, seed=8).to(gpu)
+        img, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+        want = render.frames_to_uint8(img)
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            graph, static = g.capture_graph(b, [None] * g.num_layers, frames_u8=True)
+            static["latents"].copy_(lat)
+            static["u8"].fill_(7)
+            graph.replay()
+            stream.synchronize()
+        assert static["u8"].shape == (b, size, size, 3) and static["u8"].dtype == torch.uint8
+        assert torch.equal(static["u8"], want)
+        assert (static["image"] is None) == (size >= 512)  # fused: no fp32 image; fallback: image + conversion kernel
+    finally:
+        ModulatedConv2d.winograd2d_min_cout = keep
+
+
 def _stubs():
     import sys
 

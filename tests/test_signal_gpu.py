@@ -270,6 +270,32 @@ def test_cens_and_nn_filter_vs_oracle(gpu):
             assert close.mean() > 0.999, (ch.shape, close.mean())
 
 
+def test_nn_filter_long_track_path_equals_lds_path(gpu):
+    """Tracks beyond ~16k chroma frames keep the similarity rows in a device workspace and stride the frames over a fixed
+    grid (round 1 returned them unfiltered).  The two paths of the same kernel must agree bit for bit: forced here on a
+    short clip, with fewer workspace rows than frames so that workgroups really walk several frames."""
+    from maua_stylegan2_amd import _lib
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    rng = np.random.default_rng(14)
+    ch = np.abs(rng.standard_normal((12, 700))).astype(np.float32)
+    lds_path = sig.nn_filter(torch.from_numpy(ch)).cpu().numpy()
+    lib = _lib.load()
+    try:
+        lib.maua_tuning_set(4, 37)  # workspace path with 37 rows: 19 frames per workgroup
+        assert lib.maua_nn_median_ws_doubles(12, 700, 54) == 37 * 700
+        ws_path = sig.nn_filter(torch.from_numpy(ch)).cpu().numpy()
+    finally:
+        lib.maua_tuning_set(4, 0)
+    np.testing.assert_array_equal(ws_path, lds_path)
+    # and a genuinely long sequence runs (20k frames: 160 KB of similarities per frame) and stays a median of its inputs
+    long = np.abs(rng.standard_normal((12, 20000))).astype(np.float32)
+    assert lib.maua_nn_median_ws_doubles(12, 20000, 284) == 1024 * 20000
+    out = sig.nn_filter(torch.from_numpy(long)).cpu().numpy()
+    assert out.shape == long.shape and np.isfinite(out).all() and out.min() >= long.min() and out.max() <= long.max()
+    assert 0.3 < float(np.median(out)) < 1.0  # medians of |N(0,1)| samples sit near 0.67
+
+
 def test_constant_q_transform_vs_oracle(gpu):
     """Direct constant-Q magnitude (252 bins from C1, hop 512) and the chroma fold against the oracle, on the synthetic
     track, on a pure tone (peak bin / pitch class known in closed form) and on a clip shorter than the longest filter."""
