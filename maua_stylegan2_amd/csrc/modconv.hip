@@ -650,10 +650,10 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             __syncthreads();
             for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
                 if (chunk + 1 < chunk_end) {
-                    issue_dma(chunk + 1, cur ^ 1);
-                    issue_patch(chunk + 1, cur ^ 1);
+                    if (!(g.debug & 32)) issue_dma(chunk + 1, cur ^ 1);
+                    if (!(g.debug & 64)) issue_patch(chunk + 1, cur ^ 1);
                 }
-                mfma_chunk(As + cur * A_FLOATS, Ps + cur * PBUF, Ss + (chunk - chunk_begin) * CC);
+                if (!(g.debug & 2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * PBUF, Ss + (chunk - chunk_begin) * CC);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 cur ^= 1;

@@ -102,6 +102,43 @@ def test_render_matches_reference_render_loop(gpu, tmp_path, monkeypatch, golden
         assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (tag, int(diff.max()), float((diff > 0).mean()))
 
 
+def test_render_pipes_rawvideo_to_an_ffmpeg_process(gpu, tmp_path, monkeypatch):
+    """The encoder branch of the frame sink (reference render.py:58-113: rawvideo rgb24 on the stdin of an ``ffmpeg`` child
+    process, libx264 / yuv420p / preset, audio mux arguments).  No ffmpeg binary exists in this image, so a stand-in
+    executable named ``ffmpeg`` is put on PATH: it records its argument vector and copies stdin to the output path.  Checked:
+    the arguments the reference passes, every frame's bytes in order, the child is waited for."""
+    import json
+    import stat
+
+    from maua_stylegan2_amd import render
+
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    fake = bindir / "ffmpeg"
+    fake.write_text("#!/usr/bin/env python3\nimport json, sys\nargs = sys.argv[1:]\nout = args[-1]\n"
+                    "json.dump(args, open(out + '.args.json', 'w'))\n"
+                    "data = sys.stdin.buffer.read()\nopen(out, 'wb').write(data)\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{bindir}:{os.environ['PATH']}")
+    g = build(512, gpu, 1)
+    n = 5
+    lat = seeding.seeded_latents(n, g.n_latent, seed=2)
+    out = str(tmp_path / "clip.mp4")
+    written = render.render(generator=g, latents=lat, noise=[None] * g.num_layers, offset=1.5, duration=n / 24, batch_size=2,
+                            out_size=512, output_file=out, audio_file="song.wav", ffmpeg_preset="veryfast")
+    assert written == n
+    args = json.load(open(out + ".args.json"))
+    joined = " ".join(args)
+    for expect in ("-f rawvideo", "-pix_fmt rgb24", "-s 512x512", "-i pipe:", f"-framerate {n / (n / 24)}", "-ss 1.5", f"-t {n / 24}",
+                   "-i song.wav", "-vcodec libx264", "-pix_fmt yuv420p", "-preset veryfast", "-b:a 320K", "-ac 2"):
+        assert expect in joined, (expect, joined)
+    raw = np.fromfile(out, dtype=np.uint8).reshape(n, 512, 512, 3)
+    for i in (0, n - 1):
+        img, _ = g(styles=lat[i: i + 1].to(gpu), noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+        diff = np.abs(raw[i].astype(np.int16) - render.frames_to_uint8(img).cpu().numpy()[0].astype(np.int16))
+        assert diff.max() <= 1
+
+
 def test_render_writes_ordered_frames(gpu, tmp_path, monkeypatch):
     from maua_stylegan2_amd import render
 

@@ -11,10 +11,10 @@ import subprocess
 import sys
 
 O = "gpurun_out/prof_final"
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
-def table(db, keep=("modconv_mfma", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel", "reduce_tail")):
+def table(db, keep=("modconv_mfma", "modconv_w2d", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel", "reduce_tail")):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
                        "group by kernel_name, counter_name").fetchall()
@@ -105,7 +105,9 @@ MULTI, FAST, MAXP>.
     open(f"/tmp/{TAG}_pmc_traffic_table.md", "w").write("\n".join(tr) + "\n")
     # machine-readable twin, read by bench.py for roofline.traffic (no literals in bench.py): bytes per dispatch, averaged over
     # the dispatches of an instance in `bench.py --steps 2 --warmup 1 --lanes 1 --no-breakdown` (3 steps + 2 capture passes)
-    steps_in_run = 2 + 1 + 2  # timed + warm-up + (warm-up forward, captured forward) of the single lane
+    # forwards executed in that run = dispatches of a once-per-forward kernel (eager warm-up of the capture + every replay of the
+    # timed, warm-up and PCIe-inclusive regions)
+    steps_in_run = int(next(t["n"] for n, t in fe.items() if n.startswith("style_affine_kernel")))
     kernels = {}
     for n, t in fe.items():
         w = wr.get(n, {})
