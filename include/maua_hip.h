@@ -138,6 +138,14 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
                               const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,
                               uint8_t* frames_u8, void* stream);
 
+/* StyleGAN1 (`--stylegan1`, models/stylegan1.py:258-318 LayerEpilogue) — conv bias, per-channel-weighted noise, LeakyReLU(0.2),
+ * instance norm (biased variance, eps 1e-5) and the style modulation in one launch:
+ *   y[b,c] = norm( lrelu_0.2( x[b,c] + bias[c] + noise_w[c] * noise[b or 0] ) ) * (style[b, c] + 1) + style[b, C + c]
+ * bias / noise / style may be NULL (skipped); instance_norm = 0 skips the normalisation; y == x is allowed. */
+int maua_sg1_epilogue_f32(const float* x, const float* bias, const float* noise, int64_t noise_batch_stride,
+                          const float* noise_w, const float* style, int style_stride, float* y, int batch, int channels,
+                          int h, int w, int instance_norm, void* stream);
+
 /* ToRGB (models/stylegan2.py:356-365): 1x1 modulated conv without demod + bias + 2x FIR-upsampled skip
  * (Upsample :34-52, kernel k4 = 4x4 taps in device memory, pad (2,1)).  skip == NULL: no skip.
  *   y[b,c,Y,X] = sum_i (wscale * w[c,i] * s[b,i]) * x[b,i,Y,X] + bias[c] + up2(skip)[b,c,Y,X] */

@@ -86,9 +86,13 @@ def get_noise_range(out_size, generator_resolution, is_stylegan1):
 def load_generator(ckpt, is_stylegan1, G_res, out_size, noconst, latent_dim, n_mlp, channel_multiplier, dataparallel,
                    base_res_factor):
     """Reference :37-56.  Only rank 0 reads the checkpoint; the other ranks receive the weights over RCCL."""
-    if is_stylegan1:
-        raise NotImplementedError("--stylegan1: only the StyleGAN2 generator is built (SURVEY.md §2 row 13)")
     rank, _ = sharding.rank_world()
+    if is_stylegan1:
+        from .models.stylegan1 import G_style
+
+        generator = G_style(output_size=out_size, checkpoint=ckpt if rank == 0 else None).cuda()
+        generator.truncation_latent = sharding.broadcast_tensor(generator.truncation_latent.cuda().contiguous())
+        return sharding.broadcast_module(generator).eval()
     generator = Generator(G_res, latent_dim, n_mlp, channel_multiplier=channel_multiplier, constant_input=not noconst,
                           checkpoint=ckpt if rank == 0 else None, output_size=out_size,
                           base_res_factor=base_res_factor).cuda()
@@ -218,10 +222,10 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
     generator = load_generator(ckpt=ckpt, is_stylegan1=stylegan1, G_res=G_res, out_size=out_size, noconst=noconst,
                                latent_dim=latent_dim, n_mlp=n_mlp, channel_multiplier=channel_multiplier,
                                dataparallel=dataparallel, base_res_factor=base_res_factor)
-    if world > 1 and not (isinstance(truncation, float) and truncation == 1.0):
+    if world > 1 and not stylegan1 and not (isinstance(truncation, float) and truncation == 1.0):
         # the truncation centre is a random draw (mean_latent(2**14), reference models/stylegan2.py:539-540): one draw, on rank
         # 0, for every shard — otherwise neighbouring shards are truncated toward slightly different centres
-        centre = generator.mean_latent(2 ** 14) if rank == 0 else th.empty(1, latent_dim, device=generator.input.input.device)
+        centre = generator.mean_latent(2 ** 14) if rank == 0 else th.empty(1, latent_dim, device=render.device_of(generator))
         generator.truncation_latent = sharding.broadcast_tensor(centre.contiguous())
     print(f"\npreprocessing took {time.time() - started:.2f}s\n")
 

@@ -27,6 +27,12 @@ from . import _lib, sharding
 th.set_grad_enabled(False)
 
 
+def device_of(generator):
+    """Device a generator lives on (StyleGAN2 mirror: its constant / latent input; StyleGAN1's G_style: any parameter)."""
+    inp = getattr(getattr(generator, "input", None), "input", None)
+    return inp.device if inp is not None else next(generator.parameters()).device
+
+
 def _output_dims(out_size):
     if out_size == 512:
         return 512, 512
@@ -118,7 +124,7 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
     hipGraph path: ``lanes`` graphs of ``batch_size`` frames (same weights, private activations) are replayed round-robin
     on their own streams, so consecutive batches overlap on the device — the small, latency-bound 4^2..32^2 layers and
     the last partial wave of every big launch of one batch run underneath the other batch's MFMA-bound layers."""
-    dev = generator.input.input.device
+    dev = device_of(generator)
     n_total = len(latents)
     lo, hi = frame_range if frame_range is not None else (0, n_total)
     latents = latents.to(dev, th.float32).contiguous()  # resident in HBM for the whole render
@@ -249,7 +255,7 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
     else:
         lo, hi, n_frames = _shard
         frame_range = (0, hi - lo)
-    dev = generator.input.input.device
+    dev = device_of(generator)
     sink = None
     if rank == 0:
         sink = FrameSink(output_file, width, height, n_frames / duration, audio_file, offset, duration, ffmpeg_preset)

@@ -538,6 +538,80 @@ def latent_utils_fixture(ref_latent, ref_signal):
     np.savez_compressed(os.path.join(HERE, "latent_utils.npz"), **out)
 
 
+def stylegan1_fixture(seeding):
+    """StyleGAN1 (`--stylegan1`, models/stylegan1.py): (a) a seeded narrow G_synthesis(resolution=256, fmap_base=512, fmap_max=64)
+    — 64..4 channels, so the CPU forward takes seconds; the 128 / 256 px blocks take the reference's fused conv_transpose2d
+    branch (:83-93), the others nearest upscale + conv — with per-block noise and 14 style rows; (b) G_mapping on seeded z;
+    (c) the constructor bookkeeping of G_style for a 128-px checkpoint and 1920 output (constant widened to 8 columns, one noise
+    buffer per block, state-dict keys).  Stored: reference outputs, shapes, the key list."""
+    import json
+    import tempfile
+
+    import models.stylegan1 as ref_sg1  # noqa  (/root/reference)
+    from oracle import stylegan1_oracle as s1o
+
+    print("StyleGAN1: G_synthesis / G_mapping / G_style bookkeeping")
+    out = {}
+    torch.manual_seed(0)
+    gs = ref_sg1.G_synthesis(resolution=256, fmap_base=512, fmap_max=64)
+    sd = {}
+    for key, v in gs.state_dict().items():
+        if key.endswith("intermediate.kernel"):
+            sd[key] = v.clone()
+        elif key.endswith("noise.weight"):
+            sd[key] = torch.from_numpy(seeding.seeded_array(31, key, tuple(v.shape), std=0.3))
+        elif key.endswith(".bias"):
+            sd[key] = torch.from_numpy(seeding.seeded_array(31, key, tuple(v.shape), std=0.2))
+        else:
+            sd[key] = torch.from_numpy(seeding.seeded_array(31, key, tuple(v.shape)))
+    gs.load_state_dict(sd, strict=True)
+    gs.eval()
+    n_blocks = len(gs.blocks)
+    dl = torch.from_numpy(seeding.seeded_array(32, "dlatents", (2, 2 * n_blocks, 512)))
+    noise = [torch.from_numpy(seeding.seeded_array(33, f"noise_{i}", (2 if i % 2 else 1, 1, 4 * 2 ** i, 4 * 2 ** i))) for i in range(n_blocks)]
+    x = None
+    for i, blk in enumerate(gs.blocks.values()):  # G_style.forward's loop (:600-605): one noise tensor per block
+        x = blk(dl[:, 2 * i: 2 * i + 2], noise=noise[i]) if i == 0 else blk(x, dl[:, 2 * i: 2 * i + 2], noise=noise[i])
+    img_ref = gs.torgb(x)
+    img_mine = s1o.synthesis(sd, dl, noise, prefix="")
+    check("stylegan1 G_synthesis(256, narrow)", img_mine, img_ref, tol=2e-4)
+    out["synth.image"] = img_ref.numpy()
+    out["synth.seeds"] = np.array([31, 32, 33], dtype=np.int64)
+    out["synth.keys"] = np.array(list(sd.keys()))
+    out["synth.shapes"] = np.array([";".join(str(d) for d in v.shape) for v in sd.values()])
+    # (b) mapping network
+    gm = ref_sg1.G_mapping()
+    msd = {k: torch.from_numpy(seeding.seeded_array(34, k, tuple(v.shape), std=0.2 if k.endswith("bias") else 1.0))
+           for k, v in gm.state_dict().items()}
+    gm.load_state_dict(msd, strict=True)
+    z = torch.from_numpy(seeding.seeded_array(35, "z", (3, 512)))
+    w_ref = gm(z)
+    check("stylegan1 G_mapping", s1o.mapping({f"g_mapping.{k}": v for k, v in msd.items()}, z), w_ref, tol=1e-5)
+    out["mapping.w"] = w_ref[:, 0].numpy()
+    tl = torch.from_numpy(seeding.seeded_array(36, "tl", (1, 18, 512)))
+    st = torch.from_numpy(seeding.seeded_array(36, "styles", (2, 18, 512)))
+    interp = torch.lerp(tl, st, 0.7)
+    out["trunc.y"] = torch.where((torch.arange(18) < 8).view(1, -1, 1), interp, st).numpy()[:, ::3, ::64]
+    check("stylegan1 truncation", s1o.truncate(st, tl, 0.7), torch.where((torch.arange(18) < 8).view(1, -1, 1), interp, st), tol=0)
+    # (c) G_style constructor bookkeeping: 128-px checkpoint, 1920 output
+    tmp = tempfile.mkdtemp(prefix="maua_sg1_")
+    small = ref_sg1.G_style.__new__(ref_sg1.G_style)
+    torch.nn.Sequential.__init__(small)
+    small.g_mapping = ref_sg1.G_mapping()
+    small.g_synthesis = ref_sg1.G_synthesis(resolution=128)
+    ckpt = os.path.join(tmp, "sg1_128.pt")
+    torch.save(small.state_dict(), ckpt)
+    del small
+    g = ref_sg1.G_style(output_size=1920, checkpoint=ckpt)
+    meta = {"const": list(getattr(g.g_synthesis.blocks, "4x4").const.shape), "blocks": list(g.g_synthesis.blocks.keys()),
+            "noise": [list(getattr(g, f"noise_{i}").shape) for i in range(len(g.g_synthesis.blocks))],
+            "truncation_latent": list(g.truncation_latent.shape), "keys": list(g.state_dict().keys())}
+    with open(os.path.join(HERE, "stylegan1_meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("  G_style(1920, 128-px checkpoint): const", meta["const"], "noise", meta["noise"][0], "...", meta["noise"][-1])
+    np.savez_compressed(os.path.join(HERE, "stylegan1.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the 256^2 / 1024^2 generators (minutes on CPU)")
@@ -549,6 +623,7 @@ def main():
     ap.add_argument("--only-signatures", action="store_true", help="(re)generate signatures.json only")
     ap.add_argument("--only-variants", action="store_true", help="(re)generate generator_variants.npz only")
     ap.add_argument("--only-latent-utils", action="store_true", help="(re)generate latent_utils.npz only")
+    ap.add_argument("--only-stylegan1", action="store_true", help="(re)generate stylegan1.npz / stylegan1_meta.json only")
     ap.add_argument("--only-plugin", action="store_true", help="(re)generate default_plugin.npz / generate_e2e.npz only")
     args = ap.parse_args()
 
@@ -579,6 +654,9 @@ def main():
         return
     if args.only_latent_utils:
         latent_utils_fixture(ref_latent, ref_signal)
+        return
+    if args.only_stylegan1:
+        stylegan1_fixture(seeding)
         return
     if args.only_plugin:
         plugin_fixtures(ref_sg2, ref_gav, seeding)
@@ -847,6 +925,9 @@ def main():
 
     # ------------------------------------------------------------------ (12b) latent sequencing helpers
     latent_utils_fixture(ref_latent, ref_signal)
+
+    # ------------------------------------------------------------------ (12c) StyleGAN1
+    stylegan1_fixture(seeding)
 
     # ------------------------------------------------------------------ (13) default plugin + generate() end to end
     plugin_fixtures(ref_sg2, ref_gav, seeding)

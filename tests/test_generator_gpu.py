@@ -227,3 +227,45 @@ def test_generator_variants_match_reference_golden(gpu, golden):
             graph.replay()
             stream.synchronize()
             assert torch.equal(static["image"], img), key
+
+
+def test_stylegan1_synthesis_matches_reference_golden(gpu, golden):
+    """`--stylegan1`: the mirror's G_synthesis on the HIP path (shared-weight MFMA convs, upfirdn2d upscale / blur, fused epilogue)
+    against the image of the reference's G_synthesis class (stylegan1.npz: seeded narrow 256-px network, per-block noise with
+    batch 1 and 2, fused-upscale branch at 128 / 256 px), then G_style's wrapper logic (default noise buffers, truncation on the
+    first 8 layers, (image, None) return) against the oracle."""
+    from maua_stylegan2_amd.models import stylegan1 as sg1
+    from oracle import stylegan1_oracle as s1o
+    from test_oracle_golden import _sg1_state_dict
+
+    fx = golden("stylegan1.npz")
+    sd = _sg1_state_dict(fx)
+    s_w, s_l, s_n = (int(v) for v in fx["synth.seeds"])
+    gs = sg1.G_synthesis(resolution=256, fmap_base=512, fmap_max=64)
+    gs.load_state_dict(sd, strict=True)
+    gs = gs.to(gpu).eval()
+    n_blocks = len(gs.blocks)
+    dl = torch.from_numpy(seeding.seeded_array(s_l, "dlatents", (2, 2 * n_blocks, 512)))
+    noise = [torch.from_numpy(seeding.seeded_array(s_n, f"noise_{i}", (2 if i % 2 else 1, 1, 4 * 2 ** i, 4 * 2 ** i))) for i in range(n_blocks)]
+    img = gs(dl.to(gpu), [n.to(gpu) for n in noise])
+    err = float((img.cpu() - torch.from_numpy(fx["synth.image"])).abs().max())
+    assert img.shape == (2, 3, 256, 256) and err < TOL, err
+    # G_style wrapper around the same synthesis network
+    g = sg1.G_style.__new__(sg1.G_style)
+    torch.nn.Sequential.__init__(g)
+    g.g_mapping = sg1.G_mapping()
+    g.g_synthesis = gs
+    for i, nz in enumerate(noise):
+        g.register_buffer(f"noise_{i}", nz[:1].clone())
+    g.truncation_latent = torch.from_numpy(seeding.seeded_array(36, "tl", (1, 18, 512)))
+    g = g.to(gpu)
+    styles = torch.from_numpy(seeding.seeded_array(37, "styles", (2, 18, 512)))
+    out, none = g(styles=styles.to(gpu), noise=[None] * n_blocks, truncation=0.7, transform_dict_list=[], randomize_noise=False,
+                  input_is_latent=True)
+    assert none is None
+    want = s1o.synthesis(sd, s1o.truncate(styles, g.truncation_latent.cpu(), 0.7), [n[:1] for n in noise], prefix="")
+    assert float((out.cpu() - want).abs().max()) < TOL
+    wrong = [None] * n_blocks
+    wrong[2] = torch.zeros(1, 1, 8, 8, device=gpu)
+    with pytest.raises(RuntimeError, match="noise"):
+        g(styles=styles.to(gpu), noise=wrong)

@@ -435,3 +435,78 @@ def test_plugin_stand_ins_are_deterministic():
     r2(3, 3)  # an unrelated draw in between changes nothing
     assert torch.equal(a, r2((4, 1, 8, 8))) and not torch.equal(a, r1(4, 1, 8, 8))
     assert lo.std() > 0.05 and hi.std() > 0.05  # peaky envelopes, not constants
+
+
+def _sg1_state_dict(fx):
+    """The seeded narrow G_synthesis weights of tests/golden/stylegan1.npz, regenerated from (key, shape) + the seeding rules of
+    make_golden.stylegan1_fixture."""
+    from maua_stylegan2_amd import seeding
+
+    seed = int(fx["synth.seeds"][0])
+    sd = {}
+    for key, shape in zip(fx["synth.keys"], fx["synth.shapes"]):
+        key, shape = str(key), tuple(int(v) for v in str(shape).split(";"))
+        if key.endswith("intermediate.kernel"):
+            k = np.outer([1.0, 2.0, 1.0], [1.0, 2.0, 1.0]).astype(np.float32) / 16.0
+            sd[key] = torch.from_numpy(k[None, None])
+        elif key.endswith("noise.weight"):
+            sd[key] = torch.from_numpy(seeding.seeded_array(seed, key, shape, std=0.3))
+        elif key.endswith(".bias"):
+            sd[key] = torch.from_numpy(seeding.seeded_array(seed, key, shape, std=0.2))
+        else:
+            sd[key] = torch.from_numpy(seeding.seeded_array(seed, key, shape))
+    return sd
+
+
+def test_stylegan1_oracle_matches_reference_golden(golden):
+    """oracle/stylegan1_oracle.py against outputs of the reference's G_synthesis / G_mapping classes (stylegan1.npz), and the
+    identity the device path is built on: the reference's fused conv_transpose2d upscale (>= 128 px, models/stylegan1.py:83-93)
+    is nearest-neighbour upscaling followed by the SAME 3x3 kernel flipped."""
+    from maua_stylegan2_amd import seeding
+    from oracle import stylegan1_oracle as s1o
+
+    fx = golden("stylegan1.npz")
+    sd = _sg1_state_dict(fx)
+    s_w, s_l, s_n = (int(v) for v in fx["synth.seeds"])
+    n_blocks = 7
+    dl = torch.from_numpy(seeding.seeded_array(s_l, "dlatents", (2, 2 * n_blocks, 512)))
+    noise = [torch.from_numpy(seeding.seeded_array(s_n, f"noise_{i}", (2 if i % 2 else 1, 1, 4 * 2 ** i, 4 * 2 ** i))) for i in range(n_blocks)]
+    np.testing.assert_allclose(s1o.synthesis(sd, dl, noise, prefix="").numpy(), fx["synth.image"], atol=2e-4)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((2, 5, 64, 72)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal((7, 5, 3, 3)).astype(np.float32))
+    fused = s1o.conv_layer(x, w, None, upscale=True)  # 64 * 2 >= 128: the conv_transpose2d branch
+    w_mul = np.sqrt(2) * (5 * 9) ** -0.5
+    plain = torch.nn.functional.conv2d(s1o.upscale2d(x), w.flip(-1, -2) * w_mul, padding=1)
+    np.testing.assert_allclose(fused.numpy(), plain.numpy(), atol=2e-5)
+
+
+def test_stylegan1_mirror_has_the_reference_module_tree(built_lib):
+    """Key list and shapes of the mirror's G_synthesis (narrow variant of the fixture) and the constructor bookkeeping of G_style
+    for a 128-px checkpoint and 1920-wide output (stylegan1_meta.json, read from the reference's own G_style): constant widened
+    32 -> 36 columns, one noise buffer per block doubling in size, state-dict keys."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from maua_stylegan2_amd.models import stylegan1 as sg1
+
+    fx = np.load(os.path.join(GOLDEN, "stylegan1.npz"))
+    gs = sg1.G_synthesis(resolution=256, fmap_base=512, fmap_max=64)
+    got = {k: ";".join(str(d) for d in v.shape) for k, v in gs.state_dict().items()}
+    assert list(got) == [str(k) for k in fx["synth.keys"]] and list(got.values()) == [str(v) for v in fx["synth.shapes"]]
+    gs.load_state_dict(_sg1_state_dict(fx), strict=True)
+    meta = json.load(open(os.path.join(GOLDEN, "stylegan1_meta.json")))
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="maua_sg1_")
+    small = sg1.G_style.__new__(sg1.G_style)
+    torch.nn.Sequential.__init__(small)
+    small.g_mapping = sg1.G_mapping()
+    small.g_synthesis = sg1.G_synthesis(resolution=128)
+    torch.save(small.state_dict(), os.path.join(tmp, "sg1_128.pt"))
+    g = sg1.G_style(output_size=1920, checkpoint=os.path.join(tmp, "sg1_128.pt"))
+    assert list(getattr(g.g_synthesis.blocks, "4x4").const.shape) == meta["const"]
+    assert list(g.g_synthesis.blocks.keys()) == meta["blocks"]
+    assert [list(getattr(g, f"noise_{i}").shape) for i in range(len(meta["noise"]))] == meta["noise"]
+    assert list(g.truncation_latent.shape) == meta["truncation_latent"] and list(g.state_dict().keys()) == meta["keys"]
