@@ -36,11 +36,23 @@ int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int 
                        int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                        int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* The same op for half / double tensors — the reference dispatches half, float and double (upfirdn2d_kernel.cu:313-359,
+ * fused_bias_act_kernel.cu:79).  Generic kernels (fp32 accumulation for half); the fp32 entries above are the tuned path. */
+int maua_upfirdn2d_f16(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x,
+                       int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+int maua_upfirdn2d_f64(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x,
+                       int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
 /* Replaces pybind `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)` —
  * op/fused_bias_act.cpp:11-20, op/fused_bias_act_kernel.cu:18-98.  b == NULL or size_b == 0: no bias;
  * ref == NULL: no reference tensor.  bias index = (i / step_b) % size_b. In-place (y == x) is allowed. */
 int maua_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y, int64_t size_x,
                             int size_b, int step_b, int act, int grad, float alpha, float scale, void* stream);
+
+int maua_fused_bias_act_f16(const void* x, const void* b, const void* ref, void* y, int64_t size_x, int size_b, int step_b,
+                            int act, int grad, float alpha, float scale, void* stream);
+int maua_fused_bias_act_f64(const void* x, const void* b, const void* ref, void* y, int64_t size_x, int size_b, int step_b,
+                            int act, int grad, float alpha, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ generator layers
  * Fused Blur -> NoiseInjection -> FusedLeakyReLU tail of an up-sampling StyledConv

@@ -42,6 +42,10 @@ _SIGNATURES = {
     "maua_tuning_set": (c_int, [c_int, c_int]),
     "maua_upfirdn2d_f32": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
     "maua_fused_bias_act_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "maua_fused_bias_act_f16": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "maua_fused_bias_act_f64": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "maua_upfirdn2d_f16": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
+    "maua_upfirdn2d_f64": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
     "maua_blur_noise_act_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, c_int64, _P, _P, _P]),
     "maua_style_affine_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P]),
     "maua_demod_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, _P]),
@@ -127,6 +131,18 @@ def ptr(t):
     if t is None:
         return None
     return t.data_ptr()
+
+
+def require_cuda_any(t, name):
+    """The two native ops accept half / float / double like the reference's dtype dispatch; everything else is fp32."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (HIP) tensor")  # mirrors CHECK_CUDA, op/upfirdn2d.cpp:7
+    if t.dtype not in (torch.float16, torch.float32, torch.float64):
+        raise RuntimeError(f"{name} must be float16, float32 or float64 (got {t.dtype})")
+    return t.contiguous()
+
+
+DTYPE_SUFFIX = {torch.float16: "f16", torch.float32: "f32", torch.float64: "f64"}
 
 
 def require_cuda(t, name):

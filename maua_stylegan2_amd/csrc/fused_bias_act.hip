@@ -7,6 +7,8 @@
 // <= 8 workgroups per CU.
 #include "common.h"
 
+#include <hip/hip_fp16.h>
+
 namespace {
 
 __device__ __forceinline__ float act_apply(float v, float r, int code, float alpha) {
@@ -54,7 +56,53 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* x, const flo
     }
 }
 
+// half / double instantiations of the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (op/fused_bias_act_kernel.cu:79):
+// arithmetic in the tensor's own type for double, in fp32 for half (the reference's scalar_t arithmetic on __half also
+// rounds through float on the device); scalar path only — these dtypes are off the fp32 hot path.
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void bias_act_typed_kernel(const T* x, const T* __restrict__ b, const T* __restrict__ ref, T* y,
+                                                             int64_t n, int size_b, int step_b, int code, A alpha, A scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        A v = (A)x[i];
+        if (b) v += (A)b[(i / step_b) % size_b];
+        const A r = ref ? (A)ref[i] : (A)0;
+        A out;
+        switch (code) {
+            case 12:
+            case 32: out = (A)0; break;
+            case 30: out = v > (A)0 ? v : v * alpha; break;
+            case 31: out = r > (A)0 ? v : v * alpha; break;
+            default: out = v; break;
+        }
+        y[i] = (T)(out * scale);
+    }
+}
+
+template <typename T, typename A>
+int launch_bias_act_typed(const void* x, const void* b, const void* ref, void* y, int64_t size_x, int size_b, int step_b, int act,
+                          int grad, float alpha, float scale, void* stream) {
+    if (size_x < 0 || (size_x > 0 && (!x || !y)) || step_b <= 0) return MAUA_EINVAL;
+    if (size_x == 0) return 0;
+    if (size_b <= 0) b = nullptr;
+    if (!b) size_b = 1;
+    const int64_t blocks = ceil_div64(size_x, 256);
+    hipLaunchKernelGGL((bias_act_typed_kernel<T, A>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)x, (const T*)b, (const T*)ref, (T*)y, size_x, size_b, step_b, act * 10 + grad, (A)alpha, (A)scale);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int maua_fused_bias_act_f16(const void* x, const void* b, const void* ref, void* y, int64_t size_x, int size_b, int step_b,
+                                       int act, int grad, float alpha, float scale, void* stream) {
+    return launch_bias_act_typed<__half, float>(x, b, ref, y, size_x, size_b, step_b, act, grad, alpha, scale, stream);
+}
+
+extern "C" int maua_fused_bias_act_f64(const void* x, const void* b, const void* ref, void* y, int64_t size_x, int size_b, int step_b,
+                                       int act, int grad, float alpha, float scale, void* stream) {
+    return launch_bias_act_typed<double, double>(x, b, ref, y, size_x, size_b, step_b, act, grad, alpha, scale, stream);
+}
 
 extern "C" int maua_fused_bias_act_f32(const float* x, const float* b, const float* ref, float* y, int64_t size_x,
                                        int size_b, int step_b, int act, int grad, float alpha, float scale,

@@ -22,6 +22,8 @@
 //  * fir_generic_kernel: any up/down/pad/minor, one thread per output, polyphase tap skipping.
 #include "common.h"
 
+#include <hip/hip_fp16.h>
+
 namespace {
 
 struct FirTail {
@@ -632,6 +634,57 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restric
     }
 }
 
+// half / double instantiations of the reference's dtype dispatch (op/upfirdn2d_kernel.cu:313-359): the generic gather in the
+// tensor's type (double) or with fp32 accumulation (half); taps come in the tensor's dtype like the reference's `kernel`.
+template <typename T, typename A>
+__global__ __launch_bounds__(256) void fir_generic_typed_kernel(const T* __restrict__ x, const T* __restrict__ k, T* __restrict__ y,
+                                                                int in_h, int in_w, int minor, int kh, int kw, int up_x, int up_y,
+                                                                int down_x, int down_y, int pad_x0, int pad_y0, int out_h,
+                                                                int out_w, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t rest = idx;
+        const int mi = (int)(rest % minor);
+        rest /= minor;
+        const int ox = (int)(rest % out_w);
+        rest /= out_w;
+        const int oy = (int)(rest % out_h);
+        const int64_t m = rest / out_h;
+        A acc = (A)0;
+        for (int i = 0; i < kh; ++i) {
+            const int cy = oy * down_y + i - pad_y0;
+            if (cy < 0 || cy % up_y) continue;
+            const int iy = cy / up_y;
+            if (iy >= in_h) continue;
+            for (int j = 0; j < kw; ++j) {
+                const int cx = ox * down_x + j - pad_x0;
+                if (cx < 0 || cx % up_x) continue;
+                const int ix = cx / up_x;
+                if (ix >= in_w) continue;
+                acc += (A)k[(kh - 1 - i) * kw + (kw - 1 - j)] * (A)x[((m * in_h + iy) * in_w + ix) * minor + mi];
+            }
+        }
+        y[idx] = (T)acc;
+    }
+}
+
+template <typename T, typename A>
+int launch_fir_typed(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor, int kh, int kw, int up_x,
+                     int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    if (!x || !k || !y || major <= 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kh <= 0 || kw <= 0 || up_x <= 0 || up_y <= 0 ||
+        down_x <= 0 || down_y <= 0)
+        return MAUA_EINVAL;
+    const int num_h = in_h * up_y + pad_y0 + pad_y1 - kh, num_w = in_w * up_x + pad_x0 + pad_x1 - kw;
+    if (num_h < 0 || num_w < 0) return MAUA_EINVAL;
+    const int out_h = num_h / down_y + 1, out_w = num_w / down_x + 1;
+    const int64_t total = (int64_t)major * out_h * out_w * minor;
+    const int64_t blocks = ceil_div64(total, 256);
+    hipLaunchKernelGGL((fir_generic_typed_kernel<T, A>), dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)x, (const T*)k, (T*)y, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
+                       pad_x0, pad_y0, out_h, out_w, total);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int KH, int KW, bool TAIL>
 int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
                     int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
@@ -754,4 +807,18 @@ extern "C" int maua_blur_noise_act_f32(const float* x, const float* k, float* y,
     FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels};
     return dispatch_fir_tile<true>(x, k, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, pad0, pad0, tail,
                                    (hipStream_t)stream);
+}
+
+extern "C" int maua_upfirdn2d_f16(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor, int kh, int kw,
+                                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                  void* stream) {
+    return launch_fir_typed<__half, float>(x, k, y, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                           pad_y0, pad_y1, stream);
+}
+
+extern "C" int maua_upfirdn2d_f64(const void* x, const void* k, void* y, int major, int in_h, int in_w, int minor, int kh, int kw,
+                                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                  void* stream) {
+    return launch_fir_typed<double, double>(x, k, y, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                            pad_y0, pad_y1, stream);
 }

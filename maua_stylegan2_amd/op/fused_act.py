@@ -13,9 +13,10 @@ from .. import _lib
 def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     """Native-op boundary: returns a fresh tensor shaped like ``input``."""
     lib = _lib.load()
-    x = _lib.require_cuda(input, "input")
-    b = _lib.require_cuda(bias, "bias") if bias is not None and bias.numel() else None
-    r = _lib.require_cuda(refer, "refer") if refer is not None and refer.numel() else None
+    x = _lib.require_cuda_any(input, "input")  # half / float / double, as the reference dispatches (fused_bias_act_kernel.cu:79)
+    b = _lib.require_cuda_any(bias, "bias").to(x.dtype) if bias is not None and bias.numel() else None
+    r = _lib.require_cuda_any(refer, "refer").to(x.dtype) if refer is not None and refer.numel() else None
+    fn = "maua_fused_bias_act_" + _lib.DTYPE_SUFFIX[x.dtype]
     if r is not None and r.numel() != x.numel():
         raise RuntimeError("refer must have as many elements as input")
     step_b = 1
@@ -24,11 +25,11 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     y = torch.empty_like(x)
     if x.numel():
         with torch.cuda.device(x.device):
-            rc = lib.maua_fused_bias_act_f32(
+            rc = getattr(lib, fn)(
                 x.data_ptr(), _lib.ptr(b), _lib.ptr(r), y.data_ptr(), x.numel(), b.numel() if b is not None else 0,
                 max(step_b, 1), int(act), int(grad), float(alpha), float(scale), _lib.stream_ptr(x.device),
             )
-        _lib.check(rc, "maua_fused_bias_act_f32")
+        _lib.check(rc, fn)
     return y
 
 

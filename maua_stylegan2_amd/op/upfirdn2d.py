@@ -13,8 +13,9 @@ from .. import _lib
 def upfirdn2d_native_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """The native-op boundary: input [major, in_h, in_w, minor] -> [major, out_h, out_w, minor] (fresh tensor)."""
     lib = _lib.load()
-    x = _lib.require_cuda(input, "input")
-    k = _lib.require_cuda(kernel, "kernel")
+    x = _lib.require_cuda_any(input, "input")  # half / float / double, as the reference dispatches (upfirdn2d_kernel.cu:313-359)
+    k = _lib.require_cuda_any(kernel, "kernel").to(x.dtype)
+    fn = "maua_upfirdn2d_" + _lib.DTYPE_SUFFIX[x.dtype]
     if x.dim() != 4 or k.dim() != 2:
         raise RuntimeError("upfirdn2d expects input [major,h,w,minor] and kernel [kh,kw]")
     major, in_h, in_w, minor = x.shape
@@ -23,14 +24,14 @@ def upfirdn2d_native_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x
     out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
     if out_h <= 0 or out_w <= 0:
         raise RuntimeError(f"upfirdn2d: empty output {out_h}x{out_w}")
-    y = torch.empty((major, out_h, out_w, minor), dtype=torch.float32, device=x.device)
+    y = torch.empty((major, out_h, out_w, minor), dtype=x.dtype, device=x.device)
     if major:
         with torch.cuda.device(x.device):
-            rc = lib.maua_upfirdn2d_f32(
+            rc = getattr(lib, fn)(
                 x.data_ptr(), k.data_ptr(), y.data_ptr(), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y,
                 pad_x0, pad_x1, pad_y0, pad_y1, _lib.stream_ptr(x.device),
             )
-        _lib.check(rc, "maua_upfirdn2d_f32")
+        _lib.check(rc, fn)
     return y
 
 

@@ -165,5 +165,30 @@ def test_empty_and_degenerate_inputs(gpu):
         np.testing.assert_allclose(got, want, atol=2e-5)
     with pytest.raises(RuntimeError):
         upfirdn2d(torch.zeros(1, 1, 2, 2, device=gpu), k)  # 2 + 0 - 4 -> empty output, as the reference would fail
-    with pytest.raises(RuntimeError, match="float32"):
-        upfirdn2d(torch.zeros(1, 1, 8, 8, device=gpu, dtype=torch.float16), k)
+    with pytest.raises(RuntimeError, match="float16, float32 or float64"):  # half and double are dispatched (next test)
+        upfirdn2d(torch.zeros(1, 1, 8, 8, device=gpu, dtype=torch.bfloat16), k)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-2), (torch.float64, 1e-12)])
+def test_native_ops_half_and_double(gpu, dtype, tol):
+    """The reference's two native ops dispatch half / float / double (op/upfirdn2d_kernel.cu:313-359,
+    op/fused_bias_act_kernel.cu:79): the f16 / f64 entries of the C ABI against the oracle evaluated in fp64."""
+    from maua_stylegan2_amd.op import fused_leaky_relu, upfirdn2d
+    from oracle import ops_oracle
+
+    r = np.random.default_rng(77)
+    for shape, kshape, up, down, pad in [((2, 3, 9, 11), (4, 4), 1, 1, (1, 1)), ((1, 2, 6, 5), (3, 3), 2, 1, (2, 1)),
+                                         ((1, 2, 12, 12), (4, 4), 1, 2, (1, 1))]:
+        x, k = r.standard_normal(shape), r.standard_normal(kshape)
+        want = ops_oracle.upfirdn2d_loops(x, k, up, down, pad)  # the oracle's fp64 scalar-loop definition
+        got = upfirdn2d(torch.from_numpy(x).to(gpu, dtype), torch.from_numpy(k).to(gpu, dtype), up=up, down=down, pad=pad)
+        assert got.dtype == dtype and got.shape == want.shape
+        np.testing.assert_allclose(got.double().cpu().numpy(), want, atol=tol * max(1.0, np.abs(want).max()))
+    x, b = r.standard_normal((2, 7, 5, 5)), r.standard_normal(7)
+    want = ops_oracle.fused_leaky_relu(torch.from_numpy(x), torch.from_numpy(b)).numpy()  # torch fp64
+    assert want.dtype == np.float64
+    got = fused_leaky_relu(torch.from_numpy(x).to(gpu, dtype), torch.from_numpy(b).to(gpu, dtype))
+    assert got.dtype == dtype
+    np.testing.assert_allclose(got.double().cpu().numpy(), want, atol=tol * 4)
+    with pytest.raises(RuntimeError, match="float16, float32 or float64"):
+        upfirdn2d(torch.zeros(1, 1, 4, 4, dtype=torch.int32, device=gpu), torch.ones(2, 2, device=gpu))
