@@ -510,3 +510,36 @@ def test_stylegan1_mirror_has_the_reference_module_tree(built_lib):
     assert list(g.g_synthesis.blocks.keys()) == meta["blocks"]
     assert [list(getattr(g, f"noise_{i}").shape) for i in range(len(meta["noise"]))] == meta["noise"]
     assert list(g.truncation_latent.shape) == meta["truncation_latent"] and list(g.state_dict().keys()) == meta["keys"]
+
+
+def test_plugin_oracle_matches_reference_plugin(golden):
+    """oracle/plugin_oracle.py (the CPU restatement of the reference's default plugin, used as the checker of the whole-workload GPU
+    test) against what the reference's own callbacks produced on the stand-in features (default_plugin.npz)."""
+    import sys
+
+    from conftest import GOLDEN
+
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import plugin_stubs as stubs
+
+    from maua_stylegan2_amd import seeding
+    from oracle import plugin_oracle
+
+    fx = golden("default_plugin.npz")
+    n = int(fx["n_frames"])
+    lo, hi, ch = (torch.from_numpy(a) for a in stubs.envelopes(n))
+    selection = torch.from_numpy(seeding.seeded_array(42, "selection", (12, 16, 512)))
+    lat = plugin_oracle.get_latents(selection, ch, lo, hi)
+    got = stubs.summary(lat)
+    for key in ("stats", "frame_mean", "sub"):
+        np.testing.assert_allclose(got[key], fx[f"latents.{key}"], atol=1e-5, err_msg=key)
+    randn = stubs.SeededRandn(41)
+    for h, w in [tuple(int(v) for v in hw) for hw in fx["noise_sizes"]][:4] + [(512, 512)]:  # (the larger maps: GPU test only)
+        nz = plugin_oracle.get_noise(h, w, n, lo, hi, randn)
+        if f"noise_{h}x{w}.none" in fx.files:
+            assert nz is None
+            continue
+        got = stubs.summary(nz)
+        for key in ("stats", "frame_mean", "sub"):
+            np.testing.assert_allclose(got[key], fx[f"noise_{h}x{w}.{key}"], atol=2e-5, err_msg=f"{h}x{w} {key}")

@@ -323,6 +323,97 @@ def test_generate_matches_reference_generate(gpu, golden, tmp_path, monkeypatch,
     assert np.abs(sums - fx[f"{tag}.sums"]).max() < 2e-3 * size * size * 3  # whole frames, not just the subsample
 
 
+def test_whole_workload_wav_to_frames_vs_oracle(gpu, tmp_path, monkeypatch):
+    """BASELINE config 2 / 3 as a TEST: a seeded WAV goes through ``generate()`` with the default plugin and the real HIP
+    audio kernels (HPSS, band onsets incl. complex flux, constant-Q / CENS chroma, temporal FIR), a seeded 512^2 checkpoint
+    (the smallest size render() accepts), 75 frames at 25 fps in batches of 8 (hipGraph batches + eager tail), raw rgb24 sink.
+    Checked, stage by stage, against the oracle chain on the CPU:
+      * the onset / chroma envelopes the product computed vs signal_oracle on the same WAV (5e-3; chroma up to the order of
+        near-tied bins, as in test_onsets_and_chroma_vs_oracle);
+      * latents and noise maps vs oracle/plugin_oracle.py fed with the PRODUCT's envelopes and the same seeded randn draws
+        (1e-4 / statistics 1e-4) — isolates everything between the feature calls and the generator;
+      * delivered frames vs the oracle generator on the product's latents / noise for three frames (<= 1 grey level)."""
+    import scipy.io.wavfile
+
+    import maua_stylegan2_amd.audioreactive as ar
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.audioreactive.examples import default as plugin
+    from oracle import plugin_oracle, signal_oracle
+    from oracle import stylegan2_oracle as so
+
+    stubs = _stubs()
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)
+    sr, seconds, fps, size = 22050, 3.0, 25, 512
+    y = seeding.synthetic_audio(seconds, sr)
+    scipy.io.wavfile.write("track.wav", sr, (y * 32767).astype(np.int16))
+    y = (y * 32767).astype(np.int16).astype(np.float32) / 32768.0  # what load_audio decodes
+    sd = seeding.seeded_state_dict(size, seed=43)
+    torch.save({"g_ema": sd}, "seeded512.pt")
+    selection = seeding.seeded_array(42, "selection", (12, 16, 512))
+    np.save("selection.npy", selection)
+    monkeypatch.setattr(torch, "randn", stubs.SeededRandn(45))
+    seen = {"noise": []}
+    real_onsets, real_chroma = ar.onsets, ar.chroma
+
+    def onsets(*a, **k):
+        out = real_onsets(*a, **k)
+        seen.setdefault("onsets", []).append((k, out.clone()))
+        return out
+
+    def chroma(*a, **k):
+        seen["chroma"] = real_chroma(*a, **k)
+        return seen["chroma"].clone()
+
+    def get_latents(selection, args):
+        seen["latents"] = plugin.get_latents(selection, args)
+        return seen["latents"]
+
+    def get_noise(height, width, scale, num_scales, args):
+        nz = plugin.get_noise(height, width, scale, num_scales, args)
+        seen["noise"].append(None if nz is None else nz.detach().cpu())
+        return nz
+
+    monkeypatch.setattr(ar, "onsets", onsets)
+    monkeypatch.setattr(ar, "chroma", chroma)
+    out = gav.generate(ckpt="seeded512.pt", audio_file="track.wav", initialize=plugin.initialize, get_latents=get_latents,
+                       get_noise=get_noise, latent_file="selection.npy", G_res=size, out_size=size, fps=fps, batch=8,
+                       output_file=str(tmp_path / "o.mp4"))
+    n = int(round(seconds * fps))
+    frames = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(n, size, size, 3)
+    # ---- stage 1: features vs the oracle on the same audio
+    assert len(seen["onsets"]) == 2
+    env = {}
+    for kw, got in seen["onsets"]:
+        want = signal_oracle.onsets(y, sr, n, type="mm", smf=fps / 30, **kw).numpy()
+        np.testing.assert_allclose(got.numpy(), want, atol=5e-3, err_msg=str(kw))
+        env["lo" if "fmax" in kw else "hi"] = got
+    want = signal_oracle.chroma(y, sr, n, type="cens", nearest_neighbor=True).numpy()
+    got = seen["chroma"].numpy()
+    np.testing.assert_allclose(got[:, np.argsort(got.mean(0))], want[:, np.argsort(want.mean(0))], atol=2e-3)
+    # ---- stage 2: plugin arithmetic vs the oracle plugin on the product's envelopes and the same random draws
+    lat_want = plugin_oracle.get_latents(torch.from_numpy(selection), seen["chroma"], env["lo"], env["hi"], smf=fps / 30)
+    np.testing.assert_allclose(seen["latents"].cpu().numpy(), lat_want.numpy(), atol=1e-4)
+    randn = stubs.SeededRandn(45)
+    sizes = seeding.noise_sizes(size)
+    assert len(seen["noise"]) == len(sizes)
+    for side, nz in zip(sizes, seen["noise"]):
+        nz_want = plugin_oracle.get_noise(side, side, n, env["lo"], env["hi"], randn, smf=fps / 30)
+        if nz_want is None:
+            assert nz is None
+            continue
+        np.testing.assert_allclose(stubs.summary(nz)["stats"], stubs.summary(nz_want)["stats"], atol=1e-4, err_msg=str(side))
+        np.testing.assert_allclose(stubs.summary(nz)["sub"], stubs.summary(nz_want)["sub"], atol=2e-4, err_msg=str(side))
+    # ---- stage 3: frames vs the oracle generator on the product's latents / noise (first graph batch, a middle one, eager tail)
+    for i in (0, 37, n - 1):
+        lat_i = seen["latents"][i: i + 1].cpu()
+        noise_i = [None if nz is None else nz[i: i + 1] for nz in seen["noise"]]
+        want = so.frames_to_uint8(so.generator_forward(sd, lat_i, noise_i))[0]
+        diff = np.abs(frames[i].astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (i, int(diff.max()), float((diff > 0).mean()))
+
+
 def test_generator_with_bends_and_wide_output_vs_oracle(gpu):
     """Config-5 style network bending through the whole generator: a layer-0 bend that widens the constant (the
     reference's route to 2:1 output, tauceti.py:97-100) plus a per-frame modulated Translate at layer 4 and a Zoom at
