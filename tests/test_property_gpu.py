@@ -67,6 +67,36 @@ def test_styled_conv_random_shapes_vs_oracle(gpu, cin, cout, h, w, batch, up, se
     np.testing.assert_allclose(got, want, atol=5e-4, rtol=2e-4, err_msg=f"mode {m.conv.conv_mode(h, w)}")
 
 
+@settings(max_examples=30, **COMMON)
+@given(cin=st.sampled_from([4, 8, 20, 32, 64, 96, 128]), cout=st.sampled_from([32, 64, 128, 192]), hb=st.integers(1, 6),
+       wb=st.integers(1, 4), batch=st.integers(1, 3), shared_noise=st.booleans(), seed=st.integers(0, 1 << 16))
+def test_winograd2d_random_shapes_vs_oracle(gpu, cin, cout, hb, wb, batch, shared_noise, seed):
+    """The 2-D Winograd kernel (mode 5) on random qualifying shapes — H a multiple of 8 (16 for 32 channels), W of 32, any
+    Cin % 4 == 0, 32 / 64 / 128 / 192 output channels (1..3 weight tiles), per-frame or shared noise — against the oracle."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+
+    h, w = hb * (16 if cout == 32 else 8), wb * 32
+    r = np.random.default_rng(seed)
+    m = StyledConv(cin, cout, 3, 512)
+    m.conv.winograd2d_min_cout = 32
+    assert m.conv.conv_mode(h, w) == 5
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.27]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((1 if shared_noise else batch, 1, h, w)).astype(np.float32))
+    want = so.styled_conv(sd, "L", x, s, nz, False).numpy()
+    got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-4, rtol=2e-4)
+
+
 @settings(max_examples=25, **COMMON)
 @given(cin=st.sampled_from([3, 16, 32, 40, 64, 128]), h=st.integers(2, 40), w=st.sampled_from([2, 4, 6, 10, 16, 30, 32, 64, 72]),
        batch=st.integers(1, 3), skip=st.booleans(), seed=st.integers(0, 1 << 16))

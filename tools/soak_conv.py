@@ -5,7 +5,9 @@ import sys
 
 import torch
 
-sys.path.insert(0, '/root/repo')
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maua_stylegan2_amd.models.stylegan2 import StyledConv  # noqa: E402
 
 torch.set_grad_enabled(False)
@@ -16,6 +18,8 @@ cases = [  # cin, cout, h, w, up, batch
     (256, 256, 128, 128, False, 4), (256, 128, 128, 128, True, 4), (128, 128, 256, 256, False, 2), (128, 64, 256, 256, True, 2),
     (64, 64, 512, 512, False, 2), (64, 32, 512, 512, True, 2), (32, 32, 1024, 1024, False, 2), (32, 32, 96, 68, False, 3),
     (64, 64, 40, 34, False, 3), (24, 40, 20, 38, False, 2), (72, 24, 33, 20, True, 3), (16, 16, 128, 128, False, 2),
+    # mode 5 (2-D Winograd) incl. its 32-channel tile config, forced below the generator's 128-channel threshold
+    ("w2d", 64, 64, 64, 96, 3), ("w2d", 32, 32, 64, 64, 3), ("w2d", 128, 192, 24, 32, 2),
 ]
 _empty = torch.empty
 
@@ -27,7 +31,12 @@ def poisoned_empty(*args, **kwargs):  # every buffer the layer allocates starts 
 
 bad = 0
 for cin, cout, h, w, up, b in cases:
-    m = StyledConv(cin, cout, 3, 512, upsample=up).to(dev)
+    if cin == "w2d":
+        cin, cout, h, w, b, up = cout, h, w, up, b, False
+        m = StyledConv(cin, cout, 3, 512).to(dev)
+        m.conv.winograd2d_min_cout = 32
+    else:
+        m = StyledConv(cin, cout, 3, 512, upsample=up).to(dev)
     m.conv.weight.normal_(), m.noise.weight.fill_(0.3), m.activate.bias.normal_(0, 0.2)
     x = torch.randn(b, cin, h, w, device=dev)
     s = torch.randn(b, 512, device=dev)
