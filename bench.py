@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=3,
                     help="hipGraphs replayed round-robin on their own streams (consecutive steps overlap on the device, "
                          "as render.synthesize does); 1 = strictly serial steps")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="debug: run the N > 1 timed region (per-step FrameStream push + landing wait) on one GPU as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
@@ -316,7 +318,7 @@ def main():
         sync_lanes()
         # the headline region: EXACTLY --steps steps.  One GPU: synthesis with the frames left in HBM (the PCIe-inclusive rate
         # is reported next to it).  Several GPUs: the frames of every step are gathered to rank 0 inside the timed region.
-        elapsed = run_region(args.warmup, args.steps, "gathered" if world > 1 else "synth")
+        elapsed = run_region(args.warmup, args.steps, "gathered" if (world > 1 or args.force_gather) else "synth")
         extra = {}
         side = max(3, min(args.steps, 120))
         if world > 1:
