@@ -127,6 +127,44 @@ def main():
                 ms = e0.elapsed_ms(e1) / args.iters
                 fl = 2.0 * cin * cout * 9 * h * h * B
                 out[name] = {"ms": ms, "tflops": fl / ms / 1e9, "mode": m.conv_mode(h, h), "kernel": _lib.last_modconv_instance()}
+        if "fused" in args.what:
+            # the two fused layers of the 1024^2 generator: StyledConv + ToRGB (+ skip) in one launch, feature map stored
+            # (convs.13) / not stored and frames written as uint8 (convs.15)
+            from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d, StyledConv, ToRGB, _style_table
+
+            B = args.batch
+            if args.wino2d_min_cout is not None:
+                ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
+            for name, c, h, last in [("fused64@512", 64, 512, False), ("fused32@1024", 32, 1024, True)]:
+                conv, rgb = StyledConv(c, c, 3, 512).to(dev), ToRGB(c, 512).to(dev)
+                x = torch.randn(B, c, h, h, device=dev)
+                lat = torch.randn(B, 2, 512, device=dev)
+                styles = torch.empty(B, 2 * c, device=dev)
+                demod = torch.empty(B * c, device=dev)
+                table = _style_table([conv.conv.table_entry(0, 0, 0), rgb.conv.table_entry(1, c, B * c)], dev)
+                lib.maua_style_affine_f32(lat.data_ptr(), B, 2, 512, None, None, table.data_ptr(), 2, c, styles.data_ptr(), 2 * c, sp)
+                lib.maua_demod_f32(table.data_ptr(), 2, c, styles.data_ptr(), 2 * c, demod.data_ptr(), B, sp)
+                nz = torch.randn(1, 1, h, h, device=dev)
+                skip = torch.randn(B, 3, h // 2, h // 2, device=dev)
+                feat = torch.empty(B, c, h, h, device=dev)
+                img = torch.empty(B, 3, h, h, device=dev)
+                u8 = torch.empty(B, h, h, 3, dtype=torch.uint8, device=dev)
+                bufs = lambda nm, shape: feat  # noqa: E731
+
+                def run():
+                    fuse = dict(module=rgb, s_off=c, skip=skip, out=img, store=not last, u8=u8 if last else None)
+                    conv.run(x, styles, 0, demod.view(B, c), nz, bufs, "f", rgb=fuse)
+                    assert fuse.get("done")
+
+                run()
+                e0, e1 = _lib.HipEvent(), _lib.HipEvent()
+                e0.record(sp)
+                for _ in range(args.iters):
+                    run()
+                e1.record(sp)
+                ms = e0.elapsed_ms(e1) / args.iters
+                out[name] = {"ms": ms, "tflops": 2.0 * c * c * 9 * h * h * B / ms / 1e9, "mode": conv.conv.conv_mode(h, h),
+                             "kernel": _lib.last_modconv_instance()}
         stream.synchronize()
     print(json.dumps(out))
 
