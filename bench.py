@@ -187,6 +187,8 @@ def main():
                     help="debug: run the N > 1 timed region (per-step FrameStream push + landing wait) on one GPU as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--wino2d-min-cout", type=int, default=None,
+                    help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,7 +208,10 @@ def main():
     torch.set_grad_enabled(False)
 
     from maua_stylegan2_amd import _lib, seeding
-    from maua_stylegan2_amd.models.stylegan2 import Generator
+    from maua_stylegan2_amd.models.stylegan2 import Generator, ModulatedConv2d
+
+    if args.wino2d_min_cout is not None:
+        ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
 
     lib = _lib.load()
     size, B = args.size, args.batch

@@ -34,6 +34,13 @@
 #define MAUA_DEVICE_PASS 1
 #endif
 
+// compile-time ablation mask (tools/ablate_w2d_build.sh): 1 no MFMA, 2 no DMA after the first chunk, 4 no feature stores,
+// 8 no epilogue.  0 in the product.  (Run-time switches inside the main loop disturb the MFMA stream they are meant to measure: the
+// run-time mask maua_tuning_set(3, .) selects a separate instantiation, DBG = true.)
+#ifndef MAUA_W2D_ABL
+#define MAUA_W2D_ABL 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -111,7 +118,7 @@ struct W2dArgs {
     int tiles_x, tiles_y, m_tiles, n_chunks;
     int rgb;  // 0 off, 1 on, 2 on and the feature map itself is not stored
     float rgb_wscale;
-    int debug;  // ablation switches (maua_tuning_set key 3): 1 skip MFMA, 2 skip the DMA of every chunk after the first, 4 skip stores
+    int debug;  // ablation switches (maua_tuning_set key 3): 1 skip MFMA, 2 skip the DMA of every chunk after the first, 4 skip stores, 8 no epilogue
 };
 
 __host__ __device__ constexpr int w2d_dma_per_channel(int tn) { return (4 * tn + 2 + W2D_ROWS_PER_DMA - 1) / W2D_ROWS_PER_DMA; }
@@ -130,8 +137,9 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
     return tm == 4 ? ((col + 32 * (kq & 1)) & 63) : col;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool DBG>
 __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
+    const int dbg = (DBG ? p.debug : 0) | MAUA_W2D_ABL;
     constexpr int BM = 16 * TM;
     constexpr int NPOS = 16 * TN;
     constexpr int TH = 4 * TN;  // output rows per tile
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     __syncthreads();
     int cur = 0;
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-        if (chunk + 1 < p.n_chunks && !(p.debug & 2)) issue(chunk + 1, cur ^ 1);
+        if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
         // ---- operand reads of this chunk: style, raw window rows, first weight row
         const unsigned a_off = cur ? A_BUF_BYTES : 0u, p_off = cur ? P_BUF_BYTES : 0u;
         float sc = lds_read32(s_addr);
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             constexpr int pending = xf < 5 ? TM / 2 : 0;
             if constexpr (TM == 4) lds_wait<pending>(a2[xf & 1][0], a2[xf & 1][1]);
             else lds_wait<pending>(a2[xf & 1][0]);
-            if (!(p.debug & 1)) {
+            if (!(dbg & 1)) {
 #pragma unroll
                 for (int h = 0; h < TM / 2; ++h)
 #pragma unroll
@@ -336,6 +344,19 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
         cur ^= 1;
     }
 
+    if (dbg & 8) {
+        if (p.B < 0) {  // never true: keeps the accumulators alive in builds without the epilogue
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) sum += acc[a][m][n];
+            *reinterpret_cast<f32x4*>(p.y + tid * 4) = sum;
+        }
+        return;
+    }
     // ---- epilogue
     // A_x^T m in registers: y0 = m0+m1+m2+m3+m4, y1 = (m1-m2) + 2(m3-m4), y2 = (m1+m2) + 4(m3+m4), y3 = (m1-m2) + 8(m3-m4) + m5
     // then, 16 output channels (one m-tile) per pass, the four waves' 1x4 partial rows meet in LDS:
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     float rgbp[4][3];
 #pragma unroll
     for (int px = 0; px < 4; ++px) rgbp[px][0] = rgbp[px][1] = rgbp[px][2] = 0.f;
-    const bool store_feat = p.rgb != 2 && !(p.debug & 4);
+    const bool store_feat = p.rgb != 2 && !(dbg & 4);
     float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane;
     const unsigned pix_off = (unsigned)oy * (unsigned)p.W + (unsigned)ox;
 
@@ -563,9 +584,9 @@ size_t w2d_lds_bytes(int tm, int tn, int cin) {
 char g_w2d_instance[64] = "";
 int g_w2d_debug = 0;
 
-template <int TM, int TN>
+template <int TM, int TN, bool DBG>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
-    auto kern = modconv_w2d_kernel<TM, TN>;
+    auto kern = modconv_w2d_kernel<TM, TN, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -573,7 +594,9 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
     }
     snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d>", TM, TN);
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), w2d_lds_bytes(TM, TN, a.Cin), st, a);
+    // occupancy probe (tools/occ_probe.sh): extra dynamic LDS so that a CU holds one workgroup instead of two
+    static const size_t lds_pad = getenv("MAUA_W2D_LDS_PAD") ? (size_t)atoi(getenv("MAUA_W2D_LDS_PAD")) : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), w2d_lds_bytes(TM, TN, a.Cin) + lds_pad, st, a);
     MAUA_LAUNCH_CHECK();
     return 0;
 }
@@ -617,8 +640,8 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
-    if (tm == 4) return w2d_launch_t<4, 2>(a, st);
-    return w2d_launch_t<2, 4>(a, st);
+    if (a.debug) return tm == 4 ? w2d_launch_t<4, 2, true>(a, st) : w2d_launch_t<2, 4, true>(a, st);  // ablation instantiation
+    return tm == 4 ? w2d_launch_t<4, 2, false>(a, st) : w2d_launch_t<2, 4, false>(a, st);
 }
 
 extern "C" int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {

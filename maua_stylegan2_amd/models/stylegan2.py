@@ -160,9 +160,10 @@ class ModulatedConv2d(nn.Module):
     upconv_winograd = True
     # plain layers whose shape the 2-D Winograd kernel accepts (csrc/modconv_w2d.hip, mode 5: F(2,3) along y on top of
     # F(4,3) along x, 3 instead of 4.5 MFMA products per output) with at least this many output channels.  Measured inside
-    # bench.py (profiles/r02_w2d.md): -11..24 % per launch on the 128..512-channel layers; the 32/64-channel layers with the
-    # fused ToRGB epilogue (4-16 K steps per workgroup, epilogue-bound) are 9-17 % slower than mode 3 and stay there.
-    winograd2d_min_cout = 128
+    # bench.py (profiles/r02_w2d.md): -11..24 % per launch on the 128..512-channel layers; -14 % on the 64-channel and -1 % on
+    # the 32-channel layer with the fused ToRGB epilogue (since the skip-image taps of that epilogue are unconditional loads),
+    # +1.8 % frames/s for the whole generator.
+    winograd2d_min_cout = 32
 
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 / 4 transposed, 2 Winograd F(2,3), 3 Winograd
