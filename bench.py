@@ -187,6 +187,8 @@ def main():
                     help="debug: run the N > 1 timed region (per-step FrameStream push + landing wait) on one GPU as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B switch: maua_tuning_set(KEY, VALUE) before the graphs are captured (0 = upfirdn2d kernel selection, ...)")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
     args = ap.parse_args()
@@ -214,6 +216,9 @@ def main():
         ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
 
     lib = _lib.load()
+    for kv in args.tuning:
+        key, value = kv.split("=")
+        lib.maua_tuning_set(int(key), int(value))
     size, B = args.size, args.batch
     g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
     g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
