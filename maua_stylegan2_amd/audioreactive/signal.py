@@ -16,7 +16,7 @@ any device; results come back on the device the reference would have produced th
 Divergences from the reference, all stated in DESIGN.md §7 ("parity unpinned" rows): librosa / madmom are not
 dependencies here.  ``onsets(type="mm")`` sums madmom's five onset functions (incl. the phase-based complex flux) on a
 log-filtered spectrogram built here, ``type="rosa"`` is the mel spectral flux; ``chroma`` runs harmonic
-separation -> constant-Q chromagram -> CENS -> nearest-neighbour median filter without librosa's tuning estimation,
+separation -> tuning estimation -> constant-Q chromagram -> CENS -> nearest-neighbour median filter,
 and madmom's "deep" / "clp" chroma models fall back to the constant-Q chromagram with a warning.
 """
 import math
@@ -75,10 +75,11 @@ def mel_filterbank(sr, n_fft=2048, n_mels=128, fmin=0.0, fmax=None):
     return fb.astype(np.float32)
 
 
-def chroma_filterbank(sr, n_fft=2048, n_chroma=12, ctroct=5.0, octwidth=2.0):
-    """STFT-bin -> pitch-class weights (tuning 0, C-based) — [12, n_fft/2+1] float32."""
+def chroma_filterbank(sr, n_fft=2048, n_chroma=12, ctroct=5.0, octwidth=2.0, tuning=0.0):
+    """STFT-bin -> pitch-class weights (C-based; ``tuning`` = deviation of A440 in fractions of a bin) — [12, n_fft/2+1]
+    float32."""
     f = np.arange(1, n_fft) * (sr / n_fft)
-    pos = n_chroma * np.log2(f / 27.5)
+    pos = n_chroma * np.log2(f / (27.5 * 2.0 ** (tuning / n_chroma)))
     pos = np.concatenate([[pos[0] - 1.5 * n_chroma], pos])
     bw = np.concatenate([np.maximum(np.diff(pos), 1.0), [1.0]])
     dist = pos[None, :] - np.arange(n_chroma)[:, None]
@@ -421,6 +422,58 @@ def nn_filter(ch, width=1):
     return out
 
 
+def piptrack(S, sr, n_fft=2048, fmin=150.0, fmax=4000.0, threshold=0.1):
+    """Pitch candidates of a device spectrogram ``S`` [1 + n_fft/2, T] (librosa.piptrack's published algorithm): parabolic
+    interpolation around every local maximum above ``threshold`` x the frame maximum inside [fmin, fmax) -> (pitches in Hz,
+    interpolated magnitudes), zero elsewhere.  Elementwise device work next to the HIP STFT."""
+    S = _to_dev(S).abs()
+    k = S.shape[0]
+    freqs = th.arange(k, device=S.device, dtype=th.float32) * (float(sr) / n_fft)
+    avg = 0.5 * (S[2:] - S[:-2])
+    curv = 2 * S[1:-1] - S[2:] - S[:-2]
+    shift = avg / (curv + (curv.abs() < th.finfo(th.float32).tiny).float())
+    avg = th.nn.functional.pad(avg, (0, 0, 1, 1))
+    shift = th.nn.functional.pad(shift, (0, 0, 1, 1))
+    gated = S * (S > threshold * S.max(dim=0, keepdim=True).values)
+    before = th.cat([gated[:1], gated[:-1]], 0)  # edge padding: the first row is never strictly greater than itself
+    after = th.cat([gated[1:], gated[-1:]], 0)
+    peak = ((freqs >= max(fmin, 0.0)) & (freqs < min(fmax, sr / 2.0)))[:, None] & (gated > before) & (gated >= after)
+    bins = th.arange(k, device=S.device, dtype=th.float32)[:, None]
+    zero = th.zeros((), device=S.device)
+    return th.where(peak, (bins + shift) * (float(sr) / n_fft), zero), th.where(peak, S + 0.5 * avg * shift, zero)
+
+
+def pitch_tuning(frequencies, resolution=0.01, bins_per_octave=12):
+    """Histogram peak of the deviation of ``frequencies`` (device tensor, Hz) from the bins of an A440 scale, in fractions of a
+    bin in [-0.5, 0.5) (librosa.pitch_tuning)."""
+    f = frequencies.reshape(-1).double()
+    f = f[f > 0]
+    if f.numel() == 0:
+        return 0.0
+    residual = th.remainder(bins_per_octave * th.log2(f / 27.5), 1.0)
+    residual = th.where(residual >= 0.5, residual - 1.0, residual)
+    edges = th.linspace(-0.5, 0.5, int(math.ceil(1.0 / resolution)) + 1, dtype=th.float64, device=f.device)
+    which = (th.bucketize(residual, edges, right=True) - 1).clamp_(0, edges.numel() - 2)  # numpy.histogram's bin rule
+    counts = th.bincount(which, minlength=edges.numel() - 1)
+    return float(edges[int(counts.argmax())])
+
+
+def estimate_tuning(audio=None, sr=22050, S=None, n_fft=2048, resolution=0.01, bins_per_octave=12):
+    """Tuning deviation of a track in fractions of a bin (librosa.estimate_tuning, which librosa's chroma_cqt / chroma_cens /
+    chroma_stft run when ``tuning`` is None — reference signal.py:115-119 leaves it None): piptrack on |STFT| (hop n_fft/4) or on
+    a given spectrogram, the candidates at least as strong as the median one, pitch_tuning."""
+    if S is None:
+        S = stft_power(audio, n_fft, n_fft // 4).sqrt()
+    pitch, mag = piptrack(S, sr, n_fft)
+    sel = pitch > 0
+    if not bool(sel.any()):
+        return 0.0
+    strengths = mag[sel].sort().values
+    n = strengths.numel()
+    median = 0.5 * (strengths[(n - 1) // 2] + strengths[n // 2])
+    return pitch_tuning(pitch[sel & (mag >= median)], resolution, bins_per_octave)
+
+
 CQT_FMIN = 32.70319566257483  # C1, librosa's default
 
 
@@ -459,10 +512,12 @@ def raw_chroma(audio, sr, type="cens", nearest_neighbor=True):
     if type not in ("stft", "cqt", "cens"):
         warnings.warn(f"chroma type {type!r}: madmom's chroma models are not on this path; using the constant-Q chromagram",
                       stacklevel=2)
-    if type == "stft":
-        raw = project(chroma_filterbank(sr), stft_power(audio))
+    if type == "stft":  # librosa estimates the tuning from the power spectrogram here, from |STFT| of the signal below
+        power = stft_power(audio)
+        raw = project(chroma_filterbank(sr, tuning=estimate_tuning(S=power, sr=sr, bins_per_octave=12)), power)
     else:
-        raw = project(cq_to_chroma_matrix(), cqt_magnitude(audio, sr))
+        tuning = estimate_tuning(audio, sr, bins_per_octave=36)
+        raw = project(cq_to_chroma_matrix(), cqt_magnitude(audio, sr, fmin=CQT_FMIN * 2.0 ** (tuning / 36)))
     peak = raw.max(dim=0, keepdim=True).values
     ch = raw / th.where(peak > 0, peak, th.ones_like(peak))
     if type == "cens":

@@ -166,10 +166,11 @@ def onset_strength(y, sr, fmin=0.0, fmax=None, n_fft=2048, hop=512, n_mels=128):
     return env[: db.shape[1]]
 
 
-def chroma_filterbank(sr, n_fft=2048, n_chroma=12, ctroct=5.0, octwidth=2.0):
-    """librosa.filters.chroma (tuning 0, L2-normalised columns, Gaussian octave weighting, C-based)."""
+def chroma_filterbank(sr, n_fft=2048, n_chroma=12, ctroct=5.0, octwidth=2.0, tuning=0.0):
+    """librosa.filters.chroma (L2-normalised columns, Gaussian octave weighting, C-based); ``tuning`` = deviation of A440 in
+    fractions of a chroma bin."""
     freqs = np.linspace(0, sr, n_fft, endpoint=False)[1:]
-    bins = n_chroma * np.log2(freqs / (440.0 / 16))
+    bins = n_chroma * np.log2(freqs / (440.0 * 2.0 ** (tuning / n_chroma) / 16))
     bins = np.concatenate([[bins[0] - 1.5 * n_chroma], bins])
     width = np.concatenate([np.maximum(bins[1:] - bins[:-1], 1.0), [1.0]])
     d = bins[None, :] - np.arange(n_chroma, dtype=np.float64)[:, None]
@@ -182,9 +183,64 @@ def chroma_filterbank(sr, n_fft=2048, n_chroma=12, ctroct=5.0, octwidth=2.0):
     return w[:, : 1 + n_fft // 2]
 
 
-def chroma_stft(y, sr, n_fft=2048, hop=512):
-    """Power-spectrogram chroma, each frame normalised by its max (librosa.feature.chroma_stft, tuning 0)."""
-    raw = chroma_filterbank(sr, n_fft) @ stft_power(y, n_fft, hop)
+def localmax_rows(x):
+    """librosa.util.localmax along axis 0: strictly greater than the element before, not smaller than the one after
+    (edge-padded)."""
+    xp = np.pad(x, ((1, 1), (0, 0)), mode="edge")
+    return (x > xp[:-2]) & (x >= xp[2:])
+
+
+def piptrack(S, sr, n_fft=2048, fmin=150.0, fmax=4000.0, threshold=0.1):
+    """librosa.piptrack (published algorithm, librosa/core/pitch.py): parabolic interpolation of the spectrogram ``S``
+    [1 + n_fft/2, T] around every local maximum above ``threshold`` x the frame maximum inside [fmin, fmax) ->
+    (pitches [Hz], magnitudes), zero elsewhere.  **parity unpinned** (librosa absent)."""
+    S = np.abs(np.asarray(S, dtype=np.float64))
+    fmax = min(fmax, sr / 2.0)
+    freqs = np.arange(S.shape[0]) * (float(sr) / n_fft)
+    avg = 0.5 * (S[2:] - S[:-2])
+    shift = 2 * S[1:-1] - S[2:] - S[:-2]
+    shift = avg / (shift + (np.abs(shift) < np.finfo(np.float64).tiny))
+    avg = np.pad(avg, ((1, 1), (0, 0)))
+    shift = np.pad(shift, ((1, 1), (0, 0)))
+    dskew = 0.5 * avg * shift
+    ref = threshold * S.max(axis=0, keepdims=True)
+    peak = ((max(fmin, 0.0) <= freqs) & (freqs < fmax))[:, None] & localmax_rows(S * (S > ref))
+    bins = np.arange(S.shape[0], dtype=np.float64)[:, None]
+    return np.where(peak, (bins + shift) * float(sr) / n_fft, 0.0), np.where(peak, S + dskew, 0.0)
+
+
+def pitch_tuning(frequencies, resolution=0.01, bins_per_octave=12):
+    """librosa.pitch_tuning: histogram peak of the frequencies' deviation from the bins of an A440 scale, in fractions of a bin
+    in [-0.5, 0.5)."""
+    f = np.asarray(frequencies, dtype=np.float64).ravel()
+    f = f[f > 0]
+    if f.size == 0:
+        return 0.0
+    residual = np.mod(bins_per_octave * np.log2(f / (440.0 / 16)), 1.0)
+    residual[residual >= 0.5] -= 1.0
+    edges = np.linspace(-0.5, 0.5, int(np.ceil(1.0 / resolution)) + 1)
+    counts, edges = np.histogram(residual, edges)
+    return float(edges[np.argmax(counts)])
+
+
+def estimate_tuning(y=None, sr=22050, S=None, n_fft=2048, resolution=0.01, bins_per_octave=12):
+    """librosa.estimate_tuning: pitches from piptrack (on |STFT| of ``y``, hop n_fft/4, or on a given spectrogram ``S``), those at
+    least as strong as the median peak -> pitch_tuning."""
+    if S is None:
+        S = np.sqrt(stft_power(y, n_fft, n_fft // 4))
+    pitch, mag = piptrack(S, sr, n_fft)
+    mask = pitch > 0
+    thr = np.median(mag[mask]) if mask.any() else 0.0
+    return pitch_tuning(pitch[(mag >= thr) & mask], resolution, bins_per_octave)
+
+
+def chroma_stft(y, sr, n_fft=2048, hop=512, tuning=None):
+    """Power-spectrogram chroma, each frame normalised by its max (librosa.feature.chroma_stft; ``tuning`` None = estimated
+    from the power spectrogram, as librosa does)."""
+    P = stft_power(y, n_fft, hop)
+    if tuning is None:
+        tuning = estimate_tuning(S=P, sr=sr, n_fft=n_fft, bins_per_octave=12)
+    raw = chroma_filterbank(sr, n_fft, tuning=tuning) @ P
     peak = raw.max(axis=0, keepdims=True)
     return raw / np.where(peak > np.finfo(np.float64).tiny, peak, 1.0)
 
@@ -388,10 +444,12 @@ def cq_to_chroma_matrix(n_bins=252, bins_per_octave=36, n_chroma=12):
     return w
 
 
-def chroma_cqt(y, sr, hop=512):
-    """Constant-Q chromagram, each frame normalised by its max (librosa.feature.chroma_cqt defaults without its
-    tuning estimation)."""
-    raw = cq_to_chroma_matrix() @ cqt_magnitude(y, sr, hop)
+def chroma_cqt(y, sr, hop=512, tuning=None):
+    """Constant-Q chromagram, each frame normalised by its max (librosa.feature.chroma_cqt defaults: 7 octaves x 36 bins from
+    C1 x 2^(tuning/36), ``tuning`` None = librosa.estimate_tuning(y, bins_per_octave=36))."""
+    if tuning is None:
+        tuning = estimate_tuning(y, sr, bins_per_octave=36)
+    raw = cq_to_chroma_matrix() @ cqt_magnitude(y, sr, hop, fmin=32.70319566257483 * 2.0 ** (tuning / 36))
     peak = raw.max(axis=0, keepdims=True)
     return raw / np.where(peak > np.finfo(np.float64).tiny, peak, 1.0)
 

@@ -362,3 +362,32 @@ def test_complex_flux_and_local_group_delay():
     assert abs(int(np.argmax(want[2:])) + 2 - round(0.7 * sr / hop)) <= 2  # the tone onset at 0.7 s is the envelope's peak
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * want.max())
     np.testing.assert_allclose(sig.local_group_delay(re, im).numpy(), signal_oracle.local_group_delay(spec), atol=2e-4)
+
+
+def test_tuning_estimation_known_answers():
+    """librosa.estimate_tuning restated (oracle/signal_oracle.py): tones detuned by a known fraction of a semitone come back as
+    that fraction, in 12-bin and in 36-bin units (the unit chroma_cqt uses), an empty pitch set gives 0.  (Tones above 800 Hz:
+    the parabolic peak interpolation is good to ~0.3 Hz, which is 2-3 cents at 220 Hz.)"""
+    sr = 22050
+    t = np.arange(int(2.0 * sr)) / sr
+    for cents in (0.0, 20.0, -30.0, 45.0):
+        y = sum(np.sin(2 * np.pi * f0 * 2.0 ** (cents / 1200.0) * t) / (i + 1)
+                for i, f0 in enumerate((880.0, 1108.73052390749, 1318.51022765149, 1760.0, 2637.02045530296)))
+        got12 = signal_oracle.estimate_tuning(y, sr, bins_per_octave=12)
+        assert abs(got12 - cents / 100.0) <= 0.02, (cents, got12)
+        want36 = np.mod(3 * cents / 100.0 + 0.5, 1.0) - 0.5  # the same deviation against third-of-a-semitone bins
+        got36 = signal_oracle.estimate_tuning(y, sr, bins_per_octave=36)
+        assert abs(got36 - want36) <= 0.06, (cents, got36, want36)
+    assert signal_oracle.pitch_tuning(np.array([440.0 * 2.0 ** (0.25 / 12), 880.0 * 2.0 ** (0.25 / 12)])) == pytest.approx(0.25, abs=0.011)
+    assert signal_oracle.pitch_tuning(np.zeros(4)) == 0.0
+    assert signal_oracle.estimate_tuning(np.zeros(4096), sr) == 0.0
+    # piptrack: one pure tone -> one candidate per frame, at the tone's frequency, nothing outside [fmin, fmax)
+    tone = np.sin(2 * np.pi * 1000.0 * t)
+    S = np.sqrt(signal_oracle.stft_power(tone, 2048, 512))
+    pitch, mag = signal_oracle.piptrack(S, sr)
+    mid = pitch[:, 10]
+    assert (mid > 0).sum() == 1 and abs(mid.max() - 1000.0) < 1.0 and mag[:, 10].max() > 0
+    assert not (signal_oracle.piptrack(np.sqrt(signal_oracle.stft_power(np.sin(2 * np.pi * 100.0 * t), 2048, 512)), sr)[0] > 0).any()
+    # the tuning moves the chroma filterbank's and the constant-Q transform's bin centres
+    fb0, fb1 = signal_oracle.chroma_filterbank(sr, tuning=0.0), signal_oracle.chroma_filterbank(sr, tuning=0.3)
+    assert fb0.shape == fb1.shape and not np.allclose(fb0, fb1)

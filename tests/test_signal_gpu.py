@@ -327,3 +327,37 @@ def test_slerp_loops_matches_reference_golden(gpu, golden):
         y = latent.slerp_loops(sel, n_frames, n_loops, smoothing, bool(loop))
         assert list(y.shape) == g[f"slerp_loops.{tag}.shape"].tolist() and y.dtype == torch.float32
         np.testing.assert_allclose(y.cpu().numpy()[:, ::6, :], g[f"slerp_loops.{tag}.y"], atol=1e-5, err_msg=tag)
+
+
+@pytest.mark.gpu
+def test_tuning_estimation_vs_oracle(gpu):
+    """Device piptrack / estimate_tuning (what librosa's chroma functions run when tuning is None) against the oracle's
+    restatement: same candidates on a seeded spectrogram, same tuning on detuned tone stacks and on the synthetic track, and the
+    estimate reaches the constant-Q transform (a detuned track keeps its pitch classes)."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    sr = 22050
+    y = seeding.synthetic_audio(4.0, sr)
+    S = np.sqrt(signal_oracle.stft_power(y, 2048, 512)).astype(np.float32)
+    want_p, want_m = signal_oracle.piptrack(S, sr)
+    got_p, got_m = (t.cpu().numpy() for t in sig.piptrack(S, sr))
+    assert ((got_p > 0) == (want_p > 0)).mean() > 0.9999  # a bin sitting exactly on the 0.1 x max gate may flip in fp32
+    both = (got_p > 0) & (want_p > 0)
+    np.testing.assert_allclose(got_p[both], want_p[both], rtol=1e-4)
+    np.testing.assert_allclose(got_m[both], want_m[both], rtol=1e-4)
+    for bpo in (12, 36):
+        assert abs(sig.estimate_tuning(y, sr, bins_per_octave=bpo) - signal_oracle.estimate_tuning(y, sr, bins_per_octave=bpo)) <= 0.0101
+    t = np.arange(int(2.0 * sr)) / sr
+    tones = (880.0, 1108.73052390749, 1318.51022765149, 1760.0, 2637.02045530296)
+    stacks = {}
+    for cents in (0.0, 20.0, -30.0):
+        stacks[cents] = sum(np.sin(2 * np.pi * f0 * 2.0 ** (cents / 1200.0) * t) / (i + 1) for i, f0 in enumerate(tones)).astype(np.float32)
+        got = sig.estimate_tuning(stacks[cents], sr)
+        assert abs(got - cents / 100.0) <= 0.02 and abs(got - signal_oracle.estimate_tuning(stacks[cents], sr)) <= 0.0101
+        power = sig.stft_power(stacks[cents])
+        assert abs(sig.estimate_tuning(S=power, sr=sr) - signal_oracle.estimate_tuning(S=signal_oracle.stft_power(stacks[cents]), sr=sr)) <= 0.0101
+    assert sig.estimate_tuning(np.zeros(8192, np.float32), sr) == 0.0
+    # A-major-ish stack: the pitch classes that carry energy are the same with and without detuning (the transform follows it)
+    base = sig.raw_chroma(stacks[0.0], sr, type="cqt", nearest_neighbor=False)
+    sharp = sig.raw_chroma(stacks[20.0], sr, type="cqt", nearest_neighbor=False)
+    assert set(np.argsort(base[:, 40])[-3:]) == set(np.argsort(sharp[:, 40])[-3:]) == {9, 1, 4}  # A, C#, E
