@@ -383,7 +383,8 @@ def main():
                 dom = max(rows, key=lambda r: r[2])
                 if dom[1].startswith("modconv"):
                     ach = dom[3] / dom[2] / 1e9
-                    result["roofline"] = {"kernel": f"modconv_mfma_kernel ({dom[0]})", "bound": "mfma", "achieved": ach,
+                    inst = INSTANCES.get(dom[0])
+                    result["roofline"] = {"kernel": f"{(inst or 'modconv').split('<')[0]} ({dom[0]})", "bound": "mfma", "achieved": ach,
                                           "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
                                           "traffic": None, "launch_ms": dom[2]}
                     # `achieved` counts ALGORITHMIC flops (direct 3x3).  Plain layers run through Winograd
@@ -394,15 +395,17 @@ def main():
                         n_conv = int(base.split(".")[1])
                         res = 4 * 2 ** ((n_conv + 1) // 2)
                         mode = g.convs[n_conv].conv.conv_mode(res, res)
-                        if mode in (2, 3):
-                            ratio = 2.0 / 3.0 if mode == 2 else 0.5
-                            result["roofline"]["algorithm"] = (
-                                "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic" if mode == 2 else
-                                "winograd F(4,3) along x: executed MFMA flops = 1/2 algorithmic (frac counts algorithmic "
-                                "direct-conv flops as SURVEY 8d defines them and can therefore exceed 1)")
+                        if mode in (2, 3, 5):
+                            ratio = {2: 2.0 / 3.0, 3: 0.5, 5: 1.0 / 3.0}[mode]
+                            result["roofline"]["algorithm"] = {
+                                2: "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic",
+                                3: "winograd F(4,3) along x: executed MFMA flops = 1/2 algorithmic (frac counts algorithmic "
+                                   "direct-conv flops as SURVEY 8d defines them and can therefore exceed 1)",
+                                5: "2-D winograd F(2x4,3x3): executed MFMA flops = 1/3 algorithmic (frac counts algorithmic "
+                                   "direct-conv flops as SURVEY 8d defines them and can therefore exceed 1; executed_frac is what the "
+                                   "matrix cores did)"}[mode]
                             result["roofline"]["executed"] = ach * ratio
                             result["roofline"]["executed_frac"] = ach * ratio / MFMA_F32_PEAK_TFLOPS
-                    inst = INSTANCES.get(dom[0])
                     result["roofline"]["kernel_instance"] = inst
                     table, table_path = pmc_traffic_table()
                     rec = (table or {}).get("kernels", {}).get(inst) if inst else None
@@ -413,9 +416,11 @@ def main():
                         result["roofline"]["traffic"] = rec["read_bytes"] + rec["write_bytes"]
                         result["roofline"]["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}"
                     if size == 1024 and dom[0].startswith("convs.15"):
-                        # input + skip image + noise map + packed weights, read once; RGB image written once
+                        # input + skip image + noise map + packed (Winograd-domain) weights, read once; uint8 frames written once
                         result["roofline"]["algorithmic_bytes"] = (B * 32 * size * size * 4 + B * 3 * (size // 2) ** 2 * 4
-                                                                   + size * size * 4 + 18 * 32 * 32 * 4 + B * 3 * size * size * 4)
+                                                                   + size * size * 4 + 24 * 32 * 32 * 4 + B * 3 * size * size)
+                        result["roofline"]["hbm_frac_of_launch"] = (result["roofline"]["algorithmic_bytes"] / (dom[2] * 1e-3)
+                                                                    / (HBM_PEAK_GBS * 1e9))
                 else:
                     ach = dom[4] / dom[2] / 1e6
                     result["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
