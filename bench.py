@@ -450,6 +450,15 @@ def main():
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                             "traffic": traffic, "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}" if traffic else None), "launch_ms": ms, "algorithmic_bytes": byts,
                                             "shape": f"[{xin.shape[0]},{xin.shape[1]},{r_out+1},{r_out+1}] -> {r_out}^2"}
+            # measured copy ceiling of this box (SURVEY.md 8d asks for "vs spec" and "vs measured copy"): a device-to-device copy of
+            # the same number of bytes (read n/2, write n/2) on the same stream
+            with torch.cuda.stream(torch.cuda.ExternalStream(sp, device=dev)):
+                src = torch.empty(byts // 8, dtype=torch.float32, device=dev).normal_()
+                dst = torch.empty_like(src)
+                ms_copy = time_calls(lambda: dst.copy_(src), 20, sp)
+            copy_gbs = 2 * src.numel() * 4 / ms_copy / 1e6
+            result["roofline_upfirdn2d"]["measured_copy_gbs"] = copy_gbs
+            result["roofline_upfirdn2d"]["frac_of_measured_copy"] = ach / copy_gbs
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(size)
