@@ -3,8 +3,6 @@
 chroma_weight_latents latent.py:15-26).  Pinned, through tests/golden/default_plugin.npz, to what the reference's own
 callbacks produce (tests/test_oracle_golden.py::test_plugin_oracle_matches_reference_plugin).  The two random fields of
 get_noise are drawn by the caller-supplied ``randn`` (the reference uses th.randn on the device)."""
-import torch
-
 from . import signal_oracle as so
 
 

@@ -135,8 +135,6 @@ def test_fused_leaky_relu_full_size_properties(gpu):
 
 
 def test_frames_to_u8(gpu, golden):
-    import ctypes
-
     from maua_stylegan2_amd import _lib
 
     g = golden("postprocess.npz")

@@ -213,8 +213,6 @@ def test_generate_latents_maps_through_the_mapping_network(gpu):
 def test_hpss_pieces_vs_oracle(gpu):
     """Complex STFT / inverse STFT round trip, 31-tap median filters (both axes, reflect boundary) vs scipy.ndimage, and the
     full harmonic / percussive separation vs the oracle restatement of librosa's hpss."""
-    import ctypes
-
     import scipy.ndimage
 
     from maua_stylegan2_amd import _lib

@@ -90,7 +90,6 @@ def main():
             ms = e0.elapsed_ms(e1) / args.iters
             out["fir_tail_1024"] = {"ms": ms, "gbs": byts / ms / 1e6}
         if "conv" in args.what:
-            import math
             from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
 
             B = args.batch

@@ -4,7 +4,6 @@ generator's up-sampling shapes and equality with path 0 (incl. ragged shapes tha
 
     python tools/tail_ab.py [path ...]      # default: 0 1 5 (auto, per-plane tiles, tiles + non-temporal)
 """
-import json
 import os
 import sys
 
