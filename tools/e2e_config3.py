@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--stage-times", action="store_true", help="print device-synchronised wall time per preprocessing stage")
+    ap.add_argument("--repeat", type=int, default=1, help="run generate() this many times in one process (the later runs are warm)")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="maua_e2e_")
     os.chdir(work)
@@ -77,19 +78,24 @@ def main():
         for owner, name in ((ar, "load_audio"), (ar, "generate_latents"), (plugin, "initialize"), (plugin, "get_latents"),
                             (plugin, "get_noise"), (gav, "load_generator"), (render, "render")):
             timed(owner, name)
-        for name in ("hpss", "resample", "gaussian_filter", "cqt_magnitude", "nn_filter", "cens", "stft_power"):
+        for name in ("onsets", "chroma", "hpss", "onset_strength_bands", "estimate_tuning", "resample", "gaussian_filter", "cqt_magnitude",
+                     "nn_filter", "cens", "stft_power", "percentile_clip"):
             timed(sig, name, "  signal." + name)
             if hasattr(ar, name):
                 setattr(ar, name, getattr(sig, name))
         timed(gav.gc, "collect", "  gc.collect")
-    t0 = time.time()
-    gav.generate(ckpt, wav, initialize=plugin.initialize, get_latents=plugin.get_latents, get_noise=plugin.get_noise,
-                 G_res=args.size, out_size=args.size, fps=30, batch=args.batch, output_file=os.path.join(work, "out.mp4"))
-    total = time.time() - t0
-    if args.stage_times:
-        for label, (sec, calls) in stages.items():
-            print(f"STAGE {label:28s} {sec:7.3f} s  ({calls} calls)")
-    print(f"E2E frames={counted['frames']} bytes={counted['bytes']} checksum={counted['checksum']} total_wall_s={total:.2f}")
+    for run in range(args.repeat):
+        counted.update(frames=0, bytes=0, checksum=0)
+        if args.stage_times:
+            stages.clear()
+        t0 = time.time()
+        gav.generate(ckpt, wav, initialize=plugin.initialize, get_latents=plugin.get_latents, get_noise=plugin.get_noise,
+                     G_res=args.size, out_size=args.size, fps=30, batch=args.batch, output_file=os.path.join(work, "out.mp4"))
+        total = time.time() - t0
+        if args.stage_times:
+            for label, (sec, calls) in stages.items():
+                print(f"STAGE {label:28s} {sec:7.3f} s  ({calls} calls)")
+        print(f"E2E run {run} frames={counted['frames']} bytes={counted['bytes']} checksum={counted['checksum']} total_wall_s={total:.2f}")
 
 
 if __name__ == "__main__":
