@@ -130,7 +130,9 @@ def layer_breakdown(g, batch, static, stream):
         rgb_flops = 2 * cout * 3 * (2 * h) ** 2 * batch
         if fused:
             t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=dict(fuse)), 10, sp)
-            rows.append((f"convs.{2*n+1}+to_rgbs.{n} (fused)", "modconv", t_pl, conv_flops + rgb_flops, 0))
+            # <= 64 channels: one launch; wider layers: the conv leaves per-tile partial ToRGB sums and a 3*m_tiles-plane pass adds them
+            label = "(fused)" if cout <= 64 else "(fused: partial sums + plane sum)"
+            rows.append((f"convs.{2*n+1}+to_rgbs.{n} {label}", "modconv", t_pl, conv_flops + rgb_flops, 0))
         else:
             t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}"), 10, sp)
             rows.append((f"convs.{2*n+1}", "modconv", t_pl, conv_flops, 0))
@@ -189,6 +191,7 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B switch: maua_tuning_set(KEY, VALUE) before the graphs are captured (0 = upfirdn2d kernel selection, ...)")
+    ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
     args = ap.parse_args()
@@ -210,8 +213,10 @@ def main():
     torch.set_grad_enabled(False)
 
     from maua_stylegan2_amd import _lib, seeding
-    from maua_stylegan2_amd.models.stylegan2 import Generator, ModulatedConv2d
+    from maua_stylegan2_amd.models.stylegan2 import Generator, ModulatedConv2d, StyledConv
 
+    if args.no_partial_rgb:
+        StyledConv.partial_rgb_fusion = False
     if args.wino2d_min_cout is not None:
         ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
 

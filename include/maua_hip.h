@@ -110,6 +110,8 @@ int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, vo
  * layer shape qualifies (cin % 4 == 0, cout == 32 or cout % 64 == 0, w % 32 == 0, h % 8 (16 for cout 32) == 0). */
 int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream);
 int maua_modconv_w2d_ok(int cin, int cout, int h, int w);
+/* number of output-channel tiles (workgroups per pixel tile) the 2-D Winograd kernel uses for this layer; 0 = shape not accepted */
+int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w);
 
 /* ModulatedConv2d 3x3 (models/stylegan2.py:217-254) as input-scale -> shared-weight implicit GEMM on MFMA ->
  * output-demod, with the StyledConv tail (noise + bias + leaky ReLU, :338-343) fused when `fuse_act`:
@@ -149,6 +151,16 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
                               const float* rgb_w, const float* rgb_s, float rgb_wscale, const float* rgb_bias,
                               const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,
                               uint8_t* frames_u8, void* stream);
+
+/* The same fusion for layers wider than one weight tile (128..512 output channels, mode 5 only): every output-channel tile leaves
+ * its share of the ToRGB sum  sum_{i in tile} (rgb_wscale * rgb_w[c,i] * rgb_s[b,i]) * y[b,i,Y,X]  in
+ * rgb_partial [B, 3 * maua_modconv_w2d_mtiles(), H, W] (plane 3 m + c), the feature map y is stored as usual.  The caller finishes with
+ * maua_torgb_f32 over the 3 m_tiles planes (selection weights, unit styles), which adds bias and the up-sampled skip: the ToRGB of
+ * models/stylegan2.py:356-365 then reads 3 m_tiles planes instead of all `cout` feature planes.  MAUA_ENOSYS for mode != 5. */
+int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y,
+                                      int batch, int cin, int cout, int h, int w, int mode, float wscale, const float* noise,
+                                      int64_t noise_batch_stride, const float* noise_w, const float* bias, const float* rgb_w,
+                                      const float* rgb_s, float rgb_wscale, float* rgb_partial, void* stream);
 
 /* StyleGAN1 (`--stylegan1`, models/stylegan1.py:258-318 LayerEpilogue) — conv bias, per-channel-weighted noise, LeakyReLU(0.2),
  * instance norm (biased variance, eps 1e-5) and the style modulation in one launch:

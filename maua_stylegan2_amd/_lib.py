@@ -55,11 +55,14 @@ _SIGNATURES = {
     "maua_pack_weight_upwino_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "maua_pack_weight_wino2d_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "maua_modconv_w2d_ok": (c_int, [c_int] * 4),
+    "maua_modconv_w2d_mtiles": (c_int, [c_int] * 4),
     "maua_modconv_ws_floats": (c_int64, [c_int] * 6),
     "maua_modconv_last_instance": (c_int, [c_char_p, c_int]),
     "maua_modconv3x3_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, _P, c_int64, _P, _P, _P, _P]),
     "maua_styledconv_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
                                           _P, _P, _P, _P, c_int, _P, _P]),
+    "maua_styledconv_torgb_partial_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
+                                                  _P, _P]),
     "maua_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_frames_to_u8": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "maua_sg1_epilogue_f32": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),

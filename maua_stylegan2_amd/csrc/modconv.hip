@@ -1393,6 +1393,19 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
                         noise_w, bias, ws, nullptr, stream);
 }
 
+extern "C" int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
+                                                 float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
+                                                 const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                                 const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
+                                                 float* rgb_partial, void* stream) {
+    if (mode != 5) return MAUA_ENOSYS;  // only the 2-D Winograd kernel leaves partial ToRGB sums
+    if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w)) return MAUA_EINVAL;
+    const int rc = maua_w2d_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, 1, noise, noise_batch_stride, noise_w, bias,
+                                   rgb_w, rgb_s, rgb_wscale, nullptr, nullptr, nullptr, rgb_partial, nullptr, 3, stream);
+    if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
+    return rc;
+}
+
 extern "C" int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                                          float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
                                          const float* noise, int64_t noise_batch_stride, const float* noise_w,

@@ -116,7 +116,8 @@ struct W2dArgs {
     int fuse_act;
     int64_t noise_batch_stride;
     int tiles_x, tiles_y, m_tiles, n_chunks;
-    int rgb;  // 0 off, 1 on, 2 on and the feature map itself is not stored
+    int rgb;  // 0 off, 1 on, 2 on and the feature map itself is not stored, 3 partial: this m-tile's share of the ToRGB sum goes to
+              // rgb_out [B, 3 m_tiles, H, W] (no bias, no skip), the feature map is stored
     float rgb_wscale;
     int debug;  // ablation switches (maua_tuning_set key 3): 1 skip MFMA, 2 skip the DMA of every chunk after the first, 4 skip stores, 8 no epilogue
 };
@@ -460,6 +461,13 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) rgbp[px][c] += rp[px * 3 + c];
     }
+    if (p.rgb == 3) {  // several m-tiles per pixel: leave this tile's partial sums; maua_torgb_f32 adds them up (+ bias, skip)
+        float* part = p.rgb_out + ((size_t)b0 * 3 * p.m_tiles + 3 * mt_id) * plane + pix_off;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f32x4*>(part + (size_t)c * plane) = f32x4{rgbp[0][c], rgbp[1][c], rgbp[2][c], rgbp[3][c]};
+        return;
+    }
     // upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, x): two live source rows / columns, iy0 = floor((oy-1)/2), iy0+1 with taps
     // k4[3]/k4[1] for even oy and k4[2]/k4[0] for odd (models/stylegan2.py:34-52, op/upfirdn2d.py:159-200)
     const int sh = p.H >> 1, sw = p.W >> 1;
@@ -637,7 +645,9 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     a.tiles_x = w / 32, a.tiles_y = h / (4 * tn), a.m_tiles = cout / (16 * tm), a.n_chunks = cin / W2D_CC;
     a.rgb = rgb_mode, a.rgb_wscale = rgb_wscale;
     a.debug = g_w2d_debug;
-    if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
+    if (rgb_mode == 3) {
+        if (!fuse_act || !rgb_w || !rgb_s || !rgb_out) return MAUA_EINVAL;
+    } else if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
     if (a.debug) return tm == 4 ? w2d_launch_t<4, 2, true>(a, st) : w2d_launch_t<2, 4, true>(a, st);  // ablation instantiation
@@ -657,3 +667,8 @@ extern "C" int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, 
 }
 
 extern "C" int maua_modconv_w2d_ok(int cin, int cout, int h, int w) { return maua_w2d_tiles(cin, cout, h, w, nullptr, nullptr); }
+
+extern "C" int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w) {
+    int tm = 0, tn = 0;
+    return maua_w2d_tiles(cin, cout, h, w, &tm, &tn) ? cout / (16 * tm) : 0;
+}

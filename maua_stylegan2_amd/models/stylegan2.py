@@ -356,6 +356,22 @@ class ManipulationLayer(nn.Module):
         return out
 
 
+_PARTIAL_RGB = {}
+
+
+def _partial_rgb_operands(m_tiles, batch, device):
+    """Operands that make maua_torgb_f32 add up the per-tile partial ToRGB sums [B, 3 m_tiles, H, W]: a [3, 3 m_tiles] selection
+    matrix (plane 3 m + c feeds colour c) and unit styles; cached per (m_tiles, batch, device) — static, so graph-capture safe."""
+    key = (m_tiles, batch, str(device))
+    if key not in _PARTIAL_RGB:
+        sel = th.zeros(3, 3 * m_tiles, dtype=th.float32)
+        for m in range(m_tiles):
+            for c in range(3):
+                sel[c, 3 * m + c] = 1.0
+        _PARTIAL_RGB[key] = (sel.to(device), th.ones(batch, 3 * m_tiles, dtype=th.float32, device=device))
+    return _PARTIAL_RGB[key]
+
+
 class StyledConv(nn.Module):
     """reference :310-343: ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU -> ManipulationLayer."""
 
@@ -367,6 +383,9 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
         self.manipulation = ManipulationLayer(layerID)
+
+    # layers wider than one weight tile on the 2-D Winograd kernel leave per-tile partial ToRGB sums (A/B switch)
+    partial_rgb_fusion = True
 
     def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None):
         """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers.
@@ -411,6 +430,31 @@ class StyledConv(nn.Module):
                         return out
                     if rc != -38:  # MAUA_ENOSYS = layer shape not fusable -> two launches below
                         _lib.check(rc, "maua_styledconv_torgb_f32")
+            elif rgb is not None and self.partial_rgb_fusion and n_ws == 0 and conv.conv_mode(h, w) == 5:
+                # wider layers on the 2-D Winograd kernel: every output-channel tile leaves its share of the ToRGB sum (3 planes);
+                # the ToRGB pass then adds 3 * m_tiles planes (+ bias, + up-sampled skip) instead of reading all `cout` feature planes
+                t = rgb["module"]
+                skip = rgb["skip"]
+                m_tiles = lib.maua_modconv_w2d_mtiles(cin, conv.out_channel, h, w)
+                fusable = m_tiles > 1 and (skip is None or (tuple(t.upsample.kernel.shape) == (4, 4) and t.upsample.factor == 2
+                                                            and skip.shape[2] * 2 == h and skip.shape[3] * 2 == w))
+                if fusable:
+                    part = bufs(tag + ".rgb_partial", (b, 3 * m_tiles, h, w))
+                    nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
+                    _lib.check(lib.maua_styledconv_torgb_partial_f32(
+                        x.data_ptr(), conv.packed_wino(5).data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d),
+                        out.data_ptr(), b, cin, conv.out_channel, h, w, 5, float(conv.scale), _lib.ptr(noise), nstride,
+                        self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
+                        s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), _lib.stream_ptr(x.device)),
+                        "maua_styledconv_torgb_partial_f32")
+                    sel, ones = _partial_rgb_operands(m_tiles, b, x.device)
+                    _lib.check(lib.maua_torgb_f32(part.data_ptr(), sel.data_ptr(), ones.data_ptr(), 3 * m_tiles, t.bias.data_ptr(),
+                                                  _lib.ptr(skip), _lib.ptr(t.upsample.kernel) if skip is not None else None,
+                                                  rgb["out"].data_ptr(), b, 3 * m_tiles, h, w, 1.0, _lib.stream_ptr(x.device)),
+                               "maua_torgb_f32")
+                    rgb["done"] = True
+                    rgb["u8_done"] = False  # the image is in rgb["out"] as fp32 planes: a last layer still needs the frame epilogue
+                    return out
             return conv.run(x, s, s_off, d, out, ws, fuse_act=True, noise=noise, noise_w=self.noise.weight,
                             bias=self.activate.bias)
         raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
@@ -743,7 +787,7 @@ class Generator(nn.Module):
             li += 1
             if fuse is not None and fuse.get("done"):
                 image = rgb_buf
-                if is_last and frames_u8 is not None:
+                if is_last and frames_u8 is not None and fuse.get("u8_done", True):
                     image = None  # left the device path as uint8 frames
             elif wants_rgb:
                 image = rgb.run(out, s, ent[li]["s_off"], image, rgb_buf)
