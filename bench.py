@@ -22,7 +22,11 @@ import os
 import sys
 import time
 
-import torch
+# one hardware queue per stream (3 graph lanes + copy stream + default stream; the HIP default is 4): see maua_stylegan2_amd/__init__.py.
+# Must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
