@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B switch: maua_tuning_set(KEY, VALUE) before the graphs are captured (0 = upfirdn2d kernel selection, ...)")
+    ap.add_argument("--lib", default=None, help="A/B / ablation switch: load this build of libmaua_hip.so instead of the in-tree one")
     ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
@@ -224,6 +225,8 @@ def main():
     if args.wino2d_min_cout is not None:
         ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
 
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     lib = _lib.load()
     for kv in args.tuning:
         key, value = kv.split("=")

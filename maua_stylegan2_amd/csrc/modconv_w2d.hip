@@ -35,7 +35,8 @@
 #endif
 
 // compile-time ablation mask (tools/ablate_w2d_build.sh): 1 no MFMA, 2 no DMA after the first chunk, 4 no feature stores,
-// 8 no epilogue.  0 in the product.  (Run-time switches inside the main loop disturb the MFMA stream they are meant to measure: the
+// 8 no epilogue, 256 no ToRGB tail after the passes, 512 no combine phase (barriers and the A_x^T / exchange writes stay, so the
+// accumulators remain live).  0 in the product.  (Run-time switches inside the main loop disturb the MFMA stream they are meant to measure: the
 // run-time mask maua_tuning_set(3, .) selects a separate instantiation, DBG = true.)
 #ifndef MAUA_W2D_ABL
 #define MAUA_W2D_ABL 0
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
                 *reinterpret_cast<f32x4*>(Z + (((fy * 16 + ch16) * NPOS) + n * 16 + j) * 4) = o4;
             }
         __syncthreads();
+        if constexpr (!(MAUA_W2D_ABL & 512))
 #pragma unroll
         for (int q = 0; q < CPG; ++q) {
             const int ch16 = cg * CPG + q;
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             if (store_feat) *reinterpret_cast<f32x4*>(yimg + (size_t)ol * plane + pix_off) = v4;
         }
     }
-    if (!p.rgb) return;
+    if (!p.rgb || (MAUA_W2D_ABL & 256)) return;
     // ---- fused ToRGB: sum the channel groups through LDS, add bias and the 2x FIR-upsampled skip image, store
     __syncthreads();
     {
