@@ -68,7 +68,12 @@ class FrameSink:
             self.proc = subprocess.Popen(cmd, stdin=subprocess.PIPE)
         else:
             path = output_file if output_file.endswith(".rgb24") else output_file + ".rgb24"
-            print(f"ffmpeg binary not found: writing raw rgb24 frames ({width}x{height}) to {path}")
+            audio = f" -ss {offset} -t {duration} -guess_layout_max 0 -i {audio_file}" if audio_file is not None else ""
+            mux = " -b:a 320K -ac 2" if audio_file is not None else ""
+            target = output_file[:-len(".rgb24")] if output_file.endswith(".rgb24") else output_file
+            print(f"ffmpeg binary not found: writing raw rgb24 frames ({width}x{height}) to {path}\n"
+                  f"  encode later with: ffmpeg -f rawvideo -pix_fmt rgb24 -framerate {framerate} -s {width}x{height} -i {path}{audio} "
+                  f"-r {framerate} -vcodec libx264 -pix_fmt yuv420p -preset {ffmpeg_preset}{mux} {target}")
             self.file = open(path, "wb")
 
     def write(self, frame):
