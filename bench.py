@@ -194,7 +194,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
-                    help="A/B switch: maua_tuning_set(KEY, VALUE) before the graphs are captured (0 = upfirdn2d kernel selection, ...)")
+                    help="A/B switch of an EXPERIMENTS build (tools/build_exp.sh, pass it with --lib): maua_tuning_set(KEY, VALUE) before "
+                         "the graphs are captured; the product library has no such entry")
     ap.add_argument("--lib", default=None, help="A/B / ablation switch: load this build of libmaua_hip.so instead of the in-tree one")
     ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
@@ -230,7 +231,11 @@ def main():
     lib = _lib.load()
     for kv in args.tuning:
         key, value = kv.split("=")
-        lib.maua_tuning_set(int(key), int(value))
+        try:
+            tuning_set = lib.maua_tuning_set
+        except AttributeError:
+            sys.exit("--tuning needs an experiments build of the library (tools/build_exp.sh <name>; bench.py --lib tools/bin/libmaua_<name>.so)")
+        tuning_set(int(key), int(value))
     size, B = args.size, args.batch
     g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
     g.load_state_dict(seeding.seeded_state_dict(size, seed=0))

@@ -24,9 +24,6 @@ int maua_abi_version(void);
 /* Number of compute units / name of device 0 (diagnostics for bench.py). */
 int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
 
-/* Kernel-selection override for profiling / A-B runs (key 0: upfirdn2d path, 0 = automatic). Not needed in production. */
-int maua_tuning_set(int key, int value);
-
 /* ------------------------------------------------------------------------------------------------ ops
  * Replaces pybind `upfirdn2d.upfirdn2d(input[major,in_h,in_w,minor], kernel[kh,kw], up_x, up_y, down_x,
  * down_y, pad_x0, pad_x1, pad_y0, pad_y1)` — op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369.
@@ -222,7 +219,8 @@ int maua_cqt_mag_f32(const float* y, int64_t n_samples, const float* freqs, cons
  * nn_median = per-frame median over the k frames of highest cosine similarity outside |i-j| < width (the
  * aggregate=np.median, metric="cosine" nearest-neighbour filter at :131).  The fp64 similarity row of a frame lives in LDS
  * while n_frames * 8 + k * (4 + 4 n_bins) bytes fit (~16k frames); longer tracks need a caller-owned workspace `ws` of
- * maua_nn_median_ws_doubles() doubles (0 = not needed, ws may be NULL). */
+ * maua_nn_median_ws_doubles() doubles (0 = not needed, ws may be NULL).  A non-NULL ws of min(n_frames, 1024) * n_frames doubles
+ * selects the workspace path at any size (same results, bit for bit). */
 int maua_chroma_cens_f32(const float* ch, float* out, int n_bins, int n_frames, int win_len, void* stream);
 int64_t maua_nn_median_ws_doubles(int n_bins, int n_frames, int k);
 int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, double* ws, void* stream);

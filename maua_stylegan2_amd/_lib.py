@@ -39,7 +39,6 @@ _P = c_void_p
 _SIGNATURES = {
     "maua_abi_version": (c_int, []),
     "maua_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
-    "maua_tuning_set": (c_int, [c_int, c_int]),
     "maua_upfirdn2d_f32": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
     "maua_fused_bias_act_f32": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "maua_fused_bias_act_f16": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, _P]),

@@ -72,12 +72,17 @@ def spline_loops(latent_selection, n_frames, n_loops, loop=True):
 
 def wrapping_slice(tensor, start, length, return_indices=False):
     """``length`` entries of ``tensor`` from ``start``, continuing at the beginning when the end is reached (reference
-    :110-133).  Like the reference the slice wraps at most once: a request that would lap the tensor again ends at
-    (start + length) mod n."""
+    :110-133).  Like the reference the slice wraps at most once — a request that would lap the tensor again ends at
+    (start + length) mod n — and a slice that starts AT the end has no head: it is the first (start + length) mod n entries.
+    A start beyond the end raises, as the reference's ``arange(start, n)`` does."""
     n = tensor.shape[0]
-    indices = th.arange(start, start + length) % n
-    if start + length > n:
-        indices = indices[: max(n - start, 0) + (start + length) % n]
+    end = start + length
+    if start > n and end > n:
+        raise RuntimeError(f"wrapping_slice: start {start} lies beyond the tensor ({n} entries)")
+    head = length if end <= n else max(n - start, 0)   # entries taken before the wrap
+    tail = 0 if end <= n else end % n                  # entries taken from the beginning
+    k = th.arange(head + tail)
+    indices = th.where(k < head, k + start, k - head)
     if n == 1:
         indices = indices.new_zeros(1)
     return indices if return_indices else tensor[indices]

@@ -42,6 +42,16 @@
 #define MAUA_DEVICE_PASS 1
 #endif
 
+// Ablation / A-B switches only exist in -DMAUA_EXPERIMENTS builds (tools/build_exp.sh): the product kernels carry no debug
+// branches and the product library exports no tuning entry.
+#ifdef MAUA_EXPERIMENTS
+#define MAUA_DBG(mask) ((g.debug & (mask)) != 0)
+#define MAUA_CFG(mask) ((g_conv_cfg & (mask)) != 0)
+#else
+#define MAUA_DBG(mask) false
+#define MAUA_CFG(mask) false
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -75,8 +85,8 @@ struct ConvGeom {
     int flat;         // transposed mode: tiles are runs of BN consecutive positions of the row-major (H+1)x(W+1) grid
     int rgb;          // fused ToRGB epilogue: 0 off, 1 on, 2 on and the feature map itself is not stored
     float rgb_wscale;
-    int debug;        // ablation switches (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads, 32 skip weight DMA,
-                      // 64 skip patch loads, 128 fold the patch loads onto 4 KB per channel (always cache hits; wrong results)
+    int debug;        // MAUA_EXPERIMENTS builds only (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads, 32 skip weight
+                      // DMA, 64 skip patch loads, 128 fold the patch loads onto 4 KB per channel (always cache hits; wrong results)
 };
 
 struct ConvPtrs {
@@ -197,7 +207,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         }
     }
 
-    if (g.debug & 128) {
+    if (MAUA_DBG(128)) {
 #pragma unroll
         for (int i = 0; i < MAX_POS; ++i) src_off[i] = src_off[i] < 0 ? src_off[i] : (src_off[i] & 0x3ff);
     }
@@ -650,10 +660,10 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             __syncthreads();
             for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
                 if (chunk + 1 < chunk_end) {
-                    if (!(g.debug & 32)) issue_dma(chunk + 1, cur ^ 1);
-                    if (!(g.debug & 64)) issue_patch(chunk + 1, cur ^ 1);
+                    if (!MAUA_DBG(32)) issue_dma(chunk + 1, cur ^ 1);
+                    if (!MAUA_DBG(64)) issue_patch(chunk + 1, cur ^ 1);
                 }
-                if (!(g.debug & 2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * PBUF, Ss + (chunk - chunk_begin) * CC);
+                if (!MAUA_DBG(2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * PBUF, Ss + (chunk - chunk_begin) * CC);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 cur ^= 1;
@@ -668,12 +678,12 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
         __syncthreads();
         for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
             const bool more = chunk + 1 < chunk_end;
-            if (more && !(g.debug & 4)) {
-                if (!(g.debug & 32)) issue_dma(chunk + 1, cur ^ 1);
-                if (!(g.debug & 64)) load_patch(chunk + 1);
+            if (more && !MAUA_DBG(4)) {
+                if (!MAUA_DBG(32)) issue_dma(chunk + 1, cur ^ 1);
+                if (!MAUA_DBG(64)) load_patch(chunk + 1);
             }
-            if (!(g.debug & 2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * (CC * g.PSTRIDE), nullptr);
-            if (more && !(g.debug & (4 | 64))) write_patch(chunk + 1, cur ^ 1);
+            if (!MAUA_DBG(2)) mfma_chunk(As + cur * A_FLOATS, Ps + cur * (CC * g.PSTRIDE), nullptr);
+            if (more && !MAUA_DBG(4 | 64)) write_patch(chunk + 1, cur ^ 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             cur ^= 1;
@@ -782,7 +792,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             // per workgroup) the epilogue's instruction count is a first-order cost.
             const bool apply_act = !to_ws && g.fuse_act;
             const bool do_rgb = !UP && WM == 1 && !MULTI && g.rgb;
-            const bool store_feat = !(do_rgb && g.rgb == 2) && !(g.debug & 1);
+            const bool store_feat = !(do_rgb && g.rgb == 2) && !MAUA_DBG(1);
             const int n_ok = g.Cout - m0 - wm * (TM * 32) - 4 * hi;  // this lane's channel rows oe < n_ok exist
             const unsigned lane_bytes = lane_off * 4u;
             auto elements = [&](auto interior_tag) {
@@ -1107,8 +1117,10 @@ struct Plan {
 };
 
 int pad32(int c) { return (c + 31) / 32 * 32; }
+#ifdef MAUA_EXPERIMENTS
 int g_conv_debug = 0;
-int g_conv_cfg = 0;  // tuning key 2: bit0 -> Cout<=64 uses 64x128 (WM 2); bit1 -> Cout<=32 uses 32x512
+int g_conv_cfg = 0;  // tuning key 2: bit0 -> Cout<=64 uses 64x128 (WM 2); bit1 -> Cout<=32 uses 32x512; bit2 -> no flat runs
+#endif
 
 // Tile-shape selection (host).  BM follows Cout; the pixel tile is a stack of 32-pixel MFMA groups.
 // mode 0 plain, 1 transposed stride 2, 2 plain through Winograd F(2,3) along x (needs an even width)
@@ -1125,7 +1137,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
                                                   // 18-row weight tile only leaves room for 2-channel chunks: 4-7 % slower)
     } else if (wino) {
         g.GH = h, g.GW = w / 2, g.OH = h, g.OW = w;  // positions are output pairs
-        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = (g_conv_cfg & 2) ? 256 : 128;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = MAUA_CFG(2) ? 256 : 128;
         else if (cout <= 64) pl.bm = 64, pl.wm = 1, pl.bn = 128;
         else pl.bm = 128, pl.wm = 2, pl.bn = 64;
     } else if (uw) {
@@ -1138,8 +1150,8 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         else pl.bm = 64, pl.wm = 2, pl.bn = 64;
     } else {
         g.GH = h, g.GW = w, g.OH = h, g.OW = w;
-        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = (g_conv_cfg & 2) ? 512 : 256;
-        else if (cout <= 64) pl.bm = 64, pl.wm = (g_conv_cfg & 1) ? 2 : 1, pl.bn = (g_conv_cfg & 1) ? 128 : 256;
+        if (cout <= 32) pl.bm = 32, pl.wm = 1, pl.bn = MAUA_CFG(2) ? 512 : 256;
+        else if (cout <= 64) pl.bm = 64, pl.wm = MAUA_CFG(1) ? 2 : 1, pl.bn = MAUA_CFG(1) ? 128 : 256;
         else pl.bm = 128, pl.wm = 2, pl.bn = 128;
     }
     auto shape = [&](int bn) {
@@ -1167,7 +1179,7 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.PSTRIDE = ni * g.PH * g.PWS;
     };
     shape(pl.bn);
-    if (up && g.GH * g.GW >= 2 * pl.bn && !(g_conv_cfg & 4)) {
+    if (up && g.GH * g.GW >= 2 * pl.bn && !MAUA_CFG(4)) {
         // The (H+1)x(W+1) position grid never fits power-of-two 2-D tiles (29 % idle MFMA columns at 65x65); tiles are
         // instead runs of BN consecutive positions of the flattened grid, one image each.  A position reads inputs
         // p, p-1, p-GW, p-GW-1 of the pitch-GW flattened (zero-padded) input: two runs of BN+1 floats per channel.
@@ -1243,8 +1255,10 @@ int launch_conv(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
 
 }  // namespace
 
+#ifdef MAUA_EXPERIMENTS
 int maua_conv_debug_set(int v) { g_conv_debug = v; return 0; }
 int maua_conv_cfg_set(int v) { g_conv_cfg = v; return 0; }
+#endif
 
 extern "C" int maua_pack_weight_f32(const float* w, float* wp, float* wsq, int cout, int cin, int ktaps, void* stream) {
     if (!w || cout <= 0 || cin <= 0 || ktaps <= 0) return MAUA_EINVAL;
@@ -1332,7 +1346,9 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     pl.g.wscale = wscale;
     pl.g.fuse_act = fuse_act;
     pl.g.noise_batch_stride = noise_batch_stride;
+#ifdef MAUA_EXPERIMENTS
     pl.g.debug = g_conv_debug;
+#endif
     pl.g.rgb = 0;
     pl.g.rgb_wscale = 0.f;
     ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -592,7 +592,9 @@ size_t w2d_lds_bytes(int tm, int tn, int cin) {
 }
 
 char g_w2d_instance[64] = "";
+#ifdef MAUA_EXPERIMENTS
 int g_w2d_debug = 0;
+#endif
 
 template <int TM, int TN, bool DBG>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
@@ -604,8 +606,11 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
     }
     snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %s>", TM, TN, DBG ? "true" : "false");
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
-    // occupancy probe (tools/occ_probe.sh): extra dynamic LDS so that a CU holds one workgroup instead of two
+#ifdef MAUA_EXPERIMENTS  // occupancy probe (tools/occ_probe.sh): extra dynamic LDS so that a CU holds one workgroup instead of two
     static const size_t lds_pad = getenv("MAUA_W2D_LDS_PAD") ? (size_t)atoi(getenv("MAUA_W2D_LDS_PAD")) : 0;
+#else
+    constexpr size_t lds_pad = 0;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), w2d_lds_bytes(TM, TN, a.Cin) + lds_pad, st, a);
     MAUA_LAUNCH_CHECK();
     return 0;
@@ -617,9 +622,9 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
 int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
     if (cin % W2D_CC || w % 32 || cin <= 0 || cout <= 0) return 0;
     int m, n;
-    static const bool force_tm2 = getenv("MAUA_W2D_TM2") != nullptr;  // experiment switch: 32-row tiles for every layer
-    if (cout % 64 == 0 && !(force_tm2 && h % 16 == 0)) m = 4, n = 2;
-    else if (cout % 32 == 0 && (cout == 32 || force_tm2)) m = 2, n = 4;
+    // (the tile shape depends on the channel counts only: the packed weight of a layer serves every map size)
+    if (cout % 64 == 0) m = 4, n = 2;
+    else if (cout == 32) m = 2, n = 4;
     else return 0;
     if (h % (4 * n)) return 0;
     if (tm) *tm = m;
@@ -628,7 +633,9 @@ int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
 }
 
 const char* maua_w2d_last_instance() { return g_w2d_instance; }
+#ifdef MAUA_EXPERIMENTS
 int maua_w2d_debug_set(int v) { g_w2d_debug = v; return 0; }
+#endif
 
 int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
@@ -646,13 +653,17 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     a.noise_batch_stride = noise_batch_stride;
     a.tiles_x = w / 32, a.tiles_y = h / (4 * tn), a.m_tiles = cout / (16 * tm), a.n_chunks = cin / W2D_CC;
     a.rgb = rgb_mode, a.rgb_wscale = rgb_wscale;
+#ifdef MAUA_EXPERIMENTS
     a.debug = g_w2d_debug;
+#endif
     if (rgb_mode == 3) {
         if (!fuse_act || !rgb_w || !rgb_s || !rgb_out) return MAUA_EINVAL;
     } else if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
+#ifdef MAUA_EXPERIMENTS
     if (a.debug) return tm == 4 ? w2d_launch_t<4, 2, true>(a, st) : w2d_launch_t<2, 4, true>(a, st);  // ablation instantiation
+#endif
     return tm == 4 ? w2d_launch_t<4, 2, false>(a, st) : w2d_launch_t<2, 4, false>(a, st);
 }
 

@@ -720,14 +720,15 @@ extern "C" int maua_chroma_cens_f32(const float* ch, float* out, int n_bins, int
     return 0;
 }
 
-static int g_nn_force_ws = 0;  // maua_tuning_set key 4: 1 = take the workspace path at every size (tests)
-int maua_nn_force_ws_set(int v) { g_nn_force_ws = v; return 0; }
+// Similarity rows live in LDS while they fit; beyond (> ~16k frames) the caller supplies a workspace of
+// maua_nn_median_ws_doubles() doubles.  A non-NULL `ws` selects the workspace path at ANY size (min(n_frames, 1024) rows,
+// frames strided over the grid), so both paths of the kernel can be compared on one input.
+static inline int nn_ws_rows(int n_frames) { return n_frames < 1024 ? n_frames : 1024; }
 
 extern "C" int64_t maua_nn_median_ws_doubles(int n_bins, int n_frames, int k) {
     const size_t lds = (size_t)n_frames * sizeof(double) + (size_t)k * sizeof(int) + (size_t)n_bins * k * sizeof(float);
-    if (lds <= 150 * 1024 && !g_nn_force_ws) return 0;  // the similarity row fits LDS
-    const int rows = g_nn_force_ws > 1 ? (g_nn_force_ws < n_frames ? g_nn_force_ws : n_frames) : (n_frames < 1024 ? n_frames : 1024);
-    return (int64_t)rows * n_frames;
+    if (lds <= 150 * 1024) return 0;  // the similarity row fits LDS
+    return (int64_t)nn_ws_rows(n_frames) * n_frames;
 }
 
 extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n_frames, int k, int width, double* ws, void* stream) {
@@ -743,14 +744,14 @@ extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n
                                   150 * 1024);
         attr_set = true;
     }
-    if (lds <= 150 * 1024 && !g_nn_force_ws) {
+    if (!ws) {
+        if (lds > 150 * 1024) return MAUA_EINVAL;  // long track: the caller must supply the workspace
         hipLaunchKernelGGL(nn_median_kernel<true>, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, ch, out, n_bins, n_frames, k,
                            width, (double*)nullptr);
-    } else {  // long track: similarity rows in the caller's workspace (maua_nn_median_ws_doubles), frames strided over the grid
-        if (!ws || small > 150 * 1024) return MAUA_EINVAL;
-        const int rows = g_nn_force_ws > 1 ? (g_nn_force_ws < n_frames ? g_nn_force_ws : n_frames) : (n_frames < 1024 ? n_frames : 1024);
-        hipLaunchKernelGGL(nn_median_kernel<false>, dim3(rows), dim3(256), small, (hipStream_t)stream, ch, out, n_bins, n_frames, k,
-                           width, ws);
+    } else {  // similarity rows in the caller's workspace, frames strided over the grid
+        if (small > 150 * 1024) return MAUA_EINVAL;
+        hipLaunchKernelGGL(nn_median_kernel<false>, dim3(nn_ws_rows(n_frames)), dim3(256), small, (hipStream_t)stream, ch, out, n_bins,
+                           n_frames, k, width, ws);
     }
     MAUA_LAUNCH_CHECK();
     return 0;

@@ -36,10 +36,8 @@ struct FirTail {
 };
 
 constexpr int TILE_ROWS_PER_WAVE = 32;
-int g_fir_path = 0;  // tuning switch (maua_tuning_set): 0 auto (= fir_strip_kernel, strip length 1), 1 fir_tile_kernel, 2 vec4, 3 wave tile, 4 wave tile + nt,
-                     // 5 dword tile + nt, 6.. pipelined strips of (value - 5) tiles
 
-template <int KH, int KW, int WX, bool TAIL, bool NT>
+template <int KH, int KW, int WX, bool TAIL>
 __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                        float* __restrict__ y, int planes, int in_h, int in_w,
                                                        int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
@@ -98,7 +96,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
         const int iy = iy0 + rr;
         v[i] = 0.f;
         if (rr < RH && okx && iy >= 0 && iy < in_h)
-            v[i] = NT ? __builtin_nontemporal_load(xp + (size_t)iy * in_w + ixm) : xp[(size_t)iy * in_w + ixm];
+            v[i] = xp[(size_t)iy * in_w + ixm];
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -172,24 +170,20 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
             float val = acc[o_done % KH];
             acc[o_done % KH] = 0.f;
             if (TAIL) val = lrelu_gain(fmaf(nw, nzv[TAIL ? o_done : 0], val * g) + bs);
-            if (col_ok && oy < out_h) {
-                if (NT) __builtin_nontemporal_store(val, yp + (size_t)oy * out_w + ox);
-                else yp[(size_t)oy * out_w + ox] = val;
-            }
+            if (col_ok && oy < out_h) yp[(size_t)oy * out_w + ox] = val;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// fir_strip_kernel: fir_tile_kernel with a software pipeline.  A workgroup walks DOWN a strip of `strip_len` vertically
-// adjacent tiles of one plane: the ~36 dword loads (and, with TAIL, the 32 noise values) of tile t+1 are issued right
-// after the barrier that publishes tile t in LDS and stay in flight while tile t is filtered and stored, so every CU
-// keeps HBM requests outstanding during its compute/store phases instead of alternating load-only / compute-only.
-template <int KH, int KW, int WX, bool TAIL, bool PIPE>
+// fir_strip_kernel: the plain op (no tail).  The same row-staged tile as fir_tile_kernel; a workgroup walks DOWN a strip of
+// `strip_len` vertically adjacent tiles of one plane (1 on the shapes of the path: longer, software-pipelined strips measured
+// no better, profiles/r02_w2d.md).  64 VGPRs, 8 waves/SIMD: 5.3-5.6 TB/s on [8,32,1025,1025].
+template <int KH, int KW, int WX>
 __global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                         float* __restrict__ y, int planes, int in_h, int in_w,
                                                         int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
-                                                        int tiles_y, int strip_len, FirTail tail) {
+                                                        int tiles_y, int strip_len) {
     constexpr int WY = 4 / WX;
     constexpr int TH = TILE_ROWS_PER_WAVE;
     constexpr int TW = 64 * WX;
@@ -200,21 +194,11 @@ __global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     const int strips_y = (tiles_y + strip_len - 1) / strip_len;
     int t = xcd_remap(blockIdx.x, gridDim.x);
-    int plane, tile_x, strip;
-    if (TAIL) {  // channel fastest: planes sharing one noise strip run back-to-back on one XCD
-        const int c = t % tail.channels;
-        t /= tail.channels;
-        strip = t % strips_y;
-        t /= strips_y;
-        tile_x = t % tiles_x;
-        plane = (t / tiles_x) * tail.channels + c;
-    } else {
-        const int per_plane = tiles_x * strips_y;
-        plane = t / per_plane;
-        t -= plane * per_plane;
-        tile_x = t / strips_y;
-        strip = t - tile_x * strips_y;
-    }
+    const int per_plane = tiles_x * strips_y;
+    const int plane = t / per_plane;
+    t -= plane * per_plane;
+    const int tile_x = t / strips_y;
+    const int strip = t - tile_x * strips_y;
     const int ty_begin = strip * strip_len;
     const int ty_end = min(tiles_y, ty_begin + strip_len);
     const int ox0 = tile_x * TW;
@@ -235,19 +219,6 @@ __global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict_
     const int row0 = wy * TH;
     const bool col_ok = ox < out_w;
 
-    float g = 1.f, nw = 0.f, bs = 0.f;
-    const float* nz = nullptr;
-    if (TAIL) {
-        const int b = plane / tail.channels;
-        const int c = plane - b * tail.channels;
-        if (tail.gain) g = tail.gain[plane];
-        bs = tail.bias ? tail.bias[c] : 0.f;
-        if (tail.noise) {
-            nw = tail.noise_w[0];
-            nz = tail.noise + (size_t)b * tail.noise_batch_stride;
-        }
-    }
-
     // Staging map: thread (ty, tx) owns column tx of rows ty, ty+WY, ... (a wave instruction = 64 consecutive floats of
     // one row, address = uniform row base + lane offset -> no per-element decode, no 64-bit address registers); the
     // KW-1 halo columns are spread over the first (KW-1)*RH threads.
@@ -257,7 +228,6 @@ __global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict_
     const int ixm = ix0 + tx;
     const bool okx = ixm >= 0 && ixm < in_w;
     float v[NR], vh[NH];
-    float nzn[TAIL ? TH : 1];  // noise of the tile being fetched (PIPE: a second copy, nzv, holds the tile being filtered)
     auto issue = [&](int tile_y) {
         const int iy0 = tile_y * (WY * TH) - pad_y0;
 #pragma unroll
@@ -275,19 +245,10 @@ __global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict_
             vh[h] = 0.f;
             if (e < (KW - 1) * RH && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) vh[h] = xp[(size_t)iy * in_w + ix];
         }
-        if (TAIL) {
-            const int oyb = tile_y * (WY * TH) + row0;
-#pragma unroll
-            for (int o = 0; o < TH; ++o) {
-                nzn[o] = 0.f;
-                if (nz && col_ok && oyb + o < out_h) nzn[o] = nz[(size_t)(oyb + o) * out_w + ox];
-            }
-        }
     };
 
     issue(ty_begin);
     for (int tile_y = ty_begin; tile_y < ty_end; ++tile_y) {
-        float nzv[(TAIL && PIPE) ? TH : 1];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int rr = ty + i * WY;
@@ -299,12 +260,7 @@ __global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict_
             const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
             if (e < (KW - 1) * RH) lds[hr * RW + hc] = vh[h];
         }
-        if (TAIL && PIPE) {
-#pragma unroll
-            for (int o = 0; o < TH; ++o) nzv[o] = nzn[o];
-        }
         __syncthreads();
-        if (PIPE && tile_y + 1 < ty_end) issue(tile_y + 1);
 
         const int oy0 = tile_y * (WY * TH);
         float acc[KH];
@@ -327,279 +283,13 @@ __global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict_
             const int o_done = r - (KH - 1);
             if (o_done >= 0) {
                 const int oy = oy0 + row0 + o_done;
-                float val = acc[o_done % KH];
+                const float val = acc[o_done % KH];
                 acc[o_done % KH] = 0.f;
-                if (TAIL) val = lrelu_gain(fmaf(nw, PIPE ? nzv[(TAIL && PIPE) ? o_done : 0] : nzn[TAIL ? o_done : 0], val * g) + bs);
                 if (col_ok && oy < out_h) yp[(size_t)oy * out_w + ox] = val;
             }
         }
         __syncthreads();  // every wave is done reading this tile before the next one overwrites LDS
-        if (!PIPE && tile_y + 1 < ty_end) issue(tile_y + 1);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// fir_wave_kernel: one WAVE per workgroup, 32 x 64 output tile, no cross-wave barrier.  The stream probe
-// (tools/stream_probe.hip) shows that on MI355X the copy shapes that approach the HBM ceiling (6.3-6.7 TB/s) are the
-// ones made of very many tiny independent workgroups; phase-locked 256-thread tiles top out ~25 % lower.  Here every
-// wave stages its own 35 x 67 halo tile (37 dword loads in flight per lane, 9.4 KB LDS -> 16 resident waves per CU),
-// then walks down its 64 columns exactly like fir_tile_kernel.  NT selects non-temporal loads/stores for the
-// streamed planes (read once / written once per launch).
-template <int KH, int KW, bool TAIL, bool NT>
-__global__ __launch_bounds__(64) void fir_wave_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                      float* __restrict__ y, int planes, int in_h, int in_w, int out_h,
-                                                      int out_w, int pad_x0, int pad_y0, int tiles_x, int tiles_y,
-                                                      FirTail tail) {
-    constexpr int TH = 32, TW = 64;
-    constexpr int RH = TH + KH - 1, RW = TW + KW - 1;
-    constexpr int NIT = (RH * RW + 63) / 64;
-    __shared__ float lds[RH * RW];
-    const int lane = threadIdx.x;
-    int t = xcd_remap(blockIdx.x, gridDim.x);
-    int plane, tile_x, tile_y;
-    if (TAIL) {
-        const int c = t % tail.channels;
-        t /= tail.channels;
-        tile_y = t % tiles_y;
-        t /= tiles_y;
-        tile_x = t % tiles_x;
-        plane = (t / tiles_x) * tail.channels + c;
-    } else {
-        const int tiles_per_plane = tiles_x * tiles_y;
-        plane = t / tiles_per_plane;
-        t -= plane * tiles_per_plane;
-        tile_x = t / tiles_y;
-        tile_y = t - tile_x * tiles_y;
-    }
-    const int oy0 = tile_y * TH, ox0 = tile_x * TW;
-    float kf[KH][KW];
-#pragma unroll
-    for (int i = 0; i < KH; ++i)
-#pragma unroll
-        for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
-    const float* xp = x + (size_t)plane * in_h * in_w;
-    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
-
-    float v[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = lane + it * 64;
-        const int rr = idx / RW, cc = idx - rr * RW;
-        const int iy = iy0 + rr, ix = ix0 + cc;
-        const bool ok = (idx < RH * RW) && (iy >= 0) && (iy < in_h) && (ix >= 0) && (ix < in_w);
-        v[it] = 0.f;
-        if (ok) v[it] = NT ? __builtin_nontemporal_load(xp + (size_t)iy * in_w + ix) : xp[(size_t)iy * in_w + ix];
-    }
-    const int ox = ox0 + lane;
-    const bool col_ok = ox < out_w;
-    float g = 1.f, nw = 0.f, bs = 0.f;
-    float nzv[TAIL ? TH : 1];
-    if (TAIL) {
-        const int b = plane / tail.channels;
-        const int c = plane - b * tail.channels;
-        if (tail.gain) g = tail.gain[plane];
-        bs = tail.bias ? tail.bias[c] : 0.f;
-#pragma unroll
-        for (int o = 0; o < TH; ++o) nzv[o] = 0.f;
-        if (tail.noise) {
-            nw = tail.noise_w[0];
-            const float* nz = tail.noise + (size_t)b * tail.noise_batch_stride;
-#pragma unroll
-            for (int o = 0; o < TH; ++o)
-                if (col_ok && oy0 + o < out_h) nzv[o] = nz[(size_t)(oy0 + o) * out_w + ox];
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = lane + it * 64;
-        if (idx < RH * RW) lds[idx] = v[it];
-    }
-    __syncthreads();  // single wave: lgkmcnt wait only
-
-    float* yp = y + (size_t)plane * out_h * out_w;
-    float acc[KH];
-#pragma unroll
-    for (int i = 0; i < KH; ++i) acc[i] = 0.f;
-    const float* lrow = lds + lane;
-#pragma unroll
-    for (int r = 0; r < TH + KH - 1; ++r) {
-        float in[KW];
-#pragma unroll
-        for (int j = 0; j < KW; ++j) in[j] = lrow[r * RW + j];
-#pragma unroll
-        for (int i = 0; i < KH; ++i) {
-            const int o = r - i;
-            if (o >= 0 && o < TH) {
-#pragma unroll
-                for (int j = 0; j < KW; ++j) acc[o % KH] = fmaf(kf[i][j], in[j], acc[o % KH]);
-            }
-        }
-        const int o_done = r - (KH - 1);
-        if (o_done >= 0) {
-            const int oy = oy0 + o_done;
-            float val = acc[o_done % KH];
-            acc[o_done % KH] = 0.f;
-            if (TAIL) val = lrelu_gain(fmaf(nw, nzv[TAIL ? o_done : 0], val * g) + bs);
-            if (col_ok && oy < out_h) {
-                if (NT) __builtin_nontemporal_store(val, yp + (size_t)oy * out_w + ox);
-                else yp[(size_t)oy * out_w + ox] = val;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// fir_vec4_kernel: the wide-plane fast path (out_w >= 256, out_w % 4 == 0).  Same tiling idea as fir_tile_kernel
-// (32 x 256 output tile, one barrier), but every HBM access is 16 bytes per lane:
-//   * loads : float4 at 16-byte ALIGNED absolute addresses.  Rows of the (2H+1)-wide plane start at arbitrary 4-byte
-//             phases, so the aligned quad sequence of row r is shifted by sh_r = (row start) mod 4 floats against the
-//             tile's logical columns; the shift is undone while scattering the quad into LDS (4 ds_write_b32).
-//   * stores: lane = 4 consecutive output columns -> one float4 per lane per row, 1 KiB per wave instruction.
-//   * LDS   : two ds_read_b128 per lane per input row feed 4 x KH x KW FMAs.
-// Measured on MI355X: dword-per-lane streaming peaks at ~3.5 TB/s, 16-byte-per-lane at ~5.1 TB/s (tools/microbench.py).
-template <int KH, int KW, bool TAIL>
-__global__ __launch_bounds__(256) void fir_vec4_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                       float* __restrict__ y, int planes, int in_h, int in_w,
-                                                       int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
-                                                       int tiles_y, int64_t total_in, FirTail tail) {
-    constexpr int TW = 256, WR = 8, TH = 4 * WR;
-    constexpr int RH = TH + KH - 1;
-    constexpr int RW = TW + KW - 1;
-    constexpr int LW = TW + 8;                 // LDS row stride (floats), multiple of 4
-    constexpr int NJ = (RW + 3 + 3) / 4;       // aligned quads that can overlap one staged row
-    constexpr int NIT = (RH * NJ + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x;
-    int t = xcd_remap(blockIdx.x, gridDim.x);
-    int plane, tile_x, tile_y;
-    if (TAIL) {  // channel fastest: the 32..512 planes that share one noise tile run back-to-back on one XCD
-        const int c = t % tail.channels;
-        t /= tail.channels;
-        tile_y = t % tiles_y;
-        t /= tiles_y;
-        tile_x = t % tiles_x;
-        plane = (t / tiles_x) * tail.channels + c;
-    } else {
-        const int tiles_per_plane = tiles_x * tiles_y;
-        plane = t / tiles_per_plane;
-        t -= plane * tiles_per_plane;
-        tile_x = t / tiles_y;
-        tile_y = t - tile_x * tiles_y;
-    }
-    const int oy0 = tile_y * TH, ox0 = tile_x * TW;
-
-    float kf[KH][KW];
-#pragma unroll
-    for (int i = 0; i < KH; ++i)
-#pragma unroll
-        for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
-
-    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
-    const int64_t plane_base = (int64_t)plane * in_h * in_w;
-
-    // ---- stage (all global loads first)
-    float4 v[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int item = tid + it * 256;
-        const int r = item / NJ, j = item - r * NJ;
-        const int iy = iy0 + r;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (item < RH * NJ && iy >= 0 && iy < in_h) {
-            const int64_t g0 = plane_base + (int64_t)iy * in_w + ix0;  // absolute index of logical column 0
-            const int64_t a = (g0 & ~(int64_t)3) + 4 * j;
-            if (a >= 0 && a + 3 < total_in) {
-                v[it] = *reinterpret_cast<const float4*>(x + a);
-            } else {  // first / last quad of the whole tensor
-                float e[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = (a + q >= 0 && a + q < total_in) ? x[a + q] : 0.f;
-                v[it] = make_float4(e[0], e[1], e[2], e[3]);
-            }
-        }
-    }
-    // noise quads of this lane's 8 output rows (TAIL): in flight together with the input tile
-    const int wave = tid >> 6, lane = tid & 63;
-    const int ox = ox0 + 4 * lane;
-    const bool col_ok = ox < out_w;
-    float4 nzq[WR];
-    float g = 1.f, nw = 0.f, bs = 0.f;
-    if (TAIL) {
-        const int b = plane / tail.channels;
-        const int c = plane - b * tail.channels;
-        if (tail.gain) g = tail.gain[plane];
-        bs = tail.bias ? tail.bias[c] : 0.f;
-#pragma unroll
-        for (int o = 0; o < WR; ++o) nzq[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tail.noise) {
-            nw = tail.noise_w[0];
-            const float* nz = tail.noise + (size_t)b * tail.noise_batch_stride;
-#pragma unroll
-            for (int o = 0; o < WR; ++o) {
-                const int oy = oy0 + wave * WR + o;
-                if (col_ok && oy < out_h) nzq[o] = *reinterpret_cast<const float4*>(nz + (size_t)oy * out_w + ox);
-            }
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int item = tid + it * 256;
-        const int r = item / NJ, j = item - r * NJ;
-        if (item < RH * NJ) {
-            const int64_t g0 = plane_base + (int64_t)(iy0 + r) * in_w + ix0;
-            const int sh = (int)(g0 & 3);
-            const float e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = 4 * j + q - sh;  // logical tile column of this element
-                const int ix = ix0 + c;
-                if (c >= 0 && c < RW) lds[r * LW + c] = (ix >= 0 && ix < in_w) ? e[q] : 0.f;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- compute: wave = 8 output rows, lane = 4 output columns
-    float* yp = y + (size_t)plane * out_h * out_w;
-    float acc[KH][4];
-#pragma unroll
-    for (int i = 0; i < KH; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[i][q] = 0.f;
-    const float* lrow = lds + (wave * WR) * LW + 4 * lane;
-#pragma unroll
-    for (int r = 0; r < WR + KH - 1; ++r) {
-        const float4 lo = *reinterpret_cast<const float4*>(lrow + r * LW);
-        const float4 hi4 = *reinterpret_cast<const float4*>(lrow + r * LW + 4);
-        const float in[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-#pragma unroll
-        for (int i = 0; i < KH; ++i) {
-            const int o = r - i;
-            if (o >= 0 && o < WR) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int j = 0; j < KW; ++j) acc[o % KH][q] = fmaf(kf[i][j], in[q + j], acc[o % KH][q]);
-            }
-        }
-        const int o_done = r - (KH - 1);
-        if (o_done >= 0) {
-            const int oy = oy0 + wave * WR + o_done;
-            float out4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                out4[q] = acc[o_done % KH][q];
-                acc[o_done % KH][q] = 0.f;
-            }
-            if (TAIL) {
-                const float nzv[4] = {nzq[o_done].x, nzq[o_done].y, nzq[o_done].z, nzq[o_done].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) out4[q] = lrelu_gain(fmaf(nw, nzv[q], out4[q] * g) + bs);
-            }
-            if (col_ok && oy < out_h)
-                *reinterpret_cast<float4*>(yp + (size_t)oy * out_w + ox) = make_float4(out4[0], out4[1], out4[2], out4[3]);
-        }
+        if (tile_y + 1 < ty_end) issue(tile_y + 1);
     }
 }
 
@@ -688,32 +378,6 @@ int launch_fir_typed(const void* x, const void* k, void* y, int major, int in_h,
 template <int KH, int KW, bool TAIL>
 int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
                     int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
-    if ((g_fir_path == 3 || g_fir_path == 4) && out_w >= 64) {  // 3 = wave tiles, 4 = wave tiles + non-temporal
-        const int tiles_x = ceil_div(out_w, 64), tiles_y = ceil_div(out_h, 32);
-        const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
-        if (nblocks > 0x7fffffff) return MAUA_EINVAL;
-        if (g_fir_path == 4)
-            hipLaunchKernelGGL((fir_wave_kernel<KH, KW, TAIL, true>), dim3((unsigned)nblocks), dim3(64), 0, st, x, k, y,
-                               planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
-        else
-            hipLaunchKernelGGL((fir_wave_kernel<KH, KW, TAIL, false>), dim3((unsigned)nblocks), dim3(64), 0, st, x, k, y,
-                               planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
-        MAUA_LAUNCH_CHECK();
-        return 0;
-    }
-    const bool aligned = g_fir_path == 2 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) &&
-                         (!TAIL || !tail.noise || ((((uintptr_t)tail.noise) & 15) == 0 && tail.noise_batch_stride % 4 == 0));
-    if (out_w >= 256 && out_w % 4 == 0 && aligned) {
-        constexpr int TH = 32, TW = 256, RH = TH + KH - 1, LW = TW + 8;
-        const int tiles_x = ceil_div(out_w, TW), tiles_y = ceil_div(out_h, TH);
-        const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
-        if (nblocks > 0x7fffffff) return MAUA_EINVAL;
-        hipLaunchKernelGGL((fir_vec4_kernel<KH, KW, TAIL>), dim3((unsigned)nblocks), dim3(256),
-                           (size_t)RH * LW * sizeof(float), st, x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0,
-                           tiles_x, tiles_y, (int64_t)planes * in_h * in_w, tail);
-        MAUA_LAUNCH_CHECK();
-        return 0;
-    }
     auto go = [&](auto wx_tag) -> int {
         constexpr int WX = decltype(wx_tag)::value;
         constexpr int WY = 4 / WX;
@@ -723,23 +387,12 @@ int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in
         if (nblocks <= 0) return 0;
         if (nblocks > 0x7fffffff) return MAUA_EINVAL;
         const size_t lds_bytes = (size_t)RH * RW * sizeof(float);
-        if ((g_fir_path == 0 && !TAIL) || g_fir_path >= 6) {  // plain op: fir_strip_kernel with strip length 1; 6.. = pipelined strips
-            int strip_len = g_fir_path >= 6 ? g_fir_path - 5 : 1;
-            if (strip_len > tiles_y) strip_len = tiles_y;
-            while (strip_len > 1 && (int64_t)planes * tiles_x * ceil_div(tiles_y, strip_len) < 1024) strip_len >>= 1;
-            const int64_t nb = (int64_t)planes * tiles_x * ceil_div(tiles_y, strip_len);
-            if (strip_len > 1)
-                hipLaunchKernelGGL((fir_strip_kernel<KH, KW, WX, TAIL, true>), dim3((unsigned)nb), dim3(256), lds_bytes, st,
-                                   x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, strip_len, tail);
-            else
-                hipLaunchKernelGGL((fir_strip_kernel<KH, KW, WX, TAIL, false>), dim3((unsigned)nb), dim3(256), lds_bytes, st,
-                                   x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, strip_len, tail);
-        } else if (g_fir_path == 5)
-            hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL, true>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st,
-                               x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
+        if constexpr (TAIL)
+            hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, true>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y,
+                               planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
         else
-            hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL, false>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st,
-                               x, k, y, planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
+            hipLaunchKernelGGL((fir_strip_kernel<KH, KW, WX>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y, planes,
+                               in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, 1);
         MAUA_LAUNCH_CHECK();
         return 0;
     };
@@ -758,19 +411,6 @@ int dispatch_fir_tile(const float* x, const float* k, float* y, int planes, int 
 }
 
 }  // namespace
-
-int maua_conv_debug_set(int v);
-int maua_conv_cfg_set(int v);
-int maua_w2d_debug_set(int v);
-int maua_nn_force_ws_set(int v);
-extern "C" int maua_tuning_set(int key, int value) {
-    if (key == 0) { g_fir_path = value; return 0; }
-    if (key == 1) return maua_conv_debug_set(value);
-    if (key == 2) return maua_conv_cfg_set(value);
-    if (key == 3) return maua_w2d_debug_set(value);
-    if (key == 4) return maua_nn_force_ws_set(value);
-    return MAUA_EINVAL;
-}
 
 extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
                                   int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,

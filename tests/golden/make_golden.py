@@ -518,7 +518,8 @@ def latent_utils_fixture(ref_latent, ref_signal):
     out["slerp.a"], out["slerp.b"], out["slerp.vals"] = a, b, vals
     out["slerp.y"] = np.stack([ref_latent.slerp(v, a, b) for v in vals])
     out["slerp.parallel"] = np.stack([ref_latent.slerp(v, a, 2.0 * a) for v in vals])
-    cases = [(10, 0, 10), (10, 7, 6), (10, 9, 10), (10, 3, 4), (1, 0, 1), (1, 0, 5), (7, 5, 16), (6, 0, 13)]
+    cases = [(10, 0, 10), (10, 7, 6), (10, 9, 10), (10, 3, 4), (1, 0, 1), (1, 0, 5), (7, 5, 16), (6, 0, 13),
+             (10, 10, 4), (7, 7, 9)]  # start == n: the reference restarts at index 0 (start > n raises there)
     out["wrap.cases"] = np.array(cases, dtype=np.int64)
     for n, start, length in cases:
         out[f"wrap.{n}_{start}_{length}"] = ref_latent.wrapping_slice(torch.arange(n), start, length, return_indices=True).numpy()

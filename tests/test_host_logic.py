@@ -245,8 +245,9 @@ def test_chroma_chain_oracle_properties():
 
 def test_ar_namespace_covers_the_shipped_example_plugins(tmp_path, monkeypatch):
     """Every ``ar.<name>`` the reference's example plugins use (default / temper / kelp / tauceti: onsets, chroma, rms,
-    gaussian_filter, spline_loops, wrapping_slice, perlin_noise, AddNoise, plot_signals, ...) exists in the drop-in package;
-    the inspection helpers run headless (figures land in workspace/*.png)."""
+    gaussian_filter, spline_loops, wrapping_slice, perlin_noise, AddNoise, plot_signals, ...) exists in the drop-in package.
+    The matplotlib inspection helpers (audioreactive/util.py, SURVEY.md §2 row 10: out of scope) are warn-and-ignore stubs, so
+    that an unmodified plugin that calls them (examples/kelp.py:33) still runs."""
     import maua_stylegan2_amd.audioreactive as ar
 
     used = ["gaussian_filter", "onsets", "chroma", "chroma_weight_latents", "wrapping_slice", "spline_loops", "rms",
@@ -255,10 +256,9 @@ def test_ar_namespace_covers_the_shipped_example_plugins(tmp_path, monkeypatch):
             "slerp_loops", "generate_latents", "save_latents", "NetworkBend", "Translate", "Zoom", "Rotate", "set_SMF"]
     assert [n for n in used if not hasattr(ar, n)] == []
     monkeypatch.chdir(tmp_path)
-    ar.info([np.ones(3), torch.zeros(2, 2)])
-    assert ar.plot_signals([np.sin(np.linspace(0, 6, 100)), torch.linspace(0, 1, 50)]).endswith("signals.png")
-    assert ar.plot_spectra([np.random.rand(40, 80), np.random.rand(30, 12)], chroma=True).endswith("spectra.png")
-    assert (tmp_path / "workspace" / "signals.png").stat().st_size > 0
+    with pytest.warns(UserWarning, match="out of scope"):
+        assert ar.plot_signals([np.sin(np.linspace(0, 6, 100)), torch.linspace(0, 1, 50)]) is None
+    assert not (tmp_path / "workspace").exists()
 
 
 def test_generator_constructor_bookkeeping_matches_reference(built_lib, golden):
@@ -332,6 +332,9 @@ def test_latent_helpers_match_reference_golden(golden):
         got = latent.wrapping_slice(torch.arange(int(n)), int(start), int(length), return_indices=True)
         assert got.dtype == torch.int64 and got.tolist() == want.tolist(), (n, start, length)
         assert latent.wrapping_slice(torch.arange(int(n)) * 3, int(start), int(length)).tolist() == (want * 3).tolist()
+    assert any(int(start) == int(n) for n, start, _ in g["wrap.cases"])  # the start == n edge is in the fixture
+    with pytest.raises(RuntimeError):  # the reference's arange(start, n) raises for a start beyond the end
+        latent.wrapping_slice(torch.arange(10), 12, 3)
 
 
 def test_complex_flux_and_local_group_delay():

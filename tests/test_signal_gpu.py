@@ -270,22 +270,26 @@ def test_cens_and_nn_filter_vs_oracle(gpu):
 
 def test_nn_filter_long_track_path_equals_lds_path(gpu):
     """Tracks beyond ~16k chroma frames keep the similarity rows in a device workspace and stride the frames over a fixed
-    grid (round 1 returned them unfiltered).  The two paths of the same kernel must agree bit for bit: forced here on a
-    short clip, with fewer workspace rows than frames so that workgroups really walk several frames."""
+    grid (round 1 returned them unfiltered).  The two paths of the same kernel must agree bit for bit: a caller-supplied
+    workspace selects the workspace path at any size (include/maua_hip.h), here on a clip with more frames than workspace
+    rows (1024) so that workgroups really walk several frames."""
+    import math
+
     from maua_stylegan2_amd import _lib
     from maua_stylegan2_amd.audioreactive import signal as sig
 
     rng = np.random.default_rng(14)
-    ch = np.abs(rng.standard_normal((12, 700))).astype(np.float32)
-    lds_path = sig.nn_filter(torch.from_numpy(ch)).cpu().numpy()
+    t = 1500
+    ch = torch.from_numpy(np.abs(rng.standard_normal((12, t))).astype(np.float32)).cuda()
+    lds_path = sig.nn_filter(ch).cpu().numpy()
     lib = _lib.load()
-    try:
-        lib.maua_tuning_set(4, 37)  # workspace path with 37 rows: 19 frames per workgroup
-        assert lib.maua_nn_median_ws_doubles(12, 700, 54) == 37 * 700
-        ws_path = sig.nn_filter(torch.from_numpy(ch)).cpu().numpy()
-    finally:
-        lib.maua_tuning_set(4, 0)
-    np.testing.assert_array_equal(ws_path, lds_path)
+    k = int(min(t - 1, 2 * math.ceil(math.sqrt(t - 1))))
+    assert lib.maua_nn_median_ws_doubles(12, t, k) == 0  # fits LDS: nn_filter took the LDS path
+    ws = torch.empty(1024 * t, dtype=torch.float64, device="cuda")
+    out = torch.empty_like(ch)
+    _lib.check(lib.maua_nn_median_f32(ch.data_ptr(), out.data_ptr(), 12, t, k, 1, ws.data_ptr(), _lib.stream_ptr(ch.device)),
+               "maua_nn_median_f32")
+    np.testing.assert_array_equal(out.cpu().numpy(), lds_path)
     # and a genuinely long sequence runs (20k frames: 160 KB of similarities per frame) and stays a median of its inputs
     long = np.abs(rng.standard_normal((12, 20000))).astype(np.float32)
     assert lib.maua_nn_median_ws_doubles(12, 20000, 284) == 1024 * 20000
