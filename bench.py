@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — synthesized 1024^2 StyleGAN2 frames/s on N MI355X (BASELINE.json metric), with roofline + CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size 1024]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--batches-per-step Q] [--size 1024] [--bends]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one batch of B synthetic frames on every rank: copy the batch's latents
-(already resident in HBM) into the graph's static inputs, replay the hipGraph-captured generator forward
-(style affines, demod, 17 StyledConv, 9 ToRGB; the last ToRGB writes uint8 NHWC frames, render.py:40-43 epilogue).  Frames
-are independent, so ranks shard them with no data-path collective (weak scaling: B frames per rank per step).
+A "step" = one pass of the hot path over Q (default 15) batches of B (default 8) synthetic frames on every rank.  The per-frame
+sequences (latents, noise maps <= 256^2) are resident in HBM; a batch = one 4-byte frame-index write + one replay of the
+hipGraph-captured generator forward (style affines, demod, 17 StyledConv, 9 ToRGB; the last layer writes uint8 NHWC frames,
+the render.py:40-43 epilogue), batches alternating over `--lanes` graphs on their own streams exactly as render.synthesize
+does.  Frames are independent, so ranks shard them with no data-path collective (weak scaling: Q * B frames per rank per step).
 Weights are random-init (seeded numpy streams) of the real 1024^2 architecture; arithmetic is fp32 end to end.
 
 Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the frame (largest share of device time, measured
 live with HIP events on the launch stream); `roofline_upfirdn2d` is the standalone upfirdn2d op on the Blur-after-
 up-conv shape that carries 49 % of the path's upfirdn2d bytes, which BASELINE.json's metric names.
-`cpu_baseline` times oracle/ (the CPU restatement pinned to the reference by tests/golden) on the host cores.
+`side_configs` times BASELINE configs 2 (256^2 generator) and 5 (1024^2 with per-frame Translate + Zoom network bends,
+captured) on this GPU.  `cpu_baseline` times oracle/ (the CPU restatement pinned to the reference by tests/golden) on the
+host cores (BASELINE.md §4 legs).  `frame_check` compares the frames of the last replay of every lane with the eager
+(un-captured) forward of the same frames, bit for bit.
 """
 import argparse
 import json
@@ -33,6 +37,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+POOL = 64  # distinct batches of the HBM-resident sequence (POOL * B frames), cycled through
 
 
 def pmc_traffic_table():
@@ -79,13 +84,12 @@ def time_calls(fn, iters, stream_ptr):
 INSTANCES = {}  # bench row name -> rocprofv3 kernel instance name (filled by layer_breakdown)
 
 
-def layer_breakdown(g, batch, static, stream):
-    """Per-kernel-family device time of one forward (eager launches on `stream`, HIP events)."""
+def layer_breakdown(g, batch, noise_batch, stream):
+    """Per-kernel-family device time of one forward (eager launches on `stream`, HIP events).  ``noise_batch``: per layer a
+    [batch or 1, 1, r, r] map (the first frames of the bench's sequences / the checkpoint buffers)."""
     from maua_stylegan2_amd import _lib
-    from maua_stylegan2_amd.seeding import channels_for
 
     sp = stream.cuda_stream
-    dev = static["latents"].device
     rows = []
     bufs = lambda name, shape: g._buf(batch, "bench." + name, shape)  # noqa: E731
     info = g._table(batch)
@@ -98,8 +102,7 @@ def layer_breakdown(g, batch, static, stream):
 
     li = 0
     x = g._buf(batch, "const", (batch, 512, 4, 4))
-    layers = [("conv1", g.conv1, x, 0)]
-    rows.append(("conv1", "modconv", time_calls(lambda: g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), static["noise"][0], bufs, "c1"), 20, sp),
+    rows.append(("conv1", "modconv", time_calls(lambda: g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1"), 20, sp),
                  2 * 512 * 512 * 9 * 16 * batch, 0))
     out = g._buf(batch, "conv1", (batch, 512, 4, 4))
     rows.append(("to_rgb1", "torgb", time_calls(lambda: g.to_rgb1.run(out, s, ent[1]["s_off"], None, bufs("rgb1", (batch, 3, 4, 4))), 20, sp),
@@ -111,7 +114,7 @@ def layer_breakdown(g, batch, static, stream):
         cin, cout = up.conv.in_channel, up.conv.out_channel
         h = out.shape[2]
         e_up, e_pl, e_rgb = ent[li], ent[li + 1], ent[li + 2]
-        nz1, nz2 = static["noise"][2 * n + 1], static["noise"][2 * n + 2]
+        nz1, nz2 = noise_batch[2 * n + 1], noise_batch[2 * n + 2]
         xin = out
         # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
         raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
@@ -151,48 +154,216 @@ def layer_breakdown(g, batch, static, stream):
     return rows
 
 
-def cpu_baseline(size, max_seconds=25.0):
-    """Oracle (kind "port") on the host cores: bounded sample of 1024^2 frames, batch 1."""
+def cpu_baseline(size, budget_s=75.0):
+    """Oracle (kind "port") on the host cores, the legs of BASELINE.md §4 on a bounded sample: config 1 (256^2, 16 fixed latents,
+    batch 8: 1 warm-up + 3 repetitions), the benched 1024^2 generator at batch 1 (1 warm-up + 3 repetitions) and once at batch 8
+    (the oracle is batch-parallel torch CPU code: the batch-8 leg says what batching buys on the host)."""
     from maua_stylegan2_amd import seeding
     from oracle import stylegan2_oracle as so
 
     torch.set_grad_enabled(False)
-    sd = seeding.seeded_state_dict(size, seed=0)
-    n_latent = 2 * (size.bit_length() - 1) - 2
-    lat = seeding.seeded_latents(1, n_latent, seed=1)
-    noise = seeding.seeded_noise(1, size, seed=2)
-    so.generator_forward(sd, lat, noise)  # warm-up
-    t0, n = time.perf_counter(), 0
-    while n < 3 or (time.perf_counter() - t0 < max_seconds and n < 64):
-        so.generator_forward(sd, lat, noise)
-        n += 1
-        if time.perf_counter() - t0 > max_seconds:
-            break
-    dt = time.perf_counter() - t0
+    t_start = time.perf_counter()
+
+    def leg(sz, n_frames, batch, reps, warm):
+        sd = seeding.seeded_state_dict(sz, seed=0)
+        n_latent = 2 * (sz.bit_length() - 1) - 2
+        lat = seeding.seeded_latents(n_frames, n_latent, seed=1)
+        noise = seeding.seeded_noise(n_frames, sz, seed=2)
+
+        def once():
+            t0 = time.perf_counter()
+            for i in range(0, n_frames, batch):
+                so.generator_forward(sd, lat[i:i + batch], [nz[i:i + batch] for nz in noise])
+            return n_frames / (time.perf_counter() - t0)
+
+        for _ in range(warm):
+            once()
+        rates = []
+        for _ in range(reps):
+            rates.append(once())
+            if time.perf_counter() - t_start > budget_s:
+                break
+        return {"frames_per_s_mean": sum(rates) / len(rates), "frames_per_s_min": min(rates), "repetitions": len(rates),
+                "frames_per_repetition": n_frames, "batch": batch, "size": sz}
+
+    legs = {"config1_256_b8": leg(256, 16, 8, 3, 1)}
+    if size != 256:
+        legs[f"{size}_b1"] = leg(size, 1, 1, 3, 1)
+        if time.perf_counter() - t_start < budget_s * 0.6:
+            legs[f"{size}_b8"] = leg(size, 8, 8, 1, 0)
+    head = legs[f"{size}_b1"] if size != 256 else legs["config1_256_b8"]
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), cpu_model)
     except OSError:
         pass
-    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model, "kind": "port",
-            "sample": f"{n} frames of {size}x{size}, batch 1, oracle/stylegan2_oracle.py (torch CPU fp32)"}
+    return {"value": head["frames_per_s_mean"], "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model,
+            "kind": "port",
+            "sample": (f"oracle/stylegan2_oracle.py (torch CPU fp32): {head['repetitions']} x {head['frames_per_repetition']} frame(s) of "
+                       f"{size}x{size} at batch {head['batch']} after 1 warm-up (value = mean); legs = the other BASELINE.md §4 cases"),
+            "legs": legs, "seconds": time.perf_counter() - t_start}
+
+
+class Workload:
+    """A generator + HBM-resident synthetic sequences + captured graph lanes, stepped as render.synthesize does."""
+
+    def __init__(self, size, batch, n_lanes, dev, rank, use_dist, bends=False):
+        from maua_stylegan2_amd import render, seeding
+        from maua_stylegan2_amd.models.stylegan2 import Generator
+
+        self.size, self.B, self.dev = size, batch, dev
+        g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+        g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
+        self.g = g = g.to(dev).eval()
+        if use_dist:  # weights: rank 0 is the source of truth (SURVEY.md §8e)
+            from maua_stylegan2_amd import sharding
+
+            sharding.broadcast_module(g)
+        # synthetic sequences resident in HBM: POOL * B frames of latents; noise maps for scales <= 256 are per-frame
+        # (audio-reactive in the default plugin), 512/1024 use the checkpoint buffers (get_noise -> None)
+        self.n_frames = n = POOL * batch
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1000 + rank)
+        self.latents = torch.randn(n, g.n_latent, 512, device=dev, generator=gen)
+        self.noise = [torch.randn(n, 1, r, r, device=dev, generator=gen) if r <= 256 else None for r in seeding.noise_sizes(size)]
+        self.bend_spec = []
+        if bends:  # BASELINE config 5 (SURVEY.md §8d): a modulated Translate at layer id 4 and a modulated Zoom at layer id 5 (16 x 16 features)
+            from maua_stylegan2_amd.audioreactive import bend
+
+            h = w = 16
+            saw = (torch.arange(n, device=dev, dtype=torch.float32) % 180) / 180.0 * w
+            translation = torch.stack([saw, torch.zeros_like(saw)], 1)
+            zoom = 1.0 + 0.25 * torch.sin(torch.arange(n, device=dev, dtype=torch.float32) / 30.0) ** 2
+            tnoise = 0.2 * torch.randn(1, 1, h, 5 * w, device=dev, generator=gen)
+            self.bend_spec = [
+                {"layer": 4, "modulation": translation, "transform": lambda b: bend.Translate(b, h, w, tnoise)},
+                {"layer": 5, "modulation": zoom, "transform": lambda b: bend.Zoom(b, h, w)},
+            ]
+        seq_bends, ok = render._sequence_bends(self.bend_spec)
+        assert ok
+        self.lanes = render.graph_lanes(g, batch, n_lanes, seq_bends)
+        for _, lane in self.lanes:
+            lane.bind(self.latents, self.noise, None)
+        self.n_lanes = len(self.lanes)
+        self.count = 0  # batches issued so far
+        self.last = [None] * self.n_lanes  # first frame of the last replay of every lane
+
+    def batch(self):
+        """Issue the next batch; returns (stream, lane)."""
+        k = self.count % self.n_lanes
+        stream, lane = self.lanes[k]
+        frame0 = (self.count % POOL) * self.B
+        lane.replay(frame0, stream.cuda_stream)
+        self.last[k] = frame0
+        self.count += 1
+        return stream, lane
+
+    def sync(self):
+        for stream, _ in self.lanes:
+            stream.synchronize()
+
+    def eager_frames(self, frame0):
+        """uint8 frames of [frame0, frame0 + B) through the eager (un-captured) forward of the same generator."""
+        from maua_stylegan2_amd import render
+
+        n, m = frame0, frame0 + self.B
+        bend_batch = [{"layer": bd["layer"], "transform": bd["transform"](bd["modulation"][n:m])} for bd in self.bend_spec]
+        img, _ = self.g(styles=self.latents[n:m], noise=[None if nz is None else nz[n:m] for nz in self.noise], truncation=1.0,
+                        transform_dict_list=bend_batch, randomize_noise=False, input_is_latent=True)
+        return render.frames_to_uint8(img)
+
+    def check_frames(self):
+        """The last replay of every lane against the eager forward of the same frames."""
+        self.sync()
+        worst = 0
+        for k, (stream, lane) in enumerate(self.lanes):
+            if self.last[k] is None:
+                continue
+            got = lane.u8.clone()
+            want = self.eager_frames(self.last[k])
+            torch.cuda.synchronize(self.dev)
+            worst = max(worst, int((got.int() - want.int()).abs().max()))
+        return worst
+
+
+def time_region(wl, steps, bps, mode, use_dist, world):
+    """Time ``steps`` steps of ``bps`` batches.  mode "synth": replay + uint8 epilogue only.  "gathered" (N > 1): every batch's
+    frames also travel to rank 0 through sharding.FrameStream (one asynchronous RCCL gather per batch, as render() issues them);
+    the clock stops when the last round has landed in rank 0's HBM — SURVEY.md 8d's definition of the metric ("uint8 frames
+    gathered to rank 0").  "pcie": every batch's frames also go to the host through the pinned staging ring on a copy stream
+    exactly as render() does (null sink)."""
+    import torch.distributed as dist
+
+    dev, B, size = wl.dev, wl.B, wl.size
+    fs = None
+    if mode == "gathered":
+        from maua_stylegan2_amd import sharding
+
+        fs = sharding.FrameStream(world * steps * bps * B, B, (size, size, 3), dev)
+    n_slots = 3
+    pinned = [torch.empty((B, size, size, 3), dtype=torch.uint8).pin_memory() for _ in range(n_slots)] if mode == "pcie" else None
+    copy_stream = torch.cuda.Stream(dev) if mode == "pcie" else None
+    copied = [None] * n_slots
+    wl.sync()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    k = 0
+    for _ in range(steps):
+        for _ in range(bps):
+            stream, lane = wl.batch()
+            if fs is not None:
+                with torch.cuda.stream(stream):
+                    fs.push(k, lane.u8)
+            if mode == "pcie":
+                slot = k % n_slots
+                if copied[slot] is not None:
+                    copied[slot].synchronize()  # the host consumed this slot (null sink) before it is overwritten
+                produced = torch.cuda.Event()
+                produced.record(stream)
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(produced)
+                    pinned[slot].copy_(lane.u8, non_blocking=True)
+                    copied[slot] = torch.cuda.Event()
+                    copied[slot].record(copy_stream)
+                stream.wait_event(copied[slot])  # the producer must not overwrite u8 before the copy read it
+            k += 1
+    if fs is not None:
+        fs.wait_all()
+    if copy_stream is not None:
+        copy_stream.synchronize()
+    wl.sync()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if use_dist:
+        dist.barrier()
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: ~2.5 s of device time at 8 frames/step)")
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=8, help="frames per rank per step (reference default --batch 8)")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=30, help="timed steps (default: ~3.3 s of device time at 15 x 8 frames/step)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per batch = per graph replay (reference default --batch 8)")
+    ap.add_argument("--batches-per-step", type=int, default=15,
+                    help="batches per rank per step: a step is long enough (~0.11 s) that a 20-step run times > 2 s")
+    ap.add_argument("--size", type=int, default=1024, help="generator resolution: 1024 (BASELINE configs 3-5) or 256 (configs 1-2)")
+    ap.add_argument("--bends", action="store_true",
+                    help="BASELINE config 5 workload: per-frame Translate (layer 4) + Zoom (layer 5) network bends inside the captured forward")
     ap.add_argument("--lanes", type=int, default=3,
-                    help="hipGraphs replayed round-robin on their own streams (consecutive steps overlap on the device, "
-                         "as render.synthesize does); 1 = strictly serial steps")
+                    help="hipGraphs replayed round-robin on their own streams (consecutive batches overlap on the device, "
+                         "as render.synthesize does); 1 = strictly serial batches")
     ap.add_argument("--force-gather", action="store_true",
-                    help="debug: run the N > 1 timed region (per-step FrameStream push + landing wait) on one GPU as well")
+                    help="debug: run the N > 1 timed region (per-batch FrameStream push + landing wait) on one GPU as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the config 2 / config 5 side measurements")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B switch of an EXPERIMENTS build (tools/build_exp.sh, pass it with --lib): maua_tuning_set(KEY, VALUE) before "
                          "the graphs are captured; the product library has no such entry")
@@ -200,6 +371,8 @@ def main():
     ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
+    ap.add_argument("--up2d-min-cout", type=int, default=None,
+                    help="A/B switch: override ModulatedConv2d.upwino2d_min_cout (smallest transposed layer on the 2-D F(2,2) kernel)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,12 +392,14 @@ def main():
     torch.set_grad_enabled(False)
 
     from maua_stylegan2_amd import _lib, seeding
-    from maua_stylegan2_amd.models.stylegan2 import Generator, ModulatedConv2d, StyledConv
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d, StyledConv
 
     if args.no_partial_rgb:
         StyledConv.partial_rgb_fusion = False
     if args.wino2d_min_cout is not None:
         ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
+    if args.up2d_min_cout is not None:
+        ModulatedConv2d.upwino2d_min_cout = args.up2d_min_cout
 
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
@@ -236,152 +411,90 @@ def main():
         except AttributeError:
             sys.exit("--tuning needs an experiments build of the library (tools/build_exp.sh <name>; bench.py --lib tools/bin/libmaua_<name>.so)")
         tuning_set(int(key), int(value))
-    size, B = args.size, args.batch
-    g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
-    g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
-    g = g.to(dev).eval()
-    if use_dist:  # weights: rank 0 is the source of truth, one RCCL broadcast per tensor
-        for t in list(g.parameters()) + list(g.buffers()):
-            dist.broadcast(t.data, 0)
-
-    # synthetic inputs resident in HBM: a pool of latents for every step of this rank; noise maps for scales <= 256
-    # are per-frame (audio-reactive in the default plugin), 512/1024 use the checkpoint buffers (get_noise -> None).
-    n_steps = args.steps + args.warmup
-    POOL = 64  # distinct latent batches resident in HBM, cycled through (every step still refreshes the graph's inputs)
-    lat_pool = seeding.seeded_latents(POOL * B, g.n_latent, seed=100 + rank).to(dev)
-    sizes = seeding.noise_sizes(size)
-    noise_shapes = [(r, r) if r <= 256 else None for r in sizes]
-    noise_pool = [torch.from_numpy(seeding.seeded_array(200 + rank, f"n{i}", (B, 1, r, r))).to(dev) if r <= 256 else None
-                  for i, r in enumerate(sizes)]
-
+    size, B, bps = args.size, args.batch, max(1, args.batches_per_step)
     n_lanes = max(1, args.lanes)
-    lanes = []
-    for lane_id in range(n_lanes):
-        lane_stream = torch.cuda.Stream(dev)
-        with torch.cuda.stream(lane_stream):
-            lane_graph, lane_static = g.capture_graph(B, noise_shapes, lane=lane_id, frames_u8=True)
-            for dst, src in zip(lane_static["noise"], noise_pool):
-                if src is not None:
-                    dst.copy_(src)
-        lane_stream.synchronize()
-        # (the uint8 NHWC frame epilogue of render.py:40-43 is part of the captured forward: fused into the last ToRGB)
-        lanes.append({"stream": lane_stream, "graph": lane_graph, "static": lane_static, "u8": lane_static["u8"]})
-    stream, graph, static = lanes[0]["stream"], lanes[0]["graph"], lanes[0]["static"]
-    with torch.cuda.stream(stream):
+
+    wl = Workload(size, B, n_lanes, dev, rank, use_dist, bends=args.bends)
+    g = wl.g
+    for _ in range(args.warmup * bps):
+        wl.batch()
+    wl.sync()
+    # the headline region: EXACTLY --steps steps.  One GPU: synthesis with the frames left in HBM (the PCIe-inclusive rate
+    # is reported next to it).  Several GPUs: the frames of every batch are gathered to rank 0 inside the timed region.
+    elapsed = time_region(wl, args.steps, bps, "gathered" if (world > 1 or args.force_gather) else "synth", use_dist, world)
+    frame_err = wl.check_frames()
+    extra = {}
+    side = max(1, min(args.steps, 8))
+    if world > 1 or args.force_gather:
+        extra["frames_per_sec_synth_only"] = world * side * bps * B / time_region(wl, side, bps, "synth", use_dist, world)
+    if world == 1:
+        extra["frames_per_sec_pcie_inclusive"] = side * bps * B / time_region(wl, side, bps, "pcie", use_dist, world)
+        extra["pcie_inclusive_note"] = (f"{side} steps; uint8 frames copied to pinned host memory through a 3-slot staging "
+                                        "ring on a copy stream, as render() does; null sink (no encoder)")
+
+    result = None
+    if rank == 0:
+        frames = world * args.steps * bps * B
+        fps = frames / elapsed
+        result = {
+            "metric": "1024^2 frames/sec (whole job)" if size == 1024 else f"{size}^2 frames/sec (whole job)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"StyleGAN2-{size} generator (config {'5' if args.bends else ('3' if size == 1024 else '2')} shape: random-init, "
+                                   f"channel_multiplier 2), a step = {bps} batches x {B} frames per GPU, hipGraph per batch "
+                                   f"({wl.n_lanes} graphs round-robin on {wl.n_lanes} streams), latents + per-frame noise <=256^2 read from "
+                                   f"HBM-resident sequences through a device-side frame index, uint8 NHWC frames written by the last layer"
+                                   + (", per-frame Translate@layer4 + Zoom@layer5 network bends inside the captured forward" if args.bends else ""),
+                       "frames_per_step_per_gpu": bps * B, "batch": B, "batches_per_step": bps, "lanes": wl.n_lanes,
+                       "parallelism": f"frame-shard x{world}"},
+            "frames_per_sec_per_gpu": fps / world,
+            "ms_per_batch": 1000.0 * elapsed / (args.steps * bps),
+            "timed_region_s": elapsed,
+            "value_definition": ("uint8 frames of every batch gathered to rank 0's HBM (one async RCCL gather per batch, "
+                                 "sharding.FrameStream) inside the timed region" if (world > 1 or args.force_gather) else
+                                 "uint8 frames left in HBM (see frames_per_sec_pcie_inclusive for the host-inclusive rate)"),
+            **extra,
+            "conv_tflops_sustained": conv_flops_per_frame(size) * fps / world / 1e12,
+            "frame_check": {"max_abs_grey_level_diff_graph_vs_eager": frame_err,
+                            "what": "uint8 frames of the last replay of every lane vs the eager (un-captured) forward of the same frames"},
+            "device": _lib.device_info(),
+        }
+        if frame_err != 0:
+            print(f"bench.py: captured frames differ from the eager forward by {frame_err} grey levels", file=sys.stderr)
+            result["frame_check"]["FAILED"] = True
+    # ---- side configurations (rank 0's GPU only, after the headline region; N == 1 runs only)
+    if rank == 0 and world == 1 and not args.no_side_configs and size == 1024 and not args.bends:
+        sides = {}
+        for name, (sz, bends) in {"config5_1024_bends": (1024, True), "config2_256": (256, False)}.items():
+            try:
+                w2 = Workload(sz, B, n_lanes, dev, rank, False, bends=bends)
+                for _ in range(2 * n_lanes):
+                    w2.batch()
+                w2.sync()
+                st = 4 if sz == 1024 else 8
+                dt = time_region(w2, st, bps, "synth", False, 1)
+                sides[name] = {"frames_per_s": st * bps * B / dt, "timed_region_s": dt, "frames": st * bps * B,
+                               "graph_vs_eager_max_diff": w2.check_frames(), "lanes": w2.n_lanes}
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as exc:  # a side measurement must not take the headline down
+                sides[name] = {"error": repr(exc)}
+        if "frames_per_s" in sides.get("config5_1024_bends", {}):
+            sides["config5_1024_bends"]["relative_to_plain"] = sides["config5_1024_bends"]["frames_per_s"] / (fps / world)
+        result["side_configs"] = sides
+        result["side_configs_note"] = ("same machinery as the headline (captured forward, 3 lanes, HBM-resident sequences): BASELINE config 5's "
+                                       "workload = modulated Translate at layer id 4 + modulated Zoom at layer id 5 read per frame on the "
+                                       "device; config 2's generator = StyleGAN2-256 with every noise scale per-frame")
+    if rank == 0:
+        stream = wl.lanes[0][0]
         sp = stream.cuda_stream
-
-        def step(i):
-            # refresh the graph's static inputs from the HBM-resident sequence, exactly as render.synthesize does;
-            # step i runs on lane i % n_lanes, so it overlaps with the previous step on the device
-            lane = lanes[i % n_lanes]
-            with torch.cuda.stream(lane["stream"]):
-                sp_ = lane["stream"].cuda_stream
-                j = i % POOL
-                lane["static"]["latents"].copy_(lat_pool[j * B:(j + 1) * B], non_blocking=True)
-                for dst, src in zip(lane["static"]["noise"], noise_pool):
-                    if src is not None:
-                        dst.copy_(src, non_blocking=True)
-                lane["graph"].replay(sp_)
-
-        def sync_lanes():
-            for lane in lanes:
-                lane["stream"].synchronize()
-
-        def run_region(first_step, count, mode):
-            """Time ``count`` steps.  mode "synth": replay + uint8 epilogue only.  "gathered" (N > 1): every step's frames
-            also travel to rank 0 through sharding.FrameStream (one asynchronous RCCL gather per step, as render() issues
-            them); the clock stops when the last round has landed in rank 0's HBM — SURVEY.md 8d's definition of the metric
-            ("uint8 frames gathered to rank 0").  "pcie": every step's frames also go to the host through the pinned
-            staging ring on a copy stream exactly as render() does (null sink)."""
-            fs = None
-            if mode == "gathered":
-                from maua_stylegan2_amd import sharding
-
-                fs = sharding.FrameStream(world * count * B, B, (size, size, 3), dev)
-            n_slots = 3
-            pinned = [torch.empty((B, size, size, 3), dtype=torch.uint8).pin_memory() for _ in range(n_slots)] if mode == "pcie" else None
-            copy_stream = torch.cuda.Stream(dev) if mode == "pcie" else None
-            copied = [None] * n_slots
-            sync_lanes()
-            if use_dist:
-                dist.barrier()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for k in range(count):
-                i = first_step + k
-                step(i)
-                lane = lanes[i % n_lanes]
-                if fs is not None:
-                    with torch.cuda.stream(lane["stream"]):
-                        fs.push(k, lane["u8"])
-                if mode == "pcie":
-                    slot = k % n_slots
-                    if copied[slot] is not None:
-                        copied[slot].synchronize()  # the host consumed this slot (null sink) before it is overwritten
-                    produced = torch.cuda.Event()
-                    produced.record(lane["stream"])
-                    with torch.cuda.stream(copy_stream):
-                        copy_stream.wait_event(produced)
-                        pinned[slot].copy_(lane["u8"], non_blocking=True)
-                        copied[slot] = torch.cuda.Event()
-                        copied[slot].record(copy_stream)
-                    lane["stream"].wait_event(copied[slot])  # the producer must not overwrite u8 before the copy read it
-            if fs is not None:
-                fs.wait_all()
-            if copy_stream is not None:
-                copy_stream.synchronize()
-            sync_lanes()
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t0
-            if use_dist:
-                dist.barrier()
-                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
-            return dt
-
-        for i in range(args.warmup):
-            step(i)
-        sync_lanes()
-        # the headline region: EXACTLY --steps steps.  One GPU: synthesis with the frames left in HBM (the PCIe-inclusive rate
-        # is reported next to it).  Several GPUs: the frames of every step are gathered to rank 0 inside the timed region.
-        elapsed = run_region(args.warmup, args.steps, "gathered" if (world > 1 or args.force_gather) else "synth")
-        extra = {}
-        side = max(3, min(args.steps, 120))
-        if world > 1:
-            extra["frames_per_sec_synth_only"] = world * side * B / run_region(n_steps, side, "synth")
-        else:
-            extra["frames_per_sec_pcie_inclusive"] = side * B / run_region(n_steps, side, "pcie")
-            extra["pcie_inclusive_note"] = (f"{side} steps; uint8 frames copied to pinned host memory through a 3-slot staging "
-                                            "ring on a copy stream, as render() does; null sink (no encoder)")
-        checksum = int(sum(int(lane["u8"].sum().item()) for lane in lanes))
-
-        result = None
-        if rank == 0:
-            fps = world * args.steps * B / elapsed
-            ms_per_step = 1000.0 * elapsed / args.steps
-            result = {
-                "metric": "1024^2 frames/sec (whole job)" if size == 1024 else f"{size}^2 frames/sec (whole job)",
-                "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"StyleGAN2-{size} generator (config 3 shape: random-init, channel_multiplier 2), "
-                                       f"{B} frames/step/GPU, hipGraph per batch ({n_lanes} graphs round-robin on {n_lanes} streams), "
-                                       f"per-frame noise <=256^2, uint8 NHWC frames written by the last layer",
-                           "frames_per_step_per_gpu": B, "lanes": n_lanes, "parallelism": f"frame-shard x{world}"},
-                "frames_per_sec_per_gpu": fps / world,
-                "timed_region_s": elapsed,
-                "value_definition": ("uint8 frames of every step gathered to rank 0's HBM (one async RCCL gather per step, "
-                                     "sharding.FrameStream) inside the timed region" if world > 1 else
-                                     "uint8 frames left in HBM (see frames_per_sec_pcie_inclusive for the host-inclusive rate)"),
-                **extra,
-                "conv_tflops_sustained": conv_flops_per_frame(size) * fps / world / 1e12,
-                "frame_checksum": checksum,
-                "device": _lib.device_info(),
-            }
+        with torch.cuda.stream(stream):
             # ---- roofline legs (rank 0, N==1 style measurements on this rank's stream)
-            if not args.no_breakdown:
-                rows = layer_breakdown(g, B, static, stream)
+            if not args.no_breakdown and not args.bends:
+                noise_batch = [getattr(g.noises, f"noise_{i}") if nz is None else nz[:B] for i, nz in enumerate(wl.noise)]
+                g._forward_device(wl.latents[:B].contiguous(), noise_batch, None, None, [])  # populate the eager activations
+                rows = layer_breakdown(g, B, noise_batch, stream)
                 total_ms = sum(r[2] for r in rows)
                 fam = {}
                 for name, family, ms, flops, byts in rows:
@@ -391,7 +504,7 @@ def main():
                     fam[family][2] += byts
                 result["kernel_families_note"] = (
                     "isolated eager launches on one stream (HIP events), summed per family; `share` is the share of THAT sum "
-                    f"({total_ms:.3f} ms) — the timed steps overlap {n_lanes} graph lanes, so the sum exceeds ms_per_step")
+                    f"({total_ms:.3f} ms per batch) — the timed batches overlap {wl.n_lanes} graph lanes, so the sum exceeds ms_per_batch")
                 result["kernel_families"] = {k: {"ms_isolated": v[0], "share": v[0] / total_ms,
                                                  "tflops": v[1] / v[0] / 1e9, "gbs": v[2] / v[0] / 1e6}
                                              for k, v in fam.items()}
@@ -404,32 +517,37 @@ def main():
                     result["roofline"] = {"kernel": f"{(inst or 'modconv').split('<')[0]} ({dom[0]})", "bound": "mfma", "achieved": ach,
                                           "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
                                           "traffic": None, "launch_ms": dom[2]}
-                    # `achieved` counts ALGORITHMIC flops (direct 3x3).  Plain layers run through Winograd
-                    # F(2,3) along x, which issues 4 instead of 6 multiplies per output pair: say what the matrix cores
-                    # actually executed as well, so that the fraction is not mistaken for MFMA occupancy.
+                    # `achieved` counts ALGORITHMIC flops (direct 3x3).  The Winograd forms issue fewer multiplies
+                    # per output: say what the matrix cores actually executed as well, so that the fraction is not mistaken for MFMA occupancy.
                     base = dom[0].split("+")[0].split(" ")[0]
+                    ratio, algo = None, None
                     if base.startswith("convs.") and "upconv" not in base:
                         n_conv = int(base.split(".")[1])
                         res = 4 * 2 ** ((n_conv + 1) // 2)
                         mode = g.convs[n_conv].conv.conv_mode(res, res)
-                        if mode in (2, 3, 5):
-                            ratio = {2: 2.0 / 3.0, 3: 0.5, 5: 1.0 / 3.0}[mode]
-                            result["roofline"]["algorithm"] = {
-                                2: "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic",
-                                3: "winograd F(4,3) along x: executed MFMA flops = 1/2 algorithmic (frac counts algorithmic "
-                                   "direct-conv flops as SURVEY 8d defines them and can therefore exceed 1)",
-                                5: "2-D winograd F(2x4,3x3): executed MFMA flops = 1/3 algorithmic (frac counts algorithmic "
-                                   "direct-conv flops as SURVEY 8d defines them and can therefore exceed 1; executed_frac is what the "
-                                   "matrix cores did)"}[mode]
-                            result["roofline"]["executed"] = ach * ratio
-                            result["roofline"]["executed_frac"] = ach * ratio / MFMA_F32_PEAK_TFLOPS
+                        ratio = {2: 2.0 / 3.0, 3: 0.5, 5: 1.0 / 3.0}.get(mode)
+                        algo = {2: "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic",
+                                3: "winograd F(4,3) along x: executed MFMA flops = 1/2 algorithmic",
+                                5: "2-D winograd F(2x4,3x3): executed MFMA flops = 1/3 algorithmic"}.get(mode)
+                    elif base.startswith("convs.") and "upconv" in base:
+                        n_conv = int(base.split(".")[1])
+                        res = 4 * 2 ** (n_conv // 2)
+                        mode = g.convs[n_conv].conv.conv_mode(res, res)
+                        ratio = {4: 30.0 / 36.0, 6: 25.0 / 36.0}.get(mode)
+                        algo = {4: "polyphase transposed conv with F(2,2) on the even x-phase: executed MFMA flops = 30/36 algorithmic",
+                                6: "polyphase transposed conv with F(2,2) on both axes: executed MFMA flops = 25/36 algorithmic"}.get(mode)
+                    if ratio is not None:
+                        result["roofline"]["algorithm"] = (algo + " (frac counts algorithmic direct-conv flops as SURVEY 8d defines them and can "
+                                                           "therefore exceed 1; executed_frac is what the matrix cores did)")
+                        result["roofline"]["executed"] = ach * ratio
+                        result["roofline"]["executed_frac"] = ach * ratio / MFMA_F32_PEAK_TFLOPS
                     result["roofline"]["kernel_instance"] = inst
                     table, table_path = pmc_traffic_table()
                     rec = (table or {}).get("kernels", {}).get(inst) if inst else None
                     if rec is not None and table.get("batch") == B and table.get("size") == size and rec.get("dispatches_per_step") == 1:
                         # HBM bytes of this launch from the PMC passes of the SAME bench command (tools/profile_round.sh ->
                         # tools/make_profiles.py): FETCH_SIZE x2 (guide's gfx950 correction, calibrated on a known-size copy) +
-                        # WRITE_SIZE.  Only used when that instance is launched once per step, i.e. the average IS this launch.
+                        # WRITE_SIZE.  Only used when that instance is launched once per batch, i.e. the average IS this launch.
                         result["roofline"]["traffic"] = rec["read_bytes"] + rec["write_bytes"]
                         result["roofline"]["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}"
                     if size == 1024 and dom[0].startswith("convs.15"):
@@ -442,9 +560,9 @@ def main():
                     ach = dom[4] / dom[2] / 1e6
                     result["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": dom[2]}
-            # standalone upfirdn2d on the 1024-res Blur shape (the op BASELINE.json's metric names)
+            # standalone upfirdn2d on the largest Blur shape of this generator (the op BASELINE.json's metric names)
             r_out = size
-            xin = torch.randn(B, 32 if size == 1024 else 64, r_out + 1, r_out + 1, device=dev)
+            xin = torch.randn(B, 32 if size == 1024 else 128, r_out + 1, r_out + 1, device=dev)
             kern = torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)).to(dev)
             yout = torch.empty(xin.shape[0] * xin.shape[1], r_out, r_out, 1, device=dev)
             major = xin.shape[0] * xin.shape[1]
@@ -456,23 +574,23 @@ def main():
             ms = time_calls(launch_fir, 20, sp)
             byts = 4 * major * ((r_out + 1) ** 2 + r_out ** 2)
             ach = byts / ms / 1e6
-            # HBM bytes per launch from the PMC passes of profiles/r01_pmc_upfirdn2d.md (FETCH_SIZE x2 correction,
-            # WRITE_SIZE exact), scaled to this launch's plane count; measured at 256 planes.
+            # HBM bytes per launch from the newest PMC passes (FETCH_SIZE x2 correction, WRITE_SIZE exact), scaled to this launch's planes
             table, table_path = pmc_traffic_table()
-            rec = (table or {}).get("kernels", {}).get("fir_strip_kernel<4, 4, 4, false, false>")
+            fir_name = "fir_strip_kernel<4, 4, 4>"
+            kernels = (table or {}).get("kernels", {})
+            rec = kernels.get(fir_name) or kernels.get("fir_strip_kernel<4, 4, 4, false, false>")
             traffic = None
             if rec is not None and table.get("size") == size and rec.get("planes"):
                 traffic = (rec["read_bytes"] + rec["write_bytes"]) * major / rec["planes"]  # scaled to this launch's planes
-            result["roofline_upfirdn2d"] = {"kernel": "fir_strip_kernel<4,4,4,false,false>", "bound": "hbm", "achieved": ach,
+            result["roofline_upfirdn2d"] = {"kernel": fir_name, "bound": "hbm", "achieved": ach,
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                             "traffic": traffic, "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}" if traffic else None), "launch_ms": ms, "algorithmic_bytes": byts,
                                             "shape": f"[{xin.shape[0]},{xin.shape[1]},{r_out+1},{r_out+1}] -> {r_out}^2"}
             # measured copy ceiling of this box (SURVEY.md 8d asks for "vs spec" and "vs measured copy"): a device-to-device copy of
             # the same number of bytes (read n/2, write n/2) on the same stream
-            with torch.cuda.stream(torch.cuda.ExternalStream(sp, device=dev)):
-                src = torch.empty(byts // 8, dtype=torch.float32, device=dev).normal_()
-                dst = torch.empty_like(src)
-                ms_copy = time_calls(lambda: dst.copy_(src), 20, sp)
+            src = torch.empty(byts // 8, dtype=torch.float32, device=dev).normal_()
+            dst = torch.empty_like(src)
+            ms_copy = time_calls(lambda: dst.copy_(src), 20, sp)
             copy_gbs = 2 * src.numel() * 4 / ms_copy / 1e6
             result["roofline_upfirdn2d"]["measured_copy_gbs"] = copy_gbs
             result["roofline_upfirdn2d"]["frac_of_measured_copy"] = ach / copy_gbs

@@ -20,7 +20,7 @@ extern "C" {
 #define MAUA_ENOSYS (-38)
 
 /* ABI version of this header; bumped on any signature change. */
-int maua_abi_version(void);
+int maua_abi_version(void);  /* 2: frame source (maua_frame_source_t) arguments; no tuning entry */
 /* Number of compute units / name of device 0 (diagnostics for bench.py). */
 int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
 
@@ -51,6 +51,29 @@ int maua_fused_bias_act_f16(const void* x, const void* b, const void* ref, void*
 int maua_fused_bias_act_f64(const void* x, const void* b, const void* ref, void* y, int64_t size_x, int size_b, int step_b,
                             int act, int grad, float alpha, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ frame source
+ * Per-frame inputs of a generator forward, read THROUGH device memory instead of through kernel arguments, so that one
+ * captured hipGraph serves every batch of a render (and every render): the sequences of render.py:140-182 — latents
+ * [n_frames, n_latent, style_dim], truncation [n_frames], one noise map sequence per noise slot — stay resident in HBM and a
+ * replay only moves `frame0` (maua_frame_source_seek: one 4-byte device write; the reference re-uploads every sequence slice
+ * from pinned host memory per batch).  The struct lives in DEVICE memory; the host fills the pointers once per render.
+ * Every launcher below that takes `src` ignores its own latents / trunc / noise / noise_batch_stride arguments when src != NULL:
+ *   latent of sample b   = src->latents + (frame0 + b) * n_latent * style_dim
+ *   truncation of b      = src->trunc[frame0 + b]            (src->trunc == NULL: no lerp)
+ *   noise map of b       = src->noise[slot] + (frame0 + b) * src->noise_stride[slot]   (stride 0: one shared map, e.g. a
+ *                          checkpoint's noises.noise_i buffer; src->noise[slot] == NULL: no noise) */
+#define MAUA_MAX_NOISE_SLOTS 32
+typedef struct {
+    int32_t frame0;                               /* first frame of this launch inside every per-frame sequence */
+    int32_t pad_;
+    const float* latents;
+    const float* trunc;
+    const float* noise[MAUA_MAX_NOISE_SLOTS];
+    int64_t noise_stride[MAUA_MAX_NOISE_SLOTS];   /* floats between the maps of consecutive frames */
+} maua_frame_source_t;
+/* src->frame0 = frame0, asynchronously on `stream` (a 4-byte hipMemsetD32Async: no host buffer has to outlive the call). */
+int maua_frame_source_seek(maua_frame_source_t* src, int frame0, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ generator layers
  * Fused Blur -> NoiseInjection -> FusedLeakyReLU tail of an up-sampling StyledConv
  * (models/stylegan2.py:238,262-266,338-343; op/fused_act.py:74-83):
@@ -59,7 +82,8 @@ int maua_fused_bias_act_f64(const void* x, const void* b, const void* ref, void*
  * factor of the preceding shared-weight convolution. noise [B or 1,1,out_h,out_w] (noise_batch_stride 0 = broadcast). */
 int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch, int channels, int in_h, int in_w,
                             int kh, int kw, int pad0, int pad1, const float* gain, const float* noise,
-                            int64_t noise_batch_stride, const float* noise_w, const float* bias, void* stream);
+                            int64_t noise_batch_stride, const float* noise_w, const float* bias,
+                            const maua_frame_source_t* src, int noise_slot, void* stream);
 
 /* All style affines and demodulation factors of one forward, two launches in total, table-driven.
  *  affine (EqualLinear, models/stylegan2.py:140-146,207,220), with the truncation lerp of Generator.forward
@@ -82,7 +106,7 @@ typedef struct {
 } maua_style_layer_t;
 int maua_style_affine_f32(const float* latents, int batch, int n_latent, int style_dim, const float* trunc,
                           const float* trunc_latent, const maua_style_layer_t* table, int n_layers, int max_cin,
-                          float* s, int s_stride, void* stream);
+                          float* s, int s_stride, const maua_frame_source_t* src, void* stream);
 int maua_demod_f32(const maua_style_layer_t* table, int n_layers, int max_cout, const float* s, int s_stride, float* d,
                    int batch, void* stream);
 
@@ -133,7 +157,7 @@ int maua_modconv_last_instance(char* buf, int buf_len);
 int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                         float* y, int batch, int cin, int cout, int h, int w, int up, float wscale, int fuse_act,
                         const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
-                        float* ws, void* stream);
+                        float* ws, const maua_frame_source_t* src, int noise_slot, void* stream);
 
 /* Plain StyledConv with the following ToRGB (models/stylegan2.py:338-343 then :356-365) fused into its epilogue: the
  * activated feature map is reduced to RGB while it is still in registers (all channels of a pixel sit in one wave).
@@ -147,7 +171,7 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
                               const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                               const float* rgb_w, const float* rgb_s, float rgb_wscale, const float* rgb_bias,
                               const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,
-                              uint8_t* frames_u8, void* stream);
+                              uint8_t* frames_u8, const maua_frame_source_t* src, int noise_slot, void* stream);
 
 /* The same fusion for layers wider than one weight tile (128..512 output channels, mode 5 only): every output-channel tile leaves
  * its share of the ToRGB sum  sum_{i in tile} (rgb_wscale * rgb_w[c,i] * rgb_s[b,i]) * y[b,i,Y,X]  in
@@ -157,7 +181,8 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
 int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y,
                                       int batch, int cin, int cout, int h, int w, int mode, float wscale, const float* noise,
                                       int64_t noise_batch_stride, const float* noise_w, const float* bias, const float* rgb_w,
-                                      const float* rgb_s, float rgb_wscale, float* rgb_partial, void* stream);
+                                      const float* rgb_s, float rgb_wscale, float* rgb_partial,
+                                      const maua_frame_source_t* src, int noise_slot, void* stream);
 
 /* StyleGAN1 (`--stylegan1`, models/stylegan1.py:258-318 LayerEpilogue) — conv bias, per-channel-weighted noise, LeakyReLU(0.2),
  * instance norm (biased variance, eps 1e-5) and the style modulation in one launch:
@@ -235,10 +260,11 @@ int maua_affine_reflect_warp_f32(const float* x, const float* m, float* y, int b
                                  int pad_l, int pad_r, int pad_t, int pad_b, const float* add_noise, void* stream);
 /* Same, for a canvas built by a CHAIN of ReflectionPad2d (audioreactive/bend.py:60-64 stacks three): pad_* are the total
  * paddings, xmap[w+pad_l+pad_r] / ymap[h+pad_t+pad_b] (int32, device, either may be NULL = single fold) give the source
- * column / row of every canvas column / row. */
+ * column / row of every canvas column / row.  src != NULL: m is the map SEQUENCE of the whole render [n_frames, 6] and sample
+ * b uses row src->frame0 + b (render.py:151-158 rebuilds the transform per batch; a captured graph reads it per replay). */
 int maua_affine_reflect_warp_mapped_f32(const float* x, const float* m, float* y, int batch, int channels, int h, int w,
                                         int pad_l, int pad_r, int pad_t, int pad_b, const float* add_noise,
-                                        const int* xmap, const int* ymap, void* stream);
+                                        const int* xmap, const int* ymap, const maua_frame_source_t* src, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ hipGraph runtime
  * Capture everything launched on `stream` between begin/end into a hipGraph and replay it (per-frame generator

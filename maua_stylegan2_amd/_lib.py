@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmaua_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MauaHipError(RuntimeError):
@@ -35,6 +35,22 @@ class StyleLayer(ctypes.Structure):
     ]
 
 
+MAX_NOISE_SLOTS = 32
+
+
+class FrameSource(ctypes.Structure):
+    """maua_frame_source_t (include/maua_hip.h): per-frame sequences resident in HBM + the frame a launch starts at."""
+
+    _fields_ = [
+        ("frame0", ctypes.c_int32),
+        ("pad_", ctypes.c_int32),
+        ("latents", c_void_p),
+        ("trunc", c_void_p),
+        ("noise", c_void_p * MAX_NOISE_SLOTS),
+        ("noise_stride", c_int64 * MAX_NOISE_SLOTS),
+    ]
+
+
 _P = c_void_p
 _SIGNATURES = {
     "maua_abi_version": (c_int, []),
@@ -45,8 +61,9 @@ _SIGNATURES = {
     "maua_fused_bias_act_f64": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "maua_upfirdn2d_f16": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
     "maua_upfirdn2d_f64": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
-    "maua_blur_noise_act_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, c_int64, _P, _P, _P]),
-    "maua_style_affine_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P]),
+    "maua_frame_source_seek": (c_int, [_P, c_int, _P]),
+    "maua_blur_noise_act_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, c_int64, _P, _P, _P, c_int, _P]),
+    "maua_style_affine_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "maua_demod_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, _P]),
     "maua_pack_weight_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "maua_pack_weight_wino_f32": (c_int, [_P, _P, c_int, c_int, _P]),
@@ -57,11 +74,11 @@ _SIGNATURES = {
     "maua_modconv_w2d_mtiles": (c_int, [c_int] * 4),
     "maua_modconv_ws_floats": (c_int64, [c_int] * 6),
     "maua_modconv_last_instance": (c_int, [c_char_p, c_int]),
-    "maua_modconv3x3_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, _P, c_int64, _P, _P, _P, _P]),
+    "maua_modconv3x3_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, _P, c_int64, _P, _P, _P, _P, c_int, _P]),
     "maua_styledconv_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
-                                          _P, _P, _P, _P, c_int, _P, _P]),
+                                          _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),
     "maua_styledconv_torgb_partial_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
-                                                  _P, _P]),
+                                                  _P, _P, c_int, _P]),
     "maua_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_frames_to_u8": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "maua_sg1_epilogue_f32": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -79,7 +96,7 @@ _SIGNATURES = {
     "maua_filterbank_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_perlin3d_f32": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "maua_affine_reflect_warp_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P]),
-    "maua_affine_reflect_warp_mapped_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, _P, _P]),
+    "maua_affine_reflect_warp_mapped_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, _P, _P, _P]),
     "maua_graph_begin_capture": (c_int, [_P]),
     "maua_graph_end_capture": (c_int, [_P, POINTER(c_void_p)]),
     "maua_graph_launch": (c_int, [_P, _P]),

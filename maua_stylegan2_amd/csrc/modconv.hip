@@ -107,6 +107,9 @@ struct ConvPtrs {
     const float* rgb_k4;    // 4x4 upsample taps
     float* rgb_out;         // [B, 3, H, W]
     uint8_t* rgb_u8;        // when set: the image leaves as uint8 NHWC frames [B, H, W, 3] (render.py:40-43) instead of rgb_out
+    // frame source (include/maua_hip.h): when set, the noise maps are read from src->noise[noise_slot] at frame src->frame0
+    const maua_frame_source_t* src;
+    int noise_slot;
 };
 
 // UP = false : plain 3x3, pad 1.           per wave: TM x TN MFMA tiles.
@@ -707,7 +710,14 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     // trips behind the stores — that was ~45 % of the lifetime of a 32-channel 1024^2 workgroup.)
     const bool to_ws = g.splits > 1;
     float* outp = to_ws ? (p.ws + (size_t)split * g.ws_slab) : p.y;
-    const float nw = (!to_ws && g.fuse_act && p.noise) ? p.noise_w[0] : 0.f;  // (scaled by act_gain where it is applied)
+    const float* noise_base = p.noise;
+    int64_t noise_bstride = g.noise_batch_stride;
+    if (p.src) {  // uniform scalar loads: base of this launch's first frame inside the HBM-resident sequence
+        noise_bstride = p.src->noise_stride[p.noise_slot];
+        noise_base = p.src->noise[p.noise_slot];
+        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
+    }
+    const float nw = (!to_ws && g.fuse_act && noise_base) ? p.noise_w[0] : 0.f;  // (scaled by act_gain where it is applied)
     const size_t plane_out = (size_t)g.OH * g.OW;
     float* Eg = lds;        // [BM] gain
     float* Eb = lds + BM;   // [BM] bias
@@ -751,8 +761,8 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
             nz_all[n][ph] = 0.f;
             if (WINO && ph >= WX) continue;
             if (nw != 0.f && b < g.B && gy < g.GH && gx < g.GW && oy < g.OH && ox < g.OW)
-                nz_all[n][ph] = nw * act_gain * (MULTI ? p.noise[(size_t)b * g.noise_batch_stride + (size_t)oy * g.OW + ox]
-                                                       : (p.noise + (size_t)b0 * g.noise_batch_stride)[(unsigned)(oy * g.OW + ox)]);
+                nz_all[n][ph] = nw * act_gain * (MULTI ? noise_base[(size_t)b * noise_bstride + (size_t)oy * g.OW + ox]
+                                                       : (noise_base + (size_t)b0 * noise_bstride)[(unsigned)(oy * g.OW + ox)]);
         }
     }
 #pragma unroll
@@ -985,7 +995,13 @@ __global__ __launch_bounds__(256) void reduce_tail_kernel(const float* __restric
                                                           const float* __restrict__ noise, int64_t noise_batch_stride,
                                                           const float* __restrict__ noise_w,
                                                           const float* __restrict__ bias, int fuse_act, int cout,
-                                                          int64_t plane, int64_t total) {
+                                                          int64_t plane, int64_t total,
+                                                          const maua_frame_source_t* __restrict__ src, int noise_slot) {
+    if (src) {
+        noise_batch_stride = src->noise_stride[noise_slot];
+        noise = src->noise[noise_slot];
+        if (noise) noise += (int64_t)src->frame0 * noise_batch_stride;
+    }
     const float nw = (fuse_act && noise) ? noise_w[0] : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
@@ -1325,15 +1341,16 @@ struct RgbArgs {
 int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, int batch,
                  int cin, int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise,
                  int64_t noise_batch_stride, const float* noise_w, const float* bias, float* ws, const RgbArgs* rgb,
-                 void* stream) {
+                 const maua_frame_source_t* src, int noise_slot, void* stream) {
     if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
-    if (noise && !noise_w) return MAUA_EINVAL;
+    if ((noise || (src && fuse_act)) && !noise_w) return MAUA_EINVAL;
+    if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     if (up == 5) {  // 2-D Winograd F(2x4, 3x3), modconv_w2d.hip
         const int rc = maua_w2d_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, fuse_act, noise, noise_batch_stride,
                                        noise_w, bias, rgb ? rgb->w : nullptr, rgb ? rgb->s : nullptr, rgb ? rgb->wscale : 0.f,
                                        rgb ? rgb->bias : nullptr, rgb ? rgb->skip : nullptr, rgb ? rgb->k4 : nullptr,
                                        rgb ? rgb->out : nullptr, rgb ? rgb->u8 : nullptr, rgb ? (rgb->store_features ? 1 : 2) : 0,
-                                       stream);
+                                       src, noise_slot, stream);
         if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
         return rc;
     }
@@ -1351,7 +1368,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
 #endif
     pl.g.rgb = 0;
     pl.g.rgb_wscale = 0.f;
-    ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ConvPtrs ptrs{x, wp, s, d, noise, noise_w, bias, y, ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, src, noise_slot};
     if (rgb) {
         // fusable only when one workgroup holds every channel of its pixels in a single wave row (BM >= Cout, WM == 1),
         // no split-K, one image per tile, the tail fused
@@ -1394,7 +1411,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
         const int64_t blocks = ceil_div64(total, 256);
         hipLaunchKernelGGL(reduce_tail_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, ws,
                            pl.g.splits, pl.g.ws_slab, y, d, noise, noise_batch_stride, noise_w, bias, fuse_act, cout,
-                           (int64_t)pl.g.OH * pl.g.OW, total);
+                           (int64_t)pl.g.OH * pl.g.OW, total, src, noise_slot);
         MAUA_LAUNCH_CHECK();
     }
     return 0;
@@ -1404,20 +1421,22 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
 extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                                    float* y, int batch, int cin, int cout, int h, int w, int up, float wscale,
                                    int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
-                                   const float* bias, float* ws, void* stream) {
+                                   const float* bias, float* ws, const maua_frame_source_t* src, int noise_slot, void* stream) {
     return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, up, wscale, fuse_act, noise, noise_batch_stride,
-                        noise_w, bias, ws, nullptr, stream);
+                        noise_w, bias, ws, nullptr, src, noise_slot, stream);
 }
 
 extern "C" int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                                                  float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,
                                                  const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                                  const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
-                                                 float* rgb_partial, void* stream) {
+                                                 float* rgb_partial, const maua_frame_source_t* src, int noise_slot,
+                                                 void* stream) {
     if (mode != 5) return MAUA_ENOSYS;  // only the 2-D Winograd kernel leaves partial ToRGB sums
-    if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (noise && !noise_w)) return MAUA_EINVAL;
+    if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || ((noise || src) && !noise_w)) return MAUA_EINVAL;
+    if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     const int rc = maua_w2d_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, 1, noise, noise_batch_stride, noise_w, bias,
-                                   rgb_w, rgb_s, rgb_wscale, nullptr, nullptr, nullptr, rgb_partial, nullptr, 3, stream);
+                                   rgb_w, rgb_s, rgb_wscale, nullptr, nullptr, nullptr, rgb_partial, nullptr, 3, src, noise_slot, stream);
     if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
     return rc;
 }
@@ -1427,9 +1446,10 @@ extern "C" int maua_styledconv_torgb_f32(const float* x, const float* wp, const 
                                          const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                          const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                                          const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out,
-                                         int store_features, uint8_t* frames_u8, void* stream) {
+                                         int store_features, uint8_t* frames_u8, const maua_frame_source_t* src, int noise_slot,
+                                         void* stream) {
     RgbArgs rgb{rgb_w, rgb_s, rgb_bias, rgb_skip, rgb_k4, rgb_out, rgb_wscale, store_features, frames_u8};
     if (mode == 1) return MAUA_ENOSYS;
     return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, mode, wscale, 1, noise, noise_batch_stride, noise_w,
-                        bias, nullptr, &rgb, stream);
+                        bias, nullptr, &rgb, src, noise_slot, stream);
 }

@@ -120,6 +120,8 @@ struct W2dArgs {
     int rgb;  // 0 off, 1 on, 2 on and the feature map itself is not stored, 3 partial: this m-tile's share of the ToRGB sum goes to
               // rgb_out [B, 3 m_tiles, H, W] (no bias, no skip), the feature map is stored
     float rgb_wscale;
+    const maua_frame_source_t* src;  // frame source (include/maua_hip.h): noise from src->noise[noise_slot] at frame src->frame0
+    int noise_slot;
     int debug;  // ablation switches (maua_tuning_set key 3): 1 skip MFMA, 2 skip the DMA of every chunk after the first, 4 skip stores, 8 no epilogue
 };
 
@@ -387,10 +389,17 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     const int cp = tid % NPOS, cr = (tid / NPOS) & 1, cg = tid / (2 * NPOS);
     const int cjx = cp & 7, cpy = cp >> 3;      // position column / position row inside the tile (cpy = 2 nt + jy)
     const int oy = ty0 + 2 * cpy + cr, ox = tx0 + 4 * cjx;
-    const float nw = (act && p.noise) ? p.noise_w[0] * act_gain : 0.f;
+    const float* noise_base = p.noise;
+    int64_t noise_bstride = p.noise_batch_stride;
+    if (p.src) {  // uniform scalar loads: base of this launch's first frame inside the HBM-resident sequence
+        noise_bstride = p.src->noise_stride[p.noise_slot];
+        noise_base = p.src->noise[p.noise_slot];
+        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
+    }
+    const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
     f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nw != 0.f) {
-        nz = *reinterpret_cast<const f32x4*>(p.noise + (size_t)b0 * p.noise_batch_stride + (size_t)oy * p.W + ox);
+        nz = *reinterpret_cast<const f32x4*>(noise_base + (size_t)b0 * noise_bstride + (size_t)oy * p.W + ox);
         nz = nz * nw;
     }
     float rgbp[4][3];
@@ -641,7 +650,7 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
                     const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                     const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, uint8_t* rgb_u8,
-                    int rgb_mode, void* stream) {
+                    int rgb_mode, const maua_frame_source_t* src, int noise_slot, void* stream) {
     int tm = 0, tn = 0;
     if (!maua_w2d_tiles(cin, cout, h, w, &tm, &tn)) return MAUA_EINVAL;
     if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)24 * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
@@ -651,6 +660,7 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     a.rgb_u8 = rgb_u8;
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale, a.fuse_act = fuse_act;
     a.noise_batch_stride = noise_batch_stride;
+    a.src = src, a.noise_slot = noise_slot;
     a.tiles_x = w / 32, a.tiles_y = h / (4 * tn), a.m_tiles = cout / (16 * tm), a.n_chunks = cin / W2D_CC;
     a.rgb = rgb_mode, a.rgb_wscale = rgb_wscale;
 #ifdef MAUA_EXPERIMENTS

@@ -2,9 +2,17 @@
 // uint8 frame epilogue (render.py:40-43).
 #include "common.h"
 
+#include <stddef.h>
 #include <string.h>
 
-extern "C" int maua_abi_version(void) { return 1; }
+extern "C" int maua_abi_version(void) { return 2; }
+
+// src->frame0 = frame0 on `stream`: the only per-replay input traffic of a captured forward (include/maua_hip.h, frame source)
+extern "C" int maua_frame_source_seek(maua_frame_source_t* src, int frame0, void* stream) {
+    if (!src || frame0 < 0) return MAUA_EINVAL;
+    static_assert(offsetof(maua_frame_source_t, frame0) == 0, "frame0 is the first word of the struct");
+    return (int)hipMemsetD32Async((hipDeviceptr_t)src, frame0, 1, (hipStream_t)stream);
+}
 
 extern "C" int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len) {
     int dev = 0;

@@ -326,8 +326,10 @@ __global__ __launch_bounds__(256) void affine_reflect_warp_kernel(const float* _
                                                                   int pad_l, int pad_r, int pad_t, int pad_b,
                                                                   const float* __restrict__ add_noise,
                                                                   const int* __restrict__ xmap,
-                                                                  const int* __restrict__ ymap) {
+                                                                  const int* __restrict__ ymap,
+                                                                  const maua_frame_source_t* __restrict__ src) {
     const int b = blockIdx.z;
+    if (src) m += (size_t)src->frame0 * 6;  // m is the map sequence of the whole render
     const int ch = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= h * w) return;
@@ -638,7 +640,7 @@ extern "C" int maua_affine_reflect_warp_f32(const float* x, const float* m, floa
     if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || channels > 65535 || batch > 65535) return MAUA_EINVAL;
     hipLaunchKernelGGL(affine_reflect_warp_kernel, dim3(ceil_div(h * w, 256), channels, batch), dim3(256), 0,
                        (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise,
-                       (const int*)nullptr, (const int*)nullptr);
+                       (const int*)nullptr, (const int*)nullptr, (const maua_frame_source_t*)nullptr);
     MAUA_LAUNCH_CHECK();
     return 0;
 }
@@ -646,11 +648,11 @@ extern "C" int maua_affine_reflect_warp_f32(const float* x, const float* m, floa
 extern "C" int maua_affine_reflect_warp_mapped_f32(const float* x, const float* m, float* y, int batch, int channels, int h,
                                                    int w, int pad_l, int pad_r, int pad_t, int pad_b,
                                                    const float* add_noise, const int* xmap, const int* ymap,
-                                                   void* stream) {
+                                                   const maua_frame_source_t* src, void* stream) {
     if (!x || !m || !y || batch <= 0 || channels <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     if (pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 || channels > 65535 || batch > 65535) return MAUA_EINVAL;
     hipLaunchKernelGGL(affine_reflect_warp_kernel, dim3(ceil_div(h * w, 256), channels, batch), dim3(256), 0,
-                       (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise, xmap, ymap);
+                       (hipStream_t)stream, x, m, y, channels, h, w, pad_l, pad_r, pad_t, pad_b, add_noise, xmap, ymap, src);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

@@ -26,8 +26,14 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
                                                            int style_dim, const float* __restrict__ trunc,
                                                            const float* __restrict__ trunc_latent,
                                                            const maua_style_layer_t* __restrict__ table,
-                                                           float* __restrict__ s, int s_stride) {
+                                                           float* __restrict__ s, int s_stride,
+                                                           const maua_frame_source_t* __restrict__ src) {
     extern __shared__ __attribute__((aligned(16))) float lat[];  // [BCHUNK][style_dim]
+    if (src) {  // per-frame sequences resident in HBM: this launch starts at frame src->frame0 (uniform scalar loads)
+        const int64_t f0 = src->frame0;
+        latents = src->latents + f0 * n_latent * style_dim;
+        trunc = src->trunc ? src->trunc + f0 : nullptr;
+    }
     const maua_style_layer_t L = table[blockIdx.x];
     const int row0 = blockIdx.y * ROWS;
     if (row0 >= L.cin) return;
@@ -136,12 +142,12 @@ __global__ __launch_bounds__(256) void demod_kernel(const maua_style_layer_t* __
 
 extern "C" int maua_style_affine_f32(const float* latents, int batch, int n_latent, int style_dim, const float* trunc,
                                      const float* trunc_latent, const maua_style_layer_t* table, int n_layers,
-                                     int max_cin, float* s, int s_stride, void* stream) {
-    if (!latents || !table || !s || batch <= 0 || n_layers <= 0 || max_cin <= 0) return MAUA_EINVAL;
+                                     int max_cin, float* s, int s_stride, const maua_frame_source_t* src, void* stream) {
+    if ((!latents && !src) || !table || !s || batch <= 0 || n_layers <= 0 || max_cin <= 0) return MAUA_EINVAL;
     if (style_dim <= 0 || style_dim % 64 || style_dim > 64 * MAX_PER_LANE) return MAUA_EINVAL;
     const size_t lds = (size_t)BCHUNK * style_dim * sizeof(float);
     hipLaunchKernelGGL(style_affine_kernel, dim3(n_layers, ceil_div(max_cin, ROWS)), dim3(256), lds, (hipStream_t)stream,
-                       latents, batch, n_latent, style_dim, trunc, trunc_latent, table, s, s_stride);
+                       latents, batch, n_latent, style_dim, trunc, trunc_latent, table, s, s_stride, src);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

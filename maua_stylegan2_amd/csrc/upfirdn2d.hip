@@ -33,6 +33,8 @@ struct FirTail {
     const float* bias;    // [channels]
     int64_t noise_batch_stride;
     int channels;
+    const maua_frame_source_t* src;  // when set: noise / noise_batch_stride come from src->noise[noise_slot] at frame src->frame0
+    int noise_slot;
 };
 
 constexpr int TILE_ROWS_PER_WAVE = 32;
@@ -124,9 +126,16 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
         bs = tail.bias ? tail.bias[c] : 0.f;
 #pragma unroll
         for (int o = 0; o < TH; ++o) nzv[o] = 0.f;
-        if (tail.noise) {
+        const float* noise = tail.noise;
+        int64_t nstride = tail.noise_batch_stride;
+        if (tail.src) {  // uniform scalar loads
+            nstride = tail.src->noise_stride[tail.noise_slot];
+            noise = tail.src->noise[tail.noise_slot];
+            if (noise) noise += (int64_t)tail.src->frame0 * nstride;
+        }
+        if (noise) {
             nw = tail.noise_w[0];
-            const float* nz = tail.noise + (size_t)b * tail.noise_batch_stride;
+            const float* nz = noise + (size_t)b * nstride;
 #pragma unroll
             for (int o = 0; o < TH; ++o)
                 if (col_ok && oy0 + row0 + o < out_h) nzv[o] = nz[(size_t)(oy0 + row0 + o) * out_w + ox];
@@ -439,12 +448,13 @@ extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int 
 extern "C" int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch, int channels, int in_h,
                                        int in_w, int kh, int kw, int pad0, int pad1, const float* gain,
                                        const float* noise, int64_t noise_batch_stride, const float* noise_w,
-                                       const float* bias, void* stream) {
+                                       const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream) {
     if (!x || !k || !y || batch <= 0 || channels <= 0 || in_h <= 0 || in_w <= 0) return MAUA_EINVAL;
-    if (noise && !noise_w) return MAUA_EINVAL;
+    if ((noise || src) && !noise_w) return MAUA_EINVAL;
+    if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     const int out_h = in_h + pad0 + pad1 - kh + 1, out_w = in_w + pad0 + pad1 - kw + 1;
     if (out_h <= 0 || out_w <= 0) return MAUA_EINVAL;
-    FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels};
+    FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels, src, noise_slot};
     return dispatch_fir_tile<true>(x, k, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, pad0, pad0, tail,
                                    (hipStream_t)stream);
 }

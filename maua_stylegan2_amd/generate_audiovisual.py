@@ -90,13 +90,26 @@ def load_generator(ckpt, is_stylegan1, G_res, out_size, noconst, latent_dim, n_m
     if is_stylegan1:
         from .models.stylegan1 import G_style
 
-        generator = G_style(output_size=out_size, checkpoint=ckpt if rank == 0 else None).cuda()
+        # only rank 0 probes the checkpoint for the network resolution (1024 -> 512 -> 256 -> 128); the other ranks build that
+        # very network, so that blocks, the enlarged constant and the noise buffers have one shape everywhere before broadcast_module
+        generator = G_style(output_size=out_size, checkpoint=ckpt) if rank == 0 else None
+        resolution = int(sharding.broadcast_object(generator.network_resolution if rank == 0 else None))
+        if generator is None:
+            generator = G_style(output_size=out_size, checkpoint=None, network_resolution=resolution)
+        generator = generator.cuda()
         generator.truncation_latent = sharding.broadcast_tensor(generator.truncation_latent.cuda().contiguous())
         return sharding.broadcast_module(generator).eval()
     generator = Generator(G_res, latent_dim, n_mlp, channel_multiplier=channel_multiplier, constant_input=not noconst,
                           checkpoint=ckpt if rank == 0 else None, output_size=out_size,
                           base_res_factor=base_res_factor).cuda()
     return sharding.broadcast_module(generator).eval()
+
+
+def _seed_all(seed):
+    """torch (CPU and device generators), numpy and python generators of this process."""
+    th.manual_seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    random.seed(seed)
 
 
 def _noise_sides(out_size):
@@ -159,20 +172,39 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
 
     rank, world = sharding.rank_world()
     # One process per GPU: the audio front end and the latent / noise / truncation callbacks run on rank 0 only and their
-    # per-frame results are scattered.  Bends and rewrites are closures, so a plugin that defines them is run on every rank
-    # (from one broadcast seed, so that random draws inside it agree).
+    # per-frame results are scattered.  Bends and rewrites are closures, so a plugin that defines them is run on every rank;
+    # every rank re-seeds its torch / numpy / python generators from one broadcast seed IMMEDIATELY before get_bends and before
+    # get_rewrites (rank 0 has consumed draws in the latent / noise callbacks by then, the others have not), so that random
+    # draws inside them — e.g. AddNoise(0.025 * th.randn(...)) in examples/kelp.py, tauceti.py — agree across shards.
     everywhere = world > 1 and (get_bends is not None or get_rewrites is not None)
     front_end = rank == 0 or everywhere
     if world > 1:
         seed = int(sharding.broadcast_object(random.randrange(2 ** 31) if rank == 0 else None))
         if everywhere:
-            th.manual_seed(seed), np.random.seed(seed), random.seed(seed)
+            _seed_all(seed)
 
     from .audioreactive.examples import default as default_plugin
 
     get_latents = get_latents or default_plugin.get_latents
     get_noise = get_noise or default_plugin.get_noise
     latents, noise, bends, rewrites = None, [], [], {}
+
+    def load():
+        return load_generator(ckpt=ckpt, is_stylegan1=stylegan1, G_res=G_res, out_size=out_size, noconst=noconst,
+                              latent_dim=latent_dim, n_mlp=n_mlp, channel_multiplier=channel_multiplier,
+                              dataparallel=dataparallel, base_res_factor=base_res_factor)
+
+    # One process per GPU: the weights travel FIRST (rank 0 reads the checkpoint, one flat broadcast), so that every other rank
+    # packs its weights and captures its graph lanes while rank 0 runs the audio front end and the callbacks — a captured forward
+    # reads its inputs through a frame source and needs none of them (render.prepare).  A single process keeps the reference's
+    # order (generator after the preprocessing, :215-224), so the callbacks see the same random stream as there.
+    generator = None
+    will_bend = get_bends is not None or get_rewrites is not None
+    if world > 1:
+        generator = load()
+        if rank != 0:
+            render.prepare(generator, batch, bends=will_bend)
+
     if front_end:
         args.audio, args.sr, duration = ar.load_audio(audio_file, offset, duration)
     duration = float(sharding.broadcast_object(duration if rank == 0 else None))
@@ -201,9 +233,13 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
 
     if front_end and get_bends is not None:
         print("generating network bends...")
+        if world > 1:
+            _seed_all(seed + 1)
         bends = get_bends(args=args)
     if front_end and get_rewrites is not None:
         print("generating model rewrites...")
+        if world > 1:
+            _seed_all(seed + 2)
         rewrites = get_rewrites(args=args)
     if rank == 0:
         if get_truncation is not None:
@@ -219,9 +255,8 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
         shard = (lo, hi, n_frames)
 
     gc.collect()
-    generator = load_generator(ckpt=ckpt, is_stylegan1=stylegan1, G_res=G_res, out_size=out_size, noconst=noconst,
-                               latent_dim=latent_dim, n_mlp=n_mlp, channel_multiplier=channel_multiplier,
-                               dataparallel=dataparallel, base_res_factor=base_res_factor)
+    if generator is None:
+        generator = load()
     if world > 1 and not stylegan1 and not (isinstance(truncation, float) and truncation == 1.0):
         # the truncation centre is a random draw (mean_latent(2**14), reference models/stylegan2.py:539-540): one draw, on rank
         # 0, for every shard — otherwise neighbouring shards are truncated toward slightly different centres

@@ -317,7 +317,7 @@ class G_synthesis(nn.Module):
         s = th.empty((dlatents.shape[0], t["total"]), dtype=th.float32, device=dev)
         _lib.check(lib.maua_style_affine_f32(dlatents.data_ptr(), dlatents.shape[0], dlatents.shape[1], dlatents.shape[2], None,
                                              None, t["table"].data_ptr(), t["n"], t["max_rows"], s.data_ptr(), t["total"],
-                                             _lib.stream_ptr(dev)), "maua_style_affine_f32")
+                                             None, _lib.stream_ptr(dev)), "maua_style_affine_f32")
         return s, t["total"]
 
     def run(self, dlatents, noise):
@@ -364,12 +364,16 @@ class G_synthesis(nn.Module):
 class G_style(nn.Sequential):
     """reference :503-617 — what ``load_generator(..., is_stylegan1=True)`` builds (generate_audiovisual.py:41-42)."""
 
-    def __init__(self, output_size=1920, checkpoint=None):
+    def __init__(self, output_size=1920, checkpoint=None, network_resolution=None):
+        """``network_resolution`` (not in the reference): build the synthesis network at this resolution without probing a
+        checkpoint — the ranks of a multi-GPU job that do not read the checkpoint get it from rank 0, so that every rank has
+        the same blocks, constant and noise-buffer shapes before the weights are broadcast."""
         super().__init__()
         self.g_mapping = G_mapping()
         state = th.load(checkpoint, map_location="cpu") if checkpoint is not None else None
+        candidates = (1024, 512, 256, 128) if network_resolution is None else (int(network_resolution),)
         network_resolution = None
-        for resolution in (1024, 512, 256, 128):  # the checkpoint decides: the first resolution whose shapes fit (:509-537)
+        for resolution in candidates:  # the checkpoint decides: the first resolution whose shapes fit (:509-537)
             self.g_synthesis = G_synthesis(resolution=resolution)
             try:
                 if state is not None:
@@ -381,6 +385,7 @@ class G_style(nn.Sequential):
                       "ERROR: Network too small or state_dict mismatch")
         if network_resolution is None:
             raise SystemExit(1)
+        self.network_resolution = network_resolution
         block0 = getattr(self.g_synthesis.blocks, "4x4")
         const = block0.const
         if network_resolution != 1024:  # a smaller network still renders 1024 px: larger random constant (:540-542)

@@ -14,6 +14,7 @@ Same class names, constructor arguments, ``forward`` signatures and state-dict k
 All activations live in a per-batch-size cache of static device buffers, so a forward performs no allocation after
 its first call and can be captured into a hipGraph (``capture_graph``).  There is no CPU path: CPU tensors raise.
 """
+import ctypes
 import math
 
 import torch as th
@@ -225,9 +226,10 @@ class ModulatedConv2d(nn.Module):
                     cin=self.in_channel, cout=self.out_channel, lat_idx=lat_idx, s_off=s_off, d_off=d_off,
                     wscale=self.scale)
 
-    def run(self, x, s, s_off, d, out, ws, fuse_act=False, noise=None, noise_w=None, bias=None):
+    def run(self, x, s, s_off, d, out, ws, fuse_act=False, noise=None, noise_w=None, bias=None, src=None, slot=0):
         """3x3 only. x [B,Cin,H,W]; s [B,S] (this layer's slice at s_off); d [B,Cout] or None.
-        Writes ``out`` ([B,Cout,H,W] or [B,Cout,2H+1,2W+1] when upsample)."""
+        Writes ``out`` ([B,Cout,H,W] or [B,Cout,2H+1,2W+1] when upsample).  ``src`` (device pointer of a frame source,
+        include/maua_hip.h): the noise map comes from its slot ``slot`` instead of ``noise``."""
         lib = _lib.load()
         b, cin, h, w = x.shape
         mode = self.conv_mode(h, w)
@@ -236,7 +238,7 @@ class ModulatedConv2d(nn.Module):
         rc = lib.maua_modconv3x3_f32(
             x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b, cin,
             self.out_channel, h, w, mode, float(self.scale), int(fuse_act), _lib.ptr(noise), nstride,
-            _lib.ptr(noise_w), _lib.ptr(bias), _lib.ptr(ws), _lib.stream_ptr(x.device),
+            _lib.ptr(noise_w), _lib.ptr(bias), _lib.ptr(ws), src if fuse_act else None, slot, _lib.stream_ptr(x.device),
         )
         _lib.check(rc, "maua_modconv3x3_f32")
         return out
@@ -254,7 +256,7 @@ class ModulatedConv2d(nn.Module):
             lat = style.reshape(b, 1, -1)
             st = _lib.stream_ptr(dev)
             _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 1, lat.shape[-1], None, None, table.data_ptr(), 1,
-                                                 cin, s.data_ptr(), cin, st), "maua_style_affine_f32")
+                                                 cin, s.data_ptr(), cin, None, st), "maua_style_affine_f32")
             if d is not None:
                 _lib.check(lib.maua_demod_f32(table.data_ptr(), 1, self.out_channel, s.data_ptr(), cin, d.data_ptr(), b,
                                               st), "maua_demod_f32")
@@ -315,14 +317,16 @@ class LatentInput(nn.Module):
         out = self.activate(self.linear(inputs[:, 0]))
         return out.reshape((inputs.shape[0], self.channel, self.size, self.size))
 
-    def run(self, latent, trunc, tl, out):
+    def run(self, latent, trunc, tl, out, src=None, n_latent=None, style_dim=None):
         """Device path on static buffers (capturable): the table-driven affine kernel (truncation lerp included) writes
         W x / sqrt(dim) + b into ``out`` [B, C*16]; two in-place bias-act launches apply lrelu*sqrt2 and the second
-        bias + lrelu*sqrt2."""
+        bias + lrelu*sqrt2.  ``src``: the latents / truncation come from the frame source instead of ``latent`` / ``trunc``."""
         lib = _lib.load()
-        dev = latent.device
+        dev = out.device
         n_out = self.channel * self.size * self.size
-        batch = latent.shape[0]
+        batch = out.shape[0]
+        if latent is not None:
+            n_latent, style_dim = latent.shape[1], latent.shape[2]
         key = (self.linear.weight.data_ptr(), self.linear.bias.data_ptr(), str(dev))
         if getattr(self, "_table", None) is None or self._table[0] != key:
             entry = dict(mod_w=self.linear.weight, mod_b=self.linear.bias, wsq=None, cin=n_out, cout=0, lat_idx=0, s_off=0,
@@ -330,8 +334,8 @@ class LatentInput(nn.Module):
             self._table = (key, _style_table([entry], dev))
         st = _lib.stream_ptr(dev)
         flat = out.view(batch, n_out)
-        _lib.check(lib.maua_style_affine_f32(latent.data_ptr(), batch, latent.shape[1], latent.shape[2], _lib.ptr(trunc),
-                                             _lib.ptr(tl), self._table[1].data_ptr(), 1, n_out, flat.data_ptr(), n_out, st),
+        _lib.check(lib.maua_style_affine_f32(_lib.ptr(latent), batch, n_latent, style_dim, _lib.ptr(trunc),
+                                             _lib.ptr(tl), self._table[1].data_ptr(), 1, n_out, flat.data_ptr(), n_out, src, st),
                    "maua_style_affine_f32")
         _lib.check(lib.maua_fused_bias_act_f32(flat.data_ptr(), None, None, flat.data_ptr(), flat.numel(), 0, 1, 3, 0, 0.2,
                                                2 ** 0.5, st), "maua_fused_bias_act_f32")
@@ -354,6 +358,17 @@ class ManipulationLayer(nn.Module):
             if transform_dict["layer"] == self.layer:
                 out = transform_dict["transform"].to(out.device)(out)
         return out
+
+    def run(self, x, bends, bufs, tag, src=None):
+        """Device path.  Eager (``src`` None): as ``forward``.  Inside a captured forward every bend is a module with the
+        ``run_static(x, out, src)`` protocol (audioreactive/bend.py): it writes into a static buffer and reads its per-frame
+        parameters through the frame source, so one captured graph serves every batch of the render."""
+        if src is None:
+            return self.forward(x, bends)
+        for i, bd in enumerate(bends):
+            if bd["layer"] == self.layer:
+                x = bd["transform"].run_static(x, bufs(f"{tag}.bend{i}", tuple(x.shape)), src)
+        return x
 
 
 _PARTIAL_RGB = {}
@@ -387,10 +402,11 @@ class StyledConv(nn.Module):
     # layers wider than one weight tile on the 2-D Winograd kernel leave per-tile partial ToRGB sums (A/B switch)
     partial_rgb_fusion = True
 
-    def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None):
+    def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None, src=None, slot=0):
         """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers.
         ``rgb`` (plain layers only): dict(module=ToRGB, s_off, skip, out, store) — fold the following ToRGB into the conv
-        epilogue when the layer qualifies; on success ``rgb["done"]`` is set and ``rgb["out"]`` holds the image."""
+        epilogue when the layer qualifies; on success ``rgb["done"]`` is set and ``rgb["out"]`` holds the image.
+        ``src`` / ``slot``: the noise map is read through the frame source (``noise`` is then ignored and may be None)."""
         lib = _lib.load()
         conv = self.conv
         b, cin, h, w = x.shape
@@ -398,6 +414,8 @@ class StyledConv(nn.Module):
         # one split-K workspace PER LAYER: a shared name would be re-allocated whenever the size changes, and a captured
         # hipGraph keeps writing through the pointer of the buffer that was freed
         ws = bufs(tag + ".ws", (n_ws,)) if n_ws else None
+        if src is not None:
+            noise = None
         if noise is not None:
             noise = _lib.require_cuda(noise, "noise")
             # the kernels read oh*ow floats per sample (b samples unless the map is shared): a wrongly sized map would be
@@ -424,7 +442,7 @@ class StyledConv(nn.Module):
                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
                         s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), t.bias.data_ptr(), _lib.ptr(skip),
                         _lib.ptr(t.upsample.kernel) if skip is not None else None, rgb["out"].data_ptr(),
-                        int(rgb.get("store", True)), _lib.ptr(rgb.get("u8")), _lib.stream_ptr(x.device))
+                        int(rgb.get("store", True)), _lib.ptr(rgb.get("u8")), src, slot, _lib.stream_ptr(x.device))
                     if rc == 0:
                         rgb["done"] = True
                         return out
@@ -445,8 +463,8 @@ class StyledConv(nn.Module):
                         x.data_ptr(), conv.packed_wino(5).data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d),
                         out.data_ptr(), b, cin, conv.out_channel, h, w, 5, float(conv.scale), _lib.ptr(noise), nstride,
                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
-                        s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), _lib.stream_ptr(x.device)),
-                        "maua_styledconv_torgb_partial_f32")
+                        s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), src, slot,
+                        _lib.stream_ptr(x.device)), "maua_styledconv_torgb_partial_f32")
                     sel, ones = _partial_rgb_operands(m_tiles, b, x.device)
                     _lib.check(lib.maua_torgb_f32(part.data_ptr(), sel.data_ptr(), ones.data_ptr(), 3 * m_tiles, t.bias.data_ptr(),
                                                   _lib.ptr(skip), _lib.ptr(t.upsample.kernel) if skip is not None else None,
@@ -456,7 +474,7 @@ class StyledConv(nn.Module):
                     rgb["u8_done"] = False  # the image is in rgb["out"] as fp32 planes: a last layer still needs the frame epilogue
                     return out
             return conv.run(x, s, s_off, d, out, ws, fuse_act=True, noise=noise, noise_w=self.noise.weight,
-                            bias=self.activate.bias)
+                            bias=self.activate.bias, src=src, slot=slot)
         raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
         conv.run(x, s, s_off, d, raw, ws)
         k = conv.blur.kernel
@@ -466,7 +484,7 @@ class StyledConv(nn.Module):
         nstride = 0 if noise is None or noise.shape[0] == 1 else oh * ow
         rc = lib.maua_blur_noise_act_f32(raw.data_ptr(), k.data_ptr(), out.data_ptr(), b, conv.out_channel, raw.shape[2],
                                          raw.shape[3], k.shape[0], k.shape[1], pad0, pad1, None, _lib.ptr(noise), nstride,
-                                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(),
+                                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), src, slot,
                                          _lib.stream_ptr(x.device))
         _lib.check(rc, "maua_blur_noise_act_f32")
         return out
@@ -484,7 +502,7 @@ class StyledConv(nn.Module):
             lat = style.reshape(b, 1, -1)
             st = _lib.stream_ptr(dev)
             _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 1, lat.shape[-1], None, None, table.data_ptr(), 1,
-                                                 cin, s.data_ptr(), cin, st), "maua_style_affine_f32")
+                                                 cin, s.data_ptr(), cin, None, st), "maua_style_affine_f32")
             _lib.check(lib.maua_demod_f32(table.data_ptr(), 1, self.conv.out_channel, s.data_ptr(), cin, d.data_ptr(), b,
                                           st), "maua_demod_f32")
             if noise is None:
@@ -532,7 +550,7 @@ class ToRGB(nn.Module):
             table = _style_table([self.conv.table_entry(0, 0, 0)], dev)
             lat = style.reshape(b, 1, -1)
             _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 1, lat.shape[-1], None, None, table.data_ptr(), 1,
-                                                 cin, s.data_ptr(), cin, _lib.stream_ptr(dev)), "maua_style_affine_f32")
+                                                 cin, s.data_ptr(), cin, None, _lib.stream_ptr(dev)), "maua_style_affine_f32")
             out = th.empty((b, 3, h, w), dtype=th.float32, device=dev)
             if skip is not None:
                 skip = _lib.require_cuda(skip, "skip")
@@ -680,6 +698,8 @@ class Generator(nn.Module):
                 latent = latent[:, None, :].repeat(1, self.n_latent, 1)
         latent = _lib.require_cuda(latent.to(dev), "styles")
         batch = latent.shape[0]
+        if latent.dim() != 3 or tuple(latent.shape[1:]) != (self.n_latent, self.style_dim):
+            raise RuntimeError(f"styles {tuple(latent.shape)} do not match [batch, {self.n_latent}, {self.style_dim}]")
 
         noise = list(noise) if noise is not None else [None] * self.num_layers
         for ns in range(self.num_layers):
@@ -713,21 +733,25 @@ class Generator(nn.Module):
             return image, lat_out
         return image, None
 
-    def _forward_device(self, latent, noise, trunc, tl, bends, want_acts=False, want_latents=False, frames_u8=None):
+    def _forward_device(self, latent, noise, trunc, tl, bends, want_acts=False, want_latents=False, frames_u8=None, src=None,
+                        batch=None):
         """``frames_u8`` ([B, H, W, 3] uint8): the frame epilogue of render.py:40-43 (clamp, scale, NHWC, uint8) is folded into
         the last layer's fused ToRGB epilogue — the fp32 image of the last resolution is then never written (``image`` returned
-        is None) — or, when that layer cannot take the fused path, applied by maua_frames_to_u8 right behind it."""
+        is None) — or, when that layer cannot take the fused path, applied by maua_frames_to_u8 right behind it.
+        ``src`` (device pointer of a maua_frame_source_t) + ``batch``: latents, truncation and every noise map are read through
+        the frame source (``latent`` / ``noise`` / ``trunc`` are ignored); this is the form ``capture_graph`` records."""
         lib = _lib.load()
-        dev = latent.device
-        batch = latent.shape[0]
+        dev = self.input.input.device
+        if src is None:
+            batch = latent.shape[0]
         st = _lib.stream_ptr(dev)
         info = self._table(batch)
         bufs = lambda name, shape: self._buf(batch, name, shape)  # noqa: E731
         s = bufs("styles", (batch, info["s_total"]))
         d = bufs("demod", (info["d_total"],))
-        _lib.check(lib.maua_style_affine_f32(latent.data_ptr(), batch, latent.shape[1], latent.shape[2], _lib.ptr(trunc),
+        _lib.check(lib.maua_style_affine_f32(_lib.ptr(latent), batch, self.n_latent, self.style_dim, _lib.ptr(trunc),
                                              _lib.ptr(tl), info["table"].data_ptr(), len(info["entries"]),
-                                             info["max_cin"], s.data_ptr(), info["s_total"], st), "maua_style_affine_f32")
+                                             info["max_cin"], s.data_ptr(), info["s_total"], src, st), "maua_style_affine_f32")
         _lib.check(lib.maua_demod_f32(info["table"].data_ptr(), len(info["entries"]), info["max_cout"], s.data_ptr(),
                                       info["s_total"], d.data_ptr(), batch, st), "maua_demod_f32")
         ent = info["entries"]
@@ -738,6 +762,8 @@ class Generator(nn.Module):
             return d[e["d_off"]: e["d_off"] + batch * e["cout"]].view(batch, e["cout"])
 
         def noise_for(i, h, w):
+            if src is not None:
+                return None  # slot i of the frame source
             nz = noise[i]
             if nz is None:  # randomize_noise=True: fresh N(0,1) per call (:262-265)
                 nz = bufs(f"rand_noise_{i}", (batch, 1, h, w)).normal_()
@@ -745,14 +771,16 @@ class Generator(nn.Module):
 
         acts = []
         if isinstance(self.input, LatentInput):
-            x = self.input.run(latent, trunc, tl, bufs("const", (batch, self.input.channel, self.input.size, self.input.size)))
+            x = self.input.run(latent, trunc, tl, bufs("const", (batch, self.input.channel, self.input.size, self.input.size)),
+                               src=src, n_latent=self.n_latent, style_dim=self.style_dim)
         else:
             x = bufs("const", (batch,) + tuple(self.input.input.shape[1:]))
             x.copy_(self.input.input.expand(batch, -1, -1, -1))
-        x = self.const_manipulation(x, bends)
+        x = self.const_manipulation.run(x, bends, bufs, "const", src)
         li = 0
-        out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1")
-        out = self.conv1.manipulation(out, bends)
+        out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1",
+                             src=src, slot=0)
+        out = self.conv1.manipulation.run(out, bends, bufs, "conv1", src)
         acts.append(out)
         li += 1
         # min_rgb_size (reference :553,567): resolutions below it contribute no ToRGB, the skip chain starts later
@@ -764,8 +792,8 @@ class Generator(nn.Module):
         for n in range(self.log_size - 2):
             up, plain, rgb = self.convs[2 * n], self.convs[2 * n + 1], self.to_rgbs[n]
             out = up.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 1, out.shape[2] * 2, out.shape[3] * 2),
-                         bufs, f"convs.{2 * n}")
-            out = up.manipulation(out, bends)
+                         bufs, f"convs.{2 * n}", src=src, slot=2 * n + 1)
+            out = up.manipulation.run(out, bends, bufs, f"convs.{2 * n}", src)
             acts.append(out)
             li += 1
             current_size *= 2
@@ -781,8 +809,8 @@ class Generator(nn.Module):
                 fuse = dict(module=rgb, s_off=ent[li + 1]["s_off"], skip=image, out=rgb_buf,
                             store=(not is_last) or want_acts, u8=frames_u8 if is_last else None)
             out = plain.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 2, out.shape[2], out.shape[3]),
-                            bufs, f"convs.{2 * n + 1}", rgb=fuse)
-            out = plain.manipulation(out, bends)
+                            bufs, f"convs.{2 * n + 1}", rgb=fuse, src=src, slot=2 * n + 2)
+            out = plain.manipulation.run(out, bends, bufs, f"convs.{2 * n + 1}", src)
             acts.append(out)
             li += 1
             if fuse is not None and fuse.get("done"):
@@ -801,57 +829,131 @@ class Generator(nn.Module):
         return image, acts, lat_out
 
     # ------------------------------------------------------------------ hipGraph
-    def capture_graph(self, batch, noise_static, truncated=False, lane=0, frames_u8=False):
-        """Capture one forward of ``batch`` frames into a hipGraph.  Returns (graph, static) where static holds the
-        input buffers to overwrite before each ``graph.replay()`` (latents, truncation, per-layer noise or None for
-        checkpoint noise buffers) and ``static["image"]`` is the output buffer.  Bends are not capturable.
-        Graphs captured under different ``lane`` ids share the weights but no activation / input buffer, so they can
-        be replayed concurrently on different streams."""
-        if th.cuda.current_stream(self.input.input.device).cuda_stream == 0:
+    def weights_key(self):
+        """Identity of everything a captured graph has baked in as pointers: parameters and buffers (a swapped or in-place
+        modified tensor invalidates the packed weights, style tables and therefore the graph)."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def capture_graph(self, batch, lane=0, frames_u8=False, bends=()):
+        """Capture one forward of ``batch`` frames into a hipGraph and return its ``GraphLane``.  The captured kernels read
+        their per-frame inputs (latents, truncation, noise maps, bend parameters) THROUGH a frame source in device memory
+        (include/maua_hip.h): ``lane.bind(latents, noise, truncation)`` points it at sequences resident in HBM — any render,
+        any mix of per-frame maps and checkpoint noise buffers — and ``lane.replay(frame0)`` moves only the frame index, so a
+        graph is captured once per (batch, lane, bend set) and outlives the render (the reference re-uploads every slice per
+        batch, render.py:140-149).  ``bends``: [{"layer", "transform"}] whose transforms implement ``run_static`` (audioreactive
+        /bend.py).  Lanes share the weights but no activation buffer: they may be replayed concurrently on different streams."""
+        dev = self.input.input.device
+        if th.cuda.current_stream(dev).cuda_stream == 0:
             raise RuntimeError("capture_graph must run on a non-default stream (with torch.cuda.stream(s): ...): HIP cannot "
                                "capture the legacy default stream")
+        bends = list(bends)
+        for bd in bends:
+            if not hasattr(bd["transform"], "run_static"):
+                raise RuntimeError(f"bend on layer {bd['layer']} is not capturable: {type(bd['transform']).__name__} has no run_static")
         self._lane = lane
         self._captured = True
         try:
-            return self._capture_graph(batch, noise_static, truncated, frames_u8)
+            with th.cuda.device(dev):
+                source = FrameSource(self, batch, lane)
+                u8 = None
+                if frames_u8:
+                    hw = getattr(self.noises, f"noise_{self.num_layers - 1}").shape[-2:]
+                    u8 = self._buf(batch, "g.frames_u8", (batch, int(hw[0]), int(hw[1]), 3), dtype=th.uint8)
+                tl = self._buf(0, "g.trunc_latent", (self.style_dim,))
+                run = lambda: self._forward_device(None, None, None, tl, bends, frames_u8=u8, src=source.ptr, batch=batch)  # noqa: E731
+                run()  # warm-up: allocates every static buffer, packs the weights
+                th.cuda.synchronize(dev)
+                graph = _lib.HipGraph()
+                with graph:
+                    image, _, _ = run()
+            return GraphLane(self, graph, source, image, u8, tl, batch, lane, self.weights_key())
         finally:
             self._lane = 0
 
-    def _capture_graph(self, batch, noise_static, truncated, frames_u8=False):
-        dev = self.input.input.device
-        with th.cuda.device(dev):
-            static = {
-                "latents": self._buf(batch, "g.latents", (batch, self.n_latent, self.style_dim)),
-                "trunc": self._buf(batch, "g.trunc", (batch,)) if truncated else None,
-                "noise": [],
-            }
-            static["latents"].zero_()
-            if truncated:
-                static["trunc"].fill_(1.0)
-            for i in range(self.num_layers):
-                nz = noise_static[i]
-                if nz is None:
-                    static["noise"].append(getattr(self.noises, f"noise_{i}"))
-                else:
-                    b = self._buf(batch, f"g.noise_{i}", (batch, 1) + tuple(nz))
-                    b.zero_()
-                    static["noise"].append(b)
-            tl = None
-            if truncated:
-                if self.truncation_latent is None:
-                    self.truncation_latent = self.mean_latent(2 ** 14)
-                tl = self.truncation_latent.to(dev).reshape(-1).contiguous()
-            static["trunc_latent"] = tl
-            # ``frames_u8``: the graph's output is static["u8"] ([B, H, W, 3] uint8 frames); static["image"] is then None
-            u8 = None
-            if frames_u8:
-                hw = static["noise"][-1].shape[-2:]
-                u8 = static["u8"] = self._buf(batch, "g.frames_u8", (batch, int(hw[0]), int(hw[1]), 3), dtype=th.uint8)
-            # warm-up (allocates every static buffer, packs weights), then capture
-            self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [], frames_u8=u8)
-            th.cuda.synchronize(dev)
-            graph = _lib.HipGraph()
-            with graph:
-                image, _, _ = self._forward_device(static["latents"], static["noise"], static["trunc"], tl, [], frames_u8=u8)
-            static["image"] = image
-        return graph, static
+
+class FrameSource:
+    """Host handle of a maua_frame_source_t in device memory (include/maua_hip.h): the pointers of the HBM-resident per-frame
+    sequences a captured forward reads, plus the frame it starts at."""
+
+    def __init__(self, generator, batch, lane):
+        self.generator = generator
+        self.batch = batch
+        dev = generator.input.input.device
+        self.dev = generator._buf(batch, "g.frame_source", (ctypes.sizeof(_lib.FrameSource),), dtype=th.uint8)
+        self.ptr = self.dev.data_ptr()
+        self._keep = None
+        # until bound: zero latents of one batch, the checkpoint's noise buffers (stride 0), no truncation
+        zeros = generator._buf(batch, "g.latents0", (batch, generator.n_latent, generator.style_dim))
+        zeros.zero_()
+        self.noise_hw = [tuple(getattr(generator.noises, f"noise_{i}").shape[-2:]) for i in range(generator.num_layers)]
+        self.bind(zeros, [None] * generator.num_layers, None, _n_frames=batch)
+        del dev
+
+    def bind(self, latents, noise, trunc, _n_frames=None):
+        """latents [n_frames, n_latent, style_dim]; noise: per slot None (the checkpoint's buffer for every frame), a
+        [n_frames, 1, h, w] sequence or one shared [1, 1, h, w] map; trunc [n_frames] or None — all fp32, on the device,
+        contiguous; they are kept alive by this handle until the next bind."""
+        g = self.generator
+        dev = g.input.input.device
+        n_frames = latents.shape[0] if _n_frames is None else _n_frames
+        host = _lib.FrameSource()
+        latents = _lib.require_cuda(latents, "latents")
+        if latents.dim() != 3 or tuple(latents.shape[1:]) != (g.n_latent, g.style_dim):
+            raise RuntimeError(f"latents {tuple(latents.shape)} do not match [n_frames, {g.n_latent}, {g.style_dim}]")
+        host.latents = latents.data_ptr()
+        keep = [latents]
+        if trunc is not None:
+            trunc = _lib.require_cuda(trunc, "truncation").reshape(-1)
+            if trunc.numel() != n_frames:
+                raise RuntimeError(f"truncation has {trunc.numel()} entries for {n_frames} frames")
+            host.trunc = trunc.data_ptr()
+            keep.append(trunc)
+        if len(noise) != g.num_layers or g.num_layers > _lib.MAX_NOISE_SLOTS:
+            raise RuntimeError(f"{len(noise)} noise entries for {g.num_layers} layers")
+        for i, nz in enumerate(noise):
+            if nz is None:
+                nz = getattr(g.noises, f"noise_{i}")
+            nz = _lib.require_cuda(nz.to(dev), f"noise[{i}]")
+            if nz.dim() != 4 or nz.shape[1] != 1 or tuple(nz.shape[-2:]) != self.noise_hw[i] or nz.shape[0] not in (1, n_frames):
+                raise RuntimeError(f"noise[{i}] {tuple(nz.shape)} does not match [{n_frames} or 1, 1, {self.noise_hw[i][0]}, "
+                                   f"{self.noise_hw[i][1]}]")
+            host.noise[i] = nz.data_ptr()
+            host.noise_stride[i] = 0 if nz.shape[0] == 1 else nz.shape[-1] * nz.shape[-2]
+            keep.append(nz)
+        self.n_frames = n_frames
+        self._keep = keep
+        raw = th.frombuffer(bytearray(bytes(host)), dtype=th.uint8)
+        th.cuda.synchronize(dev)  # no replay of this lane may still be reading the previous pointers (bind is once per render)
+        self.dev.copy_(raw.to(dev), non_blocking=False)
+        th.cuda.synchronize(dev)
+
+    def seek(self, frame0, stream=None):
+        if frame0 < 0 or frame0 + self.batch > self.n_frames:
+            raise RuntimeError(f"frames [{frame0}, {frame0 + self.batch}) are outside the bound sequences ({self.n_frames} frames)")
+        _lib.check(_lib.load().maua_frame_source_seek(self.ptr, int(frame0), stream if stream is not None else _lib.stream_ptr()),
+                   "maua_frame_source_seek")
+
+
+class GraphLane:
+    """One captured forward of a Generator: hipGraph + the frame source it reads + its output buffers."""
+
+    def __init__(self, generator, graph, source, image, u8, trunc_latent, batch, lane, weights_key):
+        self.generator, self.graph, self.source = generator, graph, source
+        self.image, self.u8, self.batch, self.lane = image, u8, batch, lane
+        self._trunc_latent = trunc_latent
+        self.weights_key = weights_key
+
+    def bind(self, latents, noise, truncation=None):
+        """Point the lane at the sequences of a render (see FrameSource.bind).  ``truncation`` [n_frames] switches the
+        truncation lerp on; its centre is the generator's truncation latent (drawn lazily as in the reference :539-540)."""
+        g = self.generator
+        if truncation is not None:
+            if g.truncation_latent is None:
+                g.truncation_latent = g.mean_latent(2 ** 14)
+            self._trunc_latent.copy_(g.truncation_latent.to(self._trunc_latent.device).reshape(-1))
+        self.source.bind(latents, noise, truncation)
+
+    def replay(self, frame0, stream=None):
+        """Frames [frame0, frame0 + batch) of the bound sequences: one 4-byte device write + the graph launch."""
+        self.source.seek(frame0, stream)
+        self.graph.replay(stream)

@@ -120,6 +120,69 @@ def frames_to_uint8(images, out=None):
 _LANE_STREAMS = {}
 
 
+def _lane_stream(dev, k):
+    # lane streams are kept per device: the caching allocator pools freed blocks per stream, so fresh streams on
+    # every call would strand the staging buffers of the previous render
+    stream = _LANE_STREAMS.get((dev.index, k))
+    if stream is None:
+        stream = _LANE_STREAMS[(dev.index, k)] = th.cuda.Stream(dev)
+    return stream
+
+
+def graph_lanes(generator, batch_size, n_lanes, bends=()):
+    """``n_lanes`` captured forwards (GraphLane) of ``batch_size`` frames with uint8 frame output, each on its own stream.
+    Without bends they are cached on the generator and reused by every later render (a captured forward reads its inputs
+    through a frame source, so nothing about a particular render is baked in); a changed weight drops the cache.  With bends the
+    transforms' static operands are part of the graph: captured per call."""
+    dev = device_of(generator)
+    key = generator.weights_key()
+    cache = generator.__dict__.setdefault("_graph_lanes", {})
+    lanes = []
+    for k in range(n_lanes):
+        stream = _lane_stream(dev, k)
+        lane = None if bends else cache.get((batch_size, k))
+        if lane is not None and lane.weights_key != key:
+            lane = None
+        if lane is None:
+            stream.wait_stream(th.cuda.current_stream(dev))
+            with th.cuda.stream(stream):
+                lane = generator.capture_graph(batch_size, lane=k, frames_u8=True, bends=bends)
+            stream.synchronize()
+            if not bends:
+                cache[(batch_size, k)] = lane
+        lanes.append((stream, lane))
+    return lanes
+
+
+def prepare(generator, batch_size, lanes=3, bends=False):
+    """Everything of a render that does not depend on its inputs: weight packing, static buffers and — a captured forward reads
+    its inputs through a frame source, so it needs none of them — the graph lanes themselves.  generate() calls this on the
+    ranks that do not run the audio front end WHILE rank 0 runs it (multi-GPU jobs were front-end bound: the peers used to start
+    loading / packing / capturing only after the scatter).  With bends the graphs are captured per render (the transforms'
+    operands are part of them), so only the warm-up forward is done here."""
+    if not hasattr(generator, "capture_graph"):
+        return 0
+    if bends:
+        dev = device_of(generator)
+        zeros = th.zeros(batch_size, generator.n_latent, generator.style_dim, device=dev)
+        generator(styles=zeros, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+        return 0
+    return len(graph_lanes(generator, batch_size, lanes))
+
+
+def _sequence_bends(bends):
+    """The render's bends with every modulated transform instantiated ONCE on the modulation of the whole sequence (the reference
+    rebuilds it per batch from the batch's slice, render.py:151-158).  Returns (bends, capturable): capturable when every
+    transform implements ``run_static`` (audioreactive/bend.py: picks the frame's parameters on the device)."""
+    out, capturable = [], True
+    for bend in bends:
+        transform = bend["transform"](bend["modulation"]) if "modulation" in bend else bend["transform"]
+        if not hasattr(transform, "run_static") or not getattr(transform, "capturable", True):
+            return None, False
+        out.append({"layer": bend["layer"], "transform": transform})
+    return out, capturable
+
+
 def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), rewrites=None, randomize_noise=False,
                use_graph=True, frame_range=None, lanes=3):
     """Generator -> uint8 frames for ``frame_range`` (default: all) of the sequence.  Yields (first_frame_index,
@@ -128,7 +191,8 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
 
     hipGraph path: ``lanes`` graphs of ``batch_size`` frames (same weights, private activations) are replayed round-robin
     on their own streams, so consecutive batches overlap on the device — the small, latency-bound 4^2..32^2 layers and
-    the last partial wave of every big launch of one batch run underneath the other batch's MFMA-bound layers."""
+    the last partial wave of every big launch of one batch run underneath the other batch's MFMA-bound layers.  The
+    sequences (latents, noise maps, truncation, bend modulations) stay resident in HBM; a replay moves one frame index."""
     dev = device_of(generator)
     n_total = len(latents)
     lo, hi = frame_range if frame_range is not None else (0, n_total)
@@ -136,9 +200,9 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
     noise = [None if nz is None else nz.to(dev, th.float32).contiguous() for nz in noise]
     if isinstance(truncation, (int, float)):
         truncation = float(truncation)
-        # a float != 1 (or a generator that carries a truncation latent) must reach the captured graph as well: the
-        # graph is captured with a per-frame truncation input, filled with the constant (reference
-        # models/stylegan2.py:537-543 lerps every batch); 1.0 without a truncation latent is the exact identity
+        # a float != 1 (or a generator that carries a truncation latent) must reach the captured graph as well: it becomes a
+        # per-frame truncation sequence filled with the constant (reference models/stylegan2.py:537-543 lerps every batch);
+        # 1.0 without a truncation latent is the exact identity
         needs_lerp = truncation != 1.0 or getattr(generator, "truncation_latent", None) is not None
         trunc_t = th.full((n_total,), truncation, dtype=th.float32, device=dev) if needs_lerp else None
     else:
@@ -157,75 +221,64 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
             raise KeyError(f"get_rewrites: generator has no parameter {name!r}")
         rewrites[name] = [rewrite, modulation.to(dev, th.float32).contiguous()]
         original_weights[name] = param_dict[name].detach().clone()
-    capturable = (use_graph and not bends and not rewrites and not randomize_noise
-                  and hasattr(generator, "capture_graph"))
+    capturable = use_graph and not rewrites and not randomize_noise and hasattr(generator, "capture_graph")
+    seq_bends = []
+    if capturable and bends:
+        seq_bends, capturable = _sequence_bends(bends)
     n_lanes = max(1, int(lanes)) if capturable else 1
     caller_stream = th.cuda.current_stream(dev)
-    lane_state = []  # per lane: dict(stream, graph, static, u8)
-
-    def lane_for(k):
-        if k < len(lane_state):
-            return lane_state[k]
-        # lane streams are kept per device: the caching allocator pools freed blocks per stream, so fresh streams on
-        # every call would strand the staging buffers of the previous render
-        stream = _LANE_STREAMS.setdefault((dev.index, k), None) or th.cuda.Stream(dev)
-        _LANE_STREAMS[(dev.index, k)] = stream
+    lane_state = []  # (stream, GraphLane or None)
+    if capturable and hi - lo >= batch_size:
+        lane_state = graph_lanes(generator, batch_size, min(n_lanes, (hi - lo) // batch_size), seq_bends)
+        n_lanes = len(lane_state)
+        for stream, lane in lane_state:
+            lane.bind(latents, noise, trunc_t)  # once per render: the pointers of the HBM-resident sequences
+            stream.wait_stream(caller_stream)
+    else:
+        stream = _lane_stream(dev, 0)
         stream.wait_stream(caller_stream)
-        lane_state.append({"stream": stream, "graph": None, "static": None, "u8": None})
-        return lane_state[k]
+        lane_state = [(stream, None)]
+        n_lanes = 1
+    eager_u8 = None
 
     try:
         k = 0
         for n in range(lo, hi, batch_size):
             m = min(n + batch_size, hi)
             b = m - n
-            lane_id = k % n_lanes
-            lane = lane_for(lane_id)
-            with th.cuda.stream(lane["stream"]):
-                if capturable and b == batch_size:
-                    if lane["graph"] is None:
-                        shapes = [None if nz is None else tuple(nz.shape[-2:]) for nz in noise]
-                        lane["graph"], lane["static"] = generator.capture_graph(
-                            batch_size, shapes, truncated=trunc_t is not None, lane=lane_id, frames_u8=True)
-                    static = lane["static"]
-                    static["latents"].copy_(latents[n:m])
-                    for dst, src in zip(static["noise"], noise):
-                        if src is not None:
-                            dst.copy_(src[n:m])
-                    if trunc_t is not None:
-                        static["trunc"].copy_(trunc_t[n:m])
-                    lane["graph"].replay()
-                    yield n, static["u8"]  # the frame epilogue is part of the captured forward (fused into the last ToRGB)
+            stream, lane = lane_state[k % n_lanes]
+            with th.cuda.stream(stream):
+                if lane is not None and b == batch_size:
+                    lane.replay(n)
+                    yield n, lane.u8  # the frame epilogue is part of the captured forward (fused into the last ToRGB)
                     k += 1
                     continue
-                else:
-                    noise_batch = [None if nz is None else nz[n:m] for nz in noise]
-                    bend_batch = []
-                    for bend in bends:
-                        if "modulation" in bend:
-                            transform = bend["transform"](bend["modulation"][n:m])
-                            bend_batch.append({"layer": bend["layer"], "transform": transform})
-                        else:
-                            bend_batch.append({"layer": bend["layer"], "transform": bend["transform"]})
-                    for name, (rewrite, modulation) in rewrites.items():
-                        new_weight = rewrite(modulation[n:m])(original_weights[name]).to(dev, th.float32).contiguous()
-                        module = generator
-                        *path, leaf = name.split(".")
-                        for attr in path:
-                            module = getattr(module, attr)
-                        setattr(module, leaf, th.nn.Parameter(new_weight, requires_grad=False))
-                    if n_lanes > 1:  # the eager tail batch shares lane 0's activations: let the other lanes drain first
-                        for other in lane_state:
-                            lane["stream"].wait_stream(other["stream"])
-                    images, _ = generator(styles=latents[n:m], noise=noise_batch,
-                                          truncation=truncation if trunc_t is None else trunc_t[n:m],
-                                          transform_dict_list=bend_batch, randomize_noise=randomize_noise,
-                                          input_is_latent=True)
-                u8 = lane["u8"]
-                if u8 is None or u8.shape[0] != b or u8.shape[1:3] != images.shape[2:]:
-                    u8 = lane["u8"] = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
-                frames_to_uint8(images, u8)
-                yield n, u8
+                noise_batch = [None if nz is None else nz[n:m] for nz in noise]
+                bend_batch = []
+                for bend in bends:
+                    if "modulation" in bend:
+                        transform = bend["transform"](bend["modulation"][n:m])
+                        bend_batch.append({"layer": bend["layer"], "transform": transform})
+                    else:
+                        bend_batch.append({"layer": bend["layer"], "transform": bend["transform"]})
+                for name, (rewrite, modulation) in rewrites.items():
+                    new_weight = rewrite(modulation[n:m])(original_weights[name]).to(dev, th.float32).contiguous()
+                    module = generator
+                    *path, leaf = name.split(".")
+                    for attr in path:
+                        module = getattr(module, attr)
+                    setattr(module, leaf, th.nn.Parameter(new_weight, requires_grad=False))
+                if n_lanes > 1 or lane is not None:  # the eager tail batch shares lane 0's activations: let every lane drain first
+                    for other, _ in lane_state:
+                        stream.wait_stream(other)
+                images, _ = generator(styles=latents[n:m], noise=noise_batch,
+                                      truncation=truncation if trunc_t is None else trunc_t[n:m],
+                                      transform_dict_list=bend_batch, randomize_noise=randomize_noise,
+                                      input_is_latent=True)
+                if eager_u8 is None or eager_u8.shape[0] != b or eager_u8.shape[1:3] != images.shape[2:]:
+                    eager_u8 = th.empty((b, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
+                frames_to_uint8(images, eager_u8)
+                yield n, eager_u8
             k += 1
     finally:  # also when the consumer stops early (sink error, generator closed)
         for name, w in original_weights.items():  # leave the generator as it was found
@@ -234,8 +287,8 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
             for attr in path:
                 module = getattr(module, attr)
             setattr(module, leaf, th.nn.Parameter(w, requires_grad=False))
-        for lane in lane_state:
-            caller_stream.wait_stream(lane["stream"])
+        for stream, _ in lane_state:
+            caller_stream.wait_stream(stream)
 
 
 def render(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file=None,

@@ -37,12 +37,25 @@ def shard_bounds(n_frames, rank, world):
 
 
 def broadcast_module(module, src=0):
-    """Make every rank's parameters and buffers equal rank ``src``'s (one broadcast per tensor, done once)."""
+    """Make every rank's parameters and buffers equal rank ``src``'s: ONE broadcast per dtype of a flat staging buffer (the
+    1024^2 generator is 171 tensors / 133 MB; per-tensor broadcasts were 171 collectives, most of them latency-bound)."""
     rank, world = rank_world()
     if world == 1:
         return module
+    by_dtype = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for dtype in sorted(by_dtype, key=str):
+        tensors = by_dtype[dtype]
+        flat = th.empty(sum(t.numel() for t in tensors), dtype=dtype, device=tensors[0].device)
+        if rank == src:
+            th.cat([t.reshape(-1) for t in tensors], out=flat)
+        dist.broadcast(flat, src)
+        if rank != src:
+            off = 0
+            for t in tensors:
+                t.copy_(flat[off: off + t.numel()].view_as(t))
+                off += t.numel()
     return module
 
 
@@ -141,6 +154,15 @@ class FrameStream:
         self.works = []
         self.pushed = 0
         self._cursor = (0, 0)  # (rank, round) of the next frames to hand out on dst
+        # dst's way to the host: a ring of pinned staging buffers filled by asynchronous copies on a copy stream, so that
+        # fetching round k overlaps the Python thread launching the next replays (as render() does on one GPU); on a CPU
+        # "device" (gloo tests) the rounds are handed out in place
+        self._on_gpu = th.device(device).type == "cuda"
+        self._ring, self._copy_stream, self._inflight, self._issued = [], None, [], 0
+        self._pushed_events = []
+        if self.rank == dst and self._on_gpu:
+            self._copy_stream = th.cuda.Stream(device)
+            self._ring = [th.empty((self.batch,) + self.shape, dtype=th.uint8).pin_memory() for _ in range(3)]
 
     def push(self, k, u8):
         if k != self.pushed:
@@ -148,6 +170,10 @@ class FrameStream:
         slot = self.mine[k * self.batch: (k + 1) * self.batch]
         if u8 is not None:
             slot[: u8.shape[0]].copy_(u8)
+        if self._copy_stream is not None:  # dst: the staging copy of this round must run behind the copy above
+            ev = th.cuda.Event()
+            ev.record(th.cuda.current_stream(self.mine.device))
+            self._pushed_events.append(ev)
         if self.world > 1:
             into = [self.store[p, k * self.batch: (k + 1) * self.batch] for p in range(self.world)] if self.rank == self.dst else None
             self.works.append(dist.gather(slot, into, dst=self.dst, async_op=True))
@@ -178,11 +204,9 @@ class FrameStream:
             return True
         return w.is_completed()
 
-    def drain(self, block=False):
-        """dst only: yield (global_frame_index, uint8 CPU tensor [H, W, 3]) for every frame that is next in order and whose
-        round has arrived; with ``block=True`` wait for rounds that were pushed but have not landed yet."""
-        if self.rank != self.dst:
-            return
+    def _next_round(self, block):
+        """dst: (first_frame, count, device tensor, event the data is ready behind) of the next round in global frame order
+        (rank-major: the blocks are contiguous) if it is available, else None; advances the cursor."""
         p, k = self._cursor
         while p < self.world:
             lo, hi = shard_bounds(self.n_frames, p, self.world)
@@ -192,15 +216,55 @@ class FrameStream:
                 self._cursor = (p, k)
                 continue
             count = min(self.batch, hi - first)
+            ready = None
             if p == self.rank:  # dst's own frames never wait for a transfer: they are local as soon as they are pushed
                 if k >= self.pushed:
-                    break
-                host = self.mine[k * self.batch: k * self.batch + count].cpu()
+                    return None
+                src = self.mine[k * self.batch: k * self.batch + count]
+                if self._pushed_events:
+                    ready = self._pushed_events[k]
             else:
                 if not self._landed(k, block):
+                    return None
+                src = self.store[p, k * self.batch: k * self.batch + count]
+                if self._on_gpu:  # (a completed / waited-for work orders the CURRENT stream behind the transfer)
+                    ready = th.cuda.Event()
+                    ready.record(th.cuda.current_stream(self.mine.device))
+            self._cursor = (p, k + 1)
+            return first, count, src, ready
+        return None
+
+    def drain(self, block=False):
+        """dst only: yield (global_frame_index, uint8 CPU tensor [H, W, 3]) for every frame that is next in order and whose
+        round has arrived; with ``block=True`` wait for rounds that were pushed but have not landed yet.  Rounds travel to
+        the host through the pinned ring: up to len(ring) asynchronous copies are in flight while earlier rounds are consumed."""
+        if self.rank != self.dst:
+            return
+        while True:
+            while len(self._inflight) < max(len(self._ring), 1):
+                nxt = self._next_round(block)
+                if nxt is None:
                     break
-                host = self.store[p, k * self.batch: k * self.batch + count].cpu()
-            k += 1
-            self._cursor = (p, k)
+                first, count, src, ready = nxt
+                if not self._on_gpu:
+                    self._inflight.append((first, count, src, None))
+                    continue
+                host = self._ring[self._issued % len(self._ring)][:count]
+                self._issued += 1
+                with th.cuda.stream(self._copy_stream):
+                    if ready is not None:
+                        self._copy_stream.wait_event(ready)
+                    host.copy_(src, non_blocking=True)
+                    done = th.cuda.Event()
+                    done.record(self._copy_stream)
+                self._inflight.append((first, count, host, done))
+            if not self._inflight:
+                return
+            first, count, host, done = self._inflight[0]
+            if done is not None:
+                if not block and not done.query():
+                    return  # still on its way: the caller comes back after its next replay
+                done.synchronize()
+            self._inflight.pop(0)
             for i in range(count):
                 yield first + i, host[i]

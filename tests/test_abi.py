@@ -45,7 +45,13 @@ def test_rejects_bad_arguments_without_gpu(built_lib):
     # kernel modes of maua_modconv3x3_f32: 0 direct, 1 transposed, 2 / 3 Winograd F(2,3) / F(4,3), 4 transposed + F(2,2), 5 2-D Winograd
     fake = 0x1000  # never dereferenced: these calls are rejected during validation / planning
     conv = lambda h, w, mode, fuse=0: lib.maua_modconv3x3_f32(fake, fake, fake, 64, None, fake, 1, 64, 64, h, w, mode, 1.0, fuse,  # noqa: E731
-                                                              None, 0, None, None, fake, None)
+                                                              None, 0, None, None, fake, None, 0, None)
+    # frame source (include/maua_hip.h): a noise slot outside the table, a source without noise strength, a negative frame
+    assert lib.maua_modconv3x3_f32(fake, fake, fake, 64, None, fake, 1, 64, 64, 64, 64, 0, 1.0, 1, None, 0, fake, None, fake, fake, 32, None) == -22
+    assert lib.maua_modconv3x3_f32(fake, fake, fake, 64, None, fake, 1, 64, 64, 64, 64, 0, 1.0, 1, None, 0, None, None, fake, fake, 0, None) == -22
+    assert lib.maua_frame_source_seek(fake, -1, None) == -22 and lib.maua_frame_source_seek(None, 0, None) == -22
+    import ctypes as ct
+    assert ct.sizeof(_lib.FrameSource) == 8 + 2 * 8 + 32 * 8 + 32 * 8  # layout of maua_frame_source_t
     assert conv(64, 64, 6) == -22           # unknown mode
     assert conv(64, 48, 5) == -22           # 2-D Winograd (mode 5) needs W % 32 == 0 ...
     assert conv(12, 64, 5) == -22           # ... and H % 8 == 0

@@ -69,23 +69,38 @@ def test_hipgraph_replay_equals_eager(gpu):
     noise = [n.to(gpu) for n in seeding.seeded_noise(batch, 64, seed=10)]
     eager, _ = g(styles=lat, noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
     eager = eager.clone()
+    lat2 = seeding.seeded_latents(batch, g.n_latent, seed=11).to(gpu)
+    # the captured forward reads its inputs through a frame source: bind a 3-batch sequence (batches 0 and 2 = lat, 1 = lat2;
+    # noise maps repeated accordingly), replay at different frame offsets of the SAME graph
+    seq_lat = torch.cat([lat, lat2, lat]).contiguous()
+    seq_noise = [torch.cat([n, n, n]).contiguous() for n in noise]
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        graph, static = g.capture_graph(batch, [tuple(n.shape[-2:]) for n in noise])
-        static["latents"].copy_(lat)
-        for dst, src in zip(static["noise"], noise):
-            dst.copy_(src)
-        graph.replay()
+        lane = g.capture_graph(batch)
+        lane.bind(seq_lat, seq_noise)
+        lane.replay(0)
         stream.synchronize()
-        assert torch.equal(static["image"], eager)
-        # new inputs through the same graph
-        lat2 = seeding.seeded_latents(batch, g.n_latent, seed=11).to(gpu)
-        static["latents"].copy_(lat2)
-        graph.replay()
+        assert torch.equal(lane.image, eager)
+        lane.replay(batch)  # new inputs through the same graph: only the frame index moved
         stream.synchronize()
-        replayed = static["image"].clone()
+        replayed = lane.image.clone()
+        lane.replay(2 * batch)
+        stream.synchronize()
+        assert torch.equal(lane.image, eager)
+        with pytest.raises(RuntimeError, match="outside the bound sequences"):
+            lane.replay(2 * batch + 1)
+        # a second render through the same graph: other sequences, shared [1,1,h,w] maps and a checkpoint buffer (None) mixed
+        mixed = [None if i % 3 == 0 else (n[:1].contiguous() if i % 3 == 1 else n) for i, n in enumerate(noise)]
+        lane.bind(lat2, mixed)
+        lane.replay(0)
+        stream.synchronize()
+        rebound = lane.image.clone()
+        with pytest.raises(RuntimeError, match="does not match"):
+            lane.bind(lat2, [n[..., :-1] for n in noise])
     eager2, _ = g(styles=lat2, noise=noise, truncation=1.0, randomize_noise=False, input_is_latent=True)
     assert torch.equal(replayed, eager2)
+    eager3, _ = g(styles=lat2, noise=mixed, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    assert torch.equal(rebound, eager3)
 
 
 def test_randomize_noise_and_float_truncation(gpu):
@@ -215,18 +230,15 @@ def test_generator_variants_match_reference_golden(gpu, golden):
         err = float((img.cpu() - torch.from_numpy(fx[f"{key}.image"])).abs().max())
         assert err < TOL, (key, err)
         with pytest.raises(RuntimeError, match="non-default stream"):
-            g.capture_graph(batch, [tuple(n.shape[-2:]) for n in noise], truncated=True)
+            g.capture_graph(batch)
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
-            graph, static = g.capture_graph(batch, [tuple(n.shape[-2:]) for n in noise], truncated=True)
-            static["latents"].copy_(lat)
-            static["trunc"].copy_(trunc)
-            for dst, src in zip(static["noise"], noise):
-                dst.copy_(src)
-            graph.replay()
+            lane = g.capture_graph(batch)
+            lane.bind(lat, noise, trunc)
+            lane.replay(0)
             stream.synchronize()
-            assert torch.equal(static["image"], img), key
+            assert torch.equal(lane.image, img), key
 
 
 def test_stylegan1_synthesis_matches_reference_golden(gpu, golden):

@@ -306,7 +306,7 @@ def test_fused_torgb_epilogue_equals_separate_launches(gpu, cin, cout, h, w, wit
     demod = torch.empty(b * cout, device=gpu)
     st = _lib.stream_ptr(gpu)
     _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 2, 512, None, None, table.data_ptr(), 2, max(cin, cout),
-                                         styles.data_ptr(), cin + cout, st), "affine")
+                                         styles.data_ptr(), cin + cout, None, st), "affine")
     _lib.check(lib.maua_demod_f32(table.data_ptr(), 2, cout, styles.data_ptr(), cin + cout, demod.data_ptr(), b, st), "demod")
     for store in ((True, False) if cout <= 64 else (True,)):
         out_img = torch.full((b, 3, h, w), float("nan"), device=gpu)

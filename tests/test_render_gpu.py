@@ -207,14 +207,14 @@ def test_frame_epilogue_fused_into_last_torgb(gpu, size, all2d):
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
-            graph, static = g.capture_graph(b, [None] * g.num_layers, frames_u8=True)
-            static["latents"].copy_(lat)
-            static["u8"].fill_(7)
-            graph.replay()
+            lane = g.capture_graph(b, frames_u8=True)
+            lane.bind(lat, [None] * g.num_layers)
+            lane.u8.fill_(7)
+            lane.replay(0)
             stream.synchronize()
-        assert static["u8"].shape == (b, size, size, 3) and static["u8"].dtype == torch.uint8
-        assert torch.equal(static["u8"], want)
-        assert (static["image"] is None) == (size >= 512)  # fused: no fp32 image; fallback: image + conversion kernel
+        assert lane.u8.shape == (b, size, size, 3) and lane.u8.dtype == torch.uint8
+        assert torch.equal(lane.u8, want)
+        assert (lane.image is None) == (size >= 512)  # fused: no fp32 image; fallback: image + conversion kernel
     finally:
         ModulatedConv2d.winograd2d_min_cout = keep
 
@@ -533,13 +533,13 @@ def test_graph_replay_never_writes_outside_its_static_buffers(gpu):
     lat = seeding.seeded_latents(16, g.n_latent, seed=6).to(gpu)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        graph, static = g.capture_graph(8, [None] * g.num_layers)
+        lane = g.capture_graph(8)
+        lane.bind(lat, [None] * g.num_layers)
         stream.synchronize()
         sentinels = [torch.full((size,), 7, dtype=torch.uint8, device=gpu)
                      for size in [1 << 12, 1 << 16, 1 << 20, 3 << 19, 1 << 22, 1 << 24, 1 << 26] * 6]
         for k in range(2):
-            static["latents"].copy_(lat[8 * k: 8 * k + 8])
-            graph.replay()
+            lane.replay(8 * k)
         stream.synchronize()
         assert all(bool((s == 7).all()) for s in sentinels)
 
@@ -623,3 +623,182 @@ def test_render_rank_shards_on_device_equal_single_rank(gpu, tmp_path, monkeypat
             assert written == 0
     got = np.concatenate([shards[0], shards[1]])
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_captured_bends_equal_eager_bends_and_oracle(gpu):
+    """BASELINE config 5's workload inside the captured forward: a per-frame modulated Translate at layer id 4 and a Zoom at
+    layer id 5 (audioreactive/bend.py ``run_static``: the frame's inverse map is picked on the device through the frame
+    source).  Graph path (3 lanes, 5 graph batches + eager tail) == eager per-batch path bit for bit (reference render.py:151-158
+    rebuilds the transform per batch), and both match the oracle's transforms at the same layer ids to one grey level."""
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.audioreactive import bend
+    from oracle import signal_oracle
+    from oracle import stylegan2_oracle as so
+
+    size, n, bs = 64, 11, 2
+    sd = seeding.seeded_state_dict(size, seed=8)
+    g = build(size, gpu, 8)
+    lat = seeding.seeded_latents(n, g.n_latent, seed=9)
+    noise = [torch.from_numpy(seeding.seeded_array(10, f"sq{i}", (n, 1, r, r))) if r <= 32 else None
+             for i, r in enumerate(seeding.noise_sizes(size))]
+    h = w = 16
+    shift = torch.stack([torch.linspace(0.0, 1.5 * w, n), torch.zeros(n)], 1)  # scrolls by more than one width: the stacked pads
+    zoom = 1.0 + 0.3 * torch.sin(torch.arange(n) / 2.0)
+    bnoise = torch.from_numpy(seeding.seeded_array(11, "bend_noise", (1, 1, h, 5 * w))) * 0.05
+
+    def bends():
+        return [{"layer": 4, "modulation": shift.clone(), "transform": lambda b: bend.Translate(b, h, w, bnoise)},
+                {"layer": 5, "modulation": zoom.clone(), "transform": lambda b: bend.Zoom(b, h, w)}]
+
+    seq, ok = render._sequence_bends([dict(b, modulation=b["modulation"].to(gpu)) for b in bends()])
+    assert ok and all(hasattr(b["transform"], "run_static") for b in seq)
+
+    def run(use_graph):
+        frames = np.zeros((n, size, size, 3), np.uint8)
+        for first, u8 in render.synthesize(g, lat, noise, bs, bends=bends(), use_graph=use_graph):
+            frames[first: first + u8.shape[0]] = u8.cpu().numpy()
+        return frames
+
+    graphed, eager = run(True), run(False)
+    assert np.array_equal(graphed, eager)
+    assert not getattr(g, "_graph_lanes", {}), "graphs captured with bends are per render, not cached on the generator"
+
+    def o_translate(t):
+        pads = [(int(w / 2), int(w / 2), 0, 0), (w, w, 0, 0), (w, 0, 0, 0)]
+        return torch.from_numpy(signal_oracle.affine_reflect_warp(t.numpy(), bend._inverse_maps_translate(shift).numpy(), pads,
+                                                                  bnoise.numpy())).float()
+
+    def o_zoom(t):
+        pad = max(h, w) - 1
+        m = bend._inverse_maps_scale(zoom, w + 2 * pad, h + 2 * pad).numpy()
+        return torch.from_numpy(signal_oracle.affine_reflect_warp(t.numpy(), m, (pad,) * 4)).float()
+
+    noise_o = [nz if nz is not None else sd[f"noises.noise_{i}"] for i, nz in enumerate(noise)]
+    want = so.frames_to_uint8(so.generator_forward(sd, lat, noise_o, bends={4: o_translate, 5: o_zoom}))
+    diff = np.abs(graphed.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 5e-3
+    # a transform without the protocol (torch module) makes the render fall back to the eager path instead of failing
+    seq, ok = render._sequence_bends([{"layer": 0, "transform": torch.nn.ReplicationPad2d((2, 2, 0, 0))}])
+    assert not ok
+
+
+def test_cached_graph_lanes_serve_a_second_render_and_follow_weight_changes(gpu):
+    """Graph lanes are captured once per (batch, lane) and reused by later renders with other sequences (nothing of a render is
+    baked into a captured forward); loading other weights drops them."""
+    from maua_stylegan2_amd import render
+
+    size, n, bs = 32, 8, 4
+    g = build(size, gpu, 4)
+
+    def frames_of(seed, use_graph):
+        lat = seeding.seeded_latents(n, g.n_latent, seed=seed)
+        noise = seeding.seeded_noise(n, size, seed=seed + 1)
+        out = np.zeros((n, size, size, 3), np.uint8)
+        for first, u8 in render.synthesize(g, lat, noise, bs, use_graph=use_graph, lanes=2):
+            out[first: first + u8.shape[0]] = u8.cpu().numpy()
+        return out
+
+    a = frames_of(20, True)
+    lanes_before = dict(g._graph_lanes)
+    assert len(lanes_before) == 2
+    b = frames_of(30, True)
+    assert all(g._graph_lanes[k] is v for k, v in lanes_before.items()), "second render re-captured its graphs"
+    assert np.array_equal(a, frames_of(20, False)) and np.array_equal(b, frames_of(30, False))
+    g.load_state_dict(seeding.seeded_state_dict(size, seed=5), strict=True)
+    c = frames_of(20, True)
+    assert all(g._graph_lanes[k] is not v for k, v in lanes_before.items()), "stale graphs survived a weight change"
+    assert np.array_equal(c, frames_of(20, False)) and not np.array_equal(c, a)
+
+
+def test_bench_configuration_1024_batch8_three_lanes_vs_oracle(gpu):
+    """The configuration bench.py times — 1024^2 generator, batches of 8 frames, 3 graph lanes, per-frame noise up to 256^2 and
+    checkpoint buffers above, uint8 frames written by the last layer's fused epilogue — against the ORACLE on full frames:
+    frame 19 (second batch of lane 2 ... the third lane's first replay) and frame 33 (lane 1's second replay), <= 1 grey level."""
+    from maua_stylegan2_amd import render
+    from oracle import stylegan2_oracle as so
+
+    size, n, bs = 1024, 40, 8
+    sd = seeding.seeded_state_dict(size, seed=0)
+    g = build(size, gpu, 0)
+    lat = seeding.seeded_latents(n, g.n_latent, seed=100)
+    noise = [torch.from_numpy(seeding.seeded_array(200, f"n{i}", (n, 1, r, r))) if r <= 256 else None
+             for i, r in enumerate(seeding.noise_sizes(size))]
+    picks = {19: None, 33: None}
+    batches = 0
+    for first, u8 in render.synthesize(g, lat, noise, bs, lanes=3):
+        assert u8.shape == (bs, size, size, 3)
+        batches += 1
+        for i in picks:
+            if first <= i < first + bs:
+                picks[i] = u8[i - first].cpu().numpy()
+    assert batches == 5 and len(g._graph_lanes) == 3
+    for i, got in picks.items():
+        noise_i = [sd[f"noises.noise_{k}"] if nz is None else nz[i: i + 1] for k, nz in enumerate(noise)]
+        want = so.frames_to_uint8(so.generator_forward(sd, lat[i: i + 1], noise_i))[0]
+        diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (i, int(diff.max()), float((diff > 0).mean()))
+
+
+def test_config3_900_frames_through_generate_vs_oracle(gpu, tmp_path, monkeypatch):
+    """BASELINE config 3 at FULL size through the drop-in surface: a 30 s seeded track -> ``generate()`` with the default
+    audio-reactive plugin (HIP feature kernels, chroma-weighted latents, reactive noise <= 256^2, checkpoint buffers above) on a
+    seeded 1024^2 checkpoint, 900 frames at 30 fps in batches of 8 (112 graph replays on 3 lanes + an eager tail of 4), delivered
+    in order to a host sink that keeps three frames.  Those frames are compared with the oracle generator run on the latents /
+    noise the product's callbacks returned (<= 1 grey level); every frame must arrive exactly once and in order."""
+    import wave
+
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.audioreactive.examples import default as plugin
+    from oracle import stylegan2_oracle as so
+
+    monkeypatch.chdir(tmp_path)
+    size, seconds, fps = 1024, 30.0, 30
+    n = int(round(seconds * fps))
+    sd = seeding.seeded_state_dict(size, seed=0)
+    torch.save({"g_ema": sd}, "seeded1024.pt")
+    audio = seeding.synthetic_audio(seconds)
+    with wave.open("track.wav", "wb") as f:
+        f.setnchannels(1), f.setsampwidth(2), f.setframerate(22050)
+        f.writeframes((np.clip(audio, -1, 1) * 32767).astype(np.int16).tobytes())
+    np.save("selection.npy", seeding.seeded_array(42, "selection", (12, 18, 512)))
+    keep = {0: None, 452: None, n - 1: None}
+    order = []
+
+    class KeepingSink(render.FrameSink):
+        def __init__(self, *a, **k):
+            self.count = 0
+
+        def write(self, frame):
+            if self.count in keep:
+                keep[self.count] = np.array(frame, copy=True)
+            if self.count % 64 == 0:
+                order.append((self.count, int(frame[::64, ::64].astype(np.int64).sum())))
+            self.count += 1
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(render, "FrameSink", KeepingSink)
+    seen = {"noise": []}
+
+    def get_latents(selection, args):
+        seen["latents"] = plugin.get_latents(selection, args)
+        return seen["latents"]
+
+    def get_noise(height, width, scale, num_scales, args):
+        nz = plugin.get_noise(height, width, scale, num_scales, args)
+        seen["noise"].append(None if nz is None else nz.detach().cpu())
+        return nz
+
+    gav.generate(ckpt="seeded1024.pt", audio_file="track.wav", initialize=plugin.initialize, get_latents=get_latents,
+                 get_noise=get_noise, latent_file="selection.npy", G_res=size, out_size=size, fps=fps, batch=8,
+                 output_file=str(tmp_path / "o.mp4"))
+    assert tuple(seen["latents"].shape) == (n, 18, 512) and len(seen["noise"]) == 17
+    assert [i for i, _ in order] == list(range(0, n, 64)) and len({c for _, c in order}) > len(order) // 2  # distinct frames, in order
+    for i, got in keep.items():
+        assert got is not None and got.shape == (size, size, 3), i
+        noise_i = [sd[f"noises.noise_{k}"] if nz is None else nz[i: i + 1] for k, nz in enumerate(seen["noise"])]
+        want = so.frames_to_uint8(so.generator_forward(sd, seen["latents"][i: i + 1].cpu().float(), noise_i))[0]
+        diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (i, int(diff.max()), float((diff > 0).mean()))

@@ -216,3 +216,153 @@ def test_two_rank_scatter_and_streamed_ordered_frames(tmp_path, n_frames, batch)
     its block — the transfer overlaps production instead of waiting for the end of the shard."""
     mp.spawn(_stream_worker, args=(2, _free_port(), n_frames, batch, str(tmp_path)), nprocs=2, join=True)
     assert int(np.load(tmp_path / "stream_ok.npy")[0]) == n_frames
+
+
+def _generate_worker(rank, world, port, out_dir):
+    """generate() under a 2-rank process group with CPU stand-ins for the audio decoder, the generator and the renderer: what is
+    under test is the ORDER of the multi-GPU hand-over and the random streams of the plugin callbacks."""
+    import time
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from maua_stylegan2_amd import generate_audiovisual as gav
+
+        os.chdir(out_dir)
+        log = []  # (event, monotonic time)
+        mark = lambda name: log.append((name, time.monotonic()))  # noqa: E731
+        n_frames, fps = 12, 12
+
+        class FakeGenerator:
+            truncation_latent = None
+
+        def fake_load_generator(**kw):
+            mark("load_generator")
+            # what load_generator does for the weights: one flat broadcast from rank 0
+            lin = torch.nn.Linear(4, 3)
+            sharding.broadcast_module(lin)
+            return FakeGenerator()
+
+        def fake_prepare(generator, batch_size, lanes=3, bends=False):
+            mark("prepare")
+            return 0
+
+        real_scatter = gav._scatter_from_rank0
+
+        def logged_scatter(*a, **k):
+            out = real_scatter(*a, **k)
+            mark("scatter_done")
+            return out
+
+        captured = {}
+
+        def fake_render_shard(generator, latents, noise, offset, duration, batch, out_size, output_file, audio_file, truncation,
+                              bends, rewrites, randomize_noise, ffmpeg_preset, shard):
+            mark("render")
+            captured.update(latents=latents.clone(), bend_noise=bends[0]["transform"].noise.clone(),
+                            bend_mod=bends[1]["modulation"].clone(), rewrite_draw=rewrites["w"][0].draw.clone(), shard=shard)
+            return 0
+
+        gav.ar.load_audio = lambda f, o, d: (np.zeros(2205, np.float32), 22050, 1.0)
+        gav.load_generator = fake_load_generator
+        gav.render.prepare = fake_prepare
+        gav._scatter_from_rank0 = logged_scatter
+        gav.render.render_shard = fake_render_shard
+        np.save("selection.npy", np.arange(3 * 2 * 4, dtype=np.float32).reshape(3, 2, 4))
+
+        def get_latents(selection, args):
+            mark("front_end")
+            time.sleep(0.4)  # rank 0's audio front end + callbacks take a while ...
+            torch.randn(7), np.random.rand(3)  # ... and consume random draws that the other ranks never make
+            return torch.arange(args.n_frames, dtype=torch.float32).reshape(-1, 1, 1).repeat(1, 2, 4)
+
+        def get_noise(height, width, scale, num_scales, args):
+            torch.randn(2)
+            return None
+
+        class AddNoiseLike(torch.nn.Module):
+            def __init__(self, noise):
+                super().__init__()
+                self.noise = noise
+
+        def get_bends(args):  # examples/kelp.py, tauceti.py draw their bend noise with th.randn here
+            return [{"layer": 0, "transform": AddNoiseLike(0.025 * torch.randn(1, 1, 4, 8))},
+                    {"layer": 4, "modulation": torch.rand(args.n_frames, 2), "transform": lambda b: b}]
+
+        class Rewrite:
+            def __init__(self):
+                self.draw = torch.randn(3) + np.random.rand()
+
+        def get_rewrites(args):
+            return {"w": [Rewrite(), torch.rand(args.n_frames)]}
+
+        gav.generate(ckpt="none.pt", audio_file="a.wav", get_latents=get_latents, get_noise=get_noise, get_bends=get_bends,
+                     get_rewrites=get_rewrites, latent_file="selection.npy", fps=fps, batch=4, G_res=64, out_size=512,
+                     output_file=os.path.join(out_dir, "o.mp4"))
+        lo, hi = sharding.shard_bounds(n_frames, rank, world)
+        assert captured["shard"] == (lo, hi, n_frames)
+        assert torch.equal(captured["latents"][:, 0, 0], torch.arange(lo, hi, dtype=torch.float32))
+        names = [n for n, _ in log]
+        if rank == 0:  # weights first, then the front end, then the scatter; rank 0 prepares inside its own render
+            assert names.index("load_generator") < names.index("front_end") < names.index("scatter_done") < names.index("render")
+            assert "prepare" not in names
+        else:  # loaded AND prepared before the scatter returned
+            assert names.index("load_generator") < names.index("prepare") < names.index("scatter_done") < names.index("render")
+        torch.save({"log": log, "bend_noise": captured["bend_noise"], "bend_mod": captured["bend_mod"],
+                    "rewrite_draw": captured["rewrite_draw"]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_generate_two_ranks_prepares_under_the_front_end_and_agrees_on_bend_randomness(tmp_path):
+    """world_size 2 over gloo, generate() with stand-ins for audio / generator / renderer:
+      * ranks != 0 hold a loaded and prepared (render.prepare: packed weights, captured graph lanes) generator BEFORE the scatter of
+        rank 0's per-frame inputs returns, and they got there while rank 0 was still inside its front end (the job used to be
+        front-end bound: peers started loading after the scatter);
+      * random draws inside get_bends / get_rewrites agree across ranks although rank 0 has consumed torch / numpy draws in the
+        latent and noise callbacks by then (ADVICE r2: every rank re-seeds immediately before those callbacks);
+      * modulations are rank 0's, cut to the rank's block."""
+    mp.spawn(_generate_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in (0, 1))
+    assert torch.equal(r0["bend_noise"], r1["bend_noise"]) and torch.equal(r0["rewrite_draw"], r1["rewrite_draw"])
+    assert r0["bend_mod"].shape == r1["bend_mod"].shape == (6, 2) and not torch.equal(r0["bend_mod"], r1["bend_mod"])
+    t0, t1 = dict(r0["log"]), dict(r1["log"])
+    # (time.monotonic is system-wide on Linux) rank 1 finished preparing before rank 0's front end was over
+    assert t1["prepare"] < t0["scatter_done"] and t1["prepare"] < t0["front_end"] + 0.4
+
+
+def _sg1_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from maua_stylegan2_amd import generate_audiovisual as gav
+        from maua_stylegan2_amd.models import stylegan1 as sg1
+
+        ckpt = os.path.join(out_dir, "sg1_256.pt")
+        if rank == 0:  # a 256-px checkpoint: the resolution probe goes 1024 -> 512 -> 256 on rank 0 only
+            torch.manual_seed(3)
+            src = sg1.G_style(output_size=1024, checkpoint=None, network_resolution=256)
+            state = {k: v for k, v in src.state_dict().items() if not k.startswith("noise_")}
+            state["g_synthesis.blocks.4x4.const"] = torch.randn(1, 512, 4, 4)  # a checkpoint holds the 4x4 constant G_style enlarges
+            torch.save(state, ckpt)
+        dist.barrier()
+        torch.nn.Module.cuda = lambda self, *a, **k: self  # CPU stand-in for .cuda()
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        g = gav.load_generator(ckpt, True, 1024, 1024, False, 512, 8, 2, False, 1)
+        assert g.network_resolution == 256
+        shapes = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+        torch.save({"shapes": shapes, "const": getattr(g.g_synthesis.blocks, "4x4").const.detach().clone(),
+                    "w": g.g_mapping.dense0.weight.detach().clone(), "tl": g.truncation_latent.clone(),
+                    "noise_3": g.noise_3.clone()}, os.path.join(out_dir, f"sg1_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stylegan1_two_ranks_build_the_probed_resolution_everywhere(tmp_path):
+    """``--stylegan1`` under torchrun: only rank 0 reads the checkpoint and probes its resolution; the probed value is
+    broadcast, so every rank builds the same blocks / enlarged constant / noise buffers before the weights are broadcast."""
+    mp.spawn(_sg1_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"sg1_rank{r}.pt", weights_only=False) for r in (0, 1))
+    assert r0["shapes"] == r1["shapes"] and r0["const"].shape == (1, 512, 16, 16)
+    for k in ("const", "w", "tl", "noise_3"):
+        assert torch.equal(r0[k], r1[k]), k

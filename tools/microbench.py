@@ -80,7 +80,7 @@ def main():
             nw = torch.full((1,), 0.1, device=dev)
             bias = torch.randn(C, device=dev)
             y2 = torch.empty(B, C, r, r, device=dev)
-            call2 = lambda: lib.maua_blur_noise_act_f32(x.data_ptr(), k.data_ptr(), y2.data_ptr(), B, C, r + 1, r + 1, 4, 4, 1, 1, None, nz.data_ptr(), 0, nw.data_ptr(), bias.data_ptr(), sp)  # noqa: E731
+            call2 = lambda: lib.maua_blur_noise_act_f32(x.data_ptr(), k.data_ptr(), y2.data_ptr(), B, C, r + 1, r + 1, 4, 4, 1, 1, None, nz.data_ptr(), 0, nw.data_ptr(), bias.data_ptr(), None, 0, sp)  # noqa: E731
             call2()
             e0.record(sp)
             for _ in range(args.iters):
@@ -140,7 +140,7 @@ def main():
                 styles = torch.empty(B, 2 * c, device=dev)
                 demod = torch.empty(B * c, device=dev)
                 table = _style_table([conv.conv.table_entry(0, 0, 0), rgb.conv.table_entry(1, c, B * c)], dev)
-                lib.maua_style_affine_f32(lat.data_ptr(), B, 2, 512, None, None, table.data_ptr(), 2, c, styles.data_ptr(), 2 * c, sp)
+                lib.maua_style_affine_f32(lat.data_ptr(), B, 2, 512, None, None, table.data_ptr(), 2, c, styles.data_ptr(), 2 * c, None, sp)
                 lib.maua_demod_f32(table.data_ptr(), 2, c, styles.data_ptr(), 2 * c, demod.data_ptr(), B, sp)
                 nz = torch.randn(1, 1, h, h, device=dev)
                 skip = torch.randn(B, 3, h // 2, h // 2, device=dev)
