@@ -125,6 +125,16 @@ int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, int cin, vo
  * wq[(ky*4+j)][i][o_pad] with j 0: g2, 1: g0+g2, 2: g0, 3: g1. */
 int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, void* stream);
 
+/* Transposed-conv form for mode 6 (F(2,2) on BOTH axes of the polyphase decomposition: 25 instead of 36 products per 2x2 block of
+ * positions): 16 transformed-kernel entries per (cout, cin) pair — 9 (even, even) + 3 (even row, odd column) + 3 (odd row, even
+ * column) + the centre tap, one axis transforming as (tap 2, tap 0 + tap 2, tap 0) — stored as the LDS tile images
+ * wq[cout/32][cin/4][16][cin%4][32 columns], followed by the five [cin][cout] tap matrices of the kernel's last row / column that
+ * the edge lines (output row 2H, column 2W) use.  maua_pack_weight_up2d_floats() floats.  maua_modconv_up2d_ok(): cin % 4 == 0,
+ * cout % 32 == 0, h % 8 == 0, w % 32 == 0. */
+int64_t maua_pack_weight_up2d_floats(int cout, int cin);
+int maua_pack_weight_up2d_f32(const float* w, float* wq, int cout, int cin, void* stream);
+int maua_modconv_up2d_ok(int cin, int cout, int h, int w);
+
 /* 2-D Winograd F(2x4, 3x3) form for mode 5 (F(2,3) along ky on top of F(4,3) along kx: 24 values per (cout, cin) pair),
  * stored as the LDS tile image the kernel DMAs linearly: wq[cout/BM][cin/4][fy 4][xf 6][cin%4][BM columns] (BM = 64, or 32 for
  * a 32-channel layer; m-tile pairs interleaved inside a row).  Needs 24*cin*cout floats.  maua_modconv_w2d_ok() says whether a
@@ -145,6 +155,8 @@ int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w);
  *             of 6 MFMA K-steps per position pair and kernel row; wp from maua_pack_weight_upwino_f32.
  *   up == 3 : the same through Winograd F(4,3) (W % 4 == 0): 2x fewer MFMA cycles than direct, |error| ~2e-5 of
  *             the output scale; wp from maua_pack_weight_wino43_f32.
+ *   up == 6 : the transposed convolution of up == 1 with F(2,2) on both axes (shapes accepted by maua_modconv_up2d_ok, fuse_act == 0):
+ *             25/36 of the MFMA cycles of up == 1; wp from maua_pack_weight_up2d_f32.
  *   up == 5 : the plain convolution through 2-D Winograd F(2x4, 3x3) (shapes accepted by maua_modconv_w2d_ok): 3x fewer
  *             MFMA cycles than direct, 1.5x fewer than up == 3; wp from maua_pack_weight_wino2d_f32.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];

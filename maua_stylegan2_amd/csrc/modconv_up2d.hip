@@ -1,0 +1,453 @@
+// Stride-2 transposed 3x3 modulated convolution through F(2,2) on BOTH axes of its polyphase form, on the fp32 matrix cores
+// (mode 6 of maua_modconv3x3_f32).
+//
+// Behavioural contract: /root/reference/models/stylegan2.py:229-237 (conv_transpose2d, stride 2, pad 0; the Blur that follows is
+// maua_blur_noise_act_f32) in the input-scale -> shared-weight contraction -> output-demod formulation of modconv.hip.
+//
+// Polyphase form: position (p, q) of the (H+1) x (W+1) grid owns the outputs (2p + a', 2q + b'); along one axis the even output
+// is a 2-tap correlation (taps 0 and 2 on inputs p, p-1), the odd output a 1-tap one (tap 1 on input p).  For a PAIR of
+// positions the two even outputs come from three products instead of four,
+//     m0 = g2 (d0 - d1),  m1 = (g0 + g2) d1,  m2 = g0 (d2 - d1);   e_p = m0 + m1,  e_p+1 = m1 + m2        (d = inputs p-1, p, p+1)
+// (modconv.hip's mode 4 does this along x only: 30 products per 2x2 positions).  Applied along y as well, a 2x2 BLOCK of
+// positions needs 9 (even, even) + 6 (even, odd) + 6 (odd, even) + 4 (odd, odd) = 25 products per (cin, cout) pair instead of 36
+// (direct polyphase, mode 1): 25/36 of the matrix-core cycles of mode 1, 5/6 of mode 4's.  Transform constants are +-1: the fp32
+// error stays at the level of the direct form (tests/test_winograd_algebra.py holds the identity and this kernel's index scheme).
+//
+//   window (3x3 inputs around the block, scaled by the style)  ->  row forms R = (r0 - r1, r1, r2 - r1, r2), column forms likewise
+//   -> 16 operand values B[a][b];   transformed kernel: 16 entries U (9 ee + 3 eo + 3 oe + g11: the eo / oe / oo phases reuse one
+//   entry for 2 / 2 / 4 products)   ->  25 accumulators per output channel, summed in pairs / quads in the epilogue.
+//
+// Work decomposition: a workgroup owns 32 output channels x (4 block rows x 16 block columns = 8 x 32 positions = 16 x 64
+// output pixels); wave w takes block row w: 25 x 2 accumulator tiles of v_mfma_f32_16x16x4_f32 (200 registers), 50 MFMAs per
+// 4-channel K step against 23 VALU (9 style multiplies + 14 subtractions) and 22 LDS reads (6 window + 16 weight rows).  No
+// cross-wave exchange: every wave holds all 25 products of its blocks.  Operands reach LDS by MUBUF `buffer_load ... lds` DMA,
+// double buffered, one barrier per K step; the packed weight (maua_pack_weight_up2d_f32) is stored in HBM as the LDS tile image.
+//
+// The main kernel covers the (H/2) x (W/2) blocks of positions p < H, q < W (H, W powers of two on this path: tiles never hang
+// over).  The remaining output row 2H and column 2W belong to positions whose own input is the zero padding: two 1-D polyphase
+// transposed convolutions of the last input row / column with the kernel's last row / column, 1.5 MAC per output
+// (up2d_edge_kernel: direct MFMA, ~1/H of the layer's work).
+#include "common.h"
+
+#include <cstdio>
+#include <type_traits>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAUA_DEVICE_PASS 1
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x4 f32x4u __attribute__((aligned(4)));
+typedef f32x2 f32x2u __attribute__((aligned(4)));
+
+constexpr int U2_CC = 4;                                  // input channels per K step = K of v_mfma_f32_16x16x4_f32
+constexpr int U2_NU = 16;                                 // transformed-kernel entries per (cout, cin)
+constexpr int U2_BM = 32;                                 // output channels per workgroup (two 16-row m-tiles, interleaved)
+constexpr int U2_A_FLOATS = U2_NU * U2_CC * U2_BM;        // 2048 floats = 8 DMA instructions of 1 KiB
+constexpr int U2_PROWS = 9;                               // staged input rows: 8 position rows + the row above
+constexpr int U2_PSEGS = 9;                               // 16-byte segments per staged row: image columns tx0-4 .. tx0+31
+constexpr int U2_PWS = 4 * U2_PSEGS;                      // LDS row stride (floats)
+constexpr int U2_PLANE = 352;                             // floats per staged channel: 9 x 36 = 324, padded to 32 mod 64 so that the
+                                                          // two K lane groups of a half-wave read disjoint bank halves (ds_read_b64)
+constexpr int U2_PBUF = 6 * 256;                          // one patch buffer = 6 whole DMA instructions >= 4 x 352 floats
+constexpr int U2_P_INSTR = 6;
+
+// single `ds_read_b64` / `ds_read_b32` through inline assembly with explicit lgkmcnt waits: see modconv_w2d.hip (left alone the
+// compiler pairs 8-byte reads into ds_read2_b64, which is serviced at half the bytes per clock on a 32-bank modulus)
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_read64(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ float lds_read32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct Up2dArgs {
+    const float* x;
+    const float* wq;    // packed transformed kernel (LDS tile images), then the five edge tap matrices
+    const float* s;
+    const float* d;
+    float* y;
+    int B, Cin, Cout, H, W;
+    int s_stride;
+    float wscale;
+    int tiles_x, tiles_y, m_tiles, n_chunks;
+};
+
+template <bool UNUSED>
+__global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: As[2][A_FLOATS] | Ps[2][PBUF] | Ss[Cin]
+    float* Ps = lds + 2 * U2_A_FLOATS;
+    float* Ss = Ps + 2 * U2_PBUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's block row inside the tile
+    const int j = lane & 15, kq = lane >> 4;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt_id = t % p.m_tiles;
+    t /= p.m_tiles;
+    const int tile_x = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tile_y = t % p.tiles_y;
+    const int b0 = t / p.tiles_y;
+    const int ty0 = tile_y * 8, tx0 = tile_x * 32;   // first position row / column of the tile
+    const int m0 = mt_id * U2_BM;
+    const size_t plane = (size_t)p.H * p.W;
+
+    // ---- patch DMA of this lane (decoded once).  Slot s = 64 i + lane of instruction i is 16-byte slot s of the buffer:
+    // channel s / 88, then row (s % 88) / 9 and segment (s % 88) % 9 (slots 81..87 of a channel are padding).  Rows above / below
+    // the image, the segment left of column 0 and the padding get an offset beyond the buffer descriptor's range, for which a
+    // raw buffer load returns 0: the DMA itself writes the zero padding.  Wave w issues instructions w and w + 4.
+    unsigned rel_bytes[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = 64 * (wv + 4 * g) + lane;
+        const int c = s / (U2_PLANE / 4), rem = s % (U2_PLANE / 4);
+        const int pr = rem / U2_PSEGS, sg = rem % U2_PSEGS;
+        const int yy = ty0 - 1 + pr, xx = tx0 - 4 + 4 * sg;
+        const bool ok = c < U2_CC && rem < U2_PROWS * U2_PSEGS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        rel_bytes[g] = ok ? (unsigned)((size_t)c * plane + (size_t)yy * p.W + xx) * 4u : 0x80000000u;
+    }
+    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+
+    const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
+    const size_t plane_bytes = plane * sizeof(float);
+    (void)ximg, (void)plane_bytes, (void)rel_bytes;
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wq), 0, 0x7fffffff, 0x00020000);
+#endif
+    auto issue = [&](int chunk, int buf) {
+#ifdef MAUA_DEVICE_PASS
+        const int wbase = (int)(((size_t)mt_id * p.n_chunks + chunk) * U2_A_FLOATS * sizeof(float));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {  // weight tile: linear copy, 1 KiB per wave instruction, instructions w and w + 4
+            const int i = wv + 4 * k;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(lds + buf * U2_A_FLOATS + i * 256),
+                                                     16, (i * 256 + lane * 4) * 4, wbase, 0, 0);
+        }
+        const int xbase = (int)((size_t)chunk * U2_CC * plane_bytes);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = wv + 4 * k;  // (scalar)
+            if (i < U2_P_INSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(Ps + buf * U2_PBUF + i * 256),
+                                                         16, (int)rel_bytes[k], xbase, 0, 0);
+        }
+#else
+        (void)chunk, (void)buf;
+#endif
+    };
+
+    // ---- accumulators (one 16 x 16 tile = 4 registers each; [.][m-tile]): 25 products x 2 m-tiles = 200 registers
+    f32x4 acc_ee[3][3][2], acc_eo[3][2][2], acc_oe[2][3][2], acc_oo[2][2][2];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc_ee[a][b][m] = zero4;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc_eo[a][b][m] = zero4, acc_oe[b][a][m] = zero4;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc_oo[a][b][m] = zero4;
+    }
+
+    // LDS byte addresses (buffer 0) of this lane's operands; the second buffer is a constant distance away.
+    // window of block j, channel kq: staged rows 2 w .. 2 w + 2, floats 2 j + 3 .. 2 j + 5 of a row (float 3 = image column
+    // tx0 - 1), read as two aligned 8-byte pairs (2 j + 2, 2 j + 3) and (2 j + 4, 2 j + 5)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    const unsigned b_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + kq * U2_PLANE + (2 * wv) * U2_PWS + 2 * j + 2) * 4u;
+    // weight row of entry u: (u * 4 + kq) * 32 + 2 * j (m-tile pair interleaved: one 8-byte read feeds both m-tiles)
+    const unsigned a_addr = lds0 + (unsigned)(kq * U2_BM + 2 * j) * 4u;
+    unsigned s_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + 2 * U2_PBUF + kq) * 4u;
+    constexpr unsigned A_BUF_BYTES = U2_A_FLOATS * 4u, P_BUF_BYTES = U2_PBUF * 4u;
+    constexpr int U_BYTES = U2_CC * U2_BM * 4;  // distance between transformed-kernel entries in the weight tile
+    constexpr int ROW_BYTES = U2_PWS * 4;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+        if (chunk + 1 < p.n_chunks) issue(chunk + 1, cur ^ 1);
+        const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u), pb = b_addr + (cur ? P_BUF_BYTES : 0u);
+        // ---- operand reads: style, the 3 x 3 window (six 8-byte reads), the first weight row behind them (LDS returns in order)
+        float sc = lds_read32(s_addr);
+        s_addr += U2_CC * 4u;
+        f32x2 w0l = lds_read64<0>(pb), w0h = lds_read64<8>(pb);
+        f32x2 w1l = lds_read64<ROW_BYTES>(pb), w1h = lds_read64<ROW_BYTES + 8>(pb);
+        f32x2 w2l = lds_read64<2 * ROW_BYTES>(pb), w2h = lds_read64<2 * ROW_BYTES + 8>(pb);
+        f32x2 a2[2];
+        a2[0] = lds_read64<0>(ap);
+        asm volatile("s_waitcnt lgkmcnt(1)"
+                     : "+v"(sc), "+v"(w0l), "+v"(w0h), "+v"(w1l), "+v"(w1h), "+v"(w2l), "+v"(w2h));
+        // ---- window forms: rows (r0 - r1, r1, r2 - r1, r2), then columns likewise: B[a][b], 9 multiplies + 14 subtractions
+        float bv[4][4];
+        {
+            const float d00 = w0l.y * sc, d01 = w0h.x * sc, d02 = w0h.y * sc;
+            const float d10 = w1l.y * sc, d11 = w1h.x * sc, d12 = w1h.y * sc;
+            const float d20 = w2l.y * sc, d21 = w2h.x * sc, d22 = w2h.y * sc;
+            const float r[4][3] = {{d00 - d10, d01 - d11, d02 - d12}, {d10, d11, d12}, {d20 - d10, d21 - d11, d22 - d12}, {d20, d21, d22}};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bv[a][0] = r[a][0] - r[a][1];
+                bv[a][1] = r[a][1];
+                bv[a][2] = r[a][2] - r[a][1];
+                bv[a][3] = r[a][2];
+            }
+        }
+        // ---- MFMA phase: the weight row of the next entry is read one step ahead
+        static_for<0, U2_NU>([&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            if constexpr (u + 1 < U2_NU) a2[(u + 1) & 1] = lds_read64<(u + 1) * U_BYTES>(ap);
+            lds_wait<(u + 1 < U2_NU) ? 1 : 0>(a2[u & 1]);
+            const float a_lo = a2[u & 1].x, a_hi = a2[u & 1].y;
+            auto mac = [&](f32x4(&acc)[2], float b) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, b, acc[1], 0, 0, 0);
+            };
+            if constexpr (u < 9) {                       // (even, even): entry [a][b] x window form [a][b]
+                mac(acc_ee[u / 3][u % 3], bv[u / 3][u % 3]);
+            } else if constexpr (u < 12) {               // (even row, odd column): row form a, raw columns c1 / c2
+                mac(acc_eo[u - 9][0], bv[u - 9][1]);
+                mac(acc_eo[u - 9][1], bv[u - 9][3]);
+            } else if constexpr (u < 15) {               // (odd row, even column): raw rows r1 / r2, column form b
+                mac(acc_oe[0][u - 12], bv[1][u - 12]);
+                mac(acc_oe[1][u - 12], bv[3][u - 12]);
+            } else {                                     // (odd, odd): g11 on the raw 2 x 2 inputs
+                mac(acc_oo[0][0], bv[1][1]);
+                mac(acc_oo[0][1], bv[1][3]);
+                mac(acc_oo[1][0], bv[3][1]);
+                mac(acc_oo[1][1], bv[3][3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: per-channel gain (wscale * demod) through LDS, phase sums, 16-byte stores of the 4 x 4 output patch
+    float* Eg = lds;
+    for (int i = tid; i < U2_BM; i += 256) {
+        float gain = p.wscale;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
+        Eg[i] = gain;
+    }
+    __syncthreads();
+    const int OW = 2 * p.W + 1;
+    const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
+    float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane_out;
+    const unsigned pix_off = (unsigned)(2 * (ty0 + 2 * wv)) * (unsigned)OW + (unsigned)(2 * (tx0 + 2 * j));
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ol = m * 16 + 4 * kq + v;  // row of the 16 x 16 result tile held in register v
+            const float gain = Eg[ol];
+            float* dst = yimg + (size_t)ol * plane_out + pix_off;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // even output row of position row i: (ee, eo, ee, eo);  odd one: (oe, oo, oe, oo)
+                const float e0 = (acc_ee[i][0][m][v] + acc_ee[i][1][m][v]) + (acc_ee[i + 1][0][m][v] + acc_ee[i + 1][1][m][v]);
+                const float e1 = (acc_ee[i][1][m][v] + acc_ee[i][2][m][v]) + (acc_ee[i + 1][1][m][v] + acc_ee[i + 1][2][m][v]);
+                const float o0 = acc_eo[i][0][m][v] + acc_eo[i + 1][0][m][v];
+                const float o1 = acc_eo[i][1][m][v] + acc_eo[i + 1][1][m][v];
+                *reinterpret_cast<f32x4u*>(dst + (size_t)(2 * i) * OW) = f32x4{e0 * gain, o0 * gain, e1 * gain, o1 * gain};
+                const float f0 = acc_oe[i][0][m][v] + acc_oe[i][1][m][v];
+                const float f1 = acc_oe[i][1][m][v] + acc_oe[i][2][m][v];
+                *reinterpret_cast<f32x4u*>(dst + (size_t)(2 * i + 1) * OW) =
+                    f32x4{f0 * gain, acc_oo[i][0][m][v] * gain, f1 * gain, acc_oo[i][1][m][v] * gain};
+            }
+        }
+    }
+}
+
+// Output row 2H (line 0) and column 2W (line 1) of the transposed convolution: positions whose own input is the zero padding.
+// Along the line, with v[n] = the last input row / column and (t0, t1, t2) = the kernel's last row / column:
+//     y[2n] = t0 v[n] + t2 v[n-1],   y[2n+1] = t1 v[n]      (v[-1] = v[N] = 0; the corner y[2N] belongs to line 0)
+// One wave per (image, line, 16 output channels, 16 line positions): direct v_mfma_f32_16x16x4_f32 over the input channels,
+// operands straight from global memory (the edge tap matrices [5][Cin][Cout] behind the packed weight; the line of x with its
+// element stride), four K steps of loads in flight.  ~1/H of the layer's multiply-adds.
+__global__ __launch_bounds__(64) void up2d_edge_kernel(Up2dArgs p, const float* __restrict__ taps, int n_tiles0, int n_tiles1) {
+    const int lane = threadIdx.x;
+    const int i16 = lane & 15, kq = lane >> 4;
+    int t = blockIdx.x;
+    const int per_line_mt0 = n_tiles0, per_line_mt1 = n_tiles1;
+    const int m_tiles = p.Cout / 16;
+    const int per_image = m_tiles * (per_line_mt0 + per_line_mt1);
+    const int b0 = t / per_image;
+    t -= b0 * per_image;
+    const int line = t >= m_tiles * per_line_mt0 ? 1 : 0;
+    if (line) t -= m_tiles * per_line_mt0;
+    const int nt = line ? per_line_mt1 : per_line_mt0;
+    const int mt = t / nt, n0 = (t - mt * nt) * 16;
+    const int o0 = mt * 16;
+    const int N = line ? p.H : p.W;               // inputs along the line
+    const int n = n0 + i16;                       // this lane's line position (B operand column / result column)
+    const size_t plane = (size_t)p.H * p.W;
+    // v[n]: line 0 = x[c][H-1][n], line 1 = x[c][n][W-1]
+    const float* xb = p.x + (size_t)b0 * p.Cin * plane;
+    const size_t stride = line ? (size_t)p.W : 1;
+    const size_t base = line ? (size_t)(p.W - 1) : (size_t)(p.H - 1) * p.W;
+    const bool ok_n = n < N, ok_m = n >= 1 && n - 1 < N;
+    const float* pv = xb + base + (size_t)(ok_n ? n : 0) * stride;
+    const float* pm = xb + base + (size_t)(ok_m ? n - 1 : 0) * stride;
+    // taps: line 0 -> (g20, g21, g22) = matrices 0, 1, 2;  line 1 -> (g02, g12, g22) = matrices 3, 4, 2
+    const size_t tsz = (size_t)p.Cin * p.Cout;
+    const float* t0 = taps + (line ? 3 : 0) * tsz + o0 + i16;
+    const float* t1 = taps + (line ? 4 : 1) * tsz + o0 + i16;
+    const float* t2 = taps + 2 * tsz + o0 + i16;
+    const float* sp = p.s + (size_t)b0 * p.s_stride;
+    f32x4 even = f32x4{0.f, 0.f, 0.f, 0.f}, odd = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UNR = 4;
+    for (int c0 = 0; c0 < p.Cin; c0 += 4 * UNR) {
+        float a0[UNR], a1[UNR], a2v[UNR], bn[UNR], bm[UNR];
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {  // all loads of four K steps first
+            const int c = c0 + 4 * q + kq;
+            const bool okc = c < p.Cin;
+            const int cc = okc ? c : 0;
+            const float sc = okc ? sp[cc] : 0.f;
+            a0[q] = okc ? t0[(size_t)cc * p.Cout] : 0.f;
+            a1[q] = okc ? t1[(size_t)cc * p.Cout] : 0.f;
+            a2v[q] = okc ? t2[(size_t)cc * p.Cout] : 0.f;
+            bn[q] = (ok_n ? pv[(size_t)cc * plane] : 0.f) * sc;
+            bm[q] = (ok_m ? pm[(size_t)cc * plane] : 0.f) * sc;
+        }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) {
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], bn[q], even, 0, 0, 0);
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(a2v[q], bm[q], even, 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], bn[q], odd, 0, 0, 0);
+        }
+    }
+    // result tile: column = line position n (lane & 15), row = output channel o0 + 4 kq + v
+    const int OW = 2 * p.W + 1, OH = 2 * p.H + 1;
+    const size_t plane_out = (size_t)OH * OW;
+    if (n > N || (line && n >= N)) return;  // line 1 leaves the corner (n = N) to line 0
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int o = o0 + 4 * kq + v;
+        float gain = p.wscale;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
+        float* yp = p.y + ((size_t)b0 * p.Cout + o) * plane_out;
+        if (line == 0) {
+            float* dst = yp + (size_t)(2 * p.H) * OW + 2 * n;
+            dst[0] = even[v] * gain;
+            if (n < N) dst[1] = odd[v] * gain;
+        } else {
+            yp[(size_t)(2 * n) * OW + 2 * p.W] = even[v] * gain;
+            yp[(size_t)(2 * n + 1) * OW + 2 * p.W] = odd[v] * gain;
+        }
+    }
+}
+
+// wq: [m_tile][chunk][u 16][kq 4][32 columns: 2 * (o % 16) + (o % 32) / 16], then the edge tap matrices [5][cin][cout]:
+// g20, g21, g22, g02, g12 (kernel's last row, then the other two entries of its last column)
+__global__ __launch_bounds__(256) void pack_weight_up2d_kernel(const float* __restrict__ w, float* __restrict__ wq, int cout, int cin) {
+    const int n_chunks = cin / U2_CC;
+    const int64_t total = (int64_t)cout * cin;
+    float* edge = wq + (size_t)U2_NU * cin * cout;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int o = (int)(idx % cout), i = (int)(idx / cout);
+        const float* g = w + ((size_t)o * cin + i) * 9;
+        float k[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) k[a][b] = g[a * 3 + b];
+        // one axis transforms as (tap 2, tap 0 + tap 2, tap 0)
+        float v[3][3];  // vertical transform of every kernel column
+        for (int b = 0; b < 3; ++b) v[0][b] = k[2][b], v[1][b] = k[0][b] + k[2][b], v[2][b] = k[0][b];
+        float u[U2_NU];
+        for (int a = 0; a < 3; ++a) {
+            u[3 * a + 0] = v[a][2], u[3 * a + 1] = v[a][0] + v[a][2], u[3 * a + 2] = v[a][0];  // (even, even)
+            u[9 + a] = v[a][1];                                                                 // (even row, odd column): kernel column 1
+        }
+        u[12] = k[1][2], u[13] = k[1][0] + k[1][2], u[14] = k[1][0];                            // (odd row, even column): kernel row 1
+        u[15] = k[1][1];
+        const int mtile = o / U2_BM, ol = o % U2_BM;
+        const int chunk = i / U2_CC, kq = i % U2_CC;
+        float* dst = wq + ((size_t)mtile * n_chunks + chunk) * U2_A_FLOATS + kq * U2_BM + 2 * (ol % 16) + ol / 16;
+        for (int e = 0; e < U2_NU; ++e) dst[e * (U2_CC * U2_BM)] = u[e];
+        const size_t tsz = (size_t)cin * cout;
+        float* ed = edge + (size_t)i * cout + o;
+        ed[0] = k[2][0], ed[tsz] = k[2][1], ed[2 * tsz] = k[2][2], ed[3 * tsz] = k[0][2], ed[4 * tsz] = k[1][2];
+    }
+}
+
+char g_up2d_instance[64] = "";
+
+}  // namespace
+
+// Layer shapes the kernel accepts: whole tiles of 8 x 32 positions, 32-channel m-tiles, 4-channel K steps.
+extern "C" int maua_modconv_up2d_ok(int cin, int cout, int h, int w) {
+    return cin > 0 && cout > 0 && cin % U2_CC == 0 && cout % U2_BM == 0 && h >= 8 && h % 8 == 0 && w >= 32 && w % 32 == 0;
+}
+
+extern "C" int64_t maua_pack_weight_up2d_floats(int cout, int cin) { return (int64_t)(U2_NU + 5) * cin * cout; }
+
+extern "C" int maua_pack_weight_up2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {
+    if (!w || !wq || cout <= 0 || cin <= 0 || cin % U2_CC || cout % U2_BM) return MAUA_EINVAL;
+    const int64_t blocks = ceil_div64((int64_t)cout * cin, 256);
+    hipLaunchKernelGGL(pack_weight_up2d_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, w, wq,
+                       cout, cin);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+const char* maua_up2d_last_instance() { return g_up2d_instance; }
+
+int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
+                     int cout, int h, int w, float wscale, void* stream) {
+    if (!maua_modconv_up2d_ok(cin, cout, h, w)) return MAUA_EINVAL;
+    if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)U2_NU * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
+    if ((int64_t)U2_BM * (2 * h + 1) * (2 * w + 1) * 4 > 0xffffffffLL) return MAUA_EINVAL;                              // 32-bit store offsets
+    Up2dArgs a{};
+    a.x = x, a.wq = wq, a.s = s, a.d = d, a.y = y;
+    a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
+    a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / U2_CC;
+    hipStream_t st = (hipStream_t)stream;
+    auto kern = modconv_up2d_kernel<false>;
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * U2_A_FLOATS + (size_t)2 * U2_PBUF + (size_t)cin);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<false>");
+    const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    MAUA_LAUNCH_CHECK();
+    // edge lines: W + 1 positions along the bottom row (incl. the corner), H along the right column
+    const int nt0 = ceil_div(w + 1, 16), nt1 = ceil_div(h, 16);
+    const int64_t eblocks = (int64_t)batch * (cout / 16) * (nt0 + nt1);
+    hipLaunchKernelGGL(up2d_edge_kernel, dim3((unsigned)eblocks), dim3(64), 0, st, a, wq + (size_t)U2_NU * cin * cout, nt0, nt1);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}

@@ -165,10 +165,16 @@ class ModulatedConv2d(nn.Module):
     # the 32-channel layer with the fused ToRGB epilogue (since the skip-image taps of that epilogue are unconditional loads),
     # +1.8 % frames/s for the whole generator.
     winograd2d_min_cout = 32
+    # transposed layers whose shape csrc/modconv_up2d.hip accepts (mode 6: F(2,2) on both axes of the polyphase form, 25 instead of
+    # 30 (mode 4) / 36 (mode 1) products per 2x2 positions) with at least this many output channels; a huge value turns it off
+    upwino2d_min_cout = 32
 
     def conv_mode(self, h, w):
-        """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 / 4 transposed, 2 Winograd F(2,3), 3 Winograd
+        """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 / 4 / 6 transposed, 2 Winograd F(2,3), 3 Winograd
         F(4,3), 5 2-D Winograd F(2x4,3x3), 0 direct."""
+        if self.upsample and self.out_channel >= self.upwino2d_min_cout and _lib.load().maua_modconv_up2d_ok(
+                self.in_channel, self.out_channel, h, w):
+            return 6
         if self.upsample:
             # F(2,2) on the even x-phase of the polyphase transposed conv (mode 4: -17 % MFMA work, but 2 instead of 3-4
             # workgroups per CU) once a batch of 8 frames yields at least ~4 rounds of workgroups; smaller grids lose more
@@ -196,6 +202,16 @@ class ModulatedConv2d(nn.Module):
         self.packed()  # refreshes / invalidates on weight change
         if self._packed_wino is None:
             self._packed_wino = {}
+        if mode == 6 and mode not in self._packed_wino:
+            w = self.weight
+            wd = _lib.require_cuda(w.detach(), "weight")
+            wq = th.empty(_lib.load().maua_pack_weight_up2d_floats(self.out_channel, self.in_channel), dtype=th.float32,
+                          device=w.device)
+            with th.cuda.device(w.device):
+                _lib.check(_lib.load().maua_pack_weight_up2d_f32(wd.data_ptr(), wq.data_ptr(), self.out_channel,
+                                                                 self.in_channel, _lib.stream_ptr(w.device)),
+                           "maua_pack_weight_up2d_f32")
+            self._packed_wino[mode] = wq
         if mode == 5 and mode not in self._packed_wino:
             w = self.weight
             wd = _lib.require_cuda(w.detach(), "weight")

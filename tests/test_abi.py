@@ -42,7 +42,8 @@ def test_rejects_bad_arguments_without_gpu(built_lib):
     assert lib.maua_torgb_f32(None, None, None, 0, None, None, None, None, 1, 8, 4, 4, 1.0, None) == -22
     assert lib.maua_modconv_ws_floats(1, 512, 512, 4, 4, 0) > 0  # 4x4 layers are split-K
     assert lib.maua_modconv_ws_floats(1, 32, 32, 1024, 1024, 0) == 0
-    # kernel modes of maua_modconv3x3_f32: 0 direct, 1 transposed, 2 / 3 Winograd F(2,3) / F(4,3), 4 transposed + F(2,2), 5 2-D Winograd
+    # kernel modes of maua_modconv3x3_f32: 0 direct, 1 transposed, 2 / 3 Winograd F(2,3) / F(4,3), 4 transposed + F(2,2), 5 2-D Winograd,
+    # 6 transposed + F(2,2) on both axes
     fake = 0x1000  # never dereferenced: these calls are rejected during validation / planning
     conv = lambda h, w, mode, fuse=0: lib.maua_modconv3x3_f32(fake, fake, fake, 64, None, fake, 1, 64, 64, h, w, mode, 1.0, fuse,  # noqa: E731
                                                               None, 0, None, None, fake, None, 0, None)
@@ -52,7 +53,10 @@ def test_rejects_bad_arguments_without_gpu(built_lib):
     assert lib.maua_frame_source_seek(fake, -1, None) == -22 and lib.maua_frame_source_seek(None, 0, None) == -22
     import ctypes as ct
     assert ct.sizeof(_lib.FrameSource) == 8 + 2 * 8 + 32 * 8 + 32 * 8  # layout of maua_frame_source_t
-    assert conv(64, 64, 6) == -22           # unknown mode
+    assert conv(64, 64, 7) == -22           # unknown mode
+    assert conv(64, 48, 6) == -22 and conv(12, 64, 6) == -22 and conv(64, 64, 6, fuse=1) == -22  # mode 6: W % 32, H % 8, raw output only
+    assert lib.maua_modconv_up2d_ok(64, 32, 64, 64) == 1 and lib.maua_modconv_up2d_ok(64, 48, 64, 64) == 0 and lib.maua_modconv_up2d_ok(6, 32, 64, 64) == 0
+    assert lib.maua_pack_weight_up2d_floats(32, 64) == 21 * 32 * 64
     assert conv(64, 48, 5) == -22           # 2-D Winograd (mode 5) needs W % 32 == 0 ...
     assert conv(12, 64, 5) == -22           # ... and H % 8 == 0
     assert lib.maua_modconv_w2d_ok(64, 64, 64, 64) == 1 and lib.maua_modconv_w2d_ok(64, 48, 64, 64) == 0

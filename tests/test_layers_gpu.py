@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from maua_stylegan2_amd import _lib, seeding
 
@@ -357,3 +358,53 @@ def test_upconv_winograd_matches_polyphase_and_oracle(gpu, cin, cout, h, w, batc
     m.upconv_winograd = False
     ref = m(t(x, gpu), t(s, gpu)).cpu().numpy()
     np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [
+    (64, 32, 8, 32, 1),       # one tile per image and m-tile
+    (128, 64, 64, 64, 2),     # two m-tiles, 8 x 2 tiles
+    (512, 256, 16, 32, 1),    # long K loop (128 steps), 8 m-tiles
+    (32, 32, 40, 96, 2),      # tile counts that are not powers of two
+    (8, 64, 8, 64, 3),        # two K steps only: prologue / epilogue dominated
+    (64, 32, 256, 256, 1),    # generator-sized grid (convs.12's shape class)
+])
+def test_upconv_two_axis_f22_matches_polyphase_and_oracle(gpu, cin, cout, h, w, batch):
+    """Up-sampling ModulatedConv2d on mode 6 (csrc/modconv_up2d.hip: F(2,2) on both axes of the polyphase form + the two edge
+    lines) against the oracle's conv_transpose2d + blur and against the plain polyphase kernel (mode 1); the RAW (2H+1) x (2W+1)
+    output is compared as well, on a NaN-prefilled buffer: every element must be written, by exactly the right formula."""
+    from maua_stylegan2_amd import _lib
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(cin + cout + h + w)
+    m = ModulatedConv2d(cin, cout, 3, 512, upsample=True)
+    assert m.conv_mode(h, w) == 6
+    wgt = r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)
+    mw = r.standard_normal((cin, 512)).astype(np.float32)
+    mb = (1 + 0.1 * r.standard_normal(cin)).astype(np.float32)
+    m.weight.copy_(torch.from_numpy(wgt)), m.modulation.weight.copy_(torch.from_numpy(mw)), m.modulation.bias.copy_(torch.from_numpy(mb))
+    m = m.to(gpu)
+    x = r.standard_normal((batch, cin, h, w)).astype(np.float32)
+    s = r.standard_normal((batch, 512)).astype(np.float32)
+    want = so.modulated_conv2d(torch.from_numpy(x), torch.from_numpy(s), torch.from_numpy(wgt), torch.from_numpy(mw),
+                               torch.from_numpy(mb), upsample=True, blur_kernel=m.blur.kernel.cpu()).numpy()
+    got = m(t(x, gpu), t(s, gpu)).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-4)
+    # raw transposed convolution (unit demod), mode 6 vs mode 1, every element written
+    xs = t(x, gpu)
+    styles = t(r.standard_normal((batch, cin)).astype(np.float32), gpu)
+    raws = {}
+    for mode in (6, 1):
+        m.conv_mode = lambda hh, ww, _mode=mode: _mode
+        raw = torch.full((batch, cout, 2 * h + 1, 2 * w + 1), float("nan"), device=gpu)
+        n_ws = _lib.load().maua_modconv_ws_floats(batch, cin, cout, h, w, mode)
+        ws = torch.empty(max(n_ws, 1), device=gpu)
+        m.run(xs, styles, 0, None, raw, ws if n_ws else None)
+        raws[mode] = raw.cpu().numpy()
+    assert np.isfinite(raws[6]).all(), "mode 6 left output elements unwritten"
+    scale = np.abs(raws[1]).max()
+    np.testing.assert_allclose(raws[6], raws[1], atol=2e-5 * scale, rtol=1e-4)
+    ref = F.conv_transpose2d((torch.from_numpy(x) * styles.cpu()[:, :, None, None]), torch.from_numpy(wgt[0]).transpose(0, 1).contiguous(),
+                             stride=2).numpy() * m.scale
+    np.testing.assert_allclose(raws[6], ref, atol=3e-5 * scale, rtol=1e-4)

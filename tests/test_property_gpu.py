@@ -98,6 +98,36 @@ def test_winograd2d_random_shapes_vs_oracle(gpu, cin, cout, hb, wb, batch, share
 
 
 @settings(max_examples=25, **COMMON)
+@given(cin=st.sampled_from([4, 8, 20, 64, 96, 256]), cout=st.sampled_from([32, 64, 96, 128]), hb=st.integers(1, 5),
+       wb=st.integers(1, 3), batch=st.integers(1, 3), seed=st.integers(0, 1 << 16))
+def test_upconv2d_random_shapes_vs_oracle(gpu, cin, cout, hb, wb, batch, seed):
+    """The two-axis F(2,2) transposed-conv kernel (mode 6) on random qualifying shapes — H a multiple of 8, W of 32, Cin % 4 == 0,
+    Cout % 32 == 0 — through the whole up-sampling StyledConv (blur + noise + bias + activation behind it) against the oracle."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+
+    h, w = hb * 8, wb * 32
+    r = np.random.default_rng(seed)
+    m = StyledConv(cin, cout, 3, 512, upsample=True)
+    assert m.conv.conv_mode(h, w) == 6
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.blur.kernel": m.conv.blur.kernel.clone(),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.27]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((batch, 1, 2 * h, 2 * w)).astype(np.float32))
+    want = so.styled_conv(sd, "L", x, s, nz, True).numpy()
+    got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-4, rtol=2e-4)
+
+
+@settings(max_examples=25, **COMMON)
 @given(cin=st.sampled_from([3, 16, 32, 40, 64, 128]), h=st.integers(2, 40), w=st.sampled_from([2, 4, 6, 10, 16, 30, 32, 64, 72]),
        batch=st.integers(1, 3), skip=st.booleans(), seed=st.integers(0, 1 << 16))
 def test_to_rgb_random_shapes_vs_oracle(gpu, cin, h, w, batch, skip, seed):

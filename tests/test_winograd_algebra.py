@@ -126,3 +126,69 @@ def test_two_axis_f23_by_f43_is_24_products_per_8_outputs():
     y = at2 @ (u * v) @ at4.T  # [2, 4]
     want = np.array([[(d[i:i + 3, j:j + 3] * g).sum() for j in range(4)] for i in range(2)])
     np.testing.assert_allclose(y, want, atol=1e-11)
+
+
+def up2d_pack(g):
+    """The 16 transformed-kernel entries of csrc/modconv_up2d.hip (mode 6) for one (cout, cin) 3x3 kernel g[ky][kx]:
+    u 0..8 = (even, even) phase [a][b], 9..11 = (even row, odd column) [a], 12..14 = (odd row, even column) [b], 15 = g11;
+    one axis transforms as (tap 2, tap 0 + tap 2, tap 0) — pack_weight_up2d_kernel."""
+    t = lambda k: (k[2], k[0] + k[2], k[0])  # noqa: E731
+    rows = t([g[0], g[1], g[2]])                       # vertical transform: 3 kernel rows
+    ee = [t(r) for r in rows]
+    return [ee[a][b] for a in range(3) for b in range(3)] + list(t(g[:, 1])) + list(t(g[1, :])) + [g[1, 1]]
+
+
+def up2d_block(window, u):
+    """One 2x2 block of positions from its 3x3 input window (rows / columns p-1, p, p+1): the 16 B forms, the 25 products in
+    the order the kernel issues them, and the 4x4 output patch (row 2i + a', column 2j + b')."""
+    r = [window[0] - window[1], window[1], window[2] - window[1], window[2]]          # row forms R0..R3 (each a 3-vector)
+    b = [[rf[0] - rf[1], rf[1], rf[2] - rf[1], rf[2]] for rf in r]                   # B[a][b]: column forms C0..C3
+    ee = [[u[3 * a + c] * b[a][c] for c in range(3)] for a in range(3)]
+    eo = [[u[9 + a] * b[a][1 + 2 * j] for j in range(2)] for a in range(3)]
+    oe = [[u[12 + c] * b[1 + 2 * i][c] for c in range(3)] for i in range(2)]
+    oo = [[u[15] * b[1 + 2 * i][1 + 2 * j] for j in range(2)] for i in range(2)]
+    out = np.zeros((4, 4))
+    for i in range(2):
+        for j in range(2):
+            out[2 * i, 2 * j] = ee[i][j] + ee[i][j + 1] + ee[i + 1][j] + ee[i + 1][j + 1]
+            out[2 * i, 2 * j + 1] = eo[i][j] + eo[i + 1][j]
+            out[2 * i + 1, 2 * j] = oe[i][j] + oe[i][j + 1]
+            out[2 * i + 1, 2 * j + 1] = oo[i][j]
+    return out, 9 + 6 + 6 + 4
+
+
+def test_up2d_kernel_scheme_main_blocks_plus_edge_lines():
+    """The decomposition mode 6 uses for an H x W input (both even): (H/2) x (W/2) blocks of 2x2 positions cover output rows
+    0..2H-1 and columns 0..2W-1 with 25 products each from 16 transformed-kernel entries and 16 window forms; the remaining output
+    row 2H and column 2W (positions p = H / q = W, whose own input is the zero padding) are two 1-D polyphase transposed
+    convolutions of the last input row / column with the kernel's last row / column (up2d_edge_kernel)."""
+    rng = np.random.default_rng(5)
+    h, w = 6, 8
+    x, g = rng.standard_normal((h, w)), rng.standard_normal((3, 3))
+    want = _upconv_direct(x, g)
+    got = np.full_like(want, np.nan)
+    u = up2d_pack(g)
+    products = 0
+    for br in range(h // 2):
+        for bc in range(w // 2):
+            window = np.array([[_pad_get(x, 2 * br - 1 + a, 2 * bc - 1 + b) for b in range(3)] for a in range(3)])
+            patch, n = up2d_block(window, u)
+            got[4 * br: 4 * br + 4, 4 * bc: 4 * bc + 4] = patch
+            products += n
+
+    def edge_line(v, t0, t1, t2):  # y[2n] = t0 v[n] + t2 v[n-1], y[2n+1] = t1 v[n], v[-1] = v[N] = 0
+        n_in = len(v)
+        y = np.zeros(2 * n_in + 1)
+        for n in range(n_in + 1):
+            vn = v[n] if n < n_in else 0.0
+            vm = v[n - 1] if n > 0 else 0.0
+            y[2 * n] = t0 * vn + t2 * vm
+            if n < n_in:
+                y[2 * n + 1] = t1 * vn
+        return y
+
+    got[2 * h, :] = edge_line(x[h - 1, :], g[2, 0], g[2, 1], g[2, 2])          # bottom line incl. the corner
+    got[: 2 * h, 2 * w] = edge_line(x[:, w - 1], g[0, 2], g[1, 2], g[2, 2])[: 2 * h]  # right line without the corner
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, want, atol=1e-12)
+    assert products == 25 * (h // 2) * (w // 2)
