@@ -213,6 +213,11 @@ int maua_torgb_f32(const float* x, const float* w, const float* s, int s_stride,
 
 /* Frame epilogue of render.py:40-43: [B,3,H,W] fp32 -> [B,H,W,3] uint8 via clamp(-1,1), (x+1)*127.5, truncation. */
 int maua_frames_to_u8(const float* img, uint8_t* out, int batch, int h, int w, void* stream);
+/* Wide-output delivery of render.py:97-104 on the device: crop [y0, y0+crop_h) x [x0, x0+crop_w) of uint8 NHWC frames
+ * in[B,in_h,in_w,3] and resize to out[B,out_h,out_w,3] as PIL's Image.resize(BILINEAR) does for an up-scale (2-tap triangle filter at
+ * (dst + 0.5) * in/out - 0.5, clamped taps, horizontal pass rounded to 8 bits, then vertical).  MAUA_ENOSYS for a down-scale. */
+int maua_crop_resize_u8(const uint8_t* in, uint8_t* out, int batch, int in_h, int in_w, int x0, int y0, int crop_w, int crop_h,
+                        int out_w, int out_h, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ audio / temporal
  * Circular Gaussian FIR along time (audioreactive/signal.py:319-368): x [T, F] -> y [T, F], taps[2*radius+1]

@@ -84,6 +84,7 @@ _SIGNATURES = {
                                                   _P, _P, c_int, _P]),
     "maua_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_frames_to_u8": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "maua_crop_resize_u8": (c_int, [_P, _P] + [c_int] * 9 + [_P]),
     "maua_sg1_epilogue_f32": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "maua_temporal_fir_f32": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P]),
     "maua_stft_power_f32": (c_int, [_P, c_int64, _P, c_int, c_int, _P, c_int, _P]),

@@ -43,17 +43,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef f32x4 f32x4u __attribute__((aligned(4)));
 typedef f32x2 f32x2u __attribute__((aligned(4)));
 
-constexpr int U2_CC = 4;                                  // input channels per K step = K of v_mfma_f32_16x16x4_f32
 constexpr int U2_NU = 16;                                 // transformed-kernel entries per (cout, cin)
 constexpr int U2_BM = 32;                                 // output channels per workgroup (two 16-row m-tiles, interleaved)
-constexpr int U2_A_FLOATS = U2_NU * U2_CC * U2_BM;        // 2048 floats = 8 DMA instructions of 1 KiB
 constexpr int U2_PROWS = 9;                               // staged input rows: 8 position rows + the row above
 constexpr int U2_PSEGS = 9;                               // 16-byte segments per staged row: image columns tx0-4 .. tx0+31
 constexpr int U2_PWS = 4 * U2_PSEGS;                      // LDS row stride (floats)
 constexpr int U2_PLANE = 352;                             // floats per staged channel: 9 x 36 = 324, padded to 32 mod 64 so that the
                                                           // two K lane groups of a half-wave read disjoint bank halves (ds_read_b64)
-constexpr int U2_PBUF = 6 * 256;                          // one patch buffer = 6 whole DMA instructions >= 4 x 352 floats
-constexpr int U2_P_INSTR = 6;
+// Input channels per K step (CC): 8 = two MFMA K groups per barrier wherever the channel count allows it (every layer of a real
+// generator), 4 otherwise.  The packed weight layout depends on it: both sides derive it from cin with this one rule.
+#ifndef MAUA_UP2D_MAX_CC
+#define MAUA_UP2D_MAX_CC 8
+#endif
+__host__ __device__ constexpr int u2_cc(int cin) { return (MAUA_UP2D_MAX_CC >= 8 && cin % 8 == 0) ? 8 : 4; }
+__host__ __device__ constexpr int u2_a_floats(int cc) { return U2_NU * cc * U2_BM; }       // weight tile: 2 cc DMA instructions of 1 KiB
+__host__ __device__ constexpr int u2_p_instr(int cc) { return (cc * (U2_PLANE / 4) + 63) / 64; }  // patch: whole DMA instructions
+__host__ __device__ constexpr int u2_pbuf(int cc) { return u2_p_instr(cc) * 256; }         // >= cc x 352 floats
 
 // single `ds_read_b64` / `ds_read_b32` through inline assembly with explicit lgkmcnt waits: see modconv_w2d.hip (left alone the
 // compiler pairs 8-byte reads into ds_read2_b64, which is serviced at half the bytes per clock on a 32-bank modulus)
@@ -92,8 +97,11 @@ struct Up2dArgs {
     int tiles_x, tiles_y, m_tiles, n_chunks;
 };
 
-template <bool UNUSED>
+template <int CC>
 __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
+    constexpr int U2_A_FLOATS = u2_a_floats(CC), U2_PBUF = u2_pbuf(CC), U2_P_INSTR = u2_p_instr(CC);
+    constexpr int A_PER_WAVE = 2 * CC / 4;                 // weight DMA instructions per wave and K step
+    constexpr int P_PER_WAVE = (U2_P_INSTR + 3) / 4;       // patch DMA instructions per wave and K step (the last ones may be idle)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: As[2][A_FLOATS] | Ps[2][PBUF] | Ss[Cin]
     float* Ps = lds + 2 * U2_A_FLOATS;
@@ -118,15 +126,15 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     // ---- patch DMA of this lane (decoded once).  Slot s = 64 i + lane of instruction i is 16-byte slot s of the buffer:
     // channel s / 88, then row (s % 88) / 9 and segment (s % 88) % 9 (slots 81..87 of a channel are padding).  Rows above / below
     // the image, the segment left of column 0 and the padding get an offset beyond the buffer descriptor's range, for which a
-    // raw buffer load returns 0: the DMA itself writes the zero padding.  Wave w issues instructions w and w + 4.
-    unsigned rel_bytes[2];
+    // raw buffer load returns 0: the DMA itself writes the zero padding.  Wave w issues instructions w, w + 4, ...
+    unsigned rel_bytes[P_PER_WAVE];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < P_PER_WAVE; ++g) {
         const int s = 64 * (wv + 4 * g) + lane;
         const int c = s / (U2_PLANE / 4), rem = s % (U2_PLANE / 4);
         const int pr = rem / U2_PSEGS, sg = rem % U2_PSEGS;
         const int yy = ty0 - 1 + pr, xx = tx0 - 4 + 4 * sg;
-        const bool ok = c < U2_CC && rem < U2_PROWS * U2_PSEGS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        const bool ok = c < CC && rem < U2_PROWS * U2_PSEGS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
         rel_bytes[g] = ok ? (unsigned)((size_t)c * plane + (size_t)yy * p.W + xx) * 4u : 0x80000000u;
     }
     for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
@@ -142,14 +150,14 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 #ifdef MAUA_DEVICE_PASS
         const int wbase = (int)(((size_t)mt_id * p.n_chunks + chunk) * U2_A_FLOATS * sizeof(float));
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {  // weight tile: linear copy, 1 KiB per wave instruction, instructions w and w + 4
+        for (int k = 0; k < A_PER_WAVE; ++k) {  // weight tile: linear copy, 1 KiB per wave instruction, instructions w, w + 4, ...
             const int i = wv + 4 * k;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(lds + buf * U2_A_FLOATS + i * 256),
                                                      16, (i * 256 + lane * 4) * 4, wbase, 0, 0);
         }
-        const int xbase = (int)((size_t)chunk * U2_CC * plane_bytes);
+        const int xbase = (int)((size_t)chunk * CC * plane_bytes);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < P_PER_WAVE; ++k) {
             const int i = wv + 4 * k;  // (scalar)
             if (i < U2_P_INSTR)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(Ps + buf * U2_PBUF + i * 256),
@@ -183,11 +191,14 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     // tx0 - 1), read as two aligned 8-byte pairs (2 j + 2, 2 j + 3) and (2 j + 4, 2 j + 5)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
     const unsigned b_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + kq * U2_PLANE + (2 * wv) * U2_PWS + 2 * j + 2) * 4u;
-    // weight row of entry u: (u * 4 + kq) * 32 + 2 * j (m-tile pair interleaved: one 8-byte read feeds both m-tiles)
+    // weight row of entry u, channel c of the K step: (u * CC + c) * 32 + 2 * j (m-tile pair interleaved: one 8-byte read feeds
+    // both m-tiles)
     const unsigned a_addr = lds0 + (unsigned)(kq * U2_BM + 2 * j) * 4u;
     unsigned s_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + 2 * U2_PBUF + kq) * 4u;
     constexpr unsigned A_BUF_BYTES = U2_A_FLOATS * 4u, P_BUF_BYTES = U2_PBUF * 4u;
-    constexpr int U_BYTES = U2_CC * U2_BM * 4;  // distance between transformed-kernel entries in the weight tile
+    constexpr int U_BYTES = CC * U2_BM * 4;     // distance between transformed-kernel entries in the weight tile
+    constexpr int KG_A_BYTES = 4 * U2_BM * 4;   // ... between the MFMA K groups (4 channels) of one entry
+    constexpr int KG_P_BYTES = 4 * U2_PLANE * 4;  // ... between the K groups' channel planes in the patch
     constexpr int ROW_BYTES = U2_PWS * 4;
 
     issue(0, 0);
@@ -196,10 +207,12 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     int cur = 0;
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
         if (chunk + 1 < p.n_chunks) issue(chunk + 1, cur ^ 1);
-        const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u), pb = b_addr + (cur ? P_BUF_BYTES : 0u);
+        static_for<0, CC / 4>([&](auto ks_c) {  // the MFMA K groups of this step: 4 channels each
+        constexpr int ks = decltype(ks_c)::value;
+        const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u) + ks * KG_A_BYTES, pb = b_addr + (cur ? P_BUF_BYTES : 0u) + ks * KG_P_BYTES;
         // ---- operand reads: style, the 3 x 3 window (six 8-byte reads), the first weight row behind them (LDS returns in order)
         float sc = lds_read32(s_addr);
-        s_addr += U2_CC * 4u;
+        s_addr += 4 * 4u;
         f32x2 w0l = lds_read64<0>(pb), w0h = lds_read64<8>(pb);
         f32x2 w1l = lds_read64<ROW_BYTES>(pb), w1h = lds_read64<ROW_BYTES + 8>(pb);
         f32x2 w2l = lds_read64<2 * ROW_BYTES>(pb), w2h = lds_read64<2 * ROW_BYTES + 8>(pb);
@@ -222,6 +235,9 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 bv[a][3] = r[a][2];
             }
         }
+#ifdef MAUA_UP2D_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         // ---- MFMA phase: the weight row of the next entry is read one step ahead
         static_for<0, U2_NU>([&](auto u_c) {
             constexpr int u = decltype(u_c)::value;
@@ -247,6 +263,10 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 mac(acc_oo[1][1], bv[3][3]);
             }
             __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef MAUA_UP2D_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -369,9 +389,10 @@ __global__ __launch_bounds__(64) void up2d_edge_kernel(Up2dArgs p, const float* 
     }
 }
 
-// wq: [m_tile][chunk][u 16][kq 4][32 columns: 2 * (o % 16) + (o % 32) / 16], then the edge tap matrices [5][cin][cout]:
+// wq: [m_tile][chunk][u 16][channel of the K step: CC][32 columns: 2 * (o % 16) + (o % 32) / 16], then the edge tap matrices [5][cin][cout]:
 // g20, g21, g22, g02, g12 (kernel's last row, then the other two entries of its last column)
 __global__ __launch_bounds__(256) void pack_weight_up2d_kernel(const float* __restrict__ w, float* __restrict__ wq, int cout, int cin) {
+    const int U2_CC = u2_cc(cin), U2_A_FLOATS = u2_a_floats(U2_CC);
     const int n_chunks = cin / U2_CC;
     const int64_t total = (int64_t)cout * cin;
     float* edge = wq + (size_t)U2_NU * cin * cout;
@@ -407,13 +428,13 @@ char g_up2d_instance[64] = "";
 
 // Layer shapes the kernel accepts: whole tiles of 8 x 32 positions, 32-channel m-tiles, 4-channel K steps.
 extern "C" int maua_modconv_up2d_ok(int cin, int cout, int h, int w) {
-    return cin > 0 && cout > 0 && cin % U2_CC == 0 && cout % U2_BM == 0 && h >= 8 && h % 8 == 0 && w >= 32 && w % 32 == 0;
+    return cin > 0 && cout > 0 && cin % 4 == 0 && cout % U2_BM == 0 && h >= 8 && h % 8 == 0 && w >= 32 && w % 32 == 0;
 }
 
 extern "C" int64_t maua_pack_weight_up2d_floats(int cout, int cin) { return (int64_t)(U2_NU + 5) * cin * cout; }
 
 extern "C" int maua_pack_weight_up2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {
-    if (!w || !wq || cout <= 0 || cin <= 0 || cin % U2_CC || cout % U2_BM) return MAUA_EINVAL;
+    if (!w || !wq || cout <= 0 || cin <= 0 || cin % 4 || cout % U2_BM) return MAUA_EINVAL;
     const int64_t blocks = ceil_div64((int64_t)cout * cin, 256);
     hipLaunchKernelGGL(pack_weight_up2d_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, w, wq,
                        cout, cin);
@@ -431,18 +452,20 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     Up2dArgs a{};
     a.x = x, a.wq = wq, a.s = s, a.d = d, a.y = y;
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
-    a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / U2_CC;
+    const int cc = u2_cc(cin);
+    a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
     hipStream_t st = (hipStream_t)stream;
-    auto kern = modconv_up2d_kernel<false>;
-    const size_t lds_bytes = sizeof(float) * ((size_t)2 * U2_A_FLOATS + (size_t)2 * U2_PBUF + (size_t)cin);
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)cin);
+    const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<false>");
-    const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<%d>", cc);
+    if (cc == 8) hipLaunchKernelGGL(modconv_up2d_kernel<8>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL(modconv_up2d_kernel<4>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     MAUA_LAUNCH_CHECK();
     // edge lines: W + 1 positions along the bottom row (incl. the corner), H along the right column
     const int nt0 = ceil_div(w + 1, 16), nt1 = ceil_div(h, 16);

@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             transform(n, slot);
             if constexpr (n + WSLOTS < TN) read_window(std::integral_constant<int, n + WSLOTS>{}, slot);
         });
+#ifdef MAUA_W2D_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         // ---- MFMA phase: the weight row of the next x-frequency is read one step ahead
         static_for<0, 6>([&](auto xf_c) {
             constexpr int xf = decltype(xf_c)::value;
@@ -343,6 +346,9 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifdef MAUA_W2D_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;

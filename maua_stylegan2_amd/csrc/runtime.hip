@@ -128,6 +128,65 @@ __global__ __launch_bounds__(256) void frames_to_u8_scalar_kernel(const float* _
 }
 }  // namespace
 
+namespace {
+// Crop + bilinear resize of uint8 NHWC frames, the wide-output delivery of render.py:97-104 (2048-px frames: crop 112 px from both
+// ends of the long side, PIL resize(BILINEAR) to 1920x1080 / 1080x1920).  Pillow's 8-bit resampling (ImagingResample) is restated
+// exactly: for an UP-scale the filter is the 2-tap triangle at source position (dst + 0.5) * in / out - 0.5 (a rational number:
+// evaluated in integers), taps clamped to the image, coefficients rounded to 22 fractional bits, a horizontal pass whose result is
+// rounded (half up) to uint8, then the vertical pass on that — bit-equal to PIL (tests/test_host_logic.py holds the same formula
+// in numpy against PIL itself).  One thread per output pixel; 12 bytes read per 3 written at most: HBM-bound and tiny.
+constexpr int RESIZE_BITS = 22;
+struct ResizeTap {
+    int a, b;    // source indices of the two taps (clamped)
+    int k0, k1;  // fixed-point weights
+};
+__device__ __forceinline__ ResizeTap resize_tap(int o, int n_in, int n_out) {
+    const long long num = (2ll * o + 1) * n_in - n_out, den = 2ll * n_out;
+    long long i0 = num / den;
+    if (num < 0 && i0 * den != num) --i0;  // floor division
+    const double f = (double)(num - i0 * den) / (double)den;
+    ResizeTap t;
+    t.k1 = (int)floor(0.5 + f * (double)(1 << RESIZE_BITS));
+    t.k0 = (int)floor(0.5 + (1.0 - f) * (double)(1 << RESIZE_BITS));
+    t.a = min(max((int)i0, 0), n_in - 1);
+    t.b = min(max((int)i0 + 1, 0), n_in - 1);
+    return t;
+}
+__global__ __launch_bounds__(256) void crop_resize_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int in_h, int in_w,
+                                                             int x0, int y0, int cw, int ch, int out_w, int out_h, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(idx % out_w);
+        const int oy = (int)((idx / out_w) % out_h);
+        const int64_t b = idx / ((int64_t)out_w * out_h);
+        const ResizeTap tx = resize_tap(ox, cw, out_w), ty = resize_tap(oy, ch, out_h);
+        const uint8_t* ra = in + ((b * in_h + y0 + ty.a) * in_w + x0) * 3;
+        const uint8_t* rb = in + ((b * in_h + y0 + ty.b) * in_w + x0) * 3;
+        uint8_t* o = out + idx * 3;
+        constexpr int HALF = 1 << (RESIZE_BITS - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // horizontal pass on the two source rows, rounded to 8 bits as PIL's intermediate image is; then the vertical pass
+            const int ha = min(max((tx.k0 * (int)ra[tx.a * 3 + c] + tx.k1 * (int)ra[tx.b * 3 + c] + HALF) >> RESIZE_BITS, 0), 255);
+            const int hb = min(max((tx.k0 * (int)rb[tx.a * 3 + c] + tx.k1 * (int)rb[tx.b * 3 + c] + HALF) >> RESIZE_BITS, 0), 255);
+            o[c] = (uint8_t)min(max((ty.k0 * ha + ty.k1 * hb + HALF) >> RESIZE_BITS, 0), 255);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int maua_crop_resize_u8(const uint8_t* in, uint8_t* out, int batch, int in_h, int in_w, int x0, int y0, int crop_w, int crop_h,
+                                   int out_w, int out_h, void* stream) {
+    if (!in || !out || batch <= 0 || in_h <= 0 || in_w <= 0 || crop_w <= 0 || crop_h <= 0 || out_w <= 0 || out_h <= 0) return MAUA_EINVAL;
+    if (x0 < 0 || y0 < 0 || x0 + crop_w > in_w || y0 + crop_h > in_h) return MAUA_EINVAL;
+    if (out_w < crop_w || out_h < crop_h) return MAUA_ENOSYS;  // a down-scale widens PIL's filter support: not the 2-tap form
+    const int64_t total = (int64_t)batch * out_w * out_h;
+    const int64_t blocks = ceil_div64(total, 256);
+    hipLaunchKernelGGL(crop_resize_u8_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       in_h, in_w, x0, y0, crop_w, crop_h, out_w, out_h, total);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int maua_frames_to_u8(const float* img, uint8_t* out, int batch, int h, int w, void* stream) {
     if (!img || !out || batch <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
     const int64_t plane = (int64_t)h * w;

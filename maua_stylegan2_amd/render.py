@@ -117,6 +117,31 @@ def frames_to_uint8(images, out=None):
     return out
 
 
+def crop_resize_for_delivery(u8, out_size, scratch):
+    """The wide-output delivery of reference render.py:97-104 ON THE DEVICE: 2048-px frames of a 1920 / 1080 render are cropped
+    (112 px off both ends of the long side) and resized to 1920x1080 / 1080x1920 by maua_crop_resize_u8 = PIL's bilinear resize —
+    the reference (and round 2 here) does it per frame on the host with PIL, a few milliseconds each on rank 0's Python thread.
+    Other frames pass through.  ``scratch``: dict holding the reusable output buffers (one per input buffer: the lanes' frames are
+    in flight concurrently)."""
+    b, h, w, _ = u8.shape
+    if out_size == 1920 and w == 2048:
+        x0, y0, cw, ch, ow, oh = 112, 0, w - 224, h, 1920, 1080
+    elif out_size == 1080 and h == 2048:
+        x0, y0, cw, ch, ow, oh = 0, 112, w, h - 224, 1080, 1920
+    else:
+        return u8
+    if ow < cw or oh < ch:
+        return u8  # not the up-scale the device kernel reproduces: FrameSink.write falls back to PIL on the host
+    key = (u8.data_ptr(), b)
+    out = scratch.get(key)
+    if out is None:
+        out = scratch[key] = th.empty((b, oh, ow, 3), dtype=th.uint8, device=u8.device)
+    with th.cuda.device(u8.device):
+        _lib.check(_lib.load().maua_crop_resize_u8(u8.data_ptr(), out.data_ptr(), b, h, w, x0, y0, cw, ch, ow, oh,
+                                                   _lib.stream_ptr(u8.device)), "maua_crop_resize_u8")
+    return out
+
+
 _LANE_STREAMS = {}
 
 
@@ -333,8 +358,10 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
                     sink.write(host[i])
 
             k = 0
+            resized = {}
             for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
                                         randomize_noise, lanes=n_slots):
+                u8 = crop_resize_for_delivery(u8, out_size, resized)  # 2048-px frames leave the device as 1920x1080 already
                 slot = k % n_slots
                 if len(pending) == n_slots:
                     drain(pending.pop(0))
@@ -359,8 +386,10 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
             # first — the blocks are contiguous — while the peers' frames accumulate in its HBM store).
             stream = None
             k = 0
+            resized = {}
             for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
                                         randomize_noise, frame_range=frame_range):
+                u8 = crop_resize_for_delivery(u8, out_size, resized)
                 if stream is None:  # the frame shape is whatever the generator (and its layer-0 bends) produce
                     stream = sharding.FrameStream(n_frames, batch_size, tuple(u8.shape[1:]), dev)
                 stream.push(k, u8)
@@ -387,7 +416,7 @@ def _stream_frame_shape(generator, out_size):
     that the sink crops and resizes, render.py:98-105)."""
     side = int(getattr(generator, "size", 0)) or _output_dims(out_size)[0]
     if out_size == 1920:
-        return (side, 2 * side, 3)
+        return (1080, 1920, 3) if side == 1024 else (side, 2 * side, 3)  # 2048-px frames are resized on the device before they travel
     if out_size == 1080:
-        return (2 * side, side, 3)
+        return (1920, 1080, 3) if side == 1024 else (2 * side, side, 3)
     return (side, side, 3)

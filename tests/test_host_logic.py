@@ -394,3 +394,40 @@ def test_tuning_estimation_known_answers():
     # the tuning moves the chroma filterbank's and the constant-Q transform's bin centres
     fb0, fb1 = signal_oracle.chroma_filterbank(sr, tuning=0.0), signal_oracle.chroma_filterbank(sr, tuning=0.3)
     assert fb0.shape == fb1.shape and not np.allclose(fb0, fb1)
+
+
+def pil_bilinear_upscale_restated(frame, x0, y0, cw, ch, ow, oh):
+    """The arithmetic of csrc/runtime.hip crop_resize_u8_kernel in numpy: Pillow's 8-bit bilinear resampling for an up-scale
+    (2-tap triangle at the rational source position, 22-bit fixed-point coefficients, horizontal pass rounded to uint8, then
+    vertical)."""
+    bits = 22
+
+    def taps(n_in, n_out):
+        o = np.arange(n_out, dtype=np.int64)
+        num, den = (2 * o + 1) * n_in - n_out, 2 * n_out
+        i0 = np.floor_divide(num, den)
+        f = (num - i0 * den).astype(np.float64) / den
+        k1 = np.floor(0.5 + f * (1 << bits)).astype(np.int64)
+        k0 = np.floor(0.5 + (1 - f) * (1 << bits)).astype(np.int64)
+        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), k0, k1
+
+    f = frame[y0:y0 + ch, x0:x0 + cw].astype(np.int64)
+    xa, xb, kx0, kx1 = taps(cw, ow)
+    ya, yb, ky0, ky1 = taps(ch, oh)
+    h = np.clip((kx0[None, :, None] * f[:, xa] + kx1[None, :, None] * f[:, xb] + (1 << (bits - 1))) >> bits, 0, 255)
+    v = np.clip((ky0[:, None, None] * h[ya] + ky1[:, None, None] * h[yb] + (1 << (bits - 1))) >> bits, 0, 255)
+    return v.astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape,box", [((1024, 2048, 3), (112, 0, 1824, 1024, 1920, 1080)),   # --out_size 1920 (render.py:97-100)
+                                       ((2048, 1024, 3), (0, 112, 1024, 1824, 1080, 1920)),   # --out_size 1080 (:101-104)
+                                       ((64, 128, 3), (7, 0, 114, 64, 120, 68))])
+def test_device_resize_formula_is_pils_bilinear(shape, box):
+    """The device-side wide-output delivery restates Pillow's Image.resize(BILINEAR) for the reference's crop + resize: the numpy
+    twin of the kernel's arithmetic equals PIL bit for bit (the kernel itself is compared with PIL in tests/test_render_gpu.py)."""
+    import PIL.Image
+
+    x0, y0, cw, ch, ow, oh = box
+    frame = np.random.default_rng(sum(shape)).integers(0, 256, shape, dtype=np.uint8)
+    want = np.array(PIL.Image.fromarray(np.ascontiguousarray(frame[y0:y0 + ch, x0:x0 + cw])).resize((ow, oh), PIL.Image.BILINEAR))
+    assert np.array_equal(pil_bilinear_upscale_restated(frame, x0, y0, cw, ch, ow, oh), want)

@@ -802,3 +802,178 @@ def test_config3_900_frames_through_generate_vs_oracle(gpu, tmp_path, monkeypatc
         want = so.frames_to_uint8(so.generator_forward(sd, seen["latents"][i: i + 1].cpu().float(), noise_i))[0]
         diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
         assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (i, int(diff.max()), float((diff > 0).mean()))
+
+
+@pytest.mark.parametrize("out_size,shape", [(1920, (2, 1024, 2048, 3)), (1080, (1, 2048, 1024, 3))])
+def test_wide_output_crop_resize_on_device_equals_pil(gpu, out_size, shape):
+    """render.py:97-104 (2048-px frames -> crop 112 px off both ends of the long side -> PIL bilinear resize to 1920x1080 /
+    1080x1920) on the device (maua_crop_resize_u8) against PIL itself on the same frames: bit-equal (<= 1 grey level is the bar);
+    other frame sizes pass through untouched."""
+    import PIL.Image
+
+    from maua_stylegan2_amd import render
+
+    frames = torch.from_numpy(np.random.default_rng(out_size).integers(0, 256, shape, dtype=np.uint8))
+    scratch = {}
+    got = render.crop_resize_for_delivery(frames.to(gpu), out_size, scratch)
+    torch.cuda.synchronize()
+    w, h = render._output_dims(out_size)
+    assert tuple(got.shape) == (shape[0], h, w, 3) and len(scratch) == 1
+    for i in range(shape[0]):
+        f = frames[i].numpy()
+        crop = f[:, 112:-112, :] if out_size == 1920 else f[112:-112, :, :]
+        want = np.array(PIL.Image.fromarray(np.ascontiguousarray(crop)).resize((w, h), PIL.Image.BILINEAR))
+        diff = np.abs(got[i].cpu().numpy().astype(np.int16) - want.astype(np.int16))
+        assert diff.max() == 0, (i, int(diff.max()), float((diff > 0).mean()))
+    square = torch.zeros(1, 512, 512, 3, dtype=torch.uint8, device=gpu)
+    assert render.crop_resize_for_delivery(square, 512, scratch) is square
+    # the sink accepts the delivered size directly (no host-side PIL pass any more)
+    sink = render.FrameSink(None, w, h, 30)
+    sink.write(got[0].cpu().numpy())
+    assert sink.count == 1
+
+
+def test_stylegan1_through_generate_and_render_vs_oracle(gpu, tmp_path, monkeypatch):
+    """``--stylegan1`` end to end (reference generate_audiovisual.py:41-47, models/stylegan1.py:509-617): a seeded 128-px G_style
+    checkpoint is probed (1024 -> 512 -> 256 -> 128) by ``generate(stylegan1=True)``, rendered at 512^2 (constant enlarged to 32x32
+    and centre-cropped to 16x16, six blocks, truncation 0.7 on the first 8 layers, per-frame noise below 64 px and the generator's
+    own noise buffers above) through render()'s eager path, and three delivered frames are compared with oracle/stylegan1_oracle.py
+    run on the state the generator actually holds (<= 1 grey level)."""
+    import wave
+
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.models import stylegan1 as sg1
+    from oracle import stylegan1_oracle as s1o
+    from oracle import stylegan2_oracle as so
+
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(11)
+    proto = sg1.G_style(output_size=512, checkpoint=None, network_resolution=128)
+    state = {}
+    for key, value in proto.state_dict().items():
+        if key.startswith("noise_"):
+            continue
+        shape = (1, 512, 4, 4) if key.endswith("4x4.const") else tuple(value.shape)
+        std = 0.3 if key.endswith("noise.weight") else (0.2 if key.endswith(".bias") else 1.0)
+        state[key] = value.clone() if key.endswith("kernel") else torch.from_numpy(seeding.seeded_array(77, key, shape, std=std))
+    torch.save(state, "sg1_128.pt")
+    del proto
+    n, fps, bs = 10, 10, 4
+    audio = seeding.synthetic_audio(n / fps)
+    with wave.open("track.wav", "wb") as f:
+        f.setnchannels(1), f.setsampwidth(2), f.setframerate(22050)
+        f.writeframes((np.clip(audio, -1, 1) * 32767).astype(np.int16).tobytes())
+    np.save("selection.npy", seeding.seeded_array(78, "selection", (4, 12, 512)))
+    lat = torch.from_numpy(seeding.seeded_array(79, "latents", (n, 12, 512)))
+    noise_seq = {}
+    keep, held = {0: None, 5: None, n - 1: None}, {}
+
+    class KeepingSink(render.FrameSink):
+        def __init__(self, *a, **k):
+            self.count = 0
+
+        def write(self, frame):
+            if self.count in keep:
+                keep[self.count] = np.array(frame, copy=True)
+            self.count += 1
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(render, "FrameSink", KeepingSink)
+    real_load = gav.load_generator
+
+    def load_generator(**kw):
+        held["g"] = real_load(**kw)
+        return held["g"]
+
+    monkeypatch.setattr(gav, "load_generator", load_generator)
+
+    def get_noise(height, width, scale, num_scales, args):
+        if width > 32:
+            return None  # the generator's own noise_i buffer
+        noise_seq[scale] = torch.from_numpy(seeding.seeded_array(80, f"nz{scale}", (args.n_frames, 1, height, width)))
+        return noise_seq[scale]
+
+    gav.generate(ckpt="sg1_128.pt", audio_file="track.wav", get_latents=lambda selection, args: lat.clone(), get_noise=get_noise,
+                 latent_file="selection.npy", stylegan1=True, G_res=128, out_size=512, fps=fps, batch=bs, truncation=0.7,
+                 output_file=str(tmp_path / "o.mp4"))
+    g = held["g"]
+    assert g.network_resolution == 128 and len(g.g_synthesis.blocks) == 6
+    assert tuple(getattr(g.g_synthesis.blocks, "4x4").const.shape) == (1, 512, 16, 16)
+    sd = {k: v.detach().cpu() for k, v in g.state_dict().items()}
+    tl = g.truncation_latent.cpu()
+    for i, got in keep.items():
+        assert got is not None and got.shape == (512, 512, 3), i
+        noise_i = [noise_seq[s][i: i + 1] if s in noise_seq else sd[f"noise_{s}"] for s in range(6)]
+        want = so.frames_to_uint8(s1o.synthesis(sd, s1o.truncate(lat[i: i + 1], tl, 0.7), noise_i))[0]
+        diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (i, int(diff.max()), float((diff > 0).mean()))
+
+
+def test_generate_1920_wide_output_is_delivered_as_1080p(gpu, tmp_path, monkeypatch):
+    """``--out_size 1920`` end to end: a generator built for 1920 output (2:1 noise buffers) plus the layer-0 bend that widens the
+    4x4 constant to 4x8 (the reference's route, examples/tauceti.py:97-100) renders 1024 x 2048 frames; the delivery crops 112 px
+    per side and resizes to 1920 x 1080 ON THE DEVICE (reference render.py:97-100 does it with PIL per frame on the host).  A
+    delivered frame is compared with the oracle's 1024 x 2048 frame taken through PIL's crop + resize (<= 1 grey level)."""
+    import wave
+
+    import PIL.Image
+
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import render
+    from oracle import stylegan2_oracle as so
+
+    monkeypatch.chdir(tmp_path)
+    size, n, fps = 1024, 6, 6
+    sd = seeding.seeded_state_dict(size, seed=0)
+    torch.save({"g_ema": sd}, "seeded1024.pt")
+    audio = seeding.synthetic_audio(n / fps)
+    with wave.open("track.wav", "wb") as f:
+        f.setnchannels(1), f.setsampwidth(2), f.setframerate(22050)
+        f.writeframes((np.clip(audio, -1, 1) * 32767).astype(np.int16).tobytes())
+    np.save("selection.npy", seeding.seeded_array(42, "selection", (4, 18, 512)))
+    lat = torch.from_numpy(seeding.seeded_array(43, "latents", (n, 18, 512)))
+    noise_seq, frames, held = {}, [], {}
+
+    class KeepingSink(render.FrameSink):
+        def __init__(self, output_file, width, height, *a, **k):
+            self.count, self.w, self.h = 0, width, height
+
+        def write(self, frame):
+            assert frame.shape == (1080, 1920, 3)  # already resized: the host-side PIL pass is not taken
+            frames.append(np.array(frame, copy=True))
+            self.count += 1
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(render, "FrameSink", KeepingSink)
+    real_load = gav.load_generator
+
+    def load_generator(**kw):
+        held["g"] = real_load(**kw)
+        return held["g"]
+
+    monkeypatch.setattr(gav, "load_generator", load_generator)
+
+    def get_noise(height, width, scale, num_scales, args):
+        if width > 64:
+            return None
+        noise_seq[scale] = torch.from_numpy(seeding.seeded_array(44, f"nz{scale}", (args.n_frames, 1, height, width)))
+        return noise_seq[scale]
+
+    pad = torch.nn.ReplicationPad2d((2, 2, 0, 0))
+    gav.generate(ckpt="seeded1024.pt", audio_file="track.wav", get_latents=lambda selection, args: lat.clone(), get_noise=get_noise,
+                 get_bends=lambda args: [{"layer": 0, "transform": pad}], latent_file="selection.npy", G_res=size, out_size=1920,
+                 fps=fps, batch=4, output_file=str(tmp_path / "o.mp4"))
+    assert len(frames) == n
+    g = held["g"]
+    i = 4  # second batch (eager: the layer-0 torch bend is not capturable)
+    noise_i = [noise_seq[s][i: i + 1] if s in noise_seq else getattr(g.noises, f"noise_{s}").cpu() for s in range(g.num_layers)]
+    wide = so.frames_to_uint8(so.generator_forward(sd, lat[i: i + 1], noise_i, bends={0: pad}))[0]
+    assert wide.shape == (1024, 2048, 3)
+    want = np.array(PIL.Image.fromarray(np.ascontiguousarray(wide[:, 112:-112, :])).resize((1920, 1080), PIL.Image.BILINEAR))
+    diff = np.abs(frames[i].astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (int(diff.max()), float((diff > 0).mean()))
