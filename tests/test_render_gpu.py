@@ -864,8 +864,10 @@ def test_stylegan1_through_generate_and_render_vs_oracle(gpu, tmp_path, monkeypa
     with wave.open("track.wav", "wb") as f:
         f.setnchannels(1), f.setsampwidth(2), f.setframerate(22050)
         f.writeframes((np.clip(audio, -1, 1) * 32767).astype(np.int16).tobytes())
-    np.save("selection.npy", seeding.seeded_array(78, "selection", (4, 12, 512)))
-    lat = torch.from_numpy(seeding.seeded_array(79, "latents", (n, 12, 512)))
+    # (G_mapping broadcasts to 18 latents whatever the network resolution, models/stylegan1.py:357-362: the synthesis network of a
+    # 128-px checkpoint reads the first 12 of them, the truncation lerp covers the first 8)
+    np.save("selection.npy", seeding.seeded_array(78, "selection", (4, 18, 512)))
+    lat = torch.from_numpy(seeding.seeded_array(79, "latents", (n, 18, 512)))
     noise_seq = {}
     keep, held = {0: None, 5: None, n - 1: None}, {}
 
