@@ -23,6 +23,11 @@
 // cross-wave exchange: every wave holds all 25 products of its blocks.  Operands reach LDS by MUBUF `buffer_load ... lds` DMA,
 // double buffered, one barrier per K step; the packed weight (maua_pack_weight_up2d_f32) is stored in HBM as the LDS tile image.
 //
+// Measured and NOT kept (round 3, alternating runs inside bench.py): 4 instead of 8 channels per K step (+2.5 % on this family),
+// s_setprio(1) around the MFMA phase (no change), persistent workgroups that walk several tiles and issue the next tile's first K
+// step under the current tile's last one (-0.5..+1 % : two co-resident workgroups per CU already overlap one's prologue / epilogue
+// with the other's K loop, and the tile loop costs 12 spilled registers per tile).
+//
 // The main kernel covers the (H/2) x (W/2) blocks of positions p < H, q < W (H, W powers of two on this path: tiles never hang
 // over).  The remaining output row 2H and column 2W belong to positions whose own input is the zero padding: two 1-D polyphase
 // transposed convolutions of the last input row / column with the kernel's last row / column, 1.5 MAC per output
@@ -235,9 +240,6 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 bv[a][3] = r[a][2];
             }
         }
-#ifdef MAUA_UP2D_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
         // ---- MFMA phase: the weight row of the next entry is read one step ahead
         static_for<0, U2_NU>([&](auto u_c) {
             constexpr int u = decltype(u_c)::value;
@@ -264,9 +266,6 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-#ifdef MAUA_UP2D_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

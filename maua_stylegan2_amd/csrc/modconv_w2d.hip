@@ -68,12 +68,6 @@ __device__ __forceinline__ f32x2 lds_read64(unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-template <int OFF>
-__device__ __forceinline__ float lds_read32o(unsigned addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
 __device__ __forceinline__ float lds_read32(unsigned addr) {
     float v;
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
@@ -280,20 +274,23 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
         // goes out behind the last window; LDS returns in order, so "at most k operations outstanding" identifies what landed
         // (with four n-tiles per wave the register file only has room for one window in flight)
         constexpr int WSLOTS = TN > 2 ? 1 : 2;
-        float wa0[WSLOTS], wa5[WSLOTS], wb0[WSLOTS], wb5[WSLOTS];  // window columns 0 and 5 (4-byte reads: odd float index)
-        f32x2 wa[WSLOTS][2], wb[WSLOTS][2];                         // columns 1-2 and 3-4 (8-byte aligned)
-        const unsigned pa = b_addr[0] + p_off, pb = b_addr[1] + p_off;
+        // the 6-float window (row floats 4 jx + 3 .. 4 jx + 8) is read as four aligned 8-byte pairs, columns -1|0, 1|2, 3|4, 5|6:
+        // 4-byte reads of the odd-aligned window edges are 4-way bank conflicts (4 lanes per bank in a 32-lane group), the 8-byte
+        // ones 2-way at worst (round 3: -2 % over the plain-layer family, 45 % -> ~25 % of the LDS-active cycles in conflicts)
+        f32x2 wa0[WSLOTS], wa5[WSLOTS], wb0[WSLOTS], wb5[WSLOTS];
+        f32x2 wa[WSLOTS][2], wb[WSLOTS][2];
+        const unsigned pa = b_addr[0] + p_off - 4u, pb = b_addr[1] + p_off - 4u;
         auto read_window = [&](auto n_c, int slot) {
             constexpr int o = decltype(n_c)::value * NT_BYTES;
-            wa0[slot] = lds_read32o<o>(pa), wa[slot][0] = lds_read64<o + 4>(pa), wa[slot][1] = lds_read64<o + 12>(pa);
-            wa5[slot] = lds_read32o<o + 20>(pa);
-            wb0[slot] = lds_read32o<o>(pb), wb[slot][0] = lds_read64<o + 4>(pb), wb[slot][1] = lds_read64<o + 12>(pb);
-            wb5[slot] = lds_read32o<o + 20>(pb);
+            wa0[slot] = lds_read64<o>(pa), wa[slot][0] = lds_read64<o + 8>(pa), wa[slot][1] = lds_read64<o + 16>(pa);
+            wa5[slot] = lds_read64<o + 24>(pa);
+            wb0[slot] = lds_read64<o>(pb), wb[slot][0] = lds_read64<o + 8>(pb), wb[slot][1] = lds_read64<o + 16>(pb);
+            wb5[slot] = lds_read64<o + 24>(pb);
         };
         auto transform = [&](int n, int slot) {
-            const float d0 = fmaf(sgn, wb0[slot], wa0[slot]), d1 = fmaf(sgn, wb[slot][0].x, wa[slot][0].x);
+            const float d0 = fmaf(sgn, wb0[slot].y, wa0[slot].y), d1 = fmaf(sgn, wb[slot][0].x, wa[slot][0].x);
             const float d2 = fmaf(sgn, wb[slot][0].y, wa[slot][0].y), d3 = fmaf(sgn, wb[slot][1].x, wa[slot][1].x);
-            const float d4 = fmaf(sgn, wb[slot][1].y, wa[slot][1].y), d5 = fmaf(sgn, wb5[slot], wa5[slot]);
+            const float d4 = fmaf(sgn, wb[slot][1].y, wa[slot][1].y), d5 = fmaf(sgn, wb5[slot].x, wa5[slot].x);
             // B_x^T for F(4,3) (interpolation points 0, +-1, +-2, inf), as in modconv.hip's mode 3
             const float a_ = fmaf(-4.f, d2, d4), b_ = fmaf(-4.f, d1, d3);
             const float c_ = d4 - d2, e_ = d3 - d1;
@@ -322,9 +319,6 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             transform(n, slot);
             if constexpr (n + WSLOTS < TN) read_window(std::integral_constant<int, n + WSLOTS>{}, slot);
         });
-#ifdef MAUA_W2D_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
         // ---- MFMA phase: the weight row of the next x-frequency is read one step ahead
         static_for<0, 6>([&](auto xf_c) {
             constexpr int xf = decltype(xf_c)::value;
@@ -346,9 +340,6 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-#ifdef MAUA_W2D_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
