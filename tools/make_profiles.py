@@ -11,10 +11,11 @@ import subprocess
 import sys
 
 O = "gpurun_out/prof_final"
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
-def table(db, keep=("modconv_mfma", "modconv_w2d", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel", "reduce_tail")):
+def table(db, keep=("modconv_mfma", "modconv_w2d", "modconv_up2d", "up2d_edge", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel",
+                     "reduce_tail")):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
                        "group by kernel_name, counter_name").fetchall()
@@ -37,9 +38,9 @@ def last_json(path):
 def main():
     shutil.copy(f"{O}/pytest_gpu.log", f"profiles/{TAG}_pytest_gpu.log")
     for src, dst in (("bench_default", "bench_default"), ("bench_trace_lanes1", "bench_rocprof_lanes1"),
-                     ("bench_trace_lanes2", "bench_rocprof_lanes2")):
+                     ("bench_trace_lanes3", "bench_rocprof_lanes3")):
         shutil.copy(f"{O}/{src}.json", f"profiles/{TAG}_{dst}.json")
-    l1, l2 = last_json(f"{O}/bench_trace_lanes1.json"), last_json(f"{O}/bench_trace_lanes2.json")
+    l1, l2 = last_json(f"{O}/bench_trace_lanes1.json"), last_json(f"{O}/bench_trace_lanes3.json")
 
     def stats(db):
         out = subprocess.run([sys.executable, "tools/rocpd_summary.py", db], capture_output=True, text=True).stdout
@@ -50,21 +51,23 @@ def main():
 
 Commands (tools/profile_round.sh, run through gpurun on one MI355X):
 
-    rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --lanes 1 --no-cpu-baseline   # strictly serial steps
-    rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline             # default: 2 graph lanes
+    rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --batches-per-step 3 --no-cpu-baseline --no-side-configs --lanes 1   # strictly serial batches
+    rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --batches-per-step 3 --no-cpu-baseline --no-side-configs             # default: 3 graph lanes
 
 The serial run is the one whose per-kernel averages are comparable with the live HIP-event numbers in the bench JSON
 (profiles/{TAG}_bench_rocprof_lanes1.json: {l1['value']:.0f} frames/s, roofline.launch_ms {l1['roofline']['launch_ms']:.3f} ms for
-{l1['roofline']['kernel']}).  Under two lanes ({l2['value']:.0f} frames/s) the kernels of consecutive batches share the device, so
+{l1['roofline']['kernel']}).  Under three lanes ({l2['value']:.0f} frames/s) the kernels of consecutive batches share the device, so
 individual durations stretch while the step time drops.  Each trace also contains bench.py's per-layer breakdown pass (eager
 launches), which is why calls != steps x layers.  Template arguments of modconv_mfma_kernel: <BM, BN, WM, MODE, MULTI, FAST, MAXP>,
-MODE 0 direct, 1 transposed (polyphase), 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed with F(2,2) on the even x-phase.
+MODE 0 direct, 1 transposed (polyphase), 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed with F(2,2) on the even x-phase;
+modconv_w2d_kernel<TM, TN> = 2-D Winograd F(2x4,3x3) (mode 5); modconv_up2d_kernel<CC> = transposed with F(2,2) on both axes (mode 6),
+up2d_edge_kernel = its two edge lines.  (These short runs time one cold step: the frames/s quoted here are not the headline.)
 
 ## --lanes 1
 {stats(f'{O}/trace_lanes1/bench_results.db')}
 
-## default (2 lanes)
-{stats(f'{O}/trace_lanes2/bench_results.db')}
+## default (3 lanes)
+{stats(f'{O}/trace_lanes3/bench_results.db')}
 """)
 
     sq, lds = table(f"{O}/pmc_sq/bench_results.db"), table(f"{O}/pmc_lds/bench_results.db")
@@ -73,40 +76,46 @@ MODE 0 direct, 1 transposed (polyphase), 2 Winograd F(2,3), 3 Winograd F(4,3), 4
 ## Final kernels of {TAG}, measured inside bench.py
 
 Command (tools/profile_round.sh): `rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
-SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown` and a second
-pass with `--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32` (counters only, with --kernel-trace; no
-sys/hip/hsa trace domains).  Averages over every dispatch of the template instance in the run (batch 8, 1024^2 generator).
+SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 1 --warmup 1 --batches-per-step 3 --lanes 1 --no-cpu-baseline
+--no-side-configs --no-breakdown` and a second pass with `--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32
+SQ_INSTS_VALU SQ_WAIT_ANY` (counters only, with --kernel-trace; no sys/hip/hsa trace domains).  Averages over every dispatch of the template instance in the run (batch 8, 1024^2 generator).
 MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); clock = (GRBM_GUI_ACTIVE / 8) / duration.
 Template arguments: <BM, BN, WM, MODE (0 direct, 1 transposed, 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed + F(2,2)),
-MULTI, FAST, MAXP>.
+MULTI, FAST, MAXP>; modconv_w2d_kernel<TM, TN> = mode 5, modconv_up2d_kernel<CC> = mode 6.  "executed TFLOP/s" = MFMA_MOPS_F32 x 512 flop /
+duration; "non-MFMA VALU per MFMA" = (SQ_INSTS_VALU - MOPS / 4) / (MOPS / 4).
 
-| kernel instance | dispatches | avg us | clock GHz | MFMA busy % | wave cycles waiting on an instruction % | LDS bank conflicts % of LDS active |
-|---|---:|---:|---:|---:|---:|---:|"""]
+| kernel instance | dispatches | avg us | clock GHz | MFMA busy % | executed TFLOP/s | non-MFMA VALU per MFMA | wave cycles waiting on an instruction % | waiting on a counter / barrier % | LDS bank conflicts % of LDS active |
+|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"""]
     for n, t in sorted(sq.items(), key=lambda kv: -kv[1]["us"] * kv[1]["n"]):
         if "modconv" not in n:
             continue
         cyc = t["GRBM_GUI_ACTIVE"] / 8
         ll = lds.get(n, {})
+        mops = ll.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
+        mfmas = max(mops / 4.0, 1.0)
         lines.append(f"| `{n}` | {t['n']} | {t['us']:.0f} | {cyc / t['us'] / 1e3:.2f} | "
                      f"{t['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024) * 100:.1f} | "
+                     f"{mops * 512 / (ll.get('us', t['us']) * 1e-6) / 1e12:.1f} | "
+                     f"{(ll.get('SQ_INSTS_VALU', 0.0) - mfmas) / mfmas:.2f} | "
                      f"{t['SQ_WAIT_INST_ANY'] / t['SQ_WAVE_CYCLES'] * 100:.0f} | "
+                     f"{100 * ll.get('SQ_WAIT_ANY', 0) / max(t['SQ_WAVE_CYCLES'], 1):.0f} | "
                      f"{100 * ll.get('SQ_LDS_BANK_CONFLICT', 0) / max(ll.get('SQ_LDS_IDX_ACTIVE', 1), 1):.1f} |")
-    open(f"/tmp/{TAG}_pmc_modconv_final.md", "w").write("\n".join(lines) + "\n")
+    open(f"profiles/{TAG}_pmc_modconv.md", "w").write(f"# PMC counters of the modulated-conv kernels ({TAG})\n" + "\n".join(lines) + "\n")
 
     tr = [f"# HBM traffic per launch inside bench.py ({TAG}; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)", "",
-          "Command: `rocprofv3 --pmc <CTR> --kernel-trace -- python bench.py --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown`",
+          "Command: `rocprofv3 --pmc <CTR> --kernel-trace -- python bench.py --steps 1 --warmup 1 --batches-per-step 3 --lanes 1 --no-cpu-baseline --no-side-configs --no-breakdown`",
           "(tools/profile_round.sh).  Units: KB per dispatch, averaged over the dispatches of one template instance.  Corrections as calibrated",
-          f"in {TAG}_pmc_upfirdn2d.md against kernels of known traffic (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of",
+          "in r01_pmc_upfirdn2d.md against kernels of known traffic (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of",
           "the bytes read -> x2; WRITE_SIZE is exact.", "",
           "| kernel instance | dispatches | FETCH_SIZE KB | read KB (x2) | WRITE_SIZE KB | avg us |", "|---|---:|---:|---:|---:|---:|"]
     for n, t in sorted(fe.items(), key=lambda kv: -kv[1]["us"] * kv[1]["n"]):
         w = wr.get(n, {})
         tr.append(f"| `{n}` | {t['n']} | {t['FETCH_SIZE']:.0f} | {2 * t['FETCH_SIZE']:.0f} | {w.get('WRITE_SIZE', float('nan')):.0f} | {t['us']:.0f} |")
-    open(f"/tmp/{TAG}_pmc_traffic_table.md", "w").write("\n".join(tr) + "\n")
+    open(f"profiles/{TAG}_pmc_traffic.md", "w").write("\n".join(tr) + "\n")
     # machine-readable twin, read by bench.py for roofline.traffic (no literals in bench.py): bytes per dispatch, averaged over
-    # the dispatches of an instance in `bench.py --steps 2 --warmup 1 --lanes 1 --no-breakdown` (3 steps + 2 capture passes)
-    # forwards executed in that run = dispatches of a once-per-forward kernel (eager warm-up of the capture + every replay of the
-    # timed, warm-up and PCIe-inclusive regions)
+    # the dispatches of an instance in the short serial run.  Forwards executed in that run = dispatches of a once-per-forward
+    # kernel (eager warm-up of the capture, every replay of the warm-up / timed / PCIe-inclusive regions, the frame check);
+    # "dispatches_per_step" = dispatches per FORWARD (= per batch)
     steps_in_run = int(next(t["n"] for n, t in fe.items() if n.startswith("style_affine_kernel")))
     kernels = {}
     for n, t in fe.items():
@@ -121,10 +130,10 @@ MULTI, FAST, MAXP>.
     bench = last_json(f"{O}/bench_default.json")
     with open(f"profiles/{TAG}_pmc_traffic.json", "w") as f:
         json.dump({"source": "tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python bench.py "
-                             "--steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown",
+                             "--steps 1 --warmup 1 --batches-per-step 3 --lanes 1 --no-cpu-baseline --no-side-configs --no-breakdown",
                    "correction": "FETCH_SIZE x2 (reports 1/2 of the bytes read on gfx950, calibrated on a known-size copy), WRITE_SIZE exact",
-                   "batch": bench["config"]["frames_per_step_per_gpu"], "size": 1024, "kernels": kernels}, f, indent=1)
-    print("wrote profiles/*; tables in /tmp for the hand-annotated files")
+                   "batch": bench["config"]["batch"], "size": 1024, "kernels": kernels}, f, indent=1)
+    print(f"wrote profiles/{TAG}_*")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end evidence run on the GPU box (invoked through gpurun): parity suite, smoke, bench (+CPU baseline), rocprofv3
-# kernel trace of the bench command (default two-lane run and the strictly serial --lanes 1 run) and the PMC passes
+# kernel trace of the bench command (default three-lane run and the strictly serial --lanes 1 run) and the PMC passes
 # (each counter group in its own pass, no sys/hip/hsa trace domains).  Outputs land in gpurun_out/prof_final/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -9,13 +9,16 @@ rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 ( cd "$R" && python -m pytest tests -q -m gpu > "$O/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$O/pytest_gpu.log" )
 ( cd "$R" && python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1 )
-( cd "$R" && python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err" )
-rocprofv3 --kernel-trace --stats -d "$O/trace_lanes2" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$O/bench_trace_lanes2.json" 2> "$O/trace_lanes2.err"
-rocprofv3 --kernel-trace --stats -d "$O/trace_lanes1" -o bench -- python "$R/bench.py" --steps 10 --warmup 3 --lanes 1 --no-cpu-baseline > "$O/bench_trace_lanes1.json" 2> "$O/trace_lanes1.err"
+( cd "$R" && python bench.py --steps 20 > "$O/bench_default.json" 2> "$O/bench_default.err" )
+# short traced / counted runs: 1 warm-up + 1 timed step of 3 batches (every kernel instance of the path is dispatched several times)
+SHORT="--steps 1 --warmup 1 --batches-per-step 3 --no-cpu-baseline --no-side-configs"
+rocprofv3 --kernel-trace --stats -d "$O/trace_lanes3" -o bench -- python "$R/bench.py" $SHORT > "$O/bench_trace_lanes3.json" 2> "$O/trace_lanes3.err"
+rocprofv3 --kernel-trace --stats -d "$O/trace_lanes1" -o bench -- python "$R/bench.py" $SHORT --lanes 1 > "$O/bench_trace_lanes1.json" 2> "$O/trace_lanes1.err"
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace -d "$O/pmc_$ctr" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown > /dev/null 2> "$O/pmc_$ctr.err"
+  rocprofv3 --pmc $ctr --kernel-trace -d "$O/pmc_$ctr" -o bench -- python "$R/bench.py" $SHORT --lanes 1 --no-breakdown > /dev/null 2> "$O/pmc_$ctr.err"
 done
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace -d "$O/pmc_sq" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown > /dev/null 2> "$O/pmc_sq.err"
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace -d "$O/pmc_lds" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --lanes 1 --no-cpu-baseline --no-breakdown > /dev/null 2> "$O/pmc_lds.err"
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace -d "$O/pmc_sq" -o bench -- python "$R/bench.py" $SHORT --lanes 1 --no-breakdown > /dev/null 2> "$O/pmc_sq.err"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace -d "$O/pmc_lds" -o bench -- python "$R/bench.py" $SHORT --lanes 1 --no-breakdown > /dev/null 2> "$O/pmc_lds.err"
+# the standalone upfirdn2d leg needs the breakdown-free run above to contain fir_strip_kernel: it does (roofline_upfirdn2d is always timed)
 find "$O" -name "*.db" -size +20M -delete   # keep the merge-back under gpurun's 64 MiB limit
-du -sh "$O"; tail -2 "$O/pytest_gpu.log"; cat "$O/smoke.log" | tail -1; head -c 400 "$O/bench_default.json"
+du -sh "$O"; tail -2 "$O/pytest_gpu.log"; cat "$O/smoke.log" | tail -1; head -c 600 "$O/bench_default.json"
