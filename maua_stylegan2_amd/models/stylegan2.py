@@ -943,6 +943,12 @@ class FrameSource:
         self.dev.copy_(raw.to(dev), non_blocking=False)
         th.cuda.synchronize(dev)
 
+    def release(self):
+        """Drop the references to the bound sequences (the end of a render): a replay before the next ``bind`` raises instead of
+        reading memory the allocator may have handed out again."""
+        self._keep = None
+        self.n_frames = 0
+
     def seek(self, frame0, stream=None):
         if frame0 < 0 or frame0 + self.batch > self.n_frames:
             raise RuntimeError(f"frames [{frame0}, {frame0 + self.batch}) are outside the bound sequences ({self.n_frames} frames)")
@@ -968,6 +974,9 @@ class GraphLane:
                 g.truncation_latent = g.mean_latent(2 ** 14)
             self._trunc_latent.copy_(g.truncation_latent.to(self._trunc_latent.device).reshape(-1))
         self.source.bind(latents, noise, truncation)
+
+    def release(self):
+        self.source.release()
 
     def replay(self, frame0, stream=None):
         """Frames [frame0, frame0 + batch) of the bound sequences: one 4-byte device write + the graph launch."""

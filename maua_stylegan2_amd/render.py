@@ -312,8 +312,10 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
             for attr in path:
                 module = getattr(module, attr)
             setattr(module, leaf, th.nn.Parameter(w, requires_grad=False))
-        for stream, _ in lane_state:
+        for stream, lane in lane_state:
             caller_stream.wait_stream(stream)
+            if lane is not None:
+                lane.release()  # cached lanes outlive the render: they must not keep its sequences alive (or replay into them)
 
 
 def render(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file=None,
