@@ -148,8 +148,11 @@ class FrameStream:
         self.lo, self.hi = shard_bounds(n_frames, self.rank, self.world)
         self.shape = tuple(frame_shape)
         slots = max(self.rounds, 1) * self.batch
-        # this rank's frames, kept until the gather has read them (the producer recycles its batch buffers)
-        self.mine = th.zeros((slots,) + self.shape, dtype=th.uint8, device=device)
+        # this rank's frames, kept until the gather has read them (the producer recycles its batch buffers).  Deliberately NOT
+        # zero-filled here: the constructor runs on whatever stream produced the first batch, the pushes of the other graph lanes
+        # run on theirs, and a fill kernel queued behind the first lane's replay could land on top of a faster lane's frames
+        # (seen once as a corrupted shard in the GPU suite).  Every slot is written completely by its own push, on its own stream.
+        self.mine = th.empty((slots,) + self.shape, dtype=th.uint8, device=device)
         self.store = th.empty((self.world, slots) + self.shape, dtype=th.uint8, device=device) if self.rank == dst else None
         self.works = []
         self.pushed = 0
@@ -168,8 +171,12 @@ class FrameStream:
         if k != self.pushed:
             raise RuntimeError(f"FrameStream.push: round {k} out of order (expected {self.pushed})")
         slot = self.mine[k * self.batch: (k + 1) * self.batch]
+        filled = 0
         if u8 is not None:
-            slot[: u8.shape[0]].copy_(u8)
+            filled = u8.shape[0]
+            slot[:filled].copy_(u8)
+        if filled < self.batch:
+            slot[filled:].zero_()  # ragged / empty round: defined bytes travel (dst never hands them out)
         if self._copy_stream is not None:  # dst: the staging copy of this round must run behind the copy above
             ev = th.cuda.Event()
             ev.record(th.cuda.current_stream(self.mine.device))
