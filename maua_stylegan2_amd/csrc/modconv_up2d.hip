@@ -311,21 +311,25 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 // Output row 2H (line 0) and column 2W (line 1) of the transposed convolution: positions whose own input is the zero padding.
 // Along the line, with v[n] = the last input row / column and (t0, t1, t2) = the kernel's last row / column:
 //     y[2n] = t0 v[n] + t2 v[n-1],   y[2n+1] = t1 v[n]      (v[-1] = v[N] = 0; the corner y[2N] belongs to line 0)
-// One wave per (image, line, 16 output channels, 16 line positions): direct v_mfma_f32_16x16x4_f32 over the input channels,
+// One workgroup per (image, line, 16 output channels, 16 line positions): direct v_mfma_f32_16x16x4_f32 over the input channels,
 // operands straight from global memory (the edge tap matrices [5][Cin][Cout] behind the packed weight; the line of x with its
-// element stride), four K steps of loads in flight.  ~1/H of the layer's multiply-adds.
-__global__ __launch_bounds__(64) void up2d_edge_kernel(Up2dArgs p, const float* __restrict__ taps, int n_tiles0, int n_tiles1) {
-    const int lane = threadIdx.x;
+// element stride).  The work is ~1/H of the layer's multiply-adds but a chain of dependent global loads: the four waves of the
+// workgroup split the input channels (a single wave per tile ran 32 serial round trips at one wave per SIMD: 49 us per launch,
+// 4 % of the frame) and keep eight K steps of loads in flight; the partial tiles meet in LDS.
+__global__ __launch_bounds__(256) void up2d_edge_kernel(Up2dArgs p, const float* __restrict__ taps, int n_tiles0, int n_tiles1) {
+    __shared__ float part[4][2][64][4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     int t = blockIdx.x;
-    const int per_line_mt0 = n_tiles0, per_line_mt1 = n_tiles1;
     const int m_tiles = p.Cout / 16;
-    const int per_image = m_tiles * (per_line_mt0 + per_line_mt1);
+    const int per_image = m_tiles * (n_tiles0 + n_tiles1);
     const int b0 = t / per_image;
     t -= b0 * per_image;
-    const int line = t >= m_tiles * per_line_mt0 ? 1 : 0;
-    if (line) t -= m_tiles * per_line_mt0;
-    const int nt = line ? per_line_mt1 : per_line_mt0;
+    const int line = t >= m_tiles * n_tiles0 ? 1 : 0;
+    if (line) t -= m_tiles * n_tiles0;
+    const int nt = line ? n_tiles1 : n_tiles0;
     const int mt = t / nt, n0 = (t - mt * nt) * 16;
     const int o0 = mt * 16;
     const int N = line ? p.H : p.W;               // inputs along the line
@@ -345,28 +349,40 @@ __global__ __launch_bounds__(64) void up2d_edge_kernel(Up2dArgs p, const float* 
     const float* t2 = taps + 2 * tsz + o0 + i16;
     const float* sp = p.s + (size_t)b0 * p.s_stride;
     f32x4 even = f32x4{0.f, 0.f, 0.f, 0.f}, odd = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int UNR = 4;
-    for (int c0 = 0; c0 < p.Cin; c0 += 4 * UNR) {
-        float a0[UNR], a1[UNR], a2v[UNR], bn[UNR], bm[UNR];
+    constexpr int UNR = 8;
+    const int c_per_wave = (p.Cin / 4 + 3) / 4 * 4;  // channels per wave, a multiple of the MFMA K
+    const int c_begin = wv * c_per_wave, c_end = min(p.Cin, c_begin + c_per_wave);
+    for (int c0 = c_begin; c0 < c_end; c0 += 4 * UNR) {
+        float a0[UNR], a1[UNR], a2v[UNR], bn[UNR], bm[UNR], sc[UNR];
 #pragma unroll
-        for (int q = 0; q < UNR; ++q) {  // all loads of four K steps first
+        for (int q = 0; q < UNR; ++q) {  // all loads of eight K steps first
             const int c = c0 + 4 * q + kq;
-            const bool okc = c < p.Cin;
-            const int cc = okc ? c : 0;
-            const float sc = okc ? sp[cc] : 0.f;
-            a0[q] = okc ? t0[(size_t)cc * p.Cout] : 0.f;
-            a1[q] = okc ? t1[(size_t)cc * p.Cout] : 0.f;
-            a2v[q] = okc ? t2[(size_t)cc * p.Cout] : 0.f;
-            bn[q] = (ok_n ? pv[(size_t)cc * plane] : 0.f) * sc;
-            bm[q] = (ok_m ? pm[(size_t)cc * plane] : 0.f) * sc;
+            const bool okc = c < c_end;
+            const int cc = okc ? c : c_begin;
+            sc[q] = okc ? sp[cc] : 0.f;
+            a0[q] = t0[(size_t)cc * p.Cout];
+            a1[q] = t1[(size_t)cc * p.Cout];
+            a2v[q] = t2[(size_t)cc * p.Cout];
+            bn[q] = ok_n ? pv[(size_t)cc * plane] : 0.f;
+            bm[q] = ok_m ? pm[(size_t)cc * plane] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
-            even = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], bn[q], even, 0, 0, 0);
-            even = __builtin_amdgcn_mfma_f32_16x16x4f32(a2v[q], bm[q], even, 0, 0, 0);
-            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], bn[q], odd, 0, 0, 0);
+            const float vn = bn[q] * sc[q], vm = bm[q] * sc[q];  // (sc = 0 masks the channels beyond this wave's range)
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], vn, even, 0, 0, 0);
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(a2v[q], vm, even, 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], vn, odd, 0, 0, 0);
         }
     }
+    // the four waves' partial tiles meet in LDS; wave 0 adds them up and stores
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[wv][0][lane][v] = even[v], part[wv][1][lane][v] = odd[v];
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) even[v] += part[w][0][lane][v], odd[v] += part[w][1][lane][v];
     // result tile: column = line position n (lane & 15), row = output channel o0 + 4 kq + v
     const int OW = 2 * p.W + 1, OH = 2 * p.H + 1;
     const size_t plane_out = (size_t)OH * OW;
@@ -469,7 +485,7 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     // edge lines: W + 1 positions along the bottom row (incl. the corner), H along the right column
     const int nt0 = ceil_div(w + 1, 16), nt1 = ceil_div(h, 16);
     const int64_t eblocks = (int64_t)batch * (cout / 16) * (nt0 + nt1);
-    hipLaunchKernelGGL(up2d_edge_kernel, dim3((unsigned)eblocks), dim3(64), 0, st, a, wq + (size_t)U2_NU * cin * cout, nt0, nt1);
+    hipLaunchKernelGGL(up2d_edge_kernel, dim3((unsigned)eblocks), dim3(256), 0, st, a, wq + (size_t)U2_NU * cin * cout, nt0, nt1);
     MAUA_LAUNCH_CHECK();
     return 0;
 }
