@@ -161,7 +161,8 @@ int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w);
  *             MFMA cycles than direct, 1.5x fewer than up == 3; wp from maua_pack_weight_wino2d_f32.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
- * floats used for split-K partial sums on small feature maps (may be NULL when that returns 0). */
+ * floats used for split-K partial sums on small feature maps and, for up == 6, for the exported last input column [B, cin, H]
+ * (may be NULL when that returns 0). */
 int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up);
 /* Name of the kernel template instance launched by the last modconv call of this process, as rocprofv3 prints it
  * ("modconv_mfma_kernel<BM, BN, WM, MODE, MULTI, FAST, MAXP>") — the key of the per-instance PMC tables in profiles/. */

@@ -38,5 +38,6 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
 
 // modconv_up2d.hip (mode 6 of maua_modconv3x3_f32): transposed convolution with F(2,2) on both axes of its polyphase form
 const char* maua_up2d_last_instance();
-int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
+int64_t maua_up2d_ws_floats(int batch, int cin, int h);
+int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
                      int cout, int h, int w, float wscale, void* stream);

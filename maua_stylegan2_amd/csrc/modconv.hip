@@ -1318,7 +1318,8 @@ extern "C" int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, 
 }
 
 extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
-    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || up == 5 || up == 6) return 0;
+    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || up == 5) return 0;
+    if (up == 6) return maua_up2d_ws_floats(batch, cin, h);  // the exported last input column
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     return pl.g.splits > 1 ? pl.g.ws_slab * pl.g.splits : 0;
 }
@@ -1356,7 +1357,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     }
     if (up == 6) {  // transposed conv, F(2,2) on both axes, modconv_up2d.hip: raw output only (the blur kernel applies the tail)
         if (fuse_act || rgb) return MAUA_EINVAL;
-        const int rc = maua_up2d_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, stream);
+        const int rc = maua_up2d_launch(x, wp, s, s_stride, d, y, ws, batch, cin, cout, h, w, wscale, stream);
         if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_up2d_last_instance());
         return rc;
     }

@@ -96,6 +96,7 @@ struct Up2dArgs {
     const float* s;
     const float* d;
     float* y;
+    float* xcol;        // workspace [B][Cin][H]: the last input column, exported by the main kernel's right-edge tiles for the edge kernel
     int B, Cin, Cout, H, W;
     int s_stride;
     float wscale;
@@ -209,9 +210,17 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // The right-edge tiles of the first m-tile export the last input column from their staged patch (row float 35 = image column
+    // tx0 + 31 = W - 1) into xcol[b][c][row]: the edge kernel then reads that column with unit stride (gathering it from x costs
+    // one 128-byte line per element: 32 of the edge launch's 45 us)
+    const bool export_col = mt_id == 0 && tx0 + 32 == p.W && wv == 3 && lane < CC * 8;
+    const int ex_c = lane >> 3, ex_r = lane & 7;
     int cur = 0;
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
         if (chunk + 1 < p.n_chunks) issue(chunk + 1, cur ^ 1);
+        if (export_col)
+            p.xcol[((size_t)b0 * p.Cin + (size_t)chunk * CC + ex_c) * p.H + ty0 + ex_r] =
+                Ps[cur * U2_PBUF + ex_c * U2_PLANE + (ex_r + 1) * U2_PWS + 35];
         static_for<0, CC / 4>([&](auto ks_c) {  // the MFMA K groups of this step: 4 channels each
         constexpr int ks = decltype(ks_c)::value;
         const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u) + ks * KG_A_BYTES, pb = b_addr + (cur ? P_BUF_BYTES : 0u) + ks * KG_P_BYTES;
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 //     y[2n] = t0 v[n] + t2 v[n-1],   y[2n+1] = t1 v[n]      (v[-1] = v[N] = 0; the corner y[2N] belongs to line 0)
 // One workgroup per (image, line, 16 output channels, 16 line positions): direct v_mfma_f32_16x16x4_f32 over the input channels,
 // operands straight from global memory (the edge tap matrices [5][Cin][Cout] behind the packed weight; the line of x with its
-// element stride).  The work is ~1/H of the layer's multiply-adds but a chain of dependent global loads: the four waves of the
+// unit stride; the last column comes from the main kernel's export).  The work is ~1/H of the layer's multiply-adds but a chain of dependent global loads: the four waves of the
 // workgroup split the input channels (a single wave per tile ran 32 serial round trips at one wave per SIMD: 49 us per launch,
 // 4 % of the frame) and keep eight K steps of loads in flight; the partial tiles meet in LDS.
 __global__ __launch_bounds__(256) void up2d_edge_kernel(Up2dArgs p, const float* __restrict__ taps, int n_tiles0, int n_tiles1) {
@@ -335,13 +344,12 @@ __global__ __launch_bounds__(256) void up2d_edge_kernel(Up2dArgs p, const float*
     const int N = line ? p.H : p.W;               // inputs along the line
     const int n = n0 + i16;                       // this lane's line position (B operand column / result column)
     const size_t plane = (size_t)p.H * p.W;
-    // v[n]: line 0 = x[c][H-1][n], line 1 = x[c][n][W-1]
-    const float* xb = p.x + (size_t)b0 * p.Cin * plane;
-    const size_t stride = line ? (size_t)p.W : 1;
-    const size_t base = line ? (size_t)(p.W - 1) : (size_t)(p.H - 1) * p.W;
+    // v[n]: line 0 = x[c][H-1][n] (a row of x), line 1 = x[c][n][W-1] = xcol[c][n] (exported by the main kernel): both unit stride
+    const float* xb = line ? p.xcol + (size_t)b0 * p.Cin * p.H : p.x + (size_t)b0 * p.Cin * plane + (size_t)(p.H - 1) * p.W;
+    const size_t cstride = line ? (size_t)p.H : plane;  // floats between channels
     const bool ok_n = n < N, ok_m = n >= 1 && n - 1 < N;
-    const float* pv = xb + base + (size_t)(ok_n ? n : 0) * stride;
-    const float* pm = xb + base + (size_t)(ok_m ? n - 1 : 0) * stride;
+    const float* pv = xb + (ok_n ? n : 0);
+    const float* pm = xb + (ok_m ? n - 1 : 0);
     // taps: line 0 -> (g20, g21, g22) = matrices 0, 1, 2;  line 1 -> (g02, g12, g22) = matrices 3, 4, 2
     const size_t tsz = (size_t)p.Cin * p.Cout;
     const float* t0 = taps + (line ? 3 : 0) * tsz + o0 + i16;
@@ -363,8 +371,8 @@ __global__ __launch_bounds__(256) void up2d_edge_kernel(Up2dArgs p, const float*
             a0[q] = t0[(size_t)cc * p.Cout];
             a1[q] = t1[(size_t)cc * p.Cout];
             a2v[q] = t2[(size_t)cc * p.Cout];
-            bn[q] = ok_n ? pv[(size_t)cc * plane] : 0.f;
-            bm[q] = ok_m ? pm[(size_t)cc * plane] : 0.f;
+            bn[q] = ok_n ? pv[(size_t)cc * cstride] : 0.f;
+            bm[q] = ok_m ? pm[(size_t)cc * cstride] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
@@ -459,13 +467,15 @@ extern "C" int maua_pack_weight_up2d_f32(const float* w, float* wq, int cout, in
 
 const char* maua_up2d_last_instance() { return g_up2d_instance; }
 
-int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
+int64_t maua_up2d_ws_floats(int batch, int cin, int h) { return (int64_t)batch * cin * h; }
+
+int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
                      int cout, int h, int w, float wscale, void* stream) {
-    if (!maua_modconv_up2d_ok(cin, cout, h, w)) return MAUA_EINVAL;
+    if (!maua_modconv_up2d_ok(cin, cout, h, w) || !ws) return MAUA_EINVAL;
     if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)U2_NU * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
     if ((int64_t)U2_BM * (2 * h + 1) * (2 * w + 1) * 4 > 0xffffffffLL) return MAUA_EINVAL;                              // 32-bit store offsets
     Up2dArgs a{};
-    a.x = x, a.wq = wq, a.s = s, a.d = d, a.y = y;
+    a.x = x, a.wq = wq, a.s = s, a.d = d, a.y = y, a.xcol = ws;
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
     const int cc = u2_cc(cin);
     a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
