@@ -34,7 +34,7 @@
 #define MAUA_DEVICE_PASS 1
 #endif
 
-// compile-time ablation mask (tools/ablate_w2d_build.sh): 1 no MFMA, 2 no DMA after the first chunk, 4 no feature stores,
+// compile-time ablation mask (tools/build_exp.sh w2dabl -DMAUA_W2D_ABL=<mask>): 1 no MFMA, 2 no DMA after the first chunk, 4 no feature stores,
 // 8 no epilogue, 256 no ToRGB tail after the passes, 512 no combine phase (barriers and the A_x^T / exchange writes stay, so the
 // accumulators remain live).  0 in the product.  (Run-time switches inside the main loop disturb the MFMA stream they are meant to measure: the
 // run-time mask maua_tuning_set(3, .) selects a separate instantiation, DBG = true.)
@@ -612,7 +612,7 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
     }
     snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %s>", TM, TN, DBG ? "true" : "false");
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
-#ifdef MAUA_EXPERIMENTS  // occupancy probe (tools/occ_probe.sh): extra dynamic LDS so that a CU holds one workgroup instead of two
+#ifdef MAUA_EXPERIMENTS  // occupancy probe (MAUA_W2D_LDS_PAD with an experiments build): extra dynamic LDS so that a CU holds one workgroup instead of two
     static const size_t lds_pad = getenv("MAUA_W2D_LDS_PAD") ? (size_t)atoi(getenv("MAUA_W2D_LDS_PAD")) : 0;
 #else
     constexpr size_t lds_pad = 0;
