@@ -21,7 +21,9 @@
 //   * every wave streams its own quarter of the weight tile from LDS, the patch is shared;
 //   * the inverse y transform crosses waves: after the main loop every wave applies A_x to its accumulators and the four
 //     partial 1x4 rows meet in LDS (16 channels per pass), where the tail (demod, noise, bias, leaky ReLU), the fused ToRGB
-//     reduction and the 16-byte stores are done by all 256 threads.
+//     reduction and the 16-byte stores are done by all 256 threads.  The channel a thread handles in a step of a pass is
+//     uniform over its wave: per-channel constants are one broadcast LDS read and the store is a buffer store with a scalar
+//     channel offset; no selects (row 1 of A_y^T = row 0 with a sign, leaky ReLU = max(t, slope t)).
 // Operands reach LDS by MUBUF `buffer_load ... lds` DMA, double buffered, one barrier per 4-channel K step; the packed weight
 // (maua_pack_weight_wino2d_f32) is laid out in HBM exactly as the LDS tile image, so its DMA is a linear copy.
 #include "common.h"
@@ -46,6 +48,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Staged patch: rows of ten 16-byte segments = image columns tx0-4 .. tx0+35 (16-byte aligned in HBM, so that every segment
 // lies wholly inside or wholly outside the image and the zero padding comes from the DMA's out-of-range rule); a position's
@@ -135,8 +138,28 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
     return tm == 4 ? ((col + 32 * (kq & 1)) & 63) : col;
 }
 
-template <int TM, int TN, bool DBG>
-__global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
+// Build switches (defaults = the product; tools/build_exp.sh builds the alternatives for A/B runs):
+//   MAUA_W2D_TN32 / MAUA_W2D_MINB32  n-tiles per workgroup and workgroups per CU of the 32-output-channel layers.  Round 3: 2 n-tiles
+//       (156 VGPRs, 44 KB LDS) at three workgroups per CU instead of 4 n-tiles at two: the layer is neither matrix- nor HBM-bound, its
+//       eight-step K loop leaves the prologue DMA wait, the per-step barrier and the LDS exchange of the epilogue exposed, and a third
+//       resident workgroup covers more of them (convs.15 0.79 -> 0.73 ms, convs.13 unchanged, +1-2 % frames/s under three lanes).
+//   MAUA_W2D_NMAJOR  32-channel layers: per n-tile transform -> next window read -> the tile's MFMAs (1) or all transforms first (0)
+//   MAUA_W2D_PKT     input transform on register pairs (1) or scalar (0)
+#ifndef MAUA_W2D_NMAJOR
+#define MAUA_W2D_NMAJOR 1
+#endif
+#ifndef MAUA_W2D_PKT
+#define MAUA_W2D_PKT 1
+#endif
+#ifndef MAUA_W2D_TN32
+#define MAUA_W2D_TN32 2
+#endif
+#ifndef MAUA_W2D_MINB32
+#define MAUA_W2D_MINB32 3
+#endif
+
+template <int TM, int TN, bool DBG, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     const int dbg = (DBG ? p.debug : 0) | MAUA_W2D_ABL;
     constexpr int BM = 16 * TM;
     constexpr int NPOS = 16 * TN;
@@ -225,13 +248,9 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     };
 
     // ---- accumulators: [x-frequency][m-tile][n-tile]
+    // (not zeroed: the first K step runs as a peeled copy of the loop whose matrix instructions take C = 0 — 48 TM TN / 8 register
+    // moves per wave that the VALU, which shares its datapath with the fp32 matrix instructions, does not have to issue)
     f32x4 acc[6][TM][TN];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int n = 0; n < TN; ++n) acc[a][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // window rows combined by y-frequency fy (F(2,3) B^T): fy 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
     const int ra = fy == 0 ? 0 : (fy == 2 ? 2 : 1);
@@ -259,7 +278,10 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase)  // phase 0 = the first K step (C = 0), phase 1 = the others
+    for (int chunk = phase; chunk < (phase ? p.n_chunks : 1); ++chunk) {
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
         // ---- operand reads of this chunk: style, raw window rows, first weight row
         const unsigned a_off = cur ? A_BUF_BYTES : 0u, p_off = cur ? P_BUF_BYTES : 0u;
@@ -269,7 +291,8 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
 #pragma unroll
         for (int h = 0; h < TM / 2; ++h) ap[h] = a_addr[h] + a_off;
         f32x2 a2[2][TM / 2];
-        float bv[TN][6];
+        constexpr bool NMAJOR = TM == 2 && MAUA_W2D_NMAJOR;
+        float bv[NMAJOR ? 1 : TN][6];
         // windows are read two n-tiles ahead of their transform (12 registers each: at most two are live), the first weight row
         // goes out behind the last window; LDS returns in order, so "at most k operations outstanding" identifies what landed
         // (with four n-tiles per wave the register file only has room for one window in flight)
@@ -288,6 +311,25 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             wb5[slot] = lds_read64<o + 24>(pb);
         };
         auto transform = [&](int n, int slot) {
+#if MAUA_W2D_PKT
+            // row combination and B_x^T of F(4,3) on register pairs (v_pk_*_f32 = two fp32 operations per issue slot; VALU and the
+            // fp32 matrix instructions share the datapath, so every transform instruction saved is matrix time won):
+            //   D12 = (d1, d2), D34 = (d3, d4);  (b, a) = D34 - 4 D12;  (e, c) = D34 - D12;
+            //   (bv1, bv2) = (a + b, a - b);  (bv3, bv4) = (c + 2 e, c - 2 e)   -- the two cross-lane forms through op_sel / neg_hi
+            const f32x2 D12 = wb[slot][0] * sgn + wa[slot][0], D34 = wb[slot][1] * sgn + wa[slot][1];
+            const float d0 = fmaf(sgn, wb0[slot].y, wa0[slot].y), d5 = fmaf(sgn, wb5[slot].x, wa5[slot].x);
+            const f32x2 ba = D12 * -4.f + D34, ec = D34 - D12;
+            f32x2 b12, b34;
+            asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(b12) : "v"(ba));
+            asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(b34) : "v"(ec));
+            b12 *= sc, b34 *= sc;
+            float t0 = fmaf(-5.f, D12.y, D34.y), t5 = fmaf(-5.f, D34.x, d5);
+            asm("" : "+v"(t0), "+v"(t5));  // (keeps the vectoriser from pairing the two chains through register shuffles)
+            float u0 = fmaf(4.f, d0, t0), u5 = fmaf(4.f, D12.x, t5);
+            asm("" : "+v"(u0), "+v"(u5));
+            const f32x2 b05 = f32x2{u0, u5} * sc;
+            bv[n][0] = b05.x, bv[n][1] = b12.x, bv[n][2] = b12.y, bv[n][3] = b34.x, bv[n][4] = b34.y, bv[n][5] = b05.y;
+#else
             const float d0 = fmaf(sgn, wb0[slot].y, wa0[slot].y), d1 = fmaf(sgn, wb[slot][0].x, wa[slot][0].x);
             const float d2 = fmaf(sgn, wb[slot][0].y, wa[slot][0].y), d3 = fmaf(sgn, wb[slot][1].x, wa[slot][1].x);
             const float d4 = fmaf(sgn, wb[slot][1].y, wa[slot][1].y), d5 = fmaf(sgn, wb5[slot].x, wa5[slot].x);
@@ -300,7 +342,49 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             bv[n][3] = fmaf(2.f, e_, c_) * sc;
             bv[n][4] = fmaf(-2.f, e_, c_) * sc;
             bv[n][5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5)) * sc;
+#endif
         };
+        if constexpr (NMAJOR) {
+            // n-major order (32-channel layers, TM = 2): the six weight rows of the K step are read once up front, then per n-tile
+            // transform -> window read of the next n-tile -> the tile's 6 TM MFMAs, so that the LDS latency of every window but the
+            // first hides behind 12 matrix instructions and only one transformed window (6 registers, not 6 TN) is live
+            f32x2 aw[6][TM / 2];
+            static_for<0, 6>([&](auto xf_c) {
+                constexpr int xf = decltype(xf_c)::value;
+#pragma unroll
+                for (int h = 0; h < TM / 2; ++h) aw[xf][h] = lds_read64<xf * XF_BYTES>(ap[h]);
+            });
+            read_window(std::integral_constant<int, 0>{}, 0);
+            if constexpr (TN > 1 && WSLOTS > 1) read_window(std::integral_constant<int, 1>{}, 1);
+            static_for<0, TN>([&](auto n_c) {
+                constexpr int n = decltype(n_c)::value;
+                constexpr int slot = n % WSLOTS;
+                constexpr int behind = (n + 1 < TN && WSLOTS > 1) ? 8 : 0;
+                asm volatile("s_waitcnt lgkmcnt(%9)"
+                             : "+v"(sc), "+v"(wa[slot][0]), "+v"(wa[slot][1]), "+v"(wb[slot][0]), "+v"(wb[slot][1]), "+v"(wa0[slot]),
+                               "+v"(wa5[slot]), "+v"(wb0[slot]), "+v"(wb5[slot])
+                             : "n"(behind));
+                if constexpr (n == 0) {  // the weight rows went out first: landed whenever window 0 has
+#pragma unroll
+                    for (int xf = 0; xf < 6; ++xf)
+#pragma unroll
+                        for (int h = 0; h < TM / 2; ++h) asm volatile("" : "+v"(aw[xf][h]));
+                }
+                transform(0, slot);
+                if constexpr (n + WSLOTS < TN) read_window(std::integral_constant<int, n + WSLOTS>{}, slot);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 1)) {
+#pragma unroll
+                    for (int xf = 0; xf < 6; ++xf)
+#pragma unroll
+                        for (int h = 0; h < TM / 2; ++h) {
+                            acc[xf][2 * h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[xf][h].x, bv[0][xf], phase ? acc[xf][2 * h][n] : zero4, 0, 0, 0);
+                            acc[xf][2 * h + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[xf][h].y, bv[0][xf], phase ? acc[xf][2 * h + 1][n] : zero4, 0, 0, 0);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
         read_window(std::integral_constant<int, 0>{}, 0);
         if constexpr (TN > 1 && WSLOTS > 1) read_window(std::integral_constant<int, 1>{}, 1);
         static_for<0, TN>([&](auto n_c) {
@@ -329,17 +413,24 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
             constexpr int pending = xf < 5 ? TM / 2 : 0;
             if constexpr (TM == 4) lds_wait<pending>(a2[xf & 1][0], a2[xf & 1][1]);
             else lds_wait<pending>(a2[xf & 1][0]);
+            if (DBG && (dbg & 1) && !phase) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) acc[xf][m][n] = zero4;
+            }
             if (!(dbg & 1)) {
 #pragma unroll
                 for (int h = 0; h < TM / 2; ++h)
 #pragma unroll
                     for (int n = 0; n < TN; ++n) {
-                        acc[xf][2 * h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[xf & 1][h].x, bv[n][xf], acc[xf][2 * h][n], 0, 0, 0);
-                        acc[xf][2 * h + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[xf & 1][h].y, bv[n][xf], acc[xf][2 * h + 1][n], 0, 0, 0);
+                        acc[xf][2 * h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[xf & 1][h].x, bv[n][xf], phase ? acc[xf][2 * h][n] : zero4, 0, 0, 0);
+                        acc[xf][2 * h + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[xf & 1][h].y, bv[n][xf], phase ? acc[xf][2 * h + 1][n] : zero4, 0, 0, 0);
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
@@ -363,22 +454,22 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     // then, 16 output channels (one m-tile) per pass, the four waves' 1x4 partial rows meet in LDS:
     //   output row 0 = Z0 + Z1 + Z2,  row 1 = Z1 - Z2 - Z3     (A_y^T of F(2,3))
     float* Z = lds;                               // [4 fy][16 ch][NPOS][4]
-    float* Eg = lds + 4 * 16 * NPOS * 4;          // [BM] gain
-    float* Eb = Eg + BM;                          // [BM] bias
-    float* Er = Eb + BM;                          // [3][BM] modulated ToRGB weights
-    float* Rr = Er + 3 * BM;                      // [CG][2 * NPOS][12] ToRGB partial sums
+    float* E = lds + 4 * 16 * NPOS * 4;           // [BM][8]: gain, bias, the three modulated ToRGB weights of the channel
+    float* Rr = E + 8 * BM;                       // [CG][2 * NPOS][12] ToRGB partial sums
     const bool act = p.fuse_act != 0;
     const float act_gain = act ? 1.41421356237309515f : 1.f;
     for (int i = tid; i < BM; i += 256) {
         const int o = m0 + i;
         float gain = p.wscale * act_gain;
         if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
-        Eg[i] = gain;
-        Eb[i] = (act && p.bias) ? p.bias[o] * act_gain : 0.f;
+        f32x4 e = f32x4{gain, (act && p.bias) ? p.bias[o] * act_gain : 0.f, 0.f, 0.f};
+        float r2 = 0.f;
         if (p.rgb) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Er[c * BM + i] = p.rgb_wscale * p.rgb_w[c * p.Cout + o] * p.rgb_s[(size_t)b0 * p.s_stride + o];
+            const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
+            e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
         }
+        *reinterpret_cast<f32x4*>(E + 8 * i) = e;
+        E[8 * i + 4] = r2;
     }
     // combine-phase role of this thread: position cp, output row cr of the 2-row block, channel group cg of every pass
     constexpr int CG = 256 / (2 * NPOS);        // channel groups (4 for TN = 2, 2 for TN = 4)
@@ -399,12 +490,23 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
         nz = *reinterpret_cast<const f32x4*>(noise_base + (size_t)b0 * noise_bstride + (size_t)oy * p.W + ox);
         nz = nz * nw;
     }
-    float rgbp[4][3];
+    f32x4 rgbv[3];  // this thread's share of the ToRGB sums, [rgb channel][pixel]
 #pragma unroll
-    for (int px = 0; px < 4; ++px) rgbp[px][0] = rgbp[px][1] = rgbp[px][2] = 0.f;
+    for (int c = 0; c < 3; ++c) rgbv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool store_feat = p.rgb != 2 && !(dbg & 4);
-    float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane;
     const unsigned pix_off = (unsigned)oy * (unsigned)p.W + (unsigned)ox;
+    // the channel a thread combines in step q of a pass is uniform over its wave (cg = tid / (2 NPOS), 2 NPOS >= 64): per-channel
+    // constants come from one broadcast LDS read, and the feature store is a buffer store whose channel offset is a scalar
+    const int cg_s = __builtin_amdgcn_readfirstlane(cg);
+    const float row_sign = cr ? -1.f : 1.f;      // A_y^T of F(2,3): row 0 = Z1 + (Z2 + Z0), row 1 = Z1 - (Z2 + Z3)
+    const float slope = act ? 0.2f : 1.f;        // leaky ReLU as max(t, slope t); slope 1 = no activation
+    const unsigned plane_b = (unsigned)plane * 4u;
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.y + ((size_t)b0 * p.Cout + m0) * plane, 0, 0x7fffffff, 0x00020000);
+#endif
+    const float* zbase = Z + cp * 4;
+    const int zo_off = (cr ? 3 : 0) * 16 * NPOS * 4;
 
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -424,29 +526,26 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
         if constexpr (!(MAUA_W2D_ABL & 512))
 #pragma unroll
         for (int q = 0; q < CPG; ++q) {
-            const int ch16 = cg * CPG + q;
+            const int ch16 = cg_s * CPG + q;
             const int ol = mt * 16 + ch16;
-            const float* zp = Z + ((ch16 * NPOS) + cp) * 4;
+            const float* zp = zbase + ch16 * NPOS * 4;
             const f32x4 z1 = *reinterpret_cast<const f32x4*>(zp + 1 * 16 * NPOS * 4);
             const f32x4 z2 = *reinterpret_cast<const f32x4*>(zp + 2 * 16 * NPOS * 4);
-            const f32x4 zo = *reinterpret_cast<const f32x4*>(zp + (cr ? 3 : 0) * 16 * NPOS * 4);
-            const f32x4 raw = cr ? (z1 - z2) - zo : (zo + z1) + z2;
-            const float gain = Eg[ol], bias = Eb[ol];
-            f32x4 v4;
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const float tt = fmaf(raw[px], gain, nz[px] + bias);
-                v4[px] = act ? fmaxf(tt, 0.2f * tt) : tt;
-            }
+            const f32x4 zo = *reinterpret_cast<const f32x4*>(zp + zo_off);
+            const f32x4 e = *reinterpret_cast<const f32x4*>(E + 8 * ol);  // gain, bias, ToRGB weights 0, 1
+            const float r2 = E[8 * ol + 4];
+            const f32x4 raw = (z2 + zo) * row_sign + z1;
+            const f32x4 tt = raw * e[0] + (nz + e[1]);
+            const f32x4 v4 = __builtin_elementwise_max(tt, tt * slope);
             if (p.rgb) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float rw = Er[c * BM + ol];
-#pragma unroll
-                    for (int px = 0; px < 4; ++px) rgbp[px][c] = fmaf(rw, v4[px], rgbp[px][c]);
-                }
+                rgbv[0] = v4 * e[2] + rgbv[0];
+                rgbv[1] = v4 * e[3] + rgbv[1];
+                rgbv[2] = v4 * r2 + rgbv[2];
             }
-            if (store_feat) *reinterpret_cast<f32x4*>(yimg + (size_t)ol * plane + pix_off) = v4;
+#ifdef MAUA_DEVICE_PASS
+            if (store_feat)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), y_rsrc, pix_off * 4u, (unsigned)ol * plane_b, 0);
+#endif
         }
     }
     if (!p.rgb || (MAUA_W2D_ABL & 256)) return;
@@ -455,9 +554,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     {
         float* rp = Rr + ((cg * 2 + cr) * NPOS + cp) * 12;
 #pragma unroll
-        for (int px = 0; px < 4; ++px)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rp[px * 3 + c] = rgbp[px][c];
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(rp + 4 * c) = rgbv[c];
     }
     __syncthreads();
     if (cg != 0) return;
@@ -465,15 +562,13 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     for (int g2 = 1; g2 < CG; ++g2) {
         const float* rp = Rr + ((g2 * 2 + cr) * NPOS + cp) * 12;
 #pragma unroll
-        for (int px = 0; px < 4; ++px)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rgbp[px][c] += rp[px * 3 + c];
+        for (int c = 0; c < 3; ++c) rgbv[c] += *reinterpret_cast<const f32x4*>(rp + 4 * c);
     }
     if (p.rgb == 3) {  // several m-tiles per pixel: leave this tile's partial sums; maua_torgb_f32 adds them up (+ bias, skip)
         float* part = p.rgb_out + ((size_t)b0 * 3 * p.m_tiles + 3 * mt_id) * plane + pix_off;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<f32x4*>(part + (size_t)c * plane) = f32x4{rgbp[0][c], rgbp[1][c], rgbp[2][c], rgbp[3][c]};
+            *reinterpret_cast<f32x4*>(part + (size_t)c * plane) = rgbv[c];
         return;
     }
     // upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, x): two live source rows / columns, iy0 = floor((oy-1)/2), iy0+1 with taps
@@ -483,9 +578,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2d_kernel(W2dArgs p) {
     float* rgb_img = p.rgb_out + (size_t)b0 * 3 * rgb_plane;
     f32x4 outc[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int px = 0; px < 4; ++px) outc[c][px] = rgbp[px][c] + p.rgb_bias[c];
+    for (int c = 0; c < 3; ++c) outc[c] = rgbv[c] + p.rgb_bias[c];
     if (p.rgb_skip) {
         // All 24 source values of the 4 output pixels (2 live rows x 4 live columns x 3 channels) are fetched unconditionally
         // from clamped addresses, in flight together; positions outside the skip image are masked through their tap weight
@@ -593,7 +686,7 @@ size_t w2d_lds_bytes(int tm, int tn, int cin) {
     const int bm = 16 * tm, npos = 16 * tn;
     const size_t main_loop = (size_t)2 * 24 * W2D_CC * bm + (size_t)2 * W2D_CC * w2d_pstride(tn) + (size_t)cin;
     const int cg = 256 / (2 * npos);
-    const size_t epilogue = (size_t)4 * 16 * npos * 4 + (size_t)5 * bm + (size_t)cg * 2 * npos * 12;
+    const size_t epilogue = (size_t)4 * 16 * npos * 4 + (size_t)8 * bm + (size_t)cg * 2 * npos * 12;
     return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
 }
 
@@ -602,9 +695,9 @@ char g_w2d_instance[64] = "";
 int g_w2d_debug = 0;
 #endif
 
-template <int TM, int TN, bool DBG>
+template <int TM, int TN, bool DBG, int MINB = 2>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
-    auto kern = modconv_w2d_kernel<TM, TN, DBG>;
+    auto kern = modconv_w2d_kernel<TM, TN, DBG, MINB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -630,7 +723,7 @@ int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
     int m, n;
     // (the tile shape depends on the channel counts only: the packed weight of a layer serves every map size)
     if (cout % 64 == 0) m = 4, n = 2;
-    else if (cout == 32) m = 2, n = 4;
+    else if (cout == 32) m = 2, n = MAUA_W2D_TN32;
     else return 0;
     if (h % (4 * n)) return 0;
     if (tm) *tm = m;
@@ -669,9 +762,9 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
 #ifdef MAUA_EXPERIMENTS
-    if (a.debug) return tm == 4 ? w2d_launch_t<4, 2, true>(a, st) : w2d_launch_t<2, 4, true>(a, st);  // ablation instantiation
+    if (a.debug) return tm == 4 ? w2d_launch_t<4, 2, true>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, true, MAUA_W2D_MINB32>(a, st);  // ablation instantiation
 #endif
-    return tm == 4 ? w2d_launch_t<4, 2, false>(a, st) : w2d_launch_t<2, 4, false>(a, st);
+    return tm == 4 ? w2d_launch_t<4, 2, false>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, false, MAUA_W2D_MINB32>(a, st);
 }
 
 extern "C" int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {
