@@ -175,21 +175,24 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     };
 
     // ---- accumulators (one 16 x 16 tile = 4 registers each; [.][m-tile]): 25 products x 2 m-tiles = 200 registers
+    // (zeroed here: a peeled first K group with C = 0, as in modconv_w2d.hip, spills 20 registers in the CC = 8 instance)
     f32x4 acc_ee[3][3][2], acc_eo[3][2][2], acc_oe[2][3][2], acc_oo[2][2][2];
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < 3; ++a) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) acc_ee[a][b][m] = zero4;
+                for (int b = 0; b < 3; ++b) acc_ee[a][b][m] = z4;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc_eo[a][b][m] = zero4, acc_oe[b][a][m] = zero4;
+                for (int b = 0; b < 2; ++b) acc_eo[a][b][m] = z4, acc_oe[b][a][m] = z4;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc_oo[a][b][m] = z4;
         }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc_oo[a][b][m] = zero4;
     }
 
     // LDS byte addresses (buffer 0) of this lane's operands; the second buffer is a constant distance away.
@@ -207,6 +210,14 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     constexpr int KG_P_BYTES = 4 * U2_PLANE * 4;  // ... between the K groups' channel planes in the patch
     constexpr int ROW_BYTES = U2_PWS * 4;
 
+    // per-channel gain (wscale * demod) of the epilogue: fetched under the first DMA wait into LDS behind the styles (loaded after
+    // the main loop, its round trip was exposed in every workgroup)
+    float* Eg = lds + 2 * U2_A_FLOATS + 2 * U2_PBUF + ((p.Cin + 3) & ~3);
+    for (int i = tid; i < U2_BM; i += 256) {
+        float gain = p.wscale;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
+        Eg[i] = gain;
+    }
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -281,14 +292,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: per-channel gain (wscale * demod) through LDS, phase sums, 16-byte stores of the 4 x 4 output patch
-    float* Eg = lds;
-    for (int i = tid; i < U2_BM; i += 256) {
-        float gain = p.wscale;
-        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
-        Eg[i] = gain;
-    }
-    __syncthreads();
+    // ---- epilogue: phase sums, per-channel gain, 16-byte stores of the 4 x 4 output patch
     const int OW = 2 * p.W + 1;
     const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
     float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane_out;
@@ -480,7 +484,7 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     const int cc = u2_cc(cin);
     a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)cin);
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM);
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
     static bool attr_set = false;
     if (!attr_set) {

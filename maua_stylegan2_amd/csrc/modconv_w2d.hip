@@ -213,6 +213,35 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         rel_bytes[g] = ok ? (unsigned)(yy * p.W + xx) * 4u : 0x80000000u;
     }
     for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    // per-output-channel constants of the epilogue, [BM][8] = gain, bias, the three modulated ToRGB weights: fetched here, under the
+    // first DMA wait, into LDS that neither the main loop nor the exchange buffers of the epilogue touch (loaded after the main loop
+    // their ~1 us round trip was exposed in every workgroup)
+    constexpr int EPI_FLOATS = 4 * 16 * NPOS * 4 + (256 / (2 * NPOS)) * 2 * NPOS * 12;
+    const int main_floats = 2 * A_FLOATS + 2 * PBUF + p.Cin;
+    float* E = lds + (main_floats > EPI_FLOATS ? main_floats : EPI_FLOATS);
+    const bool act = p.fuse_act != 0;
+    const float act_gain = act ? 1.41421356237309515f : 1.f;
+    const float* noise_base = p.noise;
+    int64_t noise_bstride = p.noise_batch_stride;
+    if (p.src) {  // uniform scalar loads: base of this launch's first frame inside the HBM-resident sequence
+        noise_bstride = p.src->noise_stride[p.noise_slot];
+        noise_base = p.src->noise[p.noise_slot];
+        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
+    }
+    const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
+    for (int i = tid; i < BM; i += 256) {
+        const int o = m0 + i;
+        float gain = p.wscale * act_gain;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
+        f32x4 e = f32x4{gain, (act && p.bias) ? p.bias[o] * act_gain : 0.f, 0.f, 0.f};
+        float r2 = 0.f;
+        if (p.rgb) {
+            const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
+            e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
+        }
+        *reinterpret_cast<f32x4*>(E + 8 * i) = e;
+        E[8 * i + 4] = r2;
+    }
 
     const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
     const size_t plane_bytes = plane * sizeof(float);
@@ -454,42 +483,15 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     // then, 16 output channels (one m-tile) per pass, the four waves' 1x4 partial rows meet in LDS:
     //   output row 0 = Z0 + Z1 + Z2,  row 1 = Z1 - Z2 - Z3     (A_y^T of F(2,3))
     float* Z = lds;                               // [4 fy][16 ch][NPOS][4]
-    float* E = lds + 4 * 16 * NPOS * 4;           // [BM][8]: gain, bias, the three modulated ToRGB weights of the channel
-    float* Rr = E + 8 * BM;                       // [CG][2 * NPOS][12] ToRGB partial sums
-    const bool act = p.fuse_act != 0;
-    const float act_gain = act ? 1.41421356237309515f : 1.f;
-    for (int i = tid; i < BM; i += 256) {
-        const int o = m0 + i;
-        float gain = p.wscale * act_gain;
-        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
-        f32x4 e = f32x4{gain, (act && p.bias) ? p.bias[o] * act_gain : 0.f, 0.f, 0.f};
-        float r2 = 0.f;
-        if (p.rgb) {
-            const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
-            e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
-        }
-        *reinterpret_cast<f32x4*>(E + 8 * i) = e;
-        E[8 * i + 4] = r2;
-    }
+    float* Rr = lds + 4 * 16 * NPOS * 4;          // [CG][2 * NPOS][12] ToRGB partial sums
     // combine-phase role of this thread: position cp, output row cr of the 2-row block, channel group cg of every pass
     constexpr int CG = 256 / (2 * NPOS);        // channel groups (4 for TN = 2, 2 for TN = 4)
     constexpr int CPG = 16 / CG;                // channels per thread per pass
     const int cp = tid % NPOS, cr = (tid / NPOS) & 1, cg = tid / (2 * NPOS);
     const int cjx = cp & 7, cpy = cp >> 3;      // position column / position row inside the tile (cpy = 2 nt + jy)
     const int oy = ty0 + 2 * cpy + cr, ox = tx0 + 4 * cjx;
-    const float* noise_base = p.noise;
-    int64_t noise_bstride = p.noise_batch_stride;
-    if (p.src) {  // uniform scalar loads: base of this launch's first frame inside the HBM-resident sequence
-        noise_bstride = p.src->noise_stride[p.noise_slot];
-        noise_base = p.src->noise[p.noise_slot];
-        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
-    }
-    const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
-    f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (nw != 0.f) {
-        nz = *reinterpret_cast<const f32x4*>(noise_base + (size_t)b0 * noise_bstride + (size_t)oy * p.W + ox);
-        nz = nz * nw;
-    }
+    f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};  // raw noise of this thread's four pixels (scaled by nw where it is used: no wait here)
+    if (nw != 0.f) nz = *reinterpret_cast<const f32x4*>(noise_base + (size_t)b0 * noise_bstride + (size_t)oy * p.W + ox);
     f32x4 rgbv[3];  // this thread's share of the ToRGB sums, [rgb channel][pixel]
 #pragma unroll
     for (int c = 0; c < 3; ++c) rgbv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -508,6 +510,41 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     const float* zbase = Z + cp * 4;
     const int zo_off = (cr ? 3 : 0) * 16 * NPOS * 4;
 
+    // 2x FIR-upsampled skip image of the fused ToRGB: upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, x) has two live source rows / columns,
+    // iy0 = floor((oy-1)/2), iy0+1 with taps k4[3]/k4[1] for even oy and k4[2]/k4[0] for odd (models/stylegan2.py:34-52,
+    // op/upfirdn2d.py:159-200).  All 24 source values of the 4 output pixels (2 live rows x 4 live columns x 3 channels) are fetched
+    // unconditionally from clamped addresses, in flight together; positions outside the skip image are masked through their tap
+    // weight (per-pixel conditional loads serialise ~48 dependent L2 round trips behind each other: measured 0.5 ms of the 1024^2
+    // layer).  Output column x = ox + px reads source columns (x-1)>>1 and +1: px 0 -> k 0,1; 1, 2 -> k 1,2; 3 -> k 2,3 of
+    // k = (ox>>1) - 1 + {0..3}, with taps k4[.][3], k4[.][1] for even x and k4[.][2], k4[.][0] for odd x.  The loads go out before
+    // the combine of the LAST pass (the accumulators are dead by then), so that their round trip hides behind it.
+    const int sh = p.H >> 1, sw = p.W >> 1;
+    const bool want_skip = (p.rgb == 1 || p.rgb == 2) && p.rgb_skip && cg == 0;
+    float sv[3][2][4], wy[2], wx[4];
+    auto load_skip = [&]() {
+        const float* skip_img = p.rgb_skip + (size_t)b0 * 3 * sh * sw;
+        const int iy0 = (oy - 1) >> 1;
+        int rowc[2], colc[4];
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy) {
+            const int yy = iy0 + qy;
+            wy[qy] = (yy >= 0 && yy < sh) ? 1.f : 0.f;
+            rowc[qy] = min(max(yy, 0), sh - 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = (ox >> 1) - 1 + k;
+            wx[k] = (xx >= 0 && xx < sw) ? 1.f : 0.f;
+            colc[k] = min(max(xx, 0), sw - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[c][qy][k] = skip_img[(unsigned)((c * sh + rowc[qy]) * sw + colc[k])];
+    };
+
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
         __syncthreads();  // previous pass's reads (or the main loop's LDS use) are done
@@ -523,6 +560,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
                 *reinterpret_cast<f32x4*>(Z + (((fy * 16 + ch16) * NPOS) + n * 16 + j) * 4) = o4;
             }
         __syncthreads();
+        if (mt == TM - 1 && want_skip) load_skip();
         if constexpr (!(MAUA_W2D_ABL & 512))
 #pragma unroll
         for (int q = 0; q < CPG; ++q) {
@@ -535,7 +573,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             const f32x4 e = *reinterpret_cast<const f32x4*>(E + 8 * ol);  // gain, bias, ToRGB weights 0, 1
             const float r2 = E[8 * ol + 4];
             const f32x4 raw = (z2 + zo) * row_sign + z1;
-            const f32x4 tt = raw * e[0] + (nz + e[1]);
+            const f32x4 tt = raw * e[0] + (nz * nw + e[1]);
             const f32x4 v4 = __builtin_elementwise_max(tt, tt * slope);
             if (p.rgb) {
                 rgbv[0] = v4 * e[2] + rgbv[0];
@@ -571,44 +609,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             *reinterpret_cast<f32x4*>(part + (size_t)c * plane) = rgbv[c];
         return;
     }
-    // upfirdn2d(skip, k4, up=2, pad=(2,1)) at (oy, x): two live source rows / columns, iy0 = floor((oy-1)/2), iy0+1 with taps
-    // k4[3]/k4[1] for even oy and k4[2]/k4[0] for odd (models/stylegan2.py:34-52, op/upfirdn2d.py:159-200)
-    const int sh = p.H >> 1, sw = p.W >> 1;
     const size_t rgb_plane = plane;
     float* rgb_img = p.rgb_out + (size_t)b0 * 3 * rgb_plane;
     f32x4 outc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) outc[c] = rgbv[c] + p.rgb_bias[c];
     if (p.rgb_skip) {
-        // All 24 source values of the 4 output pixels (2 live rows x 4 live columns x 3 channels) are fetched unconditionally
-        // from clamped addresses, in flight together; positions outside the skip image are masked through their tap weight
-        // (per-pixel conditional loads serialise ~48 dependent L2 round trips behind each other: measured 0.5 ms of the
-        // 1024^2 layer).  Output column x = ox + px reads source columns (x-1)>>1 and +1: px 0 -> k 0,1; 1, 2 -> k 1,2; 3 -> k 2,3
-        // of k = (ox>>1) - 1 + {0..3}, with taps k4[.][3], k4[.][1] for even x and k4[.][2], k4[.][0] for odd x.
-        const float* skip_img = p.rgb_skip + (size_t)b0 * 3 * sh * sw;
-        const int iy0 = (oy - 1) >> 1;
         const int ty_ = (oy & 1) ? 2 : 3;
-        int rowc[2], colc[4];
-        float wy[2], wx[4];
-#pragma unroll
-        for (int qy = 0; qy < 2; ++qy) {
-            const int yy = iy0 + qy;
-            wy[qy] = (yy >= 0 && yy < sh) ? 1.f : 0.f;
-            rowc[qy] = min(max(yy, 0), sh - 1);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int xx = (ox >> 1) - 1 + k;
-            wx[k] = (xx >= 0 && xx < sw) ? 1.f : 0.f;
-            colc[k] = min(max(xx, 0), sw - 1);
-        }
-        float sv[3][2][4];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int qy = 0; qy < 2; ++qy)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sv[c][qy][k] = skip_img[(unsigned)((c * sh + rowc[qy]) * sw + colc[k])];
         float kt[2][4];  // the two live tap rows
 #pragma unroll
         for (int qy = 0; qy < 2; ++qy)
@@ -686,8 +693,8 @@ size_t w2d_lds_bytes(int tm, int tn, int cin) {
     const int bm = 16 * tm, npos = 16 * tn;
     const size_t main_loop = (size_t)2 * 24 * W2D_CC * bm + (size_t)2 * W2D_CC * w2d_pstride(tn) + (size_t)cin;
     const int cg = 256 / (2 * npos);
-    const size_t epilogue = (size_t)4 * 16 * npos * 4 + (size_t)8 * bm + (size_t)cg * 2 * npos * 12;
-    return sizeof(float) * (main_loop > epilogue ? main_loop : epilogue);
+    const size_t epilogue = (size_t)4 * 16 * npos * 4 + (size_t)cg * 2 * npos * 12;
+    return sizeof(float) * ((main_loop > epilogue ? main_loop : epilogue) + (size_t)8 * bm);  // + the channel-constant table
 }
 
 char g_w2d_instance[64] = "";
