@@ -60,7 +60,7 @@ def test_rejects_bad_arguments_without_gpu(built_lib):
     assert conv(64, 48, 5) == -22           # 2-D Winograd (mode 5) needs W % 32 == 0 ...
     assert conv(12, 64, 5) == -22           # ... and H % 8 == 0
     assert lib.maua_modconv_w2d_ok(64, 64, 64, 64) == 1 and lib.maua_modconv_w2d_ok(64, 48, 64, 64) == 0
-    assert lib.maua_modconv_w2d_ok(32, 32, 24, 64) == 0 and lib.maua_modconv_w2d_ok(32, 32, 32, 64) == 1  # 32 channels: H % 16
+    assert lib.maua_modconv_w2d_ok(32, 32, 20, 64) == 0 and lib.maua_modconv_w2d_ok(32, 32, 24, 64) == 1  # every tile shape: H % 8
     assert conv(64, 63, 2) == -22           # F(2,3) needs an even width
     assert conv(64, 66, 3) == -22           # F(4,3) needs W % 4 == 0
     assert conv(64, 63, 4) == -22           # mode 4 needs an even width
