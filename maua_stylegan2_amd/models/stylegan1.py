@@ -409,6 +409,20 @@ class G_style(nn.Sequential):
         dev = self.g_mapping.dense0.weight.device
         return self.g_mapping(th.randn(n_latent, 512, device=dev)).mean(0, keepdim=True)
 
+    capturable_bends = False  # G_style takes no transform_dict_list (reference :584-617): bends keep the eager path
+
+    def weights_key(self):
+        """Identity of everything a captured forward has baked in as pointers (see Generator.weights_key)."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def capture_graph(self, batch, lane=0, frames_u8=True, bends=()):
+        """One forward of ``batch`` frames (+ the uint8 frame epilogue) captured into a hipGraph: the render loop replays it per
+        batch instead of issuing the ~100 launches of the eager synthesis (render.synthesize; same lane protocol as the StyleGAN2
+        generator's ``capture_graph``)."""
+        if bends:
+            raise NotImplementedError("G_style has no network-bending hook")
+        return StyleGAN1Lane(self, batch, lane)
+
     def forward(self, styles, noise=None, truncation=1, map_latents=False, randomize_noise=False, input_is_latent=True,
                 transform_dict_list=None):
         if map_latents:
@@ -431,3 +445,71 @@ class G_style(nn.Sequential):
         with th.cuda.device(dev):
             img = self.g_synthesis.run(styles.contiguous(), noise)
         return img, None
+
+
+class StyleGAN1Lane:
+    """A captured G_style forward.  Unlike the StyleGAN2 lanes (whose kernels read the HBM-resident sequences through a frame
+    source), the StyleGAN1 synthesis keeps static input tensors: ``replay`` copies the batch's slices into them (StyleGAN1 is the
+    compatibility path of generate(), not the measured one) and launches the graph; the capture itself is a hipGraph stream
+    capture driven through torch.cuda.CUDAGraph, so the few torch ops of G_style.forward (truncation lerp, constant expand) and
+    their allocations are part of it."""
+
+    def __init__(self, g, batch, lane):
+        from ..render import frames_to_uint8
+
+        dev = g.g_mapping.dense0.weight.device
+        self.generator, self.batch, self.lane = g, batch, lane
+        g.truncation_latent = g.truncation_latent.to(dev)  # (a plain attribute: module.cuda() leaves it on the host, and an upload cannot be captured)
+        self.weights_key = g.weights_key()
+        n_blocks = len(g.g_synthesis.blocks)
+        # (G_mapping broadcasts to 18 latents whatever the network resolution, :357-362; the synthesis reads the first 2 n_blocks)
+        self._latents = th.zeros(batch, g.truncation_latent.shape[1], g.truncation_latent.shape[2], device=dev)
+        self._trunc = th.ones(batch, device=dev)
+        self._noise = []
+        for i in range(n_blocks):
+            buf = getattr(g, f"noise_{i}")
+            self._noise.append(buf.to(dev, th.float32).expand(batch, -1, -1, -1).contiguous())
+        self._bound = None
+        stream = th.cuda.current_stream(dev)
+
+        def forward():
+            images, _ = g(styles=self._latents, noise=list(self._noise), truncation=self._trunc, input_is_latent=True)
+            return images
+
+        images = forward()  # warm-up: weight packs, style tables, function attributes — nothing of it may happen under capture
+        self.u8 = th.empty((batch, images.shape[2], images.shape[3], 3), dtype=th.uint8, device=dev)
+        frames_to_uint8(images, self.u8)
+        stream.synchronize()
+        self.graph = th.cuda.CUDAGraph()
+        with th.cuda.graph(self.graph, stream=stream):
+            self.image = forward()
+            frames_to_uint8(self.image, self.u8)
+
+    def bind(self, latents, noise, truncation=None):
+        """``latents`` [N, 18, 512], ``noise`` one [N or 1, 1, h, w] sequence or None (= the generator's buffer) per block,
+        ``truncation`` [N] or None (= 1): the sequences ``replay`` slices."""
+        noise = list(noise) + [None] * (len(self._noise) - len(noise))
+        for i, (static, seq) in enumerate(zip(self._noise, noise)):
+            if seq is None:
+                static.copy_(getattr(self.generator, f"noise_{i}").to(static.device).expand_as(static))
+            elif seq.dim() != 4 or tuple(seq.shape[1:]) != tuple(static.shape[1:]):
+                raise RuntimeError(f"noise {tuple(seq.shape)} does not match feature map {tuple(static.shape)} of block {i}")
+            elif seq.shape[0] == 1:
+                static.copy_(seq.expand_as(static))
+        if truncation is None:
+            self._trunc.fill_(1.0)
+        self._bound = (latents, noise, truncation)
+
+    def release(self):
+        self._bound = None
+
+    def replay(self, frame0, stream=None):
+        latents, noise, truncation = self._bound
+        hi = frame0 + self.batch
+        self._latents.copy_(latents[frame0:hi])
+        for static, seq in zip(self._noise, noise):
+            if seq is not None and seq.shape[0] != 1:
+                static.copy_(seq[frame0:hi])
+        if truncation is not None:
+            self._trunc.copy_(truncation[frame0:hi])
+        self.graph.replay()

@@ -185,7 +185,7 @@ def prepare(generator, batch_size, lanes=3, bends=False):
     ranks that do not run the audio front end WHILE rank 0 runs it (multi-GPU jobs were front-end bound: the peers used to start
     loading / packing / capturing only after the scatter).  With bends the graphs are captured per render (the transforms'
     operands are part of them), so only the warm-up forward is done here."""
-    if not hasattr(generator, "capture_graph"):
+    if not hasattr(generator, "capture_graph") or (bends and not getattr(generator, "capturable_bends", True)):
         return 0
     if bends:
         dev = device_of(generator)
@@ -249,7 +249,7 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
     capturable = use_graph and not rewrites and not randomize_noise and hasattr(generator, "capture_graph")
     seq_bends = []
     if capturable and bends:
-        seq_bends, capturable = _sequence_bends(bends)
+        seq_bends, capturable = _sequence_bends(bends) if getattr(generator, "capturable_bends", True) else (None, False)
     n_lanes = max(1, int(lanes)) if capturable else 1
     caller_stream = th.cuda.current_stream(dev)
     lane_state = []  # (stream, GraphLane or None)
@@ -278,7 +278,7 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
                     yield n, lane.u8  # the frame epilogue is part of the captured forward (fused into the last ToRGB)
                     k += 1
                     continue
-                noise_batch = [None if nz is None else nz[n:m] for nz in noise]
+                noise_batch = [None if nz is None else (nz if nz.shape[0] == 1 else nz[n:m]) for nz in noise]  # [1, ...] = one map for every frame
                 bend_batch = []
                 for bend in bends:
                     if "modulation" in bend:

@@ -837,7 +837,7 @@ def test_stylegan1_through_generate_and_render_vs_oracle(gpu, tmp_path, monkeypa
     """``--stylegan1`` end to end (reference generate_audiovisual.py:41-47, models/stylegan1.py:509-617): a seeded 128-px G_style
     checkpoint is probed (1024 -> 512 -> 256 -> 128) by ``generate(stylegan1=True)``, rendered at 512^2 (constant enlarged to 32x32
     and centre-cropped to 16x16, six blocks, truncation 0.7 on the first 8 layers, per-frame noise below 64 px and the generator's
-    own noise buffers above) through render()'s eager path, and three delivered frames are compared with oracle/stylegan1_oracle.py
+    own noise buffers above) through render()'s captured lanes (+ the eager tail batch), and three delivered frames are compared with oracle/stylegan1_oracle.py
     run on the state the generator actually holds (<= 1 grey level)."""
     import wave
 
@@ -912,6 +912,35 @@ def test_stylegan1_through_generate_and_render_vs_oracle(gpu, tmp_path, monkeypa
         want = so.frames_to_uint8(s1o.synthesis(sd, s1o.truncate(lat[i: i + 1], tl, 0.7), noise_i))[0]
         diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
         assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (i, int(diff.max()), float((diff > 0).mean()))
+
+
+def test_stylegan1_captured_forward_equals_eager(gpu):
+    """G_style.capture_graph (hipGraph stream capture of the whole StyleGAN1 forward + frame epilogue, three lanes): frames bit-equal
+    to the eager forward — per-frame noise on the small blocks, the generator's buffers on the others, per-frame truncation — the
+    lanes are cached on the generator and serve a second render with other sequences."""
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.models import stylegan1 as sg1
+
+    torch.manual_seed(5)
+    g = sg1.G_style(output_size=1024, checkpoint=None, network_resolution=128).cuda().eval()
+    n, bs = 14, 4
+    for seed in (0, 1):
+        lat = torch.from_numpy(seeding.seeded_array(90 + seed, "lat", (n, 18, 512))).cuda()
+        noise = [torch.from_numpy(seeding.seeded_array(91 + seed, f"nz{i}", (n if i != 1 else 1,) + tuple(getattr(g, f"noise_{i}").shape[1:]))).cuda()
+                 if i < 3 else None for i in range(6)]  # per-frame on blocks 0 and 2, one shared map on block 1, the generator's buffers above
+        trunc = torch.linspace(0.5, 1.0, n).cuda()
+        got = {k: u8.cpu().clone() for k, u8 in render.synthesize(g, lat, noise, bs, truncation=trunc, lanes=3)}
+        want = {k: u8.cpu().clone() for k, u8 in render.synthesize(g, lat, noise, bs, truncation=trunc, use_graph=False)}
+        assert sorted(got) == sorted(want) == [0, 4, 8, 12]
+        for k in got:
+            assert torch.equal(got[k], want[k]), (seed, k)
+        assert got[0].shape == (bs, 1024, 1024, 3) and not torch.equal(got[0][0], got[0][1])  # (32 x 32 constant, six blocks)
+        lanes = g.__dict__["_graph_lanes"]
+        assert sorted(lanes) == [(bs, 0), (bs, 1), (bs, 2)]
+        if seed == 0:
+            first = [lanes[key] for key in sorted(lanes)]
+        else:
+            assert all(lanes[key] is lane for key, lane in zip(sorted(lanes), first))  # nothing re-captured
 
 
 def test_generate_1920_wide_output_is_delivered_as_1080p(gpu, tmp_path, monkeypatch):

@@ -46,6 +46,30 @@ def main():
         out = subprocess.run([sys.executable, "tools/rocpd_summary.py", db], capture_output=True, text=True).stdout
         return "\n".join(line for line in out.splitlines()[1:] if "at::native" not in line)
 
+    def copies():
+        rows = {}
+        for nb in (3, 12):
+            cur = sqlite3.connect(f"{O}/trace_nb{nb}/bench_results.db").cursor()
+            cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+            name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+            q = f"select {name_col}, count(*) from kernels group by {name_col}"
+            for name, n in cur.execute(q):
+                key = ("copy kernels (`__amd_rocclr_copyBuffer*`, `__amd_rocclr_fillBuffer*`)" if "__amd_rocclr" in name else
+                       "`modconv_up2d_kernel` (8 per batch)" if "modconv_up2d_kernel" in name else None)
+                if key:
+                    rows.setdefault(key, {}).setdefault(nb, 0)
+                    rows[key][nb] += n
+        out = ["`rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 0 --batches-per-step N --lanes 1 --no-cpu-baseline --no-side-configs",
+               "--no-breakdown` with N = 3 and N = 12 (set-up, capture, the frame check against the eager forward and the host-inclusive side",
+               "measurement are in both runs; only the number of replayed batches differs):", "",
+               "| dispatches of | N = 3 | N = 12 | per extra batch |", "|---|---:|---:|---:|"]
+        for key, v in rows.items():
+            out.append(f"| {key} | {v.get(3, 0)} | {v.get(12, 0)} | {(v.get(12, 0) - v.get(3, 0)) / 9:.2f} |")
+        out.append("")
+        out.append("The per-frame inputs reach the kernels through the device-side frame source (`maua_frame_source_seek` = one 4-byte "
+                   "`hipMemsetD32Async` node per replay, which is what the fill kernel row counts); no input is copied per batch.")
+        return "\n".join(out)
+
     with open(f"profiles/{TAG}_bench_kernel_stats.md", "w") as f:
         f.write(f"""# rocprofv3 --kernel-trace --stats of bench.py ({TAG}, final kernels of the round)
 
@@ -62,6 +86,10 @@ launches), which is why calls != steps x layers.  Template arguments of modconv_
 MODE 0 direct, 1 transposed (polyphase), 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed with F(2,2) on the even x-phase;
 modconv_w2d_kernel<TM, TN> = 2-D Winograd F(2x4,3x3) (mode 5); modconv_up2d_kernel<CC> = transposed with F(2,2) on both axes (mode 6),
 up2d_edge_kernel = its two edge lines.  (These short runs time one cold step: the frames/s quoted here are not the headline.)
+
+## Copies per batch
+
+{copies()}
 
 ## --lanes 1
 {stats(f'{O}/trace_lanes1/bench_results.db')}

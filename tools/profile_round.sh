@@ -14,6 +14,11 @@ cd /tmp && export TMPDIR=/tmp
 SHORT="--steps 1 --warmup 1 --batches-per-step 3 --no-cpu-baseline --no-side-configs"
 rocprofv3 --kernel-trace --stats -d "$O/trace_lanes3" -o bench -- python "$R/bench.py" $SHORT > "$O/bench_trace_lanes3.json" 2> "$O/trace_lanes3.err"
 rocprofv3 --kernel-trace --stats -d "$O/trace_lanes1" -o bench -- python "$R/bench.py" $SHORT --lanes 1 > "$O/bench_trace_lanes1.json" 2> "$O/trace_lanes1.err"
+# copy accounting: the same traced run with 3 and with 12 batches per step and nothing else in the process (no breakdown, no warm-up);
+# whatever does not grow with the batch count is set-up, not per-batch work (make_profiles.py tabulates the copy kernels)
+for nb in 3 12; do
+  rocprofv3 --kernel-trace -d "$O/trace_nb$nb" -o bench -- python "$R/bench.py" --steps 1 --warmup 0 --batches-per-step $nb --lanes 1 --no-cpu-baseline --no-side-configs --no-breakdown > /dev/null 2> "$O/trace_nb$nb.err"
+done
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace -d "$O/pmc_$ctr" -o bench -- python "$R/bench.py" $SHORT --lanes 1 --no-breakdown > /dev/null 2> "$O/pmc_$ctr.err"
 done
