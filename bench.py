@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the config 2 / config 5 side measurements")
+    ap.add_argument("--no-pcie-side", action="store_true", help="skip the host-inclusive side measurement (copy accounting runs)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B switch of an EXPERIMENTS build (tools/build_exp.sh, pass it with --lib): maua_tuning_set(KEY, VALUE) before "
                          "the graphs are captured; the product library has no such entry")
@@ -431,7 +432,7 @@ def main():
     side = max(1, min(args.steps, 8))
     if world > 1 or args.force_gather:
         extra["frames_per_sec_synth_only"] = world * side * bps * B / time_region(wl, side, bps, "synth", use_dist, world)
-    if world == 1:
+    if world == 1 and not args.no_pcie_side:
         extra["frames_per_sec_pcie_inclusive"] = side * bps * B / time_region(wl, side, bps, "pcie", use_dist, world)
         extra["pcie_inclusive_note"] = (f"{side} steps; uint8 frames copied to pinned host memory through a 3-slot staging "
                                         "ring on a copy stream, as render() does; null sink (no encoder)")

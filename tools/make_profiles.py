@@ -42,26 +42,25 @@ def main():
         shutil.copy(f"{O}/{src}.json", f"profiles/{TAG}_{dst}.json")
     l1, l2 = last_json(f"{O}/bench_trace_lanes1.json"), last_json(f"{O}/bench_trace_lanes3.json")
 
-    def stats(db):
-        out = subprocess.run([sys.executable, "tools/rocpd_summary.py", db], capture_output=True, text=True).stdout
-        return "\n".join(line for line in out.splitlines()[1:] if "at::native" not in line)
+    def stats(md):
+        return "\n".join(line for line in open(md).read().splitlines()[1:] if "at::native" not in line)
 
     def copies():
         rows = {}
         for nb in (3, 12):
-            cur = sqlite3.connect(f"{O}/trace_nb{nb}/bench_results.db").cursor()
-            cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
-            name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-            q = f"select {name_col}, count(*) from kernels group by {name_col}"
-            for name, n in cur.execute(q):
+            for line in open(f"{O}/trace_nb{nb}.md"):
+                cells = [c.strip() for c in line.split("|")]
+                if len(cells) < 4 or not cells[2].isdigit():
+                    continue
+                name, n = cells[1], int(cells[2])
                 key = ("copy kernels (`__amd_rocclr_copyBuffer*`, `__amd_rocclr_fillBuffer*`)" if "__amd_rocclr" in name else
                        "`modconv_up2d_kernel` (8 per batch)" if "modconv_up2d_kernel" in name else None)
                 if key:
                     rows.setdefault(key, {}).setdefault(nb, 0)
                     rows[key][nb] += n
         out = ["`rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 0 --batches-per-step N --lanes 1 --no-cpu-baseline --no-side-configs",
-               "--no-breakdown` with N = 3 and N = 12 (set-up, capture, the frame check against the eager forward and the host-inclusive side",
-               "measurement are in both runs; only the number of replayed batches differs):", "",
+               "--no-breakdown --no-pcie-side` with N = 3 and N = 12 (set-up, capture and the frame check against the eager forward are in both",
+               "runs; only the number of replayed batches differs):", "",
                "| dispatches of | N = 3 | N = 12 | per extra batch |", "|---|---:|---:|---:|"]
         for key, v in rows.items():
             out.append(f"| {key} | {v.get(3, 0)} | {v.get(12, 0)} | {(v.get(12, 0) - v.get(3, 0)) / 9:.2f} |")
@@ -92,10 +91,10 @@ up2d_edge_kernel = its two edge lines.  (These short runs time one cold step: th
 {copies()}
 
 ## --lanes 1
-{stats(f'{O}/trace_lanes1/bench_results.db')}
+{stats(f'{O}/trace_lanes1.md')}
 
 ## default (3 lanes)
-{stats(f'{O}/trace_lanes3/bench_results.db')}
+{stats(f'{O}/trace_lanes3.md')}
 """)
 
     sq, lds = table(f"{O}/pmc_sq/bench_results.db"), table(f"{O}/pmc_lds/bench_results.db")

@@ -17,7 +17,11 @@ rocprofv3 --kernel-trace --stats -d "$O/trace_lanes1" -o bench -- python "$R/ben
 # copy accounting: the same traced run with 3 and with 12 batches per step and nothing else in the process (no breakdown, no warm-up);
 # whatever does not grow with the batch count is set-up, not per-batch work (make_profiles.py tabulates the copy kernels)
 for nb in 3 12; do
-  rocprofv3 --kernel-trace -d "$O/trace_nb$nb" -o bench -- python "$R/bench.py" --steps 1 --warmup 0 --batches-per-step $nb --lanes 1 --no-cpu-baseline --no-side-configs --no-breakdown > /dev/null 2> "$O/trace_nb$nb.err"
+  rocprofv3 --kernel-trace -d "$O/trace_nb$nb" -o bench -- python "$R/bench.py" --steps 1 --warmup 0 --batches-per-step $nb --lanes 1 --no-cpu-baseline --no-side-configs --no-breakdown --no-pcie-side > /dev/null 2> "$O/trace_nb$nb.err"
+  python "$R/tools/rocpd_summary.py" "$O/trace_nb$nb/bench_results.db" > "$O/trace_nb$nb.md"; rm -rf "$O/trace_nb$nb"   # (the merge-back is capped at 64 MiB)
+done
+for l in 1 3; do  # (per-kernel summaries are made here: the merge-back is capped at 64 MiB and a trace database is ~10 MiB)
+  python "$R/tools/rocpd_summary.py" "$O/trace_lanes$l/bench_results.db" > "$O/trace_lanes$l.md"; rm -rf "$O/trace_lanes$l"
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace -d "$O/pmc_$ctr" -o bench -- python "$R/bench.py" $SHORT --lanes 1 --no-breakdown > /dev/null 2> "$O/pmc_$ctr.err"
