@@ -710,7 +710,7 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %s>", TM, TN, DBG ? "true" : "false");
+    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %s, %d>", TM, TN, DBG ? "true" : "false", MINB);
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
 #ifdef MAUA_EXPERIMENTS  // occupancy probe (MAUA_W2D_LDS_PAD with an experiments build): extra dynamic LDS so that a CU holds one workgroup instead of two
     static const size_t lds_pad = getenv("MAUA_W2D_LDS_PAD") ? (size_t)atoi(getenv("MAUA_W2D_LDS_PAD")) : 0;

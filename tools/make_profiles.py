@@ -54,7 +54,7 @@ def main():
                     continue
                 name, n = cells[1], int(cells[2])
                 key = ("copy kernels (`__amd_rocclr_copyBuffer*`, `__amd_rocclr_fillBuffer*`)" if "__amd_rocclr" in name else
-                       "`modconv_up2d_kernel` (8 per batch)" if "modconv_up2d_kernel" in name else None)
+                       "`modconv_up2d_kernel` (the 5 mode-6 layers of a batch)" if "modconv_up2d_kernel" in name else None)
                 if key:
                     rows.setdefault(key, {}).setdefault(nb, 0)
                     rows[key][nb] += n
