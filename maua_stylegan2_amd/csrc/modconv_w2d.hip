@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     float* Rr = lds + 4 * 16 * NPOS * 4;          // [CG][2 * NPOS][12] ToRGB partial sums
     // combine-phase role of this thread: position cp, output row cr of the 2-row block, channel group cg of every pass
     constexpr int CG = 256 / (2 * NPOS);        // channel groups (4 for TN = 2, 2 for TN = 4)
+    static_assert(2 * NPOS >= 64, "the combine phase reads its channel index as a wave-uniform scalar: a wave must not span channel groups");
     constexpr int CPG = 16 / CG;                // channels per thread per pass
     const int cp = tid % NPOS, cr = (tid / NPOS) & 1, cg = tid / (2 * NPOS);
     const int cjx = cp & 7, cpy = cp >> 3;      // position column / position row inside the tile (cpy = 2 nt + jy)
