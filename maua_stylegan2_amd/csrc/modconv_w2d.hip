@@ -213,36 +213,6 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         rel_bytes[g] = ok ? (unsigned)(yy * p.W + xx) * 4u : 0x80000000u;
     }
     for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
-    // per-output-channel constants of the epilogue, [BM][8] = gain, bias, the three modulated ToRGB weights: fetched here, under the
-    // first DMA wait, into LDS that neither the main loop nor the exchange buffers of the epilogue touch (loaded after the main loop
-    // their ~1 us round trip was exposed in every workgroup)
-    constexpr int EPI_FLOATS = 4 * 16 * NPOS * 4 + (256 / (2 * NPOS)) * 2 * NPOS * 12;
-    const int main_floats = 2 * A_FLOATS + 2 * PBUF + p.Cin;
-    float* E = lds + (main_floats > EPI_FLOATS ? main_floats : EPI_FLOATS);
-    const bool act = p.fuse_act != 0;
-    const float act_gain = act ? 1.41421356237309515f : 1.f;
-    const float* noise_base = p.noise;
-    int64_t noise_bstride = p.noise_batch_stride;
-    if (p.src) {  // uniform scalar loads: base of this launch's first frame inside the HBM-resident sequence
-        noise_bstride = p.src->noise_stride[p.noise_slot];
-        noise_base = p.src->noise[p.noise_slot];
-        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
-    }
-    const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
-    for (int i = tid; i < BM; i += 256) {
-        const int o = m0 + i;
-        float gain = p.wscale * act_gain;
-        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
-        f32x4 e = f32x4{gain, (act && p.bias) ? p.bias[o] * act_gain : 0.f, 0.f, 0.f};
-        float r2 = 0.f;
-        if (p.rgb) {
-            const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
-            e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
-        }
-        *reinterpret_cast<f32x4*>(E + 8 * i) = e;
-        E[8 * i + 4] = r2;
-    }
-
     const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
     const size_t plane_bytes = plane * sizeof(float);
     (void)ximg, (void)plane_bytes;
@@ -276,6 +246,36 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
 #endif
     };
 
+    // per-output-channel constants of the epilogue, [BM][8] = gain, bias, the three modulated ToRGB weights: fetched here, under the
+    // first DMA wait, into LDS that neither the main loop nor the exchange buffers of the epilogue touch (loaded after the main loop
+    // their ~1 us round trip was exposed in every workgroup)
+    constexpr int EPI_FLOATS = 4 * 16 * NPOS * 4 + (256 / (2 * NPOS)) * 2 * NPOS * 12;
+    const int main_floats = 2 * A_FLOATS + 2 * PBUF + p.Cin;
+    float* E = lds + (main_floats > EPI_FLOATS ? main_floats : EPI_FLOATS);
+    const bool act = p.fuse_act != 0;
+    const float act_gain = act ? 1.41421356237309515f : 1.f;
+    const float* noise_base = p.noise;
+    int64_t noise_bstride = p.noise_batch_stride;
+    if (p.src) {  // uniform scalar loads: base of this launch's first frame inside the HBM-resident sequence
+        noise_bstride = p.src->noise_stride[p.noise_slot];
+        noise_base = p.src->noise[p.noise_slot];
+        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
+    }
+    const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
+    for (int i = tid; i < BM; i += 256) {
+        const int o = m0 + i;
+        float gain = p.wscale * act_gain;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
+        f32x4 e = f32x4{gain, (act && p.bias) ? p.bias[o] * act_gain : 0.f, 0.f, 0.f};
+        float r2 = 0.f;
+        if (p.rgb) {
+            const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
+            e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
+        }
+        *reinterpret_cast<f32x4*>(E + 8 * i) = e;
+        E[8 * i + 4] = r2;
+    }
+
     // ---- accumulators: [x-frequency][m-tile][n-tile]
     // (not zeroed: the first K step runs as a peeled copy of the loop whose matrix instructions take C = 0 — 48 TM TN / 8 register
     // moves per wave that the VALU, which shares its datapath with the fp32 matrix instructions, does not have to issue)
@@ -285,6 +285,10 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     const int ra = fy == 0 ? 0 : (fy == 2 ? 2 : 1);
     const int rb = fy == 0 ? 2 : (fy == 1 ? 2 : (fy == 2 ? 1 : 3));
     const float sgn = fy == 1 ? 1.f : -1.f;
+    const f32x2 sgn2 = f32x2{sgn, sgn};
+    float m5 = -5.f;
+    asm("" : "+v"(m5));  // (a register operand of the hand-written transform)
+    (void)sgn2;
     // LDS byte addresses (buffer 0) of this lane's operands; the second buffer is a constant distance away
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
     // window rows ra / rb of n-tile 0, channel kq; n-tile n lies a constant 4 patch rows further (immediate offset)
@@ -341,23 +345,31 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         };
         auto transform = [&](int n, int slot) {
 #if MAUA_W2D_PKT
+            const f32x2 sc2 = f32x2{sc, sc};
             // row combination and B_x^T of F(4,3) on register pairs (v_pk_*_f32 = two fp32 operations per issue slot; VALU and the
             // fp32 matrix instructions share the datapath, so every transform instruction saved is matrix time won):
             //   D12 = (d1, d2), D34 = (d3, d4);  (b, a) = D34 - 4 D12;  (e, c) = D34 - D12;
             //   (bv1, bv2) = (a + b, a - b);  (bv3, bv4) = (c + 2 e, c - 2 e)   -- the two cross-lane forms through op_sel / neg_hi
-            const f32x2 D12 = wb[slot][0] * sgn + wa[slot][0], D34 = wb[slot][1] * sgn + wa[slot][1];
-            const float d0 = fmaf(sgn, wb0[slot].y, wa0[slot].y), d5 = fmaf(sgn, wb5[slot].x, wa5[slot].x);
-            const f32x2 ba = D12 * -4.f + D34, ec = D34 - D12;
-            f32x2 b12, b34;
+            // Written instruction by instruction (16 per window): left to the compiler the same arithmetic comes out at ~20 with the
+            // register shuffles its vectoriser adds around the two scalar chains.
+            f32x2 D12, D34, ba, ec, b12, b34;
+            float d0, d5, t0, t5, u0, u5;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(D12) : "v"(wb[slot][0]), "v"(sgn2), "v"(wa[slot][0]));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(D34) : "v"(wb[slot][1]), "v"(sgn2), "v"(wa[slot][1]));
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d0) : "v"(wb0[slot].y), "v"(sgn), "v"(wa0[slot].y));
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d5) : "v"(wb5[slot].x), "v"(sgn), "v"(wa5[slot].x));
+            asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(ba) : "v"(D12), "v"(D34));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ec) : "v"(D34), "v"(D12));
             asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(b12) : "v"(ba));
             asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(b34) : "v"(ec));
-            b12 *= sc, b34 *= sc;
-            float t0 = fmaf(-5.f, D12.y, D34.y), t5 = fmaf(-5.f, D34.x, d5);
-            asm("" : "+v"(t0), "+v"(t5));  // (keeps the vectoriser from pairing the two chains through register shuffles)
-            float u0 = fmaf(4.f, d0, t0), u5 = fmaf(4.f, D12.x, t5);
-            asm("" : "+v"(u0), "+v"(u5));
-            const f32x2 b05 = f32x2{u0, u5} * sc;
-            bv[n][0] = b05.x, bv[n][1] = b12.x, bv[n][2] = b12.y, bv[n][3] = b34.x, bv[n][4] = b34.y, bv[n][5] = b05.y;
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(m5), "v"(D12.y), "v"(D34.y));
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t5) : "v"(m5), "v"(D34.x), "v"(d5));
+            asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u0) : "v"(d0), "v"(t0));
+            asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u5) : "v"(D12.x), "v"(t5));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b12) : "v"(b12), "v"(sc2));
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b34) : "v"(b34), "v"(sc2));
+            bv[n][0] = u0 * sc, bv[n][5] = u5 * sc;
+            bv[n][1] = b12.x, bv[n][2] = b12.y, bv[n][3] = b34.x, bv[n][4] = b34.y;
 #else
             const float d0 = fmaf(sgn, wb0[slot].y, wa0[slot].y), d1 = fmaf(sgn, wb[slot][0].x, wa[slot][0].x);
             const float d2 = fmaf(sgn, wb[slot][0].y, wa[slot][0].y), d3 = fmaf(sgn, wb[slot][1].x, wa[slot][1].x);

@@ -1,0 +1,50 @@
+"""Static checks of the generated gfx950 code of the two hot convolution kernels (no GPU needed: hipcc cross-compiles).
+
+Why they exist: in round 3 a prologue change made the compiler treat a buffer resource descriptor as divergent; every LDS-DMA
+instruction of the K loop was then wrapped in a waterfall loop (v_readfirstlane x4 + compare + s_and_saveexec), +25 % VALU per K step
+and -6 % on the whole plain-layer family, with every parity test still green.  Nothing but the ISA shows that."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+SOURCES = ("modconv_w2d", "modconv_up2d")
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa")
+
+    def build(name):
+        dst = str(out / f"{name}.s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", f"-I{REPO}/include",
+                        f"{REPO}/maua_stylegan2_amd/csrc/{name}.hip", "-o", dst], check=True, capture_output=True)
+        return name, open(dst).read()
+
+    with ThreadPoolExecutor(len(SOURCES)) as pool:
+        return dict(pool.map(build, SOURCES))
+
+
+@pytest.mark.parametrize("name", SOURCES)
+def test_lds_dma_loads_are_not_waterfalled(device_asm, name):
+    lines = device_asm[name].split("\n")
+    dma = [i for i, line in enumerate(lines) if "buffer_load" in line and " lds" in line]
+    assert dma, "the kernels stage their operands with buffer_load ... lds"
+    for i in dma:
+        before = " ".join(lines[max(0, i - 10):i])
+        assert not ("v_readfirstlane" in before and "s_and_saveexec" in before), (
+            f"{name}.hip: the LDS-DMA load at asm line {i} sits in a waterfall loop — its buffer descriptor is no longer uniform "
+            "(keep __builtin_amdgcn_make_buffer_rsrc ahead of thread-dependent prologue loops)")
+
+
+@pytest.mark.parametrize("name", SOURCES)
+def test_hot_kernels_do_not_spill(device_asm, name):
+    spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", device_asm[name])]
+    sspills = [int(v) for v in re.findall(r"\.sgpr_spill_count:\s+(\d+)", device_asm[name])]
+    assert spills and max(spills) == 0 and max(sspills) == 0, (spills, sspills)
