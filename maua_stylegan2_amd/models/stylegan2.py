@@ -67,13 +67,25 @@ class Blur(nn.Module):
         return upfirdn2d(inputs, self.kernel, pad=self.pad)
 
 
+_SKIP_INIT = [False]
+
+
+def _randn(*shape):
+    """``th.randn`` for a parameter / buffer of a module under construction.  While a ``Generator`` that was given a checkpoint builds
+    itself, every such tensor is about to be overwritten by the strict ``load_state_dict`` of its constructor: it is then left
+    uninitialised (the 30 M normal draws of a 1024^2 generator cost 0.4 s of host time, a quarter of a warm generate() of 900 frames;
+    the reference draws them and throws them away, models/stylegan2.py:455-459 — the only observable difference is that the CPU
+    generator's state is not advanced by the construction)."""
+    return th.empty(*shape) if _SKIP_INIT[0] else th.randn(*shape)
+
+
 class EqualLinear(nn.Module):
     """reference :123-146 (mapping network / standalone use; the per-layer modulations inside the generator forward
     go through the table-driven style kernel instead)."""
 
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
         super().__init__()
-        self.weight = nn.Parameter(th.randn(out_dim, in_dim).div_(lr_mul))
+        self.weight = nn.Parameter(_randn(out_dim, in_dim).div_(lr_mul))
         self.bias = nn.Parameter(th.zeros(out_dim).fill_(bias_init)) if bias else None
         self.activation = activation
         self.scale = (1 / math.sqrt(in_dim)) * lr_mul
@@ -122,7 +134,7 @@ class ModulatedConv2d(nn.Module):
             self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
         self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
         self.padding = kernel_size // 2
-        self.weight = nn.Parameter(th.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.weight = nn.Parameter(_randn(1, out_channel, in_channel, kernel_size, kernel_size))
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
         self._packed = None  # (key, wp, wsq)
@@ -310,7 +322,7 @@ class NoiseInjection(nn.Module):
 class ConstantInput(nn.Module):
     def __init__(self, channel, size=4):
         super().__init__()
-        self.input = nn.Parameter(th.randn(1, channel, size, size))
+        self.input = nn.Parameter(_randn(1, channel, size, size))
 
     def forward(self, inputs):
         return self.input.repeat(inputs.shape[0], 1, 1, 1)
@@ -580,6 +592,31 @@ class Generator(nn.Module):
     def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01,
                  constant_input=False, checkpoint=None, output_size=None, min_rgb_size=4, base_res_factor=1):
         super().__init__()
+        _SKIP_INIT[0] = checkpoint is not None  # (see _randn; reset below, also when construction fails)
+        try:
+            self._build(size, style_dim, n_mlp, channel_multiplier, blur_kernel, lr_mlp, constant_input, min_rgb_size)
+        finally:
+            _SKIP_INIT[0] = False
+        self.truncation_latent = None
+        if checkpoint is not None:
+            try:  # zip-format checkpoints are mapped instead of read (0.1 s for the 120 MB of a 1024^2 generator)
+                state = th.load(checkpoint, map_location="cpu", mmap=True)
+            except (RuntimeError, ValueError, TypeError):
+                state = th.load(checkpoint)
+            self.load_state_dict(state["g_ema"])
+        if size != output_size or base_res_factor != 1:  # reference :461-470 (resizes only the noise buffers)
+            for layer_idx in range(self.num_layers):
+                res = (layer_idx + 5) // 2
+                shape = [1, 1, int(base_res_factor * 2 ** res * (2 if output_size == 1080 else 1)),
+                         int(base_res_factor * 2 ** res * (2 if output_size == 1920 else 1))]
+                setattr(self.noises, f"noise_{layer_idx}", th.randn(*shape))
+        self._bufs = {}
+        self._retired = []  # replaced static buffers, kept alive for graphs that still reference them
+        self._captured = False
+        self._lane = 0  # static-buffer namespace: concurrent hipGraphs of one generator each own a lane
+        self._tables = {}
+
+    def _build(self, size, style_dim, n_mlp, channel_multiplier, blur_kernel, lr_mlp, constant_input, min_rgb_size):
         self.size = size
         self.style_dim = style_dim
         layers = [PixelNorm()]
@@ -604,7 +641,7 @@ class Generator(nn.Module):
         in_channel = self.channels[4]
         for layer_idx in range(self.num_layers):
             res = (layer_idx + 5) // 2
-            self.noises.register_buffer(f"noise_{layer_idx}", th.randn(1, 1, 2 ** res, 2 ** res))
+            self.noises.register_buffer(f"noise_{layer_idx}", _randn(1, 1, 2 ** res, 2 ** res))
         for i in range(3, self.log_size + 1):
             out_channel = self.channels[2 ** i]
             layerID += 1
@@ -614,20 +651,6 @@ class Generator(nn.Module):
             self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel, layerID=layerID))
             self.to_rgbs.append(ToRGB(out_channel, style_dim))
             in_channel = out_channel
-        self.truncation_latent = None
-        if checkpoint is not None:
-            self.load_state_dict(th.load(checkpoint)["g_ema"])
-        if size != output_size or base_res_factor != 1:  # reference :461-470 (resizes only the noise buffers)
-            for layer_idx in range(self.num_layers):
-                res = (layer_idx + 5) // 2
-                shape = [1, 1, int(base_res_factor * 2 ** res * (2 if output_size == 1080 else 1)),
-                         int(base_res_factor * 2 ** res * (2 if output_size == 1920 else 1))]
-                setattr(self.noises, f"noise_{layer_idx}", th.randn(*shape))
-        self._bufs = {}
-        self._retired = []  # replaced static buffers, kept alive for graphs that still reference them
-        self._captured = False
-        self._lane = 0  # static-buffer namespace: concurrent hipGraphs of one generator each own a lane
-        self._tables = {}
 
     # ------------------------------------------------------------------ helpers shared with the reference API
     def make_noise(self):
