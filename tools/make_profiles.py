@@ -7,7 +7,6 @@ import json
 import re
 import shutil
 import sqlite3
-import subprocess
 import sys
 
 O = "gpurun_out/prof_final"
