@@ -177,7 +177,8 @@ int maua_modconv3x3_f32(const float* x, const float* wp, const float* s, int s_s
  * Only for layers whose channels fit one weight tile in a single wave row (cout <= 64); returns MAUA_ENOSYS otherwise
  * (the caller then runs maua_modconv3x3_f32 + maua_torgb_f32).  rgb_s = the ToRGB layer's styles [B, s_stride] (same
  * stride as s).  frames_u8 != NULL (last layer): the image is not written as fp32 planes at all but leaves as uint8 NHWC frames
- * [B,H,W,3] = clamp(-1,1), (x+1)*127.5, truncating cast (the frame epilogue of render.py:40-43 folded in; rgb_out may be NULL).
+ * [B,H,W,3] = clamp(-1,1), (x+1)*127.5, truncating cast (the frame epilogue of render.py:40-43 folded in); rgb_out may then be NULL
+ * (the normal case) — when it is not, the fp32 planes are written as well (the parity tests compare them with the oracle in float).
  * mode = 0 (direct), 2, 3 or 5 (Winograd F(2,3) / F(4,3) / 2-D F(2x4,3x3), wp from the matching pack function).  store_features = 0 skips writing y (legal for the last layer: nothing downstream reads it). */
 int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
                               float* y, int batch, int cin, int cout, int h, int w, int mode, float wscale,

@@ -36,6 +36,12 @@ class NetworkBend(th.nn.Module):
     def capturable(self):
         return hasattr(self.sequential, "run_static")
 
+    @property
+    def sequence_rows(self):
+        """Rows of per-frame parameters the captured form indexes with frame0 + b (None: nothing per-frame); the render loop
+        requires 1 or the number of frames of the sequence before it captures (a shorter table would be read out of bounds)."""
+        return getattr(self.sequential, "sequence_rows", None)
+
 
 class AddNoise(th.nn.Module):
     def __init__(self, noise):
@@ -83,6 +89,10 @@ class AffineReflectWarp(th.nn.Module):
         self.noise = noise
         self._maps = None  # (h, w, device) -> int32 index tables, only for a real chain
         self._dev = None   # (device, batch) -> device-resident operands of the launch
+
+    @property
+    def sequence_rows(self):
+        return int(self.inv_maps.shape[0])
 
     def _operands(self, x, per_frame):
         """Device-resident operands, built on the first call for a (device, batch) and reused (so that a captured forward

@@ -963,7 +963,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
 #pragma unroll
                             for (int px = 0; px < PXN; ++px)
                                 pix[px] |= (uint32_t)((fminf(fmaxf(val[px], -1.f), 1.f) + 1.f) * 127.5f) << (8 * c);
-                            continue;
+                            if (!p.rgb_out) continue;  // (both given: the fp32 planes are written as well — the parity tests' tap)
                         }
                         float* ro = rgb_img + (size_t)c * plane_out + rgb_off;
                         if (PXN == 4 && ok1) *reinterpret_cast<f32x4u*>(ro) = f32x4{val[0], val[1 % PXN], val[2 % PXN], val[3 % PXN]};

@@ -107,7 +107,7 @@ struct W2dArgs {
     const float* rgb_skip;
     const float* rgb_k4;
     float* rgb_out;
-    uint8_t* rgb_u8;  // when set: uint8 NHWC frames [B, H, W, 3] (render.py:40-43) instead of rgb_out
+    uint8_t* rgb_u8;  // when set: uint8 NHWC frames [B, H, W, 3] (render.py:40-43); rgb_out may then be NULL
     int B, Cin, Cout, H, W;
     int s_stride;
     float wscale;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         fw[0] = pix[0] | (pix[1] << 24);
         fw[1] = (pix[1] >> 8) | (pix[2] << 16);
         fw[2] = (pix[2] >> 16) | (pix[3] << 8);
-        return;
+        if (!p.rgb_out) return;  // (both given: the fp32 planes are written as well — the parity tests' tap)
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(rgb_img + (size_t)c * rgb_plane + pix_off) = outc[c];

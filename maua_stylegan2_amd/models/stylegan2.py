@@ -67,7 +67,9 @@ class Blur(nn.Module):
         return upfirdn2d(inputs, self.kernel, pad=self.pad)
 
 
-_SKIP_INIT = [False]
+import threading  # noqa: E402
+
+_SKIP_INIT = threading.local()  # .on: set only on the thread that is building a Generator from a checkpoint
 
 
 def _randn(*shape):
@@ -76,7 +78,7 @@ def _randn(*shape):
     uninitialised (the 30 M normal draws of a 1024^2 generator cost 0.4 s of host time, a quarter of a warm generate() of 900 frames;
     the reference draws them and throws them away, models/stylegan2.py:455-459 — the only observable difference is that the CPU
     generator's state is not advanced by the construction)."""
-    return th.empty(*shape) if _SKIP_INIT[0] else th.randn(*shape)
+    return th.empty(*shape) if getattr(_SKIP_INIT, "on", False) else th.randn(*shape)
 
 
 class EqualLinear(nn.Module):
@@ -469,7 +471,8 @@ class StyledConv(nn.Module):
                         cin, conv.out_channel, h, w, mode, float(conv.scale), _lib.ptr(noise), nstride,
                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
                         s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), t.bias.data_ptr(), _lib.ptr(skip),
-                        _lib.ptr(t.upsample.kernel) if skip is not None else None, rgb["out"].data_ptr(),
+                        _lib.ptr(t.upsample.kernel) if skip is not None else None,
+                        rgb["out"].data_ptr() if (rgb.get("u8") is None or rgb.get("tap")) else None,
                         int(rgb.get("store", True)), _lib.ptr(rgb.get("u8")), src, slot, _lib.stream_ptr(x.device))
                     if rc == 0:
                         rgb["done"] = True
@@ -592,18 +595,24 @@ class Generator(nn.Module):
     def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01,
                  constant_input=False, checkpoint=None, output_size=None, min_rgb_size=4, base_res_factor=1):
         super().__init__()
-        _SKIP_INIT[0] = checkpoint is not None  # (see _randn; reset below, also when construction fails)
+        _SKIP_INIT.on = checkpoint is not None  # (see _randn; thread-local; reset below, also when construction fails)
         try:
             self._build(size, style_dim, n_mlp, channel_multiplier, blur_kernel, lr_mlp, constant_input, min_rgb_size)
         finally:
-            _SKIP_INIT[0] = False
+            _SKIP_INIT.on = False
         self.truncation_latent = None
         if checkpoint is not None:
             try:  # zip-format checkpoints are mapped instead of read (0.1 s for the 120 MB of a 1024^2 generator)
                 state = th.load(checkpoint, map_location="cpu", mmap=True)
             except (RuntimeError, ValueError, TypeError):
                 state = th.load(checkpoint)
-            self.load_state_dict(state["g_ema"])
+            # the tensors above were left uninitialised: EVERY parameter and buffer must come from the checkpoint (strict load,
+            # and the key sets are compared explicitly so that a later relaxation to strict=False cannot leave garbage weights)
+            missing = set(self.state_dict().keys()) - set(state["g_ema"].keys())
+            if missing:
+                raise RuntimeError(f"checkpoint {checkpoint!r} lacks {sorted(missing)[:5]} ... ({len(missing)} tensors): the generator "
+                                   "was built without initial values and cannot be completed from it")
+            self.load_state_dict(state["g_ema"], strict=True)
         if size != output_size or base_res_factor != 1:  # reference :461-470 (resizes only the noise buffers)
             for layer_idx in range(self.num_layers):
                 res = (layer_idx + 5) // 2
@@ -616,6 +625,10 @@ class Generator(nn.Module):
         self._captured = False
         self._lane = 0  # static-buffer namespace: concurrent hipGraphs of one generator each own a lane
         self._tables = {}
+
+    # parity-test tap: a forward that writes uint8 frames from the last layer's epilogue ALSO leaves the fp32 image of the last
+    # resolution (``GraphLane.image``) — the same kernel instance writes both, so the float comparison sees exactly what became the frame
+    tap_float_image = False
 
     def _build(self, size, style_dim, n_mlp, channel_multiplier, blur_kernel, lr_mlp, constant_input, min_rgb_size):
         self.size = size
@@ -763,8 +776,11 @@ class Generator(nn.Module):
                 latent = latent[:, None, :].repeat(1, self.n_latent, 1)
         latent = _lib.require_cuda(latent.to(dev), "styles")
         batch = latent.shape[0]
-        if latent.dim() != 3 or tuple(latent.shape[1:]) != (self.n_latent, self.style_dim):
-            raise RuntimeError(f"styles {tuple(latent.shape)} do not match [batch, {self.n_latent}, {self.style_dim}]")
+        # the reference only indexes latent[:, i] for i < n_latent (:549-569): surplus rows — an 18-layer latent file fed to a
+        # 256-px generator — are legal and ignored; the kernels take the row count as a stride
+        if latent.dim() != 3 or latent.shape[1] < self.n_latent or latent.shape[2] != self.style_dim:
+            raise RuntimeError(f"styles {tuple(latent.shape)} do not match [batch, >= {self.n_latent}, {self.style_dim}]")
+        latent = latent.contiguous()
 
         noise = list(noise) if noise is not None else [None] * self.num_layers
         for ns in range(self.num_layers):
@@ -814,7 +830,8 @@ class Generator(nn.Module):
         bufs = lambda name, shape: self._buf(batch, name, shape)  # noqa: E731
         s = bufs("styles", (batch, info["s_total"]))
         d = bufs("demod", (info["d_total"],))
-        _lib.check(lib.maua_style_affine_f32(_lib.ptr(latent), batch, self.n_latent, self.style_dim, _lib.ptr(trunc),
+        lat_rows = self.n_latent if latent is None else latent.shape[1]  # row stride of the latents (surplus rows are skipped)
+        _lib.check(lib.maua_style_affine_f32(_lib.ptr(latent), batch, lat_rows, self.style_dim, _lib.ptr(trunc),
                                              _lib.ptr(tl), info["table"].data_ptr(), len(info["entries"]),
                                              info["max_cin"], s.data_ptr(), info["s_total"], src, st), "maua_style_affine_f32")
         _lib.check(lib.maua_demod_f32(info["table"].data_ptr(), len(info["entries"]), info["max_cout"], s.data_ptr(),
@@ -872,7 +889,7 @@ class Generator(nn.Module):
             is_last = n == self.log_size - 3
             if wants_rgb and not bent and not getattr(self, "disable_rgb_fusion", False):
                 fuse = dict(module=rgb, s_off=ent[li + 1]["s_off"], skip=image, out=rgb_buf,
-                            store=(not is_last) or want_acts, u8=frames_u8 if is_last else None)
+                            store=(not is_last) or want_acts, u8=frames_u8 if is_last else None, tap=self.tap_float_image)
             out = plain.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 2, out.shape[2], out.shape[3]),
                             bufs, f"convs.{2 * n + 1}", rgb=fuse, src=src, slot=2 * n + 2)
             out = plain.manipulation.run(out, bends, bufs, f"convs.{2 * n + 1}", src)
@@ -880,7 +897,7 @@ class Generator(nn.Module):
             li += 1
             if fuse is not None and fuse.get("done"):
                 image = rgb_buf
-                if is_last and frames_u8 is not None and fuse.get("u8_done", True):
+                if is_last and frames_u8 is not None and fuse.get("u8_done", True) and not self.tap_float_image:
                     image = None  # left the device path as uint8 frames
             elif wants_rgb:
                 image = rgb.run(out, s, ent[li]["s_off"], image, rgb_buf)
@@ -963,8 +980,12 @@ class FrameSource:
         n_frames = latents.shape[0] if _n_frames is None else _n_frames
         host = _lib.FrameSource()
         latents = _lib.require_cuda(latents, "latents")
-        if latents.dim() != 3 or tuple(latents.shape[1:]) != (g.n_latent, g.style_dim):
-            raise RuntimeError(f"latents {tuple(latents.shape)} do not match [n_frames, {g.n_latent}, {g.style_dim}]")
+        if latents.dim() != 3 or latents.shape[1] < g.n_latent or latents.shape[2] != g.style_dim:
+            raise RuntimeError(f"latents {tuple(latents.shape)} do not match [n_frames, >= {g.n_latent}, {g.style_dim}]")
+        if latents.shape[1] != g.n_latent or not latents.is_contiguous():
+            # surplus rows (the reference only indexes latent[:, i], i < n_latent): the captured kernels have the row stride
+            # n_latent baked in, so the sequence is cut once per render
+            latents = latents[:, :g.n_latent].contiguous()
         host.latents = latents.data_ptr()
         keep = [latents]
         if trunc is not None:

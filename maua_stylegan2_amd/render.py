@@ -163,9 +163,10 @@ def graph_lanes(generator, batch_size, n_lanes, bends=()):
     key = generator.weights_key()
     cache = generator.__dict__.setdefault("_graph_lanes", {})
     lanes = []
+    tap = bool(getattr(generator, "tap_float_image", False))  # (parity tests: such lanes also write the fp32 image — other kernels arguments)
     for k in range(n_lanes):
         stream = _lane_stream(dev, k)
-        lane = None if bends else cache.get((batch_size, k))
+        lane = None if bends else cache.get((batch_size, k, tap))
         if lane is not None and lane.weights_key != key:
             lane = None
         if lane is None:
@@ -174,7 +175,7 @@ def graph_lanes(generator, batch_size, n_lanes, bends=()):
                 lane = generator.capture_graph(batch_size, lane=k, frames_u8=True, bends=bends)
             stream.synchronize()
             if not bends:
-                cache[(batch_size, k)] = lane
+                cache[(batch_size, k, tap)] = lane
         lanes.append((stream, lane))
     return lanes
 
@@ -195,14 +196,20 @@ def prepare(generator, batch_size, lanes=3, bends=False):
     return len(graph_lanes(generator, batch_size, lanes))
 
 
-def _sequence_bends(bends):
+def _sequence_bends(bends, n_frames=None):
     """The render's bends with every modulated transform instantiated ONCE on the modulation of the whole sequence (the reference
     rebuilds it per batch from the batch's slice, render.py:151-158).  Returns (bends, capturable): capturable when every
-    transform implements ``run_static`` (audioreactive/bend.py: picks the frame's parameters on the device)."""
+    transform implements ``run_static`` (audioreactive/bend.py: picks the frame's parameters on the device) and — ``n_frames``
+    given — its per-frame table has one row or one row per frame of the sequence: the captured kernel indexes it with
+    frame0 + b unchecked, so anything else (a modulation shorter than the frame range, an un-modulated transform built with
+    [batch, k] parameters) keeps the eager per-batch path, which slices and validates like the reference."""
     out, capturable = [], True
     for bend in bends:
         transform = bend["transform"](bend["modulation"]) if "modulation" in bend else bend["transform"]
         if not hasattr(transform, "run_static") or not getattr(transform, "capturable", True):
+            return None, False
+        rows = getattr(transform, "sequence_rows", None)
+        if n_frames is not None and rows is not None and rows not in (1, n_frames):
             return None, False
         out.append({"layer": bend["layer"], "transform": transform})
     return out, capturable
@@ -249,7 +256,7 @@ def synthesize(generator, latents, noise, batch_size, truncation=1.0, bends=(), 
     capturable = use_graph and not rewrites and not randomize_noise and hasattr(generator, "capture_graph")
     seq_bends = []
     if capturable and bends:
-        seq_bends, capturable = _sequence_bends(bends) if getattr(generator, "capturable_bends", True) else (None, False)
+        seq_bends, capturable = _sequence_bends(bends, n_total) if getattr(generator, "capturable_bends", True) else (None, False)
     n_lanes = max(1, int(lanes)) if capturable else 1
     caller_stream = th.cuda.current_stream(dev)
     lane_state = []  # (stream, GraphLane or None)

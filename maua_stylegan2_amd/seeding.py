@@ -98,12 +98,17 @@ def seeded_array(seed, name, shape, std=1.0, mean=0.0):
     return a
 
 
-def seeded_state_dict(size, seed=0, style_dim=512, n_mlp=8, channel_multiplier=2, constant_input=True):
+def seeded_state_dict(size, seed=0, style_dim=512, n_mlp=8, channel_multiplier=2, constant_input=True, rgb_gain=1.0):
     """Random-init-like checkpoint with *non-trivial* noise strengths and biases.
 
     The reference's random init has noise.weight = activate.bias = ToRGB.bias = 0
     (models/stylegan2.py:260,354; op/fused_act.py:78), which would leave those paths untested
     (SURVEY.md §7 "Hard parts"); here they are N(0, 0.1) around their init value.
+
+    ``rgb_gain``: factor on every ToRGB weight and bias.  The image is linear in them (ToRGB is not demodulated,
+    models/stylegan2.py:352,356-365), so the generator's output is exactly ``rgb_gain`` times the plain checkpoint's.  With N(0,1)
+    ToRGB weights a 1024^2 image has a standard deviation of ~3: three quarters of its pixels clamp to 0 / 255 in the uint8
+    frame (render.py:40-43), where a comparison of frames sees nothing.  The whole-frame parity tests use ``UNSATURATED_RGB_GAIN``.
     """
     sd = OrderedDict()
     for key, shape in generator_tensor_shapes(size, style_dim, n_mlp, channel_multiplier, constant_input).items():
@@ -119,8 +124,24 @@ def seeded_state_dict(size, seed=0, style_dim=512, n_mlp=8, channel_multiplier=2
             arr = seeded_array(seed, key, shape, std=0.1)
         else:
             arr = seeded_array(seed, key, shape)
+        if rgb_gain != 1.0 and key.startswith("to_rgb") and (key.endswith(".conv.weight") or (key.endswith(".bias") and len(shape) == 4)):
+            arr = arr * np.float32(rgb_gain)
         sd[key] = torch.from_numpy(np.ascontiguousarray(arr))
     return sd
+
+
+def unsaturated_rgb_gain(size):
+    """ToRGB gain of the whole-frame parity tests: the seeded generator's image then has a standard deviation of ~0.4 (measured std
+    at gain 1: 0.93 / 1.69 / 3.0 at 64 / 256 / 1024 px), i.e. the uint8 frame uses the whole grey range and < 5 % of it clamps."""
+    return min(1.0, 0.4 / (0.93 * (size / 64.0) ** 0.42))
+
+
+def clamped_fraction(image):
+    """Share of the values of a float image (or of a uint8 frame) that sit on the clamp of render.py:40-43."""
+    a = image.detach().cpu().numpy() if hasattr(image, "detach") else np.asarray(image)
+    if a.dtype == np.uint8:
+        return float(((a == 0) | (a == 255)).mean())
+    return float((np.abs(a) >= 1.0).mean())
 
 
 def seeded_latents(n, n_latent, seed=1, style_dim=512):

@@ -43,19 +43,23 @@ def broadcast_module(module, src=0):
     if world == 1:
         return module
     by_dtype = {}
+    # (the tensors themselves, not .data: copy_ below then advances their version counters, which is what the packed-weight cache,
+    # the style tables and the graph lanes are keyed on — a second broadcast into a generator that has already packed / captured
+    # must invalidate them)
     for t in list(module.parameters()) + list(module.buffers()):
-        by_dtype.setdefault(t.dtype, []).append(t.data)
+        by_dtype.setdefault(t.dtype, []).append(t)
     for dtype in sorted(by_dtype, key=str):
         tensors = by_dtype[dtype]
         flat = th.empty(sum(t.numel() for t in tensors), dtype=dtype, device=tensors[0].device)
-        if rank == src:
-            th.cat([t.reshape(-1) for t in tensors], out=flat)
-        dist.broadcast(flat, src)
-        if rank != src:
-            off = 0
-            for t in tensors:
-                t.copy_(flat[off: off + t.numel()].view_as(t))
-                off += t.numel()
+        with th.no_grad():
+            if rank == src:
+                th.cat([t.detach().reshape(-1) for t in tensors], out=flat)
+            dist.broadcast(flat, src)
+            if rank != src:
+                off = 0
+                for t in tensors:
+                    t.copy_(flat[off: off + t.numel()].view_as(t))
+                    off += t.numel()
     return module
 
 

@@ -281,3 +281,33 @@ def test_stylegan1_synthesis_matches_reference_golden(gpu, golden):
     wrong[2] = torch.zeros(1, 1, 8, 8, device=gpu)
     with pytest.raises(RuntimeError, match="noise"):
         g(styles=styles.to(gpu), noise=wrong)
+
+
+def test_surplus_latent_rows_are_ignored_as_in_the_reference(gpu):
+    """The reference forward only indexes ``latent[:, i]`` for i < n_latent (models/stylegan2.py:549-569), so an 18-layer latent
+    file fed to a smaller generator works there.  Eager forward (row stride taken from the tensor) and captured lanes (sequence cut
+    once per render) must give exactly what the first n_latent rows give; fewer rows than n_latent raise."""
+    from maua_stylegan2_amd import render
+
+    size, n, bs = 64, 6, 2
+    g = build(size, gpu, 2)
+    assert g.n_latent == 10
+    lat18 = seeding.seeded_latents(n, 18, seed=31)
+    lat10 = lat18[:, :10].contiguous()
+    noise = seeding.seeded_noise(n, size, seed=32)
+    a, _ = g(styles=lat18[:bs].to(gpu), noise=[z[:bs].to(gpu) for z in noise], randomize_noise=False, input_is_latent=True)
+    b, _ = g(styles=lat10[:bs].to(gpu), noise=[z[:bs].to(gpu) for z in noise], randomize_noise=False, input_is_latent=True)
+    assert torch.equal(a, b)
+    _, lat_out = g(styles=lat18[:bs].to(gpu), noise=[z[:bs].to(gpu) for z in noise], randomize_noise=False, input_is_latent=True,
+                   return_latents=True)
+    assert tuple(lat_out.shape) == (bs, 18, 512)  # handed back as given (:571-572)
+
+    def frames(lat):
+        out = np.zeros((n, size, size, 3), np.uint8)
+        for first, u8 in render.synthesize(g, lat, noise, bs, lanes=2):
+            out[first: first + u8.shape[0]] = u8.cpu().numpy()
+        return out
+
+    assert np.array_equal(frames(lat18), frames(lat10))
+    with pytest.raises(RuntimeError, match="do not match"):
+        g(styles=lat18[:bs, :9].to(gpu), noise=None, randomize_noise=False, input_is_latent=True)

@@ -246,8 +246,10 @@ def test_chroma_chain_oracle_properties():
 def test_ar_namespace_covers_the_shipped_example_plugins(tmp_path, monkeypatch):
     """Every ``ar.<name>`` the reference's example plugins use (default / temper / kelp / tauceti: onsets, chroma, rms,
     gaussian_filter, spline_loops, wrapping_slice, perlin_noise, AddNoise, plot_signals, ...) exists in the drop-in package.
-    The matplotlib inspection helpers (audioreactive/util.py, SURVEY.md §2 row 10: out of scope) are warn-and-ignore stubs, so
-    that an unmodified plugin that calls them (examples/kelp.py:33) still runs."""
+    The inspection helpers of audioreactive/util.py (diagnostics, not on the hot path) exist with matplotlib
+    imported lazily: ``ar.info`` prints array statistics as the reference's does (util.py:11-21), ``from audioreactive.util import
+    ...`` works in a plugin, and a plot call (examples/kelp.py:33) draws to workspace/ without a display — or warns and returns
+    when matplotlib is missing."""
     import maua_stylegan2_amd.audioreactive as ar
 
     used = ["gaussian_filter", "onsets", "chroma", "chroma_weight_latents", "wrapping_slice", "spline_loops", "rms",
@@ -256,9 +258,27 @@ def test_ar_namespace_covers_the_shipped_example_plugins(tmp_path, monkeypatch):
             "slerp_loops", "generate_latents", "save_latents", "NetworkBend", "Translate", "Zoom", "Rotate", "set_SMF"]
     assert [n for n in used if not hasattr(ar, n)] == []
     monkeypatch.chdir(tmp_path)
-    with pytest.warns(UserWarning, match="out of scope"):
-        assert ar.plot_signals([np.sin(np.linspace(0, 6, 100)), torch.linspace(0, 1, 50)]) is None
-    assert not (tmp_path / "workspace").exists()
+    monkeypatch.delenv("DISPLAY", raising=False)
+    from maua_stylegan2_amd.audioreactive.util import info, plot_signals  # the import form plugins use
+
+    assert plot_signals is ar.plot_signals
+    import contextlib
+    import io
+
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        info(np.arange(6.0).reshape(2, 3))
+        info([torch.ones(3), np.zeros((2, 2))])
+    assert out.getvalue().splitlines() == ["[2, 3] 0.00 2.50 5.00", "[([3], '1.00', '1.00', '1.00'), ([2, 2], '0.00', '0.00', '0.00')]"]
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        with pytest.warns(UserWarning, match="matplotlib"):
+            assert ar.plot_signals([np.sin(np.linspace(0, 6, 100))]) is None
+    else:
+        with contextlib.redirect_stdout(io.StringIO()):
+            path = ar.plot_signals([np.sin(np.linspace(0, 6, 100)), torch.linspace(0, 1, 50)])
+        assert path is not None and (tmp_path / path).exists()
 
 
 def test_generator_constructor_bookkeeping_matches_reference(built_lib, golden):

@@ -52,8 +52,11 @@ def _worker(rank, world, port, n_frames, out_dir):
         if rank == 0:
             with torch.no_grad():
                 lin.weight.fill_(1.25), lin.bias.fill_(-0.5)
+        versions = (lin.weight._version, lin.kernel._version)
         sharding.broadcast_module(lin)
         assert float(lin.weight.sum()) == 1.25 * 12 and float(lin.kernel.sum()) == 0.0
+        if rank != 0:  # the receivers' tensors changed: their version counters (key of the packed-weight / graph caches) must say so
+            assert lin.weight._version > versions[0] and lin.kernel._version > versions[1]
         tl = torch.full((1, 8), float(rank + 7))
         sharding.broadcast_tensor(tl)
         assert float(tl[0, 0]) == 7.0
