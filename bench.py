@@ -12,8 +12,11 @@ the render.py:40-43 epilogue), batches alternating over `--lanes` graphs on thei
 does.  Frames are independent, so ranks shard them with no data-path collective (weak scaling: Q * B frames per rank per step).
 Weights are random-init (seeded numpy streams) of the real 1024^2 architecture; arithmetic is fp32 end to end.
 
-Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the frame (largest share of device time, measured
-live with HIP events on the launch stream); `roofline_upfirdn2d` is the standalone upfirdn2d op on the Blur-after-
+Rank 0 prints ONE JSON line.  `roofline` is the single launch with the largest device time (measured live with HIP events on
+the launch stream): `achieved` / `frac` count the flops the matrix cores EXECUTED (the Winograd forms issue a fraction of the
+direct form's multiplies), the SURVEY-8d direct-conv figure sits under `roofline.algorithmic`; `roofline_time_dominant` is the
+kernel instance with the largest share of the serial forward (all its launches of a batch), `conv_kernel_instances` the same
+for every conv instance; `roofline_upfirdn2d` is the standalone upfirdn2d op on the Blur-after-
 up-conv shape that carries 49 % of the path's upfirdn2d bytes, which BASELINE.json's metric names.
 `side_configs` times BASELINE configs 2 (256^2 generator) and 5 (1024^2 with per-frame Translate + Zoom network bends,
 captured) on this GPU.  `cpu_baseline` times oracle/ (the CPU restatement pinned to the reference by tests/golden) on the
@@ -37,6 +40,16 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+# conv mode (ModulatedConv2d.conv_mode) -> (multiplies the matrix cores execute / direct-form multiplies, description)
+EXECUTED = {
+    0: (1.0, "direct implicit GEMM"),
+    1: (1.0, "polyphase transposed conv: exactly the reference's multiplies"),
+    2: (2.0 / 3.0, "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic"),
+    3: (0.5, "winograd F(4,3) along x: executed MFMA flops = 1/2 algorithmic"),
+    4: (30.0 / 36.0, "polyphase transposed conv with F(2,2) on the even x-phase: executed MFMA flops = 30/36 algorithmic"),
+    5: (1.0 / 3.0, "2-D winograd F(2x4,3x3): executed MFMA flops = 1/3 algorithmic"),
+    6: (25.0 / 36.0, "polyphase transposed conv with F(2,2) on both axes: executed MFMA flops = 25/36 algorithmic"),
+}
 POOL = 64  # distinct batches of the HBM-resident sequence (POOL * B frames), cycled through
 
 
@@ -196,14 +209,26 @@ def cpu_baseline(size, budget_s=90.0):
     if size != 256 and time.perf_counter() - t_start < budget_s * 0.7:
         legs[f"{size}_b8"] = leg(size, 8, 8, 1, 0)
     head = legs[f"{size}_b1"] if size != 256 else legs["config1_256_b8"]
-    cpu_model = "unknown"
+    cpu_model, topo = "unknown", {}
     try:
         with open("/proc/cpuinfo") as f:
-            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), cpu_model)
-    except OSError:
+            text = f.read()
+        cpu_model = next((ln.split(":", 1)[1].strip() for ln in text.splitlines() if ln.startswith("model name")), cpu_model)
+        cores, sockets, logical = set(), set(), 0
+        for block in text.split("\n\n"):
+            kv = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in block.splitlines() if ":" in ln}
+            if "processor" in kv:
+                logical += 1
+                sockets.add(kv.get("physical id", "0"))
+                cores.add((kv.get("physical id", "0"), kv.get("core id", kv["processor"])))
+        topo = {"sockets": len(sockets), "physical_cores": len(cores), "logical_cpus": logical,
+                "smt": (logical // max(len(cores), 1)) if cores else None}
+    except (OSError, IndexError):
         pass
-    return {"value": head["frames_per_s_mean"], "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model,
-            "kind": "port",
+    threads = torch.get_num_threads()
+    return {"value": head["frames_per_s_mean"], "unit": "frames/s", "cores": threads, "cpu_model": cpu_model,
+            "cores_definition": "intra-op threads torch used for the oracle (torch.get_num_threads()); host topology under `host`",
+            "host": topo, "kind": "port",
             "sample": (f"oracle/stylegan2_oracle.py (torch CPU fp32): {head['repetitions']} x {head['frames_per_repetition']} frame(s) of "
                        f"{size}x{size} at batch {head['batch']} after 1 warm-up (value = mean); legs = the other BASELINE.md §4 cases"),
             "legs": legs, "seconds": time.perf_counter() - t_start}
@@ -485,6 +510,36 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # a side measurement must not take the headline down
                 sides[name] = {"error": repr(exc)}
+        # --stylegan1 (models/stylegan1.py G_style at 1024 px, random init): frames through render.synthesize's captured lanes
+        try:
+            from maua_stylegan2_amd import render
+            from maua_stylegan2_amd.models import stylegan1 as sg1
+
+            torch.manual_seed(7)
+            g1 = sg1.G_style(output_size=1024, checkpoint=None, network_resolution=1024).to(dev).eval()
+            n1 = 12 * B
+            lat1 = torch.randn(n1, 18, 512, device=dev)
+            noise1 = [torch.randn(n1, 1, *getattr(g1, f"noise_{i}").shape[2:], device=dev) if getattr(g1, f"noise_{i}").shape[-1] <= 256 else None
+                      for i in range(len(g1.g_synthesis.blocks))]
+
+            def run_sg1():
+                last = None
+                for _, u8 in render.synthesize(g1, lat1, noise1, B, truncation=0.7, lanes=n_lanes):
+                    last = u8
+                torch.cuda.synchronize(dev)
+                return last
+
+            run_sg1()  # captures the lanes
+            t0 = time.perf_counter()
+            run_sg1()
+            dt = time.perf_counter() - t0
+            sides["stylegan1_1024"] = {"frames_per_s": n1 / dt, "timed_region_s": dt, "frames": n1, "lanes": n_lanes,
+                                       "what": "G_style (random init, 1024 px network) through render.synthesize: captured forward per batch, "
+                                               "per-frame noise <= 256^2, truncation 0.7; the lanes copy their batch's inputs per replay (DESIGN 7)"}
+            del g1
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            sides["stylegan1_1024"] = {"error": repr(exc)}
         if "frames_per_s" in sides.get("config5_1024_bends", {}):
             sides["config5_1024_bends"]["relative_to_plain"] = sides["config5_1024_bends"]["frames_per_s"] / (fps / world)
         result["side_configs"] = sides
@@ -514,39 +569,39 @@ def main():
                                                  "tflops": v[1] / v[0] / 1e9, "gbs": v[2] / v[0] / 1e6}
                                              for k, v in fam.items()}
                 result["layers"] = [{"name": n, "ms": ms, "tflops": fl / ms / 1e9, "gbs": by / ms / 1e6} for n, _, ms, fl, by in rows]
-                # dominant kernel instance = the single launch with the largest time
+                # ---- roofline of the conv kernels.  `frac` is what the matrix cores EXECUTED over the fp32-MFMA peak (the Winograd /
+                # polyphase forms issue 1/3 .. 25/36 of the direct form's multiplies); the SURVEY-8d figure in algorithmic direct-conv
+                # flops sits under `algorithmic` (its ratio to the peak can exceed 1 and is not an occupancy).
+                def mode_of(row_name):
+                    base = row_name.split("+")[0].split(" ")[0]
+                    n_conv = int(base.split(".")[1]) if base.startswith("convs.") else None
+                    if n_conv is None:
+                        return 0
+                    if "upconv" in base:
+                        res = 4 * 2 ** (n_conv // 2)
+                    else:
+                        res = 4 * 2 ** ((n_conv + 1) // 2)
+                    return g.convs[n_conv].conv.conv_mode(res, res)
+
+                def roof(name, ms, algo_flops, ratio, algo_text):
+                    ach = algo_flops * ratio / ms / 1e9
+                    return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
+                            "achieved_definition": "flops the matrix cores executed (algorithmic direct-conv flops x executed_ratio) / launch duration",
+                            "executed_ratio": ratio, "algorithm": algo_text,
+                            "algorithmic": {"flops": algo_flops, "achieved": algo_flops / ms / 1e9,
+                                            "frac": algo_flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                                            "note": "direct-conv flops as SURVEY 8d / BASELINE.md 3.1 count them; can exceed the peak"}}
+
+                conv_rows = [r for r in rows if r[1].startswith("modconv")]
+                # (a) the single launch with the largest device time
                 dom = max(rows, key=lambda r: r[2])
                 if dom[1].startswith("modconv"):
-                    ach = dom[3] / dom[2] / 1e9
                     inst = INSTANCES.get(dom[0])
-                    result["roofline"] = {"kernel": f"{(inst or 'modconv').split('<')[0]} ({dom[0]})", "bound": "mfma", "achieved": ach,
-                                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                                          "traffic": None, "launch_ms": dom[2]}
-                    # `achieved` counts ALGORITHMIC flops (direct 3x3).  The Winograd forms issue fewer multiplies
-                    # per output: say what the matrix cores actually executed as well, so that the fraction is not mistaken for MFMA occupancy.
-                    base = dom[0].split("+")[0].split(" ")[0]
-                    ratio, algo = None, None
-                    if base.startswith("convs.") and "upconv" not in base:
-                        n_conv = int(base.split(".")[1])
-                        res = 4 * 2 ** ((n_conv + 1) // 2)
-                        mode = g.convs[n_conv].conv.conv_mode(res, res)
-                        ratio = {2: 2.0 / 3.0, 3: 0.5, 5: 1.0 / 3.0}.get(mode)
-                        algo = {2: "winograd F(2,3) along x: executed MFMA flops = 2/3 algorithmic",
-                                3: "winograd F(4,3) along x: executed MFMA flops = 1/2 algorithmic",
-                                5: "2-D winograd F(2x4,3x3): executed MFMA flops = 1/3 algorithmic"}.get(mode)
-                    elif base.startswith("convs.") and "upconv" in base:
-                        n_conv = int(base.split(".")[1])
-                        res = 4 * 2 ** (n_conv // 2)
-                        mode = g.convs[n_conv].conv.conv_mode(res, res)
-                        ratio = {4: 30.0 / 36.0, 6: 25.0 / 36.0}.get(mode)
-                        algo = {4: "polyphase transposed conv with F(2,2) on the even x-phase: executed MFMA flops = 30/36 algorithmic",
-                                6: "polyphase transposed conv with F(2,2) on both axes: executed MFMA flops = 25/36 algorithmic"}.get(mode)
-                    if ratio is not None:
-                        result["roofline"]["algorithm"] = (algo + " (frac counts algorithmic direct-conv flops as SURVEY 8d defines them and can "
-                                                           "therefore exceed 1; executed_frac is what the matrix cores did)")
-                        result["roofline"]["executed"] = ach * ratio
-                        result["roofline"]["executed_frac"] = ach * ratio / MFMA_F32_PEAK_TFLOPS
+                    ratio, algo = EXECUTED.get(mode_of(dom[0]), (1.0, "direct form"))
+                    result["roofline"] = roof(f"{(inst or 'modconv').split('<')[0]} ({dom[0]})", dom[2], dom[3], ratio, algo)
                     result["roofline"]["kernel_instance"] = inst
+                    result["roofline"]["what"] = "the single launch with the largest device time (isolated, HIP events on the launch stream)"
                     table, table_path = pmc_traffic_table()
                     rec = (table or {}).get("kernels", {}).get(inst) if inst else None
                     if rec is not None and table.get("batch") == B and table.get("size") == size and rec.get("dispatches_per_step") == 1:
@@ -565,6 +620,28 @@ def main():
                     ach = dom[4] / dom[2] / 1e6
                     result["roofline"] = {"kernel": dom[0], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": dom[2]}
+                # (b) the kernel INSTANCE with the largest share of the serial forward (all its launches of one batch together)
+                by_inst = {}
+                for name, family, ms, flops, byts in conv_rows:
+                    inst = INSTANCES.get(name) or family
+                    ratio = EXECUTED.get(mode_of(name), (1.0, ""))[0]
+                    acc = by_inst.setdefault(inst, {"ms": 0.0, "algo": 0.0, "exec": 0.0, "layers": []})
+                    acc["ms"] += ms
+                    acc["algo"] += flops
+                    acc["exec"] += flops * ratio
+                    acc["layers"].append(name)
+                if by_inst:
+                    inst, acc = max(by_inst.items(), key=lambda kv: kv[1]["ms"])
+                    result["roofline_time_dominant"] = {
+                        "kernel_instance": inst, "layers": acc["layers"], "ms_per_batch": acc["ms"], "share_of_serial_forward": acc["ms"] / total_ms,
+                        "bound": "mfma", "achieved": acc["exec"] / acc["ms"] / 1e9, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": acc["exec"] / acc["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                        "algorithmic": {"achieved": acc["algo"] / acc["ms"] / 1e9, "frac": acc["algo"] / acc["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS},
+                        "what": "all launches of this template instance in one forward (isolated launch times summed); achieved = executed flops"}
+                    result["conv_kernel_instances"] = {
+                        k: {"ms_per_batch": v["ms"], "share_of_serial_forward": v["ms"] / total_ms, "executed_tflops": v["exec"] / v["ms"] / 1e9,
+                            "executed_frac": v["exec"] / v["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS, "algorithmic_tflops": v["algo"] / v["ms"] / 1e9,
+                            "layers": v["layers"]} for k, v in sorted(by_inst.items(), key=lambda kv: -kv[1]["ms"])}
             # standalone upfirdn2d on the largest Blur shape of this generator (the op BASELINE.json's metric names)
             r_out = size
             xin = torch.randn(B, 32 if size == 1024 else 128, r_out + 1, r_out + 1, device=dev)

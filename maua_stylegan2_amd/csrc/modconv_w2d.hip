@@ -36,10 +36,11 @@
 #define MAUA_DEVICE_PASS 1
 #endif
 
-// compile-time ablation mask (tools/build_exp.sh w2dabl -DMAUA_W2D_ABL=<mask>): 1 no MFMA, 2 no DMA after the first chunk, 4 no feature stores,
-// 8 no epilogue, 256 no ToRGB tail after the passes, 512 no combine phase (barriers and the A_x^T / exchange writes stay, so the
-// accumulators remain live).  0 in the product.  (Run-time switches inside the main loop disturb the MFMA stream they are meant to measure: the
-// run-time mask maua_tuning_set(3, .) selects a separate instantiation, DBG = true.)
+// Compile-time ablation mask, experiment builds only (tools/build_exp.sh <name> -DMAUA_W2D_ABL=<mask>; results are wrong by construction,
+// the timing is an upper bound of what optimising that part could return): 1 no MFMA, 2 no DMA after the first chunk, 4 no feature
+// stores, 8 no epilogue, 16 no K-step barrier, 32 no input transform (raw window values feed the MFMAs), 64 no window reads, 128 half the weight DMA pieces, 1024 no patch DMA,
+// 256 no ToRGB tail after the passes, 512 no combine phase (barriers and the A_x^T / exchange writes stay, so the accumulators
+// remain live).  0 in the product, which carries no run-time switch of any kind.
 #ifndef MAUA_W2D_ABL
 #define MAUA_W2D_ABL 0
 #endif
@@ -119,16 +120,25 @@ struct W2dArgs {
     float rgb_wscale;
     const maua_frame_source_t* src;  // frame source (include/maua_hip.h): noise from src->noise[noise_slot] at frame src->frame0
     int noise_slot;
-    int debug;  // ablation switches (maua_tuning_set key 3): 1 skip MFMA, 2 skip the DMA of every chunk after the first, 4 skip stores, 8 no epilogue
 };
 
 __host__ __device__ constexpr int w2d_dma_per_channel(int tn) { return (4 * tn + 2 + W2D_ROWS_PER_DMA - 1) / W2D_ROWS_PER_DMA; }
 __host__ __device__ constexpr int w2d_pstride(int tn) {
-    // floats per channel of the staged patch: whole DMA instructions (the last one runs 16 floats past its fifth row).  Planes
-    // stay 16-byte aligned for the DMA, which leaves the 8-byte window reads of the two K lane groups of a half-wave on the
-    // same banks (2-way) and the 4-byte edge reads 4-way: ~100 LDS cycles per wave and K step next to 1536 MFMA cycles.
+    // floats per channel of the staged patch: whole DMA instructions (the last one runs 16 floats past its fifth row)
     return w2d_dma_per_channel(tn) * W2D_ROWS_PER_DMA * W2D_PWS + 16;
 }
+// Odd channel planes of a chunk sit W2D_ODD_SHIFT floats further: the window of a position is read as 8-byte pairs that start at an
+// even float of its row (floats 4 jx + 2 ..), i.e. on banks = 2, 3 (mod 4) whatever 16-byte-aligned offset the plane has, and a
+// 32-lane group of ds_read_b64 holds TWO K lanes (channels kq, kq + 1): 64 eight-byte accesses onto the 32 banks = 2, 3 (mod 4), a
+// 2-way conflict on every window read (round 3: 30 % of the LDS-active cycles; removing the window reads alone is worth 0.10 ms of
+// a 0.50 ms launch, profiles/r04_w2d_ablation.md).  With the odd planes two floats off their pairs fall on banks = 0, 1 (mod 4):
+// conflict-free.  The LDS-DMA takes an 8-byte-aligned LDS destination (tools/dma_align_probe.hip, measured on the MI355X), the
+// global side stays 16-byte aligned, so the zero padding still comes from whole out-of-range segments.
+#ifndef MAUA_W2D_ODD_SHIFT
+#define MAUA_W2D_ODD_SHIFT 2
+#endif
+constexpr int W2D_ODD_SHIFT = MAUA_W2D_ODD_SHIFT;
+__host__ __device__ constexpr int w2d_pbuf(int tn) { return W2D_CC * w2d_pstride(tn) + 4; }  // (+4: the last plane's shifted overrun)
 
 // physical column of (m-tile mt, row i16) inside a weight row of BM = 16 TM floats: m-tile pairs interleaved so that one
 // 8-byte LDS read feeds two MFMAs; for BM = 64 odd K lanes are rotated by half a row (their 256-byte row stride would put
@@ -145,6 +155,17 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
 //       resident workgroup covers more of them (convs.15 0.79 -> 0.73 ms, convs.13 unchanged, +1-2 % frames/s under three lanes).
 //   MAUA_W2D_NMAJOR  32-channel layers: per n-tile transform -> next window read -> the tile's MFMAs (1) or all transforms first (0)
 //   MAUA_W2D_PKT     input transform on register pairs (1) or scalar (0)
+//   MAUA_W2D_READ_FIRST  the window reads of a K step go out BEFORE the DMA of the next chunk is issued (1) or behind it (0)
+#ifndef MAUA_W2D_READ_FIRST
+#define MAUA_W2D_READ_FIRST 0
+#endif
+//   MAUA_W2D_PP / MAUA_W2D_PP_MIN_CIN  phase-locked pairs of four-wave groups (512-thread workgroups) for layers with at least that many input channels
+#ifndef MAUA_W2D_PP
+#define MAUA_W2D_PP 1
+#endif
+#ifndef MAUA_W2D_PP_MIN_CIN
+#define MAUA_W2D_PP_MIN_CIN 128
+#endif
 #ifndef MAUA_W2D_NMAJOR
 #define MAUA_W2D_NMAJOR 1
 #endif
@@ -158,9 +179,17 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
 #define MAUA_W2D_MINB32 3
 #endif
 
-template <int TM, int TN, bool DBG, int MINB = 2>
-__global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
-    const int dbg = (DBG ? p.debug : 0) | MAUA_W2D_ABL;
+// PP ("ping-pong", the >= 64-channel instance): a workgroup is TWO such four-wave groups (512 threads, one workgroup per CU), each with
+// its own tile and its own LDS region, phase-locked by the workgroup barrier so that on every SIMD one wave is in the matrix segment of
+// a K step (weight-row reads + 48 MFMAs) while its partner is in the load segment of ITS K step (DMA of the next chunk, window reads,
+// input transforms): group 1 runs one barrier behind group 0.  The matrix pipe of a SIMD is shared by its two waves and a wave issues in
+// order: with two independent workgroups per CU (round 3) both waves of a SIMD sat in their load segments — or both in their matrix
+// segments, at half rate each — a good part of the time (MFMA-busy 63 %); locked in opposite phases the pipe always has exactly one
+// matrix stream (MI355X_MICROARCH.md, "Two waves per SIMD").  Group 0 finishes one segment early and its waves terminate; s_barrier
+// then waits for the surviving waves only.
+template <int TM, int TN, int MINB = 2, bool PP = false>
+__global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : MINB) void modconv_w2d_kernel(W2dArgs p) {
+    constexpr int dbg = MAUA_W2D_ABL;
     constexpr int BM = 16 * TM;
     constexpr int NPOS = 16 * TN;
     constexpr int TH = 4 * TN;  // output rows per tile
@@ -170,22 +199,28 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     constexpr int A_FLOATS = 24 * W2D_CC * BM;
     constexpr int A_INSTR = A_FLOATS / 256;  // 1-KiB DMA instructions per weight tile
     constexpr int A_PER_WAVE = A_INSTR / 4;
-    constexpr int PBUF = W2D_CC * PSTRIDE;
+    constexpr int PBUF = w2d_pbuf(TN);
     static_assert(A_INSTR % 4 == 0, "weight tile must split evenly over the four waves");
     (void)A_PER_WAVE;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    // per-channel constants of the epilogue live behind whatever is larger, the main loop's buffers or the epilogue's exchange buffers
+    constexpr int EPI_FLOATS = 4 * 16 * NPOS * 4 + (256 / (2 * NPOS)) * 2 * NPOS * 12;
+    const int main_floats = 2 * A_FLOATS + 2 * PBUF + p.Cin;
+    const int e_off = main_floats > EPI_FLOATS ? main_floats : EPI_FLOATS;
+    const int grp = PP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;  // four-wave group of this wave
+    float* lds = lds_all + grp * ((e_off + 8 * BM + 3) & ~3);  // (the layout of w2d_lds_bytes, once per group)
     float* As = lds;                      // [2][A_FLOATS]
     (void)As;
     float* Ps = lds + 2 * A_FLOATS;       // [2][PBUF]
     float* Ss = Ps + 2 * PBUF;            // [Cin] styles of this image
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;    // thread of the four-wave group
     const int lane = tid & 63;
     const int fy = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's y-frequency
     const int j = lane & 15, kq = lane >> 4;
     const int jx = j & 7, jy = j >> 3;
 
-    int t = xcd_remap(blockIdx.x, gridDim.x);
+    int t = PP ? 2 * xcd_remap(blockIdx.x, gridDim.x) + grp : xcd_remap(blockIdx.x, gridDim.x);
     const int mt_id = t % p.m_tiles;
     t /= p.m_tiles;
     const int tile_x = t % p.tiles_x;
@@ -227,15 +262,16 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
 #pragma unroll
         for (int k = 0; k < A_PER_WAVE; ++k) {
             const int i = fy + 4 * k;
+            if ((dbg & 128) && (k & 1) && chunk) continue;  // (ablation: half the weight pieces)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(As + buf * A_FLOATS + i * 256),
                                                      16, (i * 256 + lane * 4) * 4, wbase, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < (4 * NQ + 3) / 4; ++k) {
             const int id = fy + 4 * k;  // (scalar) instruction id = channel * NQ + row group
-            if (id < W2D_CC * NQ) {
+            if (id < W2D_CC * NQ && !((dbg & 1024) && chunk)) {  // (ablation 1024: no patch DMA after the first chunk)
                 const int c = id / NQ, q = id % NQ;
-                float* dst = Ps + buf * PBUF + c * PSTRIDE + q * (W2D_ROWS_PER_DMA * W2D_PWS);
+                float* dst = Ps + buf * PBUF + c * PSTRIDE + (c & 1) * W2D_ODD_SHIFT + q * (W2D_ROWS_PER_DMA * W2D_PWS);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
                                                          (int)rel_bytes[(NQ % 4 == 0) ? (k % (NQ / 4 > 0 ? NQ / 4 : 1)) : 0],
                                                          (int)((size_t)(chunk * W2D_CC + c) * plane_bytes), 0, 0);
@@ -249,9 +285,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     // per-output-channel constants of the epilogue, [BM][8] = gain, bias, the three modulated ToRGB weights: fetched here, under the
     // first DMA wait, into LDS that neither the main loop nor the exchange buffers of the epilogue touch (loaded after the main loop
     // their ~1 us round trip was exposed in every workgroup)
-    constexpr int EPI_FLOATS = 4 * 16 * NPOS * 4 + (256 / (2 * NPOS)) * 2 * NPOS * 12;
-    const int main_floats = 2 * A_FLOATS + 2 * PBUF + p.Cin;
-    float* E = lds + (main_floats > EPI_FLOATS ? main_floats : EPI_FLOATS);
+    float* E = lds + e_off;
     const bool act = p.fuse_act != 0;
     const float act_gain = act ? 1.41421356237309515f : 1.f;
     const float* noise_base = p.noise;
@@ -294,7 +328,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     // window rows ra / rb of n-tile 0, channel kq; n-tile n lies a constant 4 patch rows further (immediate offset)
     unsigned b_addr[2];
     {
-        const int top = kq * PSTRIDE + (2 * jy) * W2D_PWS + 4 * jx + 3;  // the window starts one column left of the position
+        const int top = kq * PSTRIDE + (kq & 1) * W2D_ODD_SHIFT + (2 * jy) * W2D_PWS + 4 * jx + 3;  // the window starts one column left of the position
         b_addr[0] = lds0 + (unsigned)(2 * A_FLOATS + top + ra * W2D_PWS) * 4u;
         b_addr[1] = lds0 + (unsigned)(2 * A_FLOATS + top + rb * W2D_PWS) * 4u;
     }
@@ -310,12 +344,15 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (PP && grp == 1) __syncthreads();  // group 1 runs one segment behind: its load segments meet group 0's matrix segments
     int cur = 0;
 #pragma unroll
     for (int phase = 0; phase < 2; ++phase)  // phase 0 = the first K step (C = 0), phase 1 = the others
     for (int chunk = phase; chunk < (phase ? p.n_chunks : 1); ++chunk) {
         const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !MAUA_W2D_READ_FIRST
         if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+#endif
         // ---- operand reads of this chunk: style, raw window rows, first weight row
         const unsigned a_off = cur ? A_BUF_BYTES : 0u, p_off = cur ? P_BUF_BYTES : 0u;
         float sc = lds_read32(s_addr);
@@ -325,6 +362,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         for (int h = 0; h < TM / 2; ++h) ap[h] = a_addr[h] + a_off;
         f32x2 a2[2][TM / 2];
         constexpr bool NMAJOR = TM == 2 && MAUA_W2D_NMAJOR;
+        static_assert(!(PP && NMAJOR), "the phase-locked form splits the K step of the xf-major order");
         float bv[NMAJOR ? 1 : TN][6];
         // windows are read two n-tiles ahead of their transform (12 registers each: at most two are live), the first weight row
         // goes out behind the last window; LDS returns in order, so "at most k operations outstanding" identifies what landed
@@ -338,12 +376,22 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         const unsigned pa = b_addr[0] + p_off - 4u, pb = b_addr[1] + p_off - 4u;
         auto read_window = [&](auto n_c, int slot) {
             constexpr int o = decltype(n_c)::value * NT_BYTES;
+            if constexpr ((dbg & 64) != 0) {  // (ablation: the registers keep whatever they held)
+                asm volatile("" : "=v"(wa0[slot]), "=v"(wa5[slot]), "=v"(wb0[slot]), "=v"(wb5[slot]), "=v"(wa[slot][0]), "=v"(wa[slot][1]),
+                             "=v"(wb[slot][0]), "=v"(wb[slot][1]));
+                return;
+            }
             wa0[slot] = lds_read64<o>(pa), wa[slot][0] = lds_read64<o + 8>(pa), wa[slot][1] = lds_read64<o + 16>(pa);
             wa5[slot] = lds_read64<o + 24>(pa);
             wb0[slot] = lds_read64<o>(pb), wb[slot][0] = lds_read64<o + 8>(pb), wb[slot][1] = lds_read64<o + 16>(pb);
             wb5[slot] = lds_read64<o + 24>(pb);
         };
         auto transform = [&](int n, int slot) {
+            if constexpr ((dbg & 32) != 0) {  // (ablation: raw window values feed the matrix instructions)
+                bv[n][0] = wa0[slot].y, bv[n][1] = wa[slot][0].x, bv[n][2] = wa[slot][0].y, bv[n][3] = wb[slot][1].x, bv[n][4] = wb[slot][1].y;
+                bv[n][5] = wb5[slot].x + sc;
+                return;
+            }
 #if MAUA_W2D_PKT
             const f32x2 sc2 = f32x2{sc, sc};
             // row combination and B_x^T of F(4,3) on register pairs (v_pk_*_f32 = two fp32 operations per issue slot; VALU and the
@@ -397,6 +445,9 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             });
             read_window(std::integral_constant<int, 0>{}, 0);
             if constexpr (TN > 1 && WSLOTS > 1) read_window(std::integral_constant<int, 1>{}, 1);
+#if MAUA_W2D_READ_FIRST
+            if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+#endif
             static_for<0, TN>([&](auto n_c) {
                 constexpr int n = decltype(n_c)::value;
                 constexpr int slot = n % WSLOTS;
@@ -428,6 +479,9 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         } else {
         read_window(std::integral_constant<int, 0>{}, 0);
         if constexpr (TN > 1 && WSLOTS > 1) read_window(std::integral_constant<int, 1>{}, 1);
+#if MAUA_W2D_READ_FIRST
+        if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+#endif
         static_for<0, TN>([&](auto n_c) {
             constexpr int n = decltype(n_c)::value;
             constexpr int slot = n % WSLOTS;
@@ -444,6 +498,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             transform(n, slot);
             if constexpr (n + WSLOTS < TN) read_window(std::integral_constant<int, n + WSLOTS>{}, slot);
         });
+        if constexpr (PP) {
+            // load segment | matrix segment (the partner group switches the other way).  A bare s_barrier: a phase lock, not a memory
+            // fence — __syncthreads() would drain vmcnt here and expose the latency of the DMA this segment has just issued
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- MFMA phase: the weight row of the next x-frequency is read one step ahead
         static_for<0, 6>([&](auto xf_c) {
             constexpr int xf = decltype(xf_c)::value;
@@ -454,7 +515,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             constexpr int pending = xf < 5 ? TM / 2 : 0;
             if constexpr (TM == 4) lds_wait<pending>(a2[xf & 1][0], a2[xf & 1][1]);
             else lds_wait<pending>(a2[xf & 1][0]);
-            if (DBG && (dbg & 1) && !phase) {
+            if ((dbg & 1) && !phase) {
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -473,7 +534,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (!(dbg & 16)) __syncthreads();
         cur ^= 1;
     }
 
@@ -704,33 +765,29 @@ __global__ __launch_bounds__(256) void pack_weight_wino2d_kernel(const float* __
 
 size_t w2d_lds_bytes(int tm, int tn, int cin) {
     const int bm = 16 * tm, npos = 16 * tn;
-    const size_t main_loop = (size_t)2 * 24 * W2D_CC * bm + (size_t)2 * W2D_CC * w2d_pstride(tn) + (size_t)cin;
+    const size_t main_loop = (size_t)2 * 24 * W2D_CC * bm + (size_t)2 * w2d_pbuf(tn) + (size_t)cin;
     const int cg = 256 / (2 * npos);
     const size_t epilogue = (size_t)4 * 16 * npos * 4 + (size_t)cg * 2 * npos * 12;
-    return sizeof(float) * ((main_loop > epilogue ? main_loop : epilogue) + (size_t)8 * bm);  // + the channel-constant table
+    return sizeof(float) * (((main_loop > epilogue ? main_loop : epilogue) + (size_t)8 * bm + 3) & ~(size_t)3);  // + the channel-constant table
 }
 
 char g_w2d_instance[64] = "";
-#ifdef MAUA_EXPERIMENTS
-int g_w2d_debug = 0;
-#endif
 
-template <int TM, int TN, bool DBG, int MINB = 2>
+template <int TM, int TN, int MINB = 2, bool PP = false>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
-    auto kern = modconv_w2d_kernel<TM, TN, DBG, MINB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %s, %d>", TM, TN, DBG ? "true" : "false", MINB);
-    const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
+    auto kern = modconv_w2d_kernel<TM, TN, MINB, PP>;
+    static int attr_rc = -1;  // (set once per instantiation; a failure is returned by every launch instead of being swallowed)
+    if (attr_rc < 0)
+        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc) return attr_rc;
+    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %d, %s>", TM, TN, MINB, PP ? "true" : "false");
+    const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles / (PP ? 2 : 1);
 #ifdef MAUA_EXPERIMENTS  // occupancy probe (MAUA_W2D_LDS_PAD with an experiments build): extra dynamic LDS so that a CU holds one workgroup instead of two
     static const size_t lds_pad = getenv("MAUA_W2D_LDS_PAD") ? (size_t)atoi(getenv("MAUA_W2D_LDS_PAD")) : 0;
 #else
     constexpr size_t lds_pad = 0;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), w2d_lds_bytes(TM, TN, a.Cin) + lds_pad, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PP ? 512 : 256), (PP ? 2 : 1) * w2d_lds_bytes(TM, TN, a.Cin) + lds_pad, st, a);
     MAUA_LAUNCH_CHECK();
     return 0;
 }
@@ -752,9 +809,6 @@ int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
 }
 
 const char* maua_w2d_last_instance() { return g_w2d_instance; }
-#ifdef MAUA_EXPERIMENTS
-int maua_w2d_debug_set(int v) { g_w2d_debug = v; return 0; }
-#endif
 
 int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin,
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
@@ -773,18 +827,16 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     a.src = src, a.noise_slot = noise_slot;
     a.tiles_x = w / 32, a.tiles_y = h / (4 * tn), a.m_tiles = cout / (16 * tm), a.n_chunks = cin / W2D_CC;
     a.rgb = rgb_mode, a.rgb_wscale = rgb_wscale;
-#ifdef MAUA_EXPERIMENTS
-    a.debug = g_w2d_debug;
-#endif
     if (rgb_mode == 3) {
         if (!fuse_act || !rgb_w || !rgb_s || !rgb_out) return MAUA_EINVAL;
     } else if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
-#ifdef MAUA_EXPERIMENTS
-    if (a.debug) return tm == 4 ? w2d_launch_t<4, 2, true>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, true, MAUA_W2D_MINB32>(a, st);  // ablation instantiation
-#endif
-    return tm == 4 ? w2d_launch_t<4, 2, false>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, false, MAUA_W2D_MINB32>(a, st);
+    if (tm != 4) return w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32>(a, st);
+    // two tiles per workgroup (phase-locked four-wave groups) where the K loop is long enough to pay for one workgroup per CU
+    const int64_t tiles = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
+    if (MAUA_W2D_PP && tiles % 2 == 0 && cin >= MAUA_W2D_PP_MIN_CIN) return w2d_launch_t<4, 2, 1, true>(a, st);
+    return w2d_launch_t<4, 2>(a, st);
 }
 
 extern "C" int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {

@@ -31,14 +31,12 @@ extern "C" int maua_device_info(int* cu_count, int* lds_bytes, char* name, int n
 
 #ifdef MAUA_EXPERIMENTS
 // Ablation / A-B switches of tools/ (NOT part of the product ABI: include/maua_hip.h does not declare it and the default build does
-// not export it).  key 1: conv ablation mask, 2: conv tile-shape switches, 3: 2-D Winograd ablation mask.
+// not export it).  key 1: conv ablation mask, 2: conv tile-shape switches (the 2-D Winograd kernel has compile-time masks only).
 int maua_conv_debug_set(int v);
 int maua_conv_cfg_set(int v);
-int maua_w2d_debug_set(int v);
 extern "C" int maua_tuning_set(int key, int value) {
     if (key == 1) return maua_conv_debug_set(value);
     if (key == 2) return maua_conv_cfg_set(value);
-    if (key == 3) return maua_w2d_debug_set(value);
     return MAUA_EINVAL;
 }
 #endif

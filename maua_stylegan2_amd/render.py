@@ -16,8 +16,10 @@ with ``input_is_latent=True``), different machinery:
 Sinks: ffmpeg rawvideo pipe (same pixel format / codec arguments as render.py:58-91) when an ``ffmpeg`` binary exists,
 otherwise raw rgb24 bytes to ``output_file`` (+ ".rgb24"), or a null sink for benchmarking (``output_file=None``).
 """
+import queue
 import shutil
 import subprocess
+import threading
 
 import numpy as np
 import torch as th
@@ -88,10 +90,10 @@ class FrameSink:
         assert frame.shape[1] == self.w and frame.shape[0] == self.h, (
             f"generator's output image size does not match specified output size: \n"
             f"got: {frame.shape[1]}x{frame.shape[0]}\t\tshould be {self.w}x{self.h}")
-        if self.proc is not None:
-            self.proc.stdin.write(frame.tobytes())
-        elif self.file is not None:
-            self.file.write(frame.tobytes())
+        if self.proc is not None or self.file is not None:
+            # the frame's own bytes go to the pipe / file (a view of the pinned staging buffer): no tobytes() copy of 3 MiB per frame
+            data = memoryview(np.ascontiguousarray(frame)).cast("B")
+            (self.proc.stdin if self.proc is not None else self.file).write(data)
         self.count += 1
 
     def close(self):
@@ -100,6 +102,57 @@ class FrameSink:
             self.proc.wait()
         if self.file is not None:
             self.file.close()
+
+
+class SinkWorker:
+    """Ordered frame delivery OFF the thread that launches the graphs — the role of the reference's two daemon threads and
+    queues (render.py:30-44,94-113: `make_video` / `split_batches`).  The launch thread hands over whole batches
+    (``submit(wait, frames, count, release)``: ``wait()`` blocks until the batch's device-to-host copy has landed, ``frames[i]`` are
+    its uint8 [H, W, 3] frames in a pinned staging slot, ``release()`` returns the slot to its ring) and never calls
+    ``sink.write`` itself: a slow encoder fills the ring and then throttles the producer through the ring's free list, it does
+    not sit between two graph launches.  Batches are written in submission order.  An exception of the sink is kept and
+    re-raised on the launch thread (next ``submit`` or ``close``)."""
+
+    def __init__(self, sink):
+        self.sink = sink
+        self.error = None
+        self._work = queue.Queue()
+        self._thread = threading.Thread(target=self._run, name="maua-sink", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        while True:
+            item = self._work.get()
+            if item is None:
+                return
+            wait, frames, count, release = item
+            try:
+                if self.error is None:
+                    if wait is not None:
+                        wait()
+                    for i in range(count):
+                        self.sink.write(frames[i])
+            except BaseException as exc:  # noqa: BLE001 - handed to the launch thread
+                self.error = exc
+            finally:
+                if release is not None:
+                    release()
+
+    def _check(self):
+        if self.error is not None:
+            exc, self.error = self.error, None
+            raise exc
+
+    def submit(self, wait, frames, count, release=None):
+        self._check()
+        self._work.put((wait, frames, count, release))
+
+    def close(self):
+        """Wait until everything submitted has been written (or dropped after an error), then re-raise a sink error."""
+        if self._thread.is_alive():
+            self._work.put(None)
+            self._thread.join()
+        self._check()
 
 
 def frames_to_uint8(images, out=None):
@@ -352,28 +405,22 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
     if rank == 0:
         sink = FrameSink(output_file, width, height, n_frames / duration, audio_file, offset, duration, ffmpeg_preset)
 
+    worker = SinkWorker(sink) if sink is not None else None
     try:
         if world == 1:
-            # pinned staging ring, one slot per graph lane: the D2H of batch k overlaps the replays of the next batches
-            n_slots = 3
+            # pinned staging ring: the D2H of batch k overlaps the replays of the next batches; the sink thread writes a slot and
+            # hands it back through `free` (the launch thread blocks here only when the sink is `n_slots` batches behind)
+            n_lanes, n_slots = 3, 6
             copy_stream = th.cuda.Stream(dev)
-            pinned, events, pending = [None] * n_slots, [None] * n_slots, []
-
-            def drain(slot_first):
-                slot, first, count = slot_first
-                events[slot].synchronize()
-                host = pinned[slot].numpy()
-                for i in range(count):
-                    sink.write(host[i])
-
-            k = 0
+            pinned = [None] * n_slots
+            free = queue.Queue()
+            for i in range(n_slots):
+                free.put(i)
             resized = {}
             for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
-                                        randomize_noise, lanes=n_slots):
+                                        randomize_noise, lanes=n_lanes):
                 u8 = crop_resize_for_delivery(u8, out_size, resized)  # 2048-px frames leave the device as 1920x1080 already
-                slot = k % n_slots
-                if len(pending) == n_slots:
-                    drain(pending.pop(0))
+                slot = free.get()
                 if pinned[slot] is None or pinned[slot].shape != u8.shape:
                     pinned[slot] = th.empty(u8.shape, dtype=th.uint8).pin_memory()
                 produced = th.cuda.Event()
@@ -381,21 +428,23 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
                 with th.cuda.stream(copy_stream):
                     copy_stream.wait_event(produced)
                     pinned[slot].copy_(u8, non_blocking=True)
-                    events[slot] = th.cuda.Event()
-                    events[slot].record(copy_stream)
+                    copied = th.cuda.Event()
+                    copied.record(copy_stream)
                 # the producer must not overwrite u8 before the copy has read it
-                th.cuda.current_stream(dev).wait_event(events[slot])
-                pending.append((slot, first, u8.shape[0]))
-                k += 1
-            for p in pending:
-                drain(p)
+                th.cuda.current_stream(dev).wait_event(copied)
+                worker.submit(copied.synchronize, pinned[slot].numpy(), u8.shape[0], lambda s=slot: free.put(s))
         else:
             # One asynchronous gather per batch-round, issued as soon as the round's frames exist: the transfer of round k
-            # runs under the compute of rounds k+1.., rank 0 writes frames to the sink as their rounds land (its own block
+            # runs under the compute of rounds k+1.., rank 0 hands rounds to its sink thread as they land (its own block
             # first — the blocks are contiguous — while the peers' frames accumulate in its HBM store).
             stream = None
             k = 0
             resized = {}
+
+            def deliver(block):
+                for _, count, host, release in stream.drain_rounds(block=block):
+                    worker.submit(None, host.numpy(), count, release)
+
             for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
                                         randomize_noise, frame_range=frame_range):
                 u8 = crop_resize_for_delivery(u8, out_size, resized)
@@ -404,17 +453,22 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
                 stream.push(k, u8)
                 k += 1
                 if rank == 0:
-                    for _, frame in stream.drain(block=False):
-                        sink.write(frame.numpy())
+                    deliver(False)
             if stream is None:  # a rank whose block is empty (more ranks than frames) still takes part in every round
                 stream = sharding.FrameStream(n_frames, batch_size, _stream_frame_shape(generator, out_size), dev)
             stream.finish()
             if rank == 0:
-                for _, frame in stream.drain(block=True):
-                    sink.write(frame.numpy())
+                deliver(True)
             else:
                 stream.wait_all()
+        if worker is not None:
+            worker.close()
     finally:  # the encoder process / output file must not outlive a failed render
+        if worker is not None:
+            try:
+                worker.close()
+            except BaseException:  # noqa: BLE001 - (a second failure while unwinding must not mask the first)
+                pass
         if sink is not None:
             sink.close()
     return sink.count if sink is not None else 0

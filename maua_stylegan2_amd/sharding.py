@@ -15,6 +15,8 @@ tests):
 ``truncation_latent`` is random in the reference (models/stylegan2.py:539-540); generate() draws it on rank 0 and
 ``broadcast_tensor`` makes it identical on every rank.
 """
+import queue
+
 import torch as th
 import torch.distributed as dist
 
@@ -127,9 +129,19 @@ def scatter_frames(t, n_frames, src=0, device=None):
     if rank == src:
         if t.shape[0] != n_frames:
             raise RuntimeError(f"per-frame tensor has {t.shape[0]} entries for {n_frames} frames")
-        padded = th.zeros((world * per,) + shape, dtype=dtype, device=device)
-        padded[:n_frames].copy_(t)
-        chunks = list(padded.view((world, per) + shape).unbind(0))
+        # scatter wants equally sized chunks: rank r's is the `per` frames starting at its block — a VIEW of the sequence (it may run
+        # into the next rank's frames, which the receiver drops); only a block that would run past the end gets a zero-padded copy
+        # of its own (round 3 built a padded [world * per] copy of every per-frame tensor: ~1.3 GB of reactive noise twice on rank 0)
+        t = t.to(device).contiguous()
+        chunks = []
+        for r in range(world):
+            lo_r, hi_r = shard_bounds(n_frames, r, world)
+            if lo_r + per <= n_frames:
+                chunks.append(t[lo_r: lo_r + per])
+            else:
+                tail = th.zeros((per,) + shape, dtype=dtype, device=device)
+                tail[: hi_r - lo_r].copy_(t[lo_r: hi_r])
+                chunks.append(tail)
     dist.scatter(mine, chunks, src=src)
     lo, hi = shard_bounds(n_frames, rank, world)
     return mine[: hi - lo]
@@ -144,7 +156,7 @@ class FrameStream:
     fetched to the host one round at a time — reference render.py:94-113 semantics (an ordered writer that consumes while
     the generator runs) without its per-frame D2H."""
 
-    def __init__(self, n_frames, batch_size, frame_shape, device, dst=0):
+    def __init__(self, n_frames, batch_size, frame_shape, device, dst=0, ring_slots=6):
         self.rank, self.world = rank_world()
         self.n_frames, self.batch, self.dst = int(n_frames), int(batch_size), dst
         self.per = max_shard(n_frames, self.world)
@@ -165,11 +177,14 @@ class FrameStream:
         # fetching round k overlaps the Python thread launching the next replays (as render() does on one GPU); on a CPU
         # "device" (gloo tests) the rounds are handed out in place
         self._on_gpu = th.device(device).type == "cuda"
-        self._ring, self._copy_stream, self._inflight, self._issued = [], None, [], 0
+        self._ring, self._copy_stream, self._inflight = [], None, []
         self._pushed_events = []
+        self._free = queue.Queue()  # ring slots a consumer has released (the sink may run on its own thread: render.SinkWorker)
         if self.rank == dst and self._on_gpu:
             self._copy_stream = th.cuda.Stream(device)
-            self._ring = [th.empty((self.batch,) + self.shape, dtype=th.uint8).pin_memory() for _ in range(3)]
+            self._ring = [th.empty((self.batch,) + self.shape, dtype=th.uint8).pin_memory() for _ in range(ring_slots)]
+            for i in range(ring_slots):
+                self._free.put(i)
 
     def push(self, k, u8):
         if k != self.pushed:
@@ -245,37 +260,55 @@ class FrameStream:
             return first, count, src, ready
         return None
 
-    def drain(self, block=False):
-        """dst only: yield (global_frame_index, uint8 CPU tensor [H, W, 3]) for every frame that is next in order and whose
-        round has arrived; with ``block=True`` wait for rounds that were pushed but have not landed yet.  Rounds travel to
-        the host through the pinned ring: up to len(ring) asynchronous copies are in flight while earlier rounds are consumed."""
+    def drain_rounds(self, block=False):
+        """dst only: yield (first_frame_index, count, uint8 host tensor [count, H, W, 3], release) for every ROUND that is next in
+        global frame order and has arrived.  The host tensor is a slot of the pinned ring (the round itself on a CPU "device"); the
+        consumer calls ``release()`` when it is done with it — possibly from another thread (render.SinkWorker), which is what keeps
+        a slow sink off the thread that launches the graphs.  ``block=False`` never waits: not for a transfer, not for a copy and
+        not for a ring slot (the caller comes back after its next replay); ``block=True`` waits for all three."""
         if self.rank != self.dst:
             return
         while True:
-            while len(self._inflight) < max(len(self._ring), 1):
-                nxt = self._next_round(block)
+            while self._on_gpu or not self._inflight:  # start copies while there are rounds and ring slots (CPU: one round at a time)
+                slot = None
+                if self._on_gpu:
+                    try:
+                        slot = self._free.get(block=block and not self._inflight)
+                    except queue.Empty:
+                        break
+                nxt = self._next_round(block and not self._inflight)  # (never wait for a later round while an earlier one can be handed out)
                 if nxt is None:
+                    if slot is not None:
+                        self._free.put(slot)
                     break
                 first, count, src, ready = nxt
                 if not self._on_gpu:
-                    self._inflight.append((first, count, src, None))
+                    self._inflight.append((first, count, src, None, None))
                     continue
-                host = self._ring[self._issued % len(self._ring)][:count]
-                self._issued += 1
+                host = self._ring[slot][:count]
                 with th.cuda.stream(self._copy_stream):
                     if ready is not None:
                         self._copy_stream.wait_event(ready)
                     host.copy_(src, non_blocking=True)
                     done = th.cuda.Event()
                     done.record(self._copy_stream)
-                self._inflight.append((first, count, host, done))
+                self._inflight.append((first, count, host, done, slot))
             if not self._inflight:
                 return
-            first, count, host, done = self._inflight[0]
+            first, count, host, done, slot = self._inflight[0]
             if done is not None:
                 if not block and not done.query():
                     return  # still on its way: the caller comes back after its next replay
                 done.synchronize()
             self._inflight.pop(0)
-            for i in range(count):
-                yield first + i, host[i]
+            yield first, count, host, (lambda s=slot: self._free.put(s)) if slot is not None else (lambda: None)
+
+    def drain(self, block=False):
+        """dst only: yield (global_frame_index, uint8 CPU tensor [H, W, 3]) for every frame that is next in order and whose
+        round has arrived (see drain_rounds); the round's ring slot is released when the consumer asks for the frame behind it."""
+        for first, count, host, release in self.drain_rounds(block):
+            try:
+                for i in range(count):
+                    yield first + i, host[i]
+            finally:
+                release()

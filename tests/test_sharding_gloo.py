@@ -221,6 +221,127 @@ def test_two_rank_scatter_and_streamed_ordered_frames(tmp_path, n_frames, batch)
     assert int(np.load(tmp_path / "stream_ok.npy")[0]) == n_frames
 
 
+def _slow_sink_worker(rank, world, port, out_dir):
+    """Rank 0's launch loop (push a round, hand landed rounds to the sink thread) with a sink that takes 30 ms per frame: the loop
+    itself must run at the producer's pace, the frames must still arrive complete and in order."""
+    import time
+
+    from maua_stylegan2_amd import render
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_frames, batch = 40, 4
+        lo, hi = sharding.shard_bounds(n_frames, rank, world)
+        stream = sharding.FrameStream(n_frames, batch, (4, 5, 3), torch.device("cpu"))
+        written, thread_ids = [], set()
+
+        class SlowSink:
+            count = 0
+
+            def write(self, frame):
+                import threading
+
+                time.sleep(0.03)
+                thread_ids.add(threading.get_ident())
+                written.append(int(frame[0, 0, 0]))
+                self.count += 1
+
+        worker = render.SinkWorker(SlowSink()) if rank == 0 else None
+
+        def deliver(block):
+            for _, count, host, release in stream.drain_rounds(block=block):
+                worker.submit(None, host.numpy(), count, release)
+
+        t0 = time.monotonic()
+        k = 0
+        for first in range(lo, hi, batch):
+            count = min(batch, hi - first)
+            u8 = torch.zeros((count, 4, 5, 3), dtype=torch.uint8)
+            for i in range(count):
+                u8[i] = first + i
+            stream.push(k, u8)
+            k += 1
+            if rank == 0:
+                deliver(False)
+        launch_loop_s = time.monotonic() - t0
+        stream.finish()
+        if rank == 0:
+            deliver(True)
+            handed_over_s = time.monotonic() - t0
+            worker.close()
+            total_s = time.monotonic() - t0
+            import threading
+
+            assert written == list(range(n_frames))
+            assert thread_ids and threading.get_ident() not in thread_ids, "sink.write ran on the launch thread"
+            # 40 frames x 30 ms = 1.2 s of sink time; the launch loop (5 rounds of rank 0) and the hand-over of all 10 rounds do not wait for it
+            assert total_s >= 1.1 and launch_loop_s < 0.3 and handed_over_s < 0.6, (launch_loop_s, handed_over_s, total_s)
+            np.save(os.path.join(out_dir, "slow_sink_ok.npy"), np.array([launch_loop_s, handed_over_s, total_s]))
+        else:
+            stream.wait_all()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slow_sink_does_not_delay_the_launch_loop(tmp_path):
+    """rank 0's ``sink.write`` runs on a sink thread (render.SinkWorker) fed with whole rounds; a sink that is
+    slower than the producers delays neither rank 0's launch loop nor the hand-over of the peers' rounds (world_size 2, gloo)."""
+    mp.spawn(_slow_sink_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "slow_sink_ok.npy")[2] >= 1.1
+
+
+def test_sink_worker_keeps_order_bounds_the_ring_and_reraises():
+    """render.SinkWorker on its own: batches are written in submission order from ring slots that come back through ``release``
+    (a producer that takes slots from a free list is throttled by a slow sink, never ahead by more than the ring), and an exception of the
+    sink reaches the submitting thread."""
+    import queue
+    import time
+
+    from maua_stylegan2_amd import render
+
+    seen, in_flight, worst = [], [0], [0]
+
+    class Sink:
+        def write(self, frame):
+            time.sleep(0.002)
+            seen.append(int(frame[0]))
+
+    worker = render.SinkWorker(Sink())
+    free = queue.Queue()
+    slots = [np.zeros((3, 1), np.int64) for _ in range(2)]
+    for i in range(2):
+        free.put(i)
+
+    def release(slot):
+        in_flight[0] -= 1
+        free.put(slot)
+
+    for b in range(12):
+        slot = free.get()
+        in_flight[0] += 1
+        worst[0] = max(worst[0], in_flight[0])
+        slots[slot][:, 0] = [3 * b, 3 * b + 1, 3 * b + 2]
+        worker.submit(None, slots[slot], 3, lambda s=slot: release(s))
+    worker.close()
+    assert seen == list(range(36)) and worst[0] <= 2
+
+    class Broken:
+        def write(self, frame):
+            raise OSError("encoder went away")
+
+    worker = render.SinkWorker(Broken())
+    released = []
+    worker.submit(None, np.zeros((2, 1)), 2, lambda: released.append(1))
+    with pytest.raises(OSError, match="encoder went away"):
+        for _ in range(50):
+            time.sleep(0.01)
+            worker.submit(None, np.zeros((1, 1)), 1, lambda: released.append(1))
+    worker.close()  # the error was delivered once; close does not raise it again
+    assert released  # slots are handed back even when the write failed
+
+
 def _generate_worker(rank, world, port, out_dir):
     """generate() under a 2-rank process group with CPU stand-ins for the audio decoder, the generator and the renderer: what is
     under test is the ORDER of the multi-GPU hand-over and the random streams of the plugin callbacks."""

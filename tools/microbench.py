@@ -25,7 +25,6 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--conv-debug", type=int, default=0)
     ap.add_argument("--conv-cfg", type=int, default=0)
-    ap.add_argument("--w2d-debug", type=int, default=0, help="ablation of modconv_w2d_kernel: 1 no MFMA, 2 no DMA after chunk 0, 4 no stores")
     ap.add_argument("--lib", default=None, help="experimental build of libmaua_hip.so to load instead (tools/bin/...)")
     ap.add_argument("--wino-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd_min_cout")
     ap.add_argument("--no-up-wino", action="store_true", help="transposed layers use the plain polyphase kernel (mode 1)")
@@ -36,10 +35,9 @@ def main():
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
     lib = _lib.load()
-    if args.conv_debug or args.conv_cfg or args.w2d_debug:  # ablation switches: experiments builds only (tools/build_exp.sh + --lib)
+    if args.conv_debug or args.conv_cfg:  # ablation switches: experiments builds only (tools/build_exp.sh + --lib)
         lib.maua_tuning_set(1, args.conv_debug)
         lib.maua_tuning_set(2, args.conv_cfg)
-        lib.maua_tuning_set(3, args.w2d_debug)
     dev = torch.device("cuda:0")
     stream = torch.cuda.Stream(dev)
     sp = stream.cuda_stream
