@@ -1240,11 +1240,9 @@ int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI, FAST, MAXP>;
     snprintf(g_last_instance, sizeof(g_last_instance), "modconv_mfma_kernel<%d, %d, %d, %d, %s, %s, %d>", BM, BN, WM, UP,
              MULTI ? "true" : "false", FAST ? "true" : "false", MAXP);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static int attr_rc = -1;  // (per instantiation; a failure is returned by every launch instead of being swallowed)
+    if (attr_rc < 0) attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc) return attr_rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(256), pl.lds_bytes, st, pl.g, ptrs);
     MAUA_LAUNCH_CHECK();
     return 0;

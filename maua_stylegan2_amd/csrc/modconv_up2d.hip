@@ -486,12 +486,13 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM);
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    static int attr_rc = -1;  // (a failure is returned by every launch instead of being swallowed)
+    if (attr_rc < 0) {
+        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (!attr_rc)
+            attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+    if (attr_rc) return attr_rc;
     snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<%d>", cc);
     if (cc == 8) hipLaunchKernelGGL(modconv_up2d_kernel<8>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     else hipLaunchKernelGGL(modconv_up2d_kernel<4>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);

@@ -159,13 +159,6 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
 #ifndef MAUA_W2D_READ_FIRST
 #define MAUA_W2D_READ_FIRST 0
 #endif
-//   MAUA_W2D_PP / MAUA_W2D_PP_MIN_CIN  phase-locked pairs of four-wave groups (512-thread workgroups) for layers with at least that many input channels
-#ifndef MAUA_W2D_PP
-#define MAUA_W2D_PP 1
-#endif
-#ifndef MAUA_W2D_PP_MIN_CIN
-#define MAUA_W2D_PP_MIN_CIN 128
-#endif
 #ifndef MAUA_W2D_NMAJOR
 #define MAUA_W2D_NMAJOR 1
 #endif
@@ -179,16 +172,8 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
 #define MAUA_W2D_MINB32 3
 #endif
 
-// PP ("ping-pong", the >= 64-channel instance): a workgroup is TWO such four-wave groups (512 threads, one workgroup per CU), each with
-// its own tile and its own LDS region, phase-locked by the workgroup barrier so that on every SIMD one wave is in the matrix segment of
-// a K step (weight-row reads + 48 MFMAs) while its partner is in the load segment of ITS K step (DMA of the next chunk, window reads,
-// input transforms): group 1 runs one barrier behind group 0.  The matrix pipe of a SIMD is shared by its two waves and a wave issues in
-// order: with two independent workgroups per CU (round 3) both waves of a SIMD sat in their load segments — or both in their matrix
-// segments, at half rate each — a good part of the time (MFMA-busy 63 %); locked in opposite phases the pipe always has exactly one
-// matrix stream (MI355X_MICROARCH.md, "Two waves per SIMD").  Group 0 finishes one segment early and its waves terminate; s_barrier
-// then waits for the surviving waves only.
-template <int TM, int TN, int MINB = 2, bool PP = false>
-__global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : MINB) void modconv_w2d_kernel(W2dArgs p) {
+template <int TM, int TN, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     constexpr int dbg = MAUA_W2D_ABL;
     constexpr int BM = 16 * TM;
     constexpr int NPOS = 16 * TN;
@@ -207,20 +192,19 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : MINB) void modconv_w2d_ker
     constexpr int EPI_FLOATS = 4 * 16 * NPOS * 4 + (256 / (2 * NPOS)) * 2 * NPOS * 12;
     const int main_floats = 2 * A_FLOATS + 2 * PBUF + p.Cin;
     const int e_off = main_floats > EPI_FLOATS ? main_floats : EPI_FLOATS;
-    const int grp = PP ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;  // four-wave group of this wave
-    float* lds = lds_all + grp * ((e_off + 8 * BM + 3) & ~3);  // (the layout of w2d_lds_bytes, once per group)
+    float* lds = lds_all;
     float* As = lds;                      // [2][A_FLOATS]
     (void)As;
     float* Ps = lds + 2 * A_FLOATS;       // [2][PBUF]
     float* Ss = Ps + 2 * PBUF;            // [Cin] styles of this image
 
-    const int tid = threadIdx.x & 255;    // thread of the four-wave group
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int fy = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's y-frequency
     const int j = lane & 15, kq = lane >> 4;
     const int jx = j & 7, jy = j >> 3;
 
-    int t = PP ? 2 * xcd_remap(blockIdx.x, gridDim.x) + grp : xcd_remap(blockIdx.x, gridDim.x);
+    int t = xcd_remap(blockIdx.x, gridDim.x);
     const int mt_id = t % p.m_tiles;
     t /= p.m_tiles;
     const int tile_x = t % p.tiles_x;
@@ -344,7 +328,6 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : MINB) void modconv_w2d_ker
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (PP && grp == 1) __syncthreads();  // group 1 runs one segment behind: its load segments meet group 0's matrix segments
     int cur = 0;
 #pragma unroll
     for (int phase = 0; phase < 2; ++phase)  // phase 0 = the first K step (C = 0), phase 1 = the others
@@ -362,7 +345,6 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : MINB) void modconv_w2d_ker
         for (int h = 0; h < TM / 2; ++h) ap[h] = a_addr[h] + a_off;
         f32x2 a2[2][TM / 2];
         constexpr bool NMAJOR = TM == 2 && MAUA_W2D_NMAJOR;
-        static_assert(!(PP && NMAJOR), "the phase-locked form splits the K step of the xf-major order");
         float bv[NMAJOR ? 1 : TN][6];
         // windows are read two n-tiles ahead of their transform (12 registers each: at most two are live), the first weight row
         // goes out behind the last window; LDS returns in order, so "at most k operations outstanding" identifies what landed
@@ -498,13 +480,6 @@ __global__ __launch_bounds__(PP ? 512 : 256, PP ? 1 : MINB) void modconv_w2d_ker
             transform(n, slot);
             if constexpr (n + WSLOTS < TN) read_window(std::integral_constant<int, n + WSLOTS>{}, slot);
         });
-        if constexpr (PP) {
-            // load segment | matrix segment (the partner group switches the other way).  A bare s_barrier: a phase lock, not a memory
-            // fence — __syncthreads() would drain vmcnt here and expose the latency of the DMA this segment has just issued
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
         // ---- MFMA phase: the weight row of the next x-frequency is read one step ahead
         static_for<0, 6>([&](auto xf_c) {
             constexpr int xf = decltype(xf_c)::value;
@@ -773,21 +748,21 @@ size_t w2d_lds_bytes(int tm, int tn, int cin) {
 
 char g_w2d_instance[64] = "";
 
-template <int TM, int TN, int MINB = 2, bool PP = false>
+template <int TM, int TN, int MINB = 2>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
-    auto kern = modconv_w2d_kernel<TM, TN, MINB, PP>;
+    auto kern = modconv_w2d_kernel<TM, TN, MINB>;
     static int attr_rc = -1;  // (set once per instantiation; a failure is returned by every launch instead of being swallowed)
     if (attr_rc < 0)
         attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_rc) return attr_rc;
-    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %d, %s>", TM, TN, MINB, PP ? "true" : "false");
-    const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles / (PP ? 2 : 1);
+    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %d>", TM, TN, MINB);
+    const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
 #ifdef MAUA_EXPERIMENTS  // occupancy probe (MAUA_W2D_LDS_PAD with an experiments build): extra dynamic LDS so that a CU holds one workgroup instead of two
     static const size_t lds_pad = getenv("MAUA_W2D_LDS_PAD") ? (size_t)atoi(getenv("MAUA_W2D_LDS_PAD")) : 0;
 #else
     constexpr size_t lds_pad = 0;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PP ? 512 : 256), (PP ? 2 : 1) * w2d_lds_bytes(TM, TN, a.Cin) + lds_pad, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), w2d_lds_bytes(TM, TN, a.Cin) + lds_pad, st, a);
     MAUA_LAUNCH_CHECK();
     return 0;
 }
@@ -832,11 +807,7 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     } else if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
-    if (tm != 4) return w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32>(a, st);
-    // two tiles per workgroup (phase-locked four-wave groups) where the K loop is long enough to pay for one workgroup per CU
-    const int64_t tiles = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
-    if (MAUA_W2D_PP && tiles % 2 == 0 && cin >= MAUA_W2D_PP_MIN_CIN) return w2d_launch_t<4, 2, 1, true>(a, st);
-    return w2d_launch_t<4, 2>(a, st);
+    return tm == 4 ? w2d_launch_t<4, 2>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32>(a, st);
 }
 
 extern "C" int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {

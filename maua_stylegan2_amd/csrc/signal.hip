@@ -738,14 +738,15 @@ extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n
         return MAUA_EINVAL;
     const size_t small = (size_t)k * sizeof(int) + (size_t)n_bins * k * sizeof(float);
     const size_t lds = (size_t)n_frames * sizeof(double) + small;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  150 * 1024);
-        attr_set = true;
+    static int attr_rc = -1;  // (a failure is returned by every call instead of being swallowed)
+    if (attr_rc < 0) {
+        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024);
+        if (!attr_rc)
+            attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     }
+    if (attr_rc) return attr_rc;
     if (!ws) {
         if (lds > 150 * 1024) return MAUA_EINVAL;  // long track: the caller must supply the workspace
         hipLaunchKernelGGL(nn_median_kernel<true>, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, ch, out, n_bins, n_frames, k,

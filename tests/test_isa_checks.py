@@ -49,35 +49,3 @@ def test_hot_kernels_do_not_spill(device_asm, name):
     sspills = [int(v) for v in re.findall(r"\.sgpr_spill_count:\s+(\d+)", device_asm[name])]
     assert spills and max(spills) == 0 and max(sspills) == 0, (spills, sspills)
 
-
-def _main_loop(asm, mangled_fragment):
-    """Instruction lines of the loop with the most MFMAs of the kernel whose mangled name contains ``mangled_fragment``."""
-    lines = asm.split("\n")
-    start = next(i for i, line in enumerate(lines) if line.startswith("_Z") and mangled_fragment in line.split(":")[0])
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-    body = lines[start + 1:end]
-    labels = {m.group(1): i for i, line in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", line))}
-    loops = []
-    for i, line in enumerate(body):
-        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", line)
-        if m and labels.get(m.group(1), len(body)) < i:
-            loops.append((labels[m.group(1)], i))
-    lo, hi = max(loops, key=lambda ab: sum("v_mfma" in line for line in body[ab[0]:ab[1]]))
-    return [line.strip() for line in body[lo:hi + 1] if line.strip() and line.strip()[0] not in ".;"]
-
-
-def test_phase_locked_k_step_has_a_load_segment_and_a_matrix_segment(device_asm):
-    """modconv_w2d_kernel<4, 2, 1, true> (two four-wave groups per workgroup, locked in opposite phases): the K step must be
-    [8 LDS-DMA pieces, window reads, input transforms] s_barrier [weight-row reads, 48 MFMAs] s_waitcnt vmcnt(0) s_barrier — no
-    matrix instruction and no VMEM wait in the load segment (a `__syncthreads()` there drains vmcnt and exposes the latency of the DMA
-    the segment has just issued; transforms that slide behind the barrier steal issue slots from the partner's matrix segment)."""
-    loop = _main_loop(device_asm["modconv_w2d"], "modconv_w2d_kernelILi4ELi2ELi1ELb1")
-    barriers = [i for i, op in enumerate(loop) if op.startswith("s_barrier")]
-    assert len(barriers) == 2, barriers
-    load, matrix = loop[:barriers[0]], loop[barriers[0] + 1:barriers[1]]
-    assert sum("buffer_load" in op and " lds" in op for op in load) == 8
-    assert not any(op.startswith("v_mfma") for op in load) and not any("vmcnt" in op for op in load)
-    assert sum(op.startswith("v_mfma") for op in matrix) == 48
-    valu_in_matrix = [op for op in matrix if op.startswith("v_") and not op.startswith("v_mfma")]
-    assert len(valu_in_matrix) <= 8, valu_in_matrix  # (address bumps only: the transforms live in the load segment)
-    assert any("vmcnt(0)" in op for op in matrix[-8:])
