@@ -6,19 +6,16 @@
 //
 //  * fir_tile_kernel (up = down = 1, the Blur-after-up-conv hot case, 96 % of the path's upfirdn2d bytes —
 //    BASELINE.md §3.2): HBM-bound streaming.  One 256-thread workgroup owns a (WY*32) x (WX*64) output tile of one
-//    plane.  The input tile (+ KH-1 / KW-1 halo) is fetched with dense, lane-consecutive dword loads — rows of the
-//    (2H+1)-wide up-conv output are only 4-byte aligned, so 16-byte vector loads are not available — ALL issued
-//    before the first LDS write (~36 loads/thread, ~36 KB in flight per workgroup, 4 workgroups per CU).  After
+//    plane.  The input tile (+ KH-1 / KW-1 halo) is fetched with dense, lane-consecutive dword BUFFER loads — rows of the
+//    (2H+1)-wide up-conv output are only 4-byte aligned, so 16-byte vector loads are not available; the row offset of an
+//    access is a scalar, the column offset one lane register, out-of-range columns come from the descriptor's range check —
+//    ALL issued before the first LDS write (~36 loads/thread, ~36 KB in flight per workgroup, 4 workgroups per CU).  After
 //    one barrier each wave walks down its 64 columns: lane = column, KW conflict-free ds_read_b32 per input row,
-//    KH rotating accumulators, one dense 256-byte store per wave per output row.  Optional fused tail
-//    (demod gain, noise, bias, leaky-ReLU*sqrt2) = the rest of StyledConv.forward.
-//    Logical tile order is (plane, tile_x, tile_y) with tile_y fastest and an XCD-aware remap so that vertically
-//    adjacent tiles (which share KH-1 halo rows) are served by the same L2.
-//  * fir_strip_kernel: the same tile, staged row-wise (thread = one column of the tile, uniform row base + lane offset:
-//    64 VGPRs, 8 waves/SIMD) — the default for the plain op: 5.56 TB/s on [8,32,1025,1025] (69 % of 8 TB/s, 88 % of the
-//    6.3 TB/s copy ceiling of tools/stream_probe.hip); its software-pipelined strip mode (loads of tile t+1 under the
-//    filtering of tile t) measured no better.  The fused-tail variant keeps fir_tile_kernel (4.6 TB/s): its 32 prefetched
-//    noise values per lane cost occupancy in the strip form.
+//    KH rotating accumulators, one dense 256-byte buffer store per wave per output row.  Optional fused tail
+//    (demod gain, noise, bias, leaky-ReLU*sqrt2) = the rest of StyledConv.forward: the lane's 32 noise values are fetched with
+//    the tile.  Logical tile order is (plane, tile_x, tile_y) with tile_y fastest and an XCD-aware remap so that vertically
+//    adjacent tiles (which share KH-1 halo rows) are served by the same L2; with the tail the channel is fastest (planes that
+//    share a noise tile run back-to-back).
 //  * fir_generic_kernel: any up/down/pad/minor, one thread per output, polyphase tap skipping.
 #include "common.h"
 
@@ -37,21 +34,38 @@ struct FirTail {
     int noise_slot;
 };
 
-constexpr int TILE_ROWS_PER_WAVE = 32;
+// output rows per wave: 32 with the fused tail; 24 for the plain op (27 KB of LDS: five workgroups per CU instead of four — measured
+// 5.51 vs 5.33 TB/s on [8,32,1025,1025], 16 rows 5.46; with the tail 24 and 16 measure the same as 32)
+__host__ __device__ constexpr int fir_tile_rows(bool tail) { return tail ? 32 : 24; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAUA_DEVICE_PASS 1
+#endif
+constexpr unsigned FIR_OOB = 0x80000000u;  // a voffset beyond every descriptor range: loads return 0, stores are dropped
+
+// up = down = 1 FIR of one (WY*32) x (WX*64) output tile per 256-thread workgroup (the Blur after an up-convolution and its fused
+// tail).  Round 4 form: every global access is a raw BUFFER instruction whose row offset is a SCALAR (soffset) and whose column
+// offset is one lane register computed once — a wave instruction reads / writes 64 consecutive floats of one row, and which row
+// that is is uniform over the wave.  The round-3 kernels (fir_strip_kernel / fir_tile_kernel, flat 64-bit addresses + predicates)
+// spent 1400-1520 VALU instructions per wave on 512 useful FMAs (2 VALU of 64-bit address arithmetic per load, a compare + branch
+// per access, a zero-initialising move per staged value): 4 waves per SIMD x 4 cycles made the VALU 70-80 % busy at the rates
+// they reached, i.e. they were as much issue-bound as HBM-bound.  Here out-of-range columns are an out-of-range voffset (the
+// descriptor returns 0 / drops the store), out-of-range rows a scalar branch.
 template <int KH, int KW, int WX, bool TAIL>
 __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                        float* __restrict__ y, int planes, int in_h, int in_w,
                                                        int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
                                                        int tiles_y, FirTail tail) {
     constexpr int WY = 4 / WX;
-    constexpr int TH = TILE_ROWS_PER_WAVE;
+    constexpr int TH = fir_tile_rows(TAIL);
     constexpr int TW = 64 * WX;
     constexpr int RH = WY * TH + KH - 1;  // staged rows
     constexpr int RW = TW + KW - 1;       // staged cols
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblocks = gridDim.x;
     int t = xcd_remap(blockIdx.x, nblocks);
     int plane, tile_x, tile_y;
@@ -79,42 +93,53 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
 
-    const float* xp = x + (size_t)plane * in_h * in_w;
     const int iy0 = oy0 - pad_y0;
     const int ix0 = ox0 - pad_x0;
-
-    // ---- stage: issue every global load first, then write LDS.  Thread (ty, tx) owns column tx of rows ty, ty+WY, ...:
-    // a wave instruction reads 64 consecutive floats of one row (uniform row base + lane offset: no per-element decode,
-    // no 64-bit address registers -> 64 VGPRs, 8 waves/SIMD); the KW-1 halo columns go to the first (KW-1)*RH threads.
+    // staging map: wave w owns columns (w % WX) * 64 + lane of the rows w / WX, w / WX + WY, ...; the KW-1 halo columns of the tile
+    // go to the first (KW-1) * RH threads
     constexpr int NR = (RH + WY - 1) / WY;
     constexpr int NH = ((KW - 1) * RH + 255) / 256;
-    const int tx = tid % TW, ty = tid / TW;
+    const int tx = (wave % WX) * 64 + lane;
+    const int ty = wave / WX;  // (scalar)
     const int ixm = ix0 + tx;
-    const bool okx = ixm >= 0 && ixm < in_w;
+    const unsigned in_voff = (ixm >= 0 && ixm < in_w) ? (unsigned)ixm * 4u : FIR_OOB;
+    const unsigned in_row_bytes = (unsigned)in_w * 4u, out_row_bytes = (unsigned)out_w * 4u;
+#ifdef MAUA_DEVICE_PASS
+    // one descriptor per plane: offsets stay below 2^31 (checked by the launcher), anything past the plane's end is out of range
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x) + (size_t)plane * in_h * in_w, 0, (int)((unsigned)in_h * in_row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(y + (size_t)plane * out_h * out_w, 0, (int)((unsigned)out_h * out_row_bytes), 0x00020000);
+#endif
     float v[NR], vh[NH];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int rr = ty + i * WY;
+        const int rr = ty + i * WY;  // (scalar)
         const int iy = iy0 + rr;
         v[i] = 0.f;
-        if (rr < RH && okx && iy >= 0 && iy < in_h)
-            v[i] = xp[(size_t)iy * in_w + ixm];
+#ifdef MAUA_DEVICE_PASS
+        if (rr < RH && iy >= 0 && iy < in_h)  // uniform over the wave: a scalar branch
+            v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, in_voff, (unsigned)iy * in_row_bytes, 0));
+#endif
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int e = tid + h * 256;
         const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
         const int iy = iy0 + hr, ix = ix0 + hc;
+        const bool ok = e < (KW - 1) * RH && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
         vh[h] = 0.f;
-        if (e < (KW - 1) * RH && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) vh[h] = xp[(size_t)iy * in_w + ix];
+#ifdef MAUA_DEVICE_PASS
+        vh[h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              x_rsrc, ok ? ((unsigned)iy * (unsigned)in_w + (unsigned)ix) * 4u : FIR_OOB, 0, 0));
+#endif
     }
-    // wave (wx, wy), lane = column
-    const int wave = tid >> 6, lane = tid & 63;
+    // compute map: wave (wx, wy), lane = column
     const int wx = wave % WX, wy = wave / WX;
     const int col = wx * 64 + lane;
     const int ox = ox0 + col;
     const int row0 = wy * TH;
-    const bool col_ok = ox < out_w;
+    const unsigned out_voff = ox < out_w ? (unsigned)ox * 4u : FIR_OOB;
 
     // tail operands: this lane's 32 noise values are fetched now, in flight together with the input tile
     float g = 1.f, nw = 0.f, bs = 0.f;
@@ -122,8 +147,9 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     if (TAIL) {
         const int b = plane / tail.channels;
         const int c = plane - b * tail.channels;
-        if (tail.gain) g = tail.gain[plane];
-        bs = tail.bias ? tail.bias[c] : 0.f;
+        // leaky ReLU * sqrt2 as max(t, 0.2 t) on pre-scaled operands: t = sqrt2 (g v + nw noise + bias)
+        g = 1.41421356237309515f * (tail.gain ? tail.gain[plane] : 1.f);
+        bs = tail.bias ? tail.bias[c] * 1.41421356237309515f : 0.f;
 #pragma unroll
         for (int o = 0; o < TH; ++o) nzv[o] = 0.f;
         const float* noise = tail.noise;
@@ -134,11 +160,17 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
             if (noise) noise += (int64_t)tail.src->frame0 * nstride;
         }
         if (noise) {
-            nw = tail.noise_w[0];
-            const float* nz = noise + (size_t)b * nstride;
+            nw = tail.noise_w[0] * 1.41421356237309515f;
+#ifdef MAUA_DEVICE_PASS
+            const __amdgpu_buffer_rsrc_t n_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(noise) + (size_t)b * nstride, 0, (int)((unsigned)out_h * out_row_bytes), 0x00020000);
 #pragma unroll
-            for (int o = 0; o < TH; ++o)
-                if (col_ok && oy0 + row0 + o < out_h) nzv[o] = nz[(size_t)(oy0 + row0 + o) * out_w + ox];
+            for (int o = 0; o < TH; ++o) {
+                const int oy = oy0 + row0 + o;  // (scalar)
+                if (oy < out_h)
+                    nzv[o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(n_rsrc, out_voff, (unsigned)oy * out_row_bytes, 0));
+            }
+#endif
         }
     }
 #pragma unroll
@@ -154,151 +186,41 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     }
     __syncthreads();
 
-    float* yp = y + (size_t)plane * out_h * out_w;
-
     float acc[KH];
 #pragma unroll
     for (int i = 0; i < KH; ++i) acc[i] = 0.f;
-    const float* lrow = lds + row0 * RW + col;
+    // (the row pointer is advanced, not indexed: ds_read2_b32 takes 8-bit dword offsets, and r * RW as an immediate made the compiler
+    // rebuild the address with a VALU add for every pair of reads)
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* lrow = (lds_float*)lds + (row0 * RW + col);
 #pragma unroll
     for (int r = 0; r < TH + KH - 1; ++r) {
         float in[KW];
 #pragma unroll
-        for (int j = 0; j < KW; ++j) in[j] = lrow[r * RW + j];
+        for (int j = 0; j < KW; ++j) in[j] = lrow[j];
+        lrow += RW;
+        asm volatile("" : "+v"(lrow));  // (one VALU add of the running LDS address per row instead of re-derived addresses)
 #pragma unroll
         for (int i = 0; i < KH; ++i) {
             const int o = r - i;  // output row (within the wave's strip) this input row feeds through tap row i
             if (o >= 0 && o < TH) {
 #pragma unroll
-                for (int j = 0; j < KW; ++j) acc[o % KH] = fmaf(kf[i][j], in[j], acc[o % KH]);
+                for (int j = 0; j < KW; ++j) acc[o % KH] = (i == 0 && j == 0) ? kf[i][j] * in[j] : fmaf(kf[i][j], in[j], acc[o % KH]);
             }
         }
         const int o_done = r - (KH - 1);
         if (o_done >= 0) {
-            const int oy = oy0 + row0 + o_done;
+            const int oy = oy0 + row0 + o_done;  // (scalar)
             float val = acc[o_done % KH];
-            acc[o_done % KH] = 0.f;
-            if (TAIL) val = lrelu_gain(fmaf(nw, nzv[TAIL ? o_done : 0], val * g) + bs);
-            if (col_ok && oy < out_h) yp[(size_t)oy * out_w + ox] = val;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// fir_strip_kernel: the plain op (no tail).  The same row-staged tile as fir_tile_kernel; a workgroup walks DOWN a strip of
-// `strip_len` vertically adjacent tiles of one plane (1 on the shapes of the path: longer, software-pipelined strips measured
-// no better, profiles/r02_w2d.md).  64 VGPRs, 8 waves/SIMD: 5.3-5.6 TB/s on [8,32,1025,1025].
-template <int KH, int KW, int WX>
-__global__ __launch_bounds__(256) void fir_strip_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                        float* __restrict__ y, int planes, int in_h, int in_w,
-                                                        int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
-                                                        int tiles_y, int strip_len) {
-    constexpr int WY = 4 / WX;
-    constexpr int TH = TILE_ROWS_PER_WAVE;
-    constexpr int TW = 64 * WX;
-    constexpr int RH = WY * TH + KH - 1;
-    constexpr int RW = TW + KW - 1;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x;
-    const int strips_y = (tiles_y + strip_len - 1) / strip_len;
-    int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_plane = tiles_x * strips_y;
-    const int plane = t / per_plane;
-    t -= plane * per_plane;
-    const int tile_x = t / strips_y;
-    const int strip = t - tile_x * strips_y;
-    const int ty_begin = strip * strip_len;
-    const int ty_end = min(tiles_y, ty_begin + strip_len);
-    const int ox0 = tile_x * TW;
-
-    float kf[KH][KW];
-#pragma unroll
-    for (int i = 0; i < KH; ++i)
-#pragma unroll
-        for (int j = 0; j < KW; ++j) kf[i][j] = k[(KH - 1 - i) * KW + (KW - 1 - j)];
-
-    const float* xp = x + (size_t)plane * in_h * in_w;
-    float* yp = y + (size_t)plane * out_h * out_w;
-    const int ix0 = ox0 - pad_x0;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wx = wave % WX, wy = wave / WX;
-    const int col = wx * 64 + lane;
-    const int ox = ox0 + col;
-    const int row0 = wy * TH;
-    const bool col_ok = ox < out_w;
-
-    // Staging map: thread (ty, tx) owns column tx of rows ty, ty+WY, ... (a wave instruction = 64 consecutive floats of
-    // one row, address = uniform row base + lane offset -> no per-element decode, no 64-bit address registers); the
-    // KW-1 halo columns are spread over the first (KW-1)*RH threads.
-    constexpr int NR = (RH + WY - 1) / WY;
-    constexpr int NH = ((KW - 1) * RH + 255) / 256;
-    const int tx = tid % TW, ty = tid / TW;
-    const int ixm = ix0 + tx;
-    const bool okx = ixm >= 0 && ixm < in_w;
-    float v[NR], vh[NH];
-    auto issue = [&](int tile_y) {
-        const int iy0 = tile_y * (WY * TH) - pad_y0;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int rr = ty + i * WY;
-            const int iy = iy0 + rr;
-            v[i] = 0.f;
-            if (rr < RH && okx && iy >= 0 && iy < in_h) v[i] = xp[(size_t)iy * in_w + ixm];
-        }
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const int e = tid + h * 256;
-            const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
-            const int iy = iy0 + hr, ix = ix0 + hc;
-            vh[h] = 0.f;
-            if (e < (KW - 1) * RH && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) vh[h] = xp[(size_t)iy * in_w + ix];
-        }
-    };
-
-    issue(ty_begin);
-    for (int tile_y = ty_begin; tile_y < ty_end; ++tile_y) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int rr = ty + i * WY;
-            if (rr < RH) lds[rr * RW + tx] = v[i];
-        }
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const int e = tid + h * 256;
-            const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
-            if (e < (KW - 1) * RH) lds[hr * RW + hc] = vh[h];
-        }
-        __syncthreads();
-
-        const int oy0 = tile_y * (WY * TH);
-        float acc[KH];
-#pragma unroll
-        for (int i = 0; i < KH; ++i) acc[i] = 0.f;
-        const float* lrow = lds + row0 * RW + col;
-#pragma unroll
-        for (int r = 0; r < TH + KH - 1; ++r) {
-            float in[KW];
-#pragma unroll
-            for (int j = 0; j < KW; ++j) in[j] = lrow[r * RW + j];
-#pragma unroll
-            for (int i = 0; i < KH; ++i) {
-                const int o = r - i;
-                if (o >= 0 && o < TH) {
-#pragma unroll
-                    for (int j = 0; j < KW; ++j) acc[o % KH] = fmaf(kf[i][j], in[j], acc[o % KH]);
-                }
+            if (TAIL) {
+                const float tt = fmaf(val, g, fmaf(nw, nzv[TAIL ? o_done : 0], bs));
+                val = fmaxf(tt, 0.2f * tt);
             }
-            const int o_done = r - (KH - 1);
-            if (o_done >= 0) {
-                const int oy = oy0 + row0 + o_done;
-                const float val = acc[o_done % KH];
-                acc[o_done % KH] = 0.f;
-                if (col_ok && oy < out_h) yp[(size_t)oy * out_w + ox] = val;
-            }
+#ifdef MAUA_DEVICE_PASS
+            if (oy < out_h)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), y_rsrc, out_voff, (unsigned)oy * out_row_bytes, 0);
+#endif
         }
-        __syncthreads();  // every wave is done reading this tile before the next one overwrites LDS
-        if (tile_y + 1 < ty_end) issue(tile_y + 1);
     }
 }
 
@@ -390,21 +312,19 @@ int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in
     auto go = [&](auto wx_tag) -> int {
         constexpr int WX = decltype(wx_tag)::value;
         constexpr int WY = 4 / WX;
-        constexpr int RH = WY * TILE_ROWS_PER_WAVE + KH - 1, RW = 64 * WX + KW - 1;
-        const int tiles_x = ceil_div(out_w, 64 * WX), tiles_y = ceil_div(out_h, WY * TILE_ROWS_PER_WAVE);
+        constexpr int RH = WY * fir_tile_rows(TAIL) + KH - 1, RW = 64 * WX + KW - 1;
+        const int tiles_x = ceil_div(out_w, 64 * WX), tiles_y = ceil_div(out_h, WY * fir_tile_rows(TAIL));
         const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
         if (nblocks <= 0) return 0;
         if (nblocks > 0x7fffffff) return MAUA_EINVAL;
         const size_t lds_bytes = (size_t)RH * RW * sizeof(float);
-        if constexpr (TAIL)
-            hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, true>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y,
-                               planes, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
-        else
-            hipLaunchKernelGGL((fir_strip_kernel<KH, KW, WX>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y, planes,
-                               in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, 1);
+        hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y, planes,
+                           in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
         MAUA_LAUNCH_CHECK();
         return 0;
     };
+    // (the kernel addresses a plane through 32-bit buffer offsets)
+    if ((int64_t)in_h * in_w * 4 >= 0x7fffffffLL || (int64_t)out_h * out_w * 4 >= 0x7fffffffLL) return MAUA_ENOSYS;
     if (out_w <= 64) return go(std::integral_constant<int, 1>{});
     if (out_w <= 128) return go(std::integral_constant<int, 2>{});
     return go(std::integral_constant<int, 4>{});
@@ -434,7 +354,8 @@ extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int 
     hipStream_t st = (hipStream_t)stream;
     if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == kw && kh >= 2 && kh <= 4) {
         FirTail none{};
-        return dispatch_fir_tile<false>(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, none, st);
+        const int rc = dispatch_fir_tile<false>(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, none, st);
+        if (rc != MAUA_ENOSYS) return rc;  // (planes of 2 GiB and more take the generic gather below)
     }
     const int64_t total = (int64_t)major * out_h * out_w * minor;
     const int64_t blocks = ceil_div64(total, 256);

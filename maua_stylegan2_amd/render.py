@@ -16,6 +16,7 @@ with ``input_is_latent=True``), different machinery:
 Sinks: ffmpeg rawvideo pipe (same pixel format / codec arguments as render.py:58-91) when an ``ffmpeg`` binary exists,
 otherwise raw rgb24 bytes to ``output_file`` (+ ".rgb24"), or a null sink for benchmarking (``output_file=None``).
 """
+import os
 import queue
 import shutil
 import subprocess
@@ -388,11 +389,16 @@ def render(generator, latents, noise, offset, duration, batch_size, out_size, ou
 
 
 def render_shard(generator, latents, noise, offset, duration, batch_size, out_size, output_file, audio_file, truncation,
-                 bends, rewrites, randomize_noise, ffmpeg_preset, _shard):
+                 bends, rewrites, randomize_noise, ffmpeg_preset, _shard, transport=None):
     """``render`` with an optional ``_shard = (lo, hi, n_frames)``: set by generate() after sharding.scatter_frames, it says
     that ``latents`` / ``noise`` / ``truncation`` / bend modulations already hold only this rank's block of the frames."""
     width, height = _output_dims(out_size)
     rank, world = sharding.rank_world()
+    # multi-GPU frame transport: "gather" (default: RCCL gather of every round into rank 0's HBM, sharding.FrameStream) or "host"
+    # (per-rank D2H into shared memory, sharding.HostFrameStore)
+    transport = transport or os.environ.get("MAUA_FRAME_TRANSPORT", "gather")
+    if transport not in ("gather", "host"):
+        raise ValueError(f"unknown frame transport {transport!r} (gather | host)")
     if _shard is None:
         n_frames = len(latents)
         lo, hi = sharding.shard_bounds(n_frames, rank, world)
@@ -433,6 +439,45 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
                 # the producer must not overwrite u8 before the copy has read it
                 th.cuda.current_stream(dev).wait_event(copied)
                 worker.submit(copied.synchronize, pinned[slot].numpy(), u8.shape[0], lambda s=slot: free.put(s))
+        elif transport == "host":
+            # every rank copies its rounds to a pinned shared-memory segment over its own PCIe link; rank 0's sink thread reads the
+            # segments in global order (sharding.HostFrameStore) — no xGMI traffic, no funnel through rank 0's link
+            token = sharding.broadcast_object(f"{os.getpid():x}{int.from_bytes(os.urandom(4), 'little'):08x}" if rank == 0 else None)
+            store = None
+            reader = None
+            k = 0
+            resized = {}
+
+            def start_reader():
+                def run():
+                    for _, count, host in store.rounds_in_order():
+                        worker.submit(None, host.numpy(), count, None)
+
+                t = threading.Thread(target=run, name="maua-host-gather", daemon=True)
+                t.start()
+                return t
+
+            try:
+                for first, u8 in synthesize(generator, latents, noise, batch_size, truncation, bends, rewrites,
+                                            randomize_noise, frame_range=frame_range):
+                    u8 = crop_resize_for_delivery(u8, out_size, resized)
+                    if store is None:
+                        store = sharding.HostFrameStore(n_frames, batch_size, tuple(u8.shape[1:]), dev, token)
+                        if rank == 0:
+                            reader = start_reader()
+                    store.push(k, u8)
+                    k += 1
+                if store is None:
+                    store = sharding.HostFrameStore(n_frames, batch_size, _stream_frame_shape(generator, out_size), dev, token)
+                    if rank == 0:
+                        reader = start_reader()
+                store.finish()
+                if reader is not None:
+                    reader.join()
+                    worker.close()
+            finally:
+                if store is not None:
+                    store.close()
         else:
             # One asynchronous gather per batch-round, issued as soon as the round's frames exist: the transfer of round k
             # runs under the compute of rounds k+1.., rank 0 hands rounds to its sink thread as they land (its own block

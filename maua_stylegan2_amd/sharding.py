@@ -312,3 +312,151 @@ class FrameStream:
                     yield first + i, host[i]
             finally:
                 release()
+
+
+class HostFrameStore:
+    """Alternative frame transport for a multi-GPU job on ONE host (``MAUA_FRAME_TRANSPORT=host`` / ``render(..., transport="host")``):
+    every rank copies its batch-rounds to the host over ITS OWN PCIe link, into a POSIX shared-memory segment it owns (pinned in
+    place with hipHostRegister, so the copy is an asynchronous DMA), and publishes a round counter in the segment's header; rank 0's
+    sink thread maps the peers' segments and reads the frames in global order.  Nothing travels over xGMI and nothing funnels
+    through rank 0's single PCIe link — with the default transport (FrameStream: RCCL gather into rank 0's HBM, then rank 0's D2H)
+    8 x 1200 frames/s of 1024^2 frames are 30 GB/s through one link and one process.  The default stays the RCCL gather that
+    BASELINE.json's north_star names; this path exists for jobs whose encoder keeps up with more than one link's worth of frames.
+    UNMEASURED on more than one GPU (no multi-GPU box in this environment); covered by a world-size-2 gloo test.
+
+    Segment of rank r: [int64 published_rounds, int64 reserved] + rounds x batch x frame bytes (the rank's whole block: a peer never
+    stalls on a slow sink, as with FrameStream's HBM store)."""
+
+    HEADER = 64
+
+    def __init__(self, n_frames, batch_size, frame_shape, device, token):
+        import threading
+        from multiprocessing import shared_memory
+
+        import numpy as np
+
+        self._np, self._shm_mod = np, shared_memory
+        self.rank, self.world = rank_world()
+        self.n_frames, self.batch = int(n_frames), int(batch_size)
+        self.shape = tuple(frame_shape)
+        self.per = max_shard(n_frames, self.world)
+        self.rounds = (self.per + self.batch - 1) // self.batch
+        self.lo, self.hi = shard_bounds(n_frames, self.rank, self.world)
+        self.token = str(token)
+        self.round_bytes = self.batch * int(np.prod(self.shape))
+        size = self.HEADER + max(self.rounds, 1) * self.round_bytes
+        self._mine = shared_memory.SharedMemory(name=self._name(self.rank), create=True, size=size)
+        self._header = np.ndarray((2,), dtype=np.int64, buffer=self._mine.buf)
+        self._header[:] = 0
+        self._frames = th.from_numpy(np.ndarray((max(self.rounds, 1), self.batch) + self.shape, dtype=np.uint8, buffer=self._mine.buf,
+                                                offset=self.HEADER))
+        self._on_gpu = th.device(device).type == "cuda"
+        self._registered = False
+        self._copy_stream = None
+        if self._on_gpu:
+            rc = th.cuda.cudart().cudaHostRegister(self._frames.data_ptr(), self._frames.numel(), 0)
+            self._registered = int(rc) == 0  # (an unpinned segment still works: the copy is then staged by the runtime)
+            self._copy_stream = th.cuda.Stream(device)
+        self.pushed = 0
+        self._events = []
+        self._published = 0
+        self._lock = threading.Lock()
+        self._peers = {}
+        if self.world > 1:
+            dist.barrier()  # every segment exists before anybody attaches
+
+    def _name(self, rank):
+        return f"maua_{self.token}_r{rank}"
+
+    def push(self, k, u8):
+        """Round k of this rank's block ([b <= batch, H, W, 3] uint8 on the device, or None): asynchronous copy into the segment."""
+        if k != self.pushed:
+            raise RuntimeError(f"HostFrameStore.push: round {k} out of order (expected {self.pushed})")
+        if u8 is not None:
+            dst = self._frames[k, : u8.shape[0]]
+            if self._on_gpu:
+                produced = th.cuda.Event()
+                produced.record(th.cuda.current_stream(u8.device))
+                with th.cuda.stream(self._copy_stream):
+                    self._copy_stream.wait_event(produced)
+                    dst.copy_(u8, non_blocking=True)
+                    done = th.cuda.Event()
+                    done.record(self._copy_stream)
+                th.cuda.current_stream(u8.device).wait_event(done)  # the producer must not overwrite u8 before the copy has read it
+                self._events.append(done)
+            else:
+                dst.copy_(u8)
+                self._events.append(None)
+        else:
+            self._events.append(None)
+        self.pushed += 1
+        self.publish(block=False)
+
+    def publish(self, block):
+        """Advance the published-round counter over every round whose copy has completed (in order)."""
+        with self._lock:
+            while self._published < len(self._events):
+                ev = self._events[self._published]
+                if ev is not None:
+                    if block:
+                        ev.synchronize()
+                    elif not ev.query():
+                        break
+                self._published += 1
+            self._header[0] = self._published
+
+    def finish(self):
+        while self.pushed < self.rounds:
+            self.push(self.pushed, None)
+        self.publish(block=True)
+
+    def _peer(self, p):
+        if p == self.rank:
+            return self._header, self._frames
+        if p not in self._peers:
+            np = self._np
+            shm = self._shm_mod.SharedMemory(name=self._name(p))
+            header = np.ndarray((2,), dtype=np.int64, buffer=shm.buf)
+            frames = th.from_numpy(np.ndarray((max(self.rounds, 1), self.batch) + self.shape, dtype=np.uint8, buffer=shm.buf,
+                                              offset=self.HEADER))
+            self._peers[p] = (shm, header, frames)
+        return self._peers[p][1], self._peers[p][2]
+
+    def rounds_in_order(self, poll_s=0.0005, own_progress=None):
+        """Rank 0: yield (first_frame_index, count, uint8 host tensor [count, H, W, 3]) for every round in global frame order
+        (rank-major), waiting for each to be published.  ``own_progress()`` is called while waiting on rank 0's OWN rounds (its
+        publisher runs on the thread that pushes)."""
+        import time
+
+        for p in range(self.world):
+            lo, hi = shard_bounds(self.n_frames, p, self.world)
+            header, frames = self._peer(p)
+            k = 0
+            while lo + k * self.batch < hi:
+                while int(header[0]) <= k:
+                    if p == self.rank:
+                        self.publish(block=False)
+                        if own_progress is not None:
+                            own_progress()
+                    time.sleep(poll_s)
+                first = lo + k * self.batch
+                count = min(self.batch, hi - first)
+                yield first, count, frames[k, :count]
+                k += 1
+
+    def close(self):
+        """Collective: every rank keeps its segment until rank 0 has read it."""
+        if self.world > 1:
+            dist.barrier()
+        for shm, _, _ in self._peers.values():
+            shm.close()
+        self._peers = {}
+        if self._registered:
+            th.cuda.cudart().cudaHostUnregister(self._frames.data_ptr())
+            self._registered = False
+        self._header = self._frames = None
+        try:
+            self._mine.close()
+            self._mine.unlink()
+        except (FileNotFoundError, BufferError):
+            pass

@@ -342,6 +342,73 @@ def test_sink_worker_keeps_order_bounds_the_ring_and_reraises():
     assert released  # slots are handed back even when the write failed
 
 
+def _host_store_worker(rank, world, port, out_dir, n_frames, batch):
+    """sharding.HostFrameStore under two ranks (CPU "device": the copies are synchronous, the segments are not pinned): every rank
+    writes its rounds into its own shared-memory segment, rank 0 reads all segments in global frame order through the same reader
+    thread + SinkWorker wiring render_shard uses."""
+    import threading
+    import time
+
+    from maua_stylegan2_amd import render
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        token = sharding.broadcast_object(f"t{os.getpid():x}" if rank == 0 else None)
+        lo, hi = sharding.shard_bounds(n_frames, rank, world)
+        store = sharding.HostFrameStore(n_frames, batch, (4, 5, 3), torch.device("cpu"), token)
+        written = []
+
+        class Sink:
+            def write(self, frame):
+                assert frame.shape == (4, 5, 3) and int(frame.min()) == int(frame.max())
+                written.append(int(frame[0, 0, 0]))
+
+        worker = reader = None
+        if rank == 0:
+            worker = render.SinkWorker(Sink())
+
+            def run():
+                for _, count, host in store.rounds_in_order():
+                    worker.submit(None, host.numpy(), count, None)
+
+            reader = threading.Thread(target=run, daemon=True)
+            reader.start()
+        k = 0
+        for first in range(lo, hi, batch):
+            if rank == 1:
+                time.sleep(0.05)  # the peer is the slow producer: rank 0's reader has to wait for its rounds
+            count = min(batch, hi - first)
+            u8 = torch.zeros((count, 4, 5, 3), dtype=torch.uint8)
+            for i in range(count):
+                u8[i] = (first + i) % 251
+            store.push(k, u8)
+            k += 1
+        store.finish()
+        if rank == 0:
+            reader.join(timeout=30)
+            assert not reader.is_alive()
+            worker.close()
+            assert written == [i % 251 for i in range(n_frames)]
+            np.save(os.path.join(out_dir, "host_store_ok.npy"), np.array([n_frames]))
+        store.close()
+        import glob
+
+        dist.barrier()
+        assert not glob.glob(f"/dev/shm/maua_{token}_r*"), "shared-memory segments must not outlive the render"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames,batch", [(23, 3), (8, 4), (3, 8)])
+def test_host_frame_store_delivers_ordered_frames_through_shared_memory(tmp_path, n_frames, batch):
+    """the per-rank D2H transport (MAUA_FRAME_TRANSPORT=host) — every rank's rounds go to its own shared-memory
+    segment, rank 0's sink thread reads them in global order; ragged tails and a round shorter than a batch included;
+    the segments are unlinked at the end."""
+    mp.spawn(_host_store_worker, args=(2, _free_port(), str(tmp_path), n_frames, batch), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "host_store_ok.npy")[0]) == n_frames
+
+
 def _generate_worker(rank, world, port, out_dir):
     """generate() under a 2-rank process group with CPU stand-ins for the audio decoder, the generator and the renderer: what is
     under test is the ORDER of the multi-GPU hand-over and the random streams of the plugin callbacks."""

@@ -28,6 +28,6 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace -d "$O/pmc_sq" -o bench -- python "$R/bench.py" $SHORT --lanes 1 --no-breakdown > /dev/null 2> "$O/pmc_sq.err"
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace -d "$O/pmc_lds" -o bench -- python "$R/bench.py" $SHORT --lanes 1 --no-breakdown > /dev/null 2> "$O/pmc_lds.err"
-# the standalone upfirdn2d leg needs the breakdown-free run above to contain fir_strip_kernel: it does (roofline_upfirdn2d is always timed)
+# the standalone upfirdn2d leg needs the breakdown-free run above to contain fir_tile_kernel<4, 4, 4, false>: it does (roofline_upfirdn2d is always timed)
 find "$O" -name "*.db" -size +20M -delete   # keep the merge-back under gpurun's 64 MiB limit
 du -sh "$O"; tail -2 "$O/pytest_gpu.log"; cat "$O/smoke.log" | tail -1; head -c 600 "$O/bench_default.json"
