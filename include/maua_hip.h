@@ -134,6 +134,12 @@ int maua_pack_weight_upwino_f32(const float* w, float* wq, int cout, int cin, vo
 int64_t maua_pack_weight_up2d_floats(int cout, int cin);
 int maua_pack_weight_up2d_f32(const float* w, float* wq, int cout, int cin, void* stream);
 int maua_modconv_up2d_ok(int cin, int cout, int h, int w);
+/* SIDE MEASUREMENT (off by default, never the headline): packed weight of the split-bf16 plain convolution (up == 7 below) — every
+ * fp32 weight as two bf16 terms w_h + w_l in MFMA lane order, maua_pack_weight_sbf16_bytes() bytes.  maua_modconv_sbf16_ok():
+ * cin % 16 == 0, cout % 128 == 0, h % 8 == 0, w % 32 == 0. */
+int64_t maua_pack_weight_sbf16_bytes(int cout, int cin);
+int maua_pack_weight_sbf16_f32(const float* w, void* wq, int cout, int cin, void* stream);
+int maua_modconv_sbf16_ok(int cin, int cout, int h, int w);
 
 /* 2-D Winograd F(2x4, 3x3) form for mode 5 (F(2,3) along ky on top of F(4,3) along kx: 24 values per (cout, cin) pair),
  * stored as the LDS tile image the kernel DMAs linearly: wq[cout/BM][cin/4][fy 4][xf 6][cin%4][BM columns] (BM = 64, or 32 for
@@ -159,6 +165,9 @@ int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w);
  *             25/36 of the MFMA cycles of up == 1; wp from maua_pack_weight_up2d_f32.
  *   up == 5 : the plain convolution through 2-D Winograd F(2x4, 3x3) (shapes accepted by maua_modconv_w2d_ok): 3x fewer
  *             MFMA cycles than direct, 1.5x fewer than up == 3; wp from maua_pack_weight_wino2d_f32.
+ *   up == 7 : SIDE MEASUREMENT — the plain convolution in its direct 9-tap form with split-bf16 products on the bf16 matrix cores
+ *             (a b ~= a_h b_h + a_h b_l + a_l b_h, fp32 accumulation; relative error of a product <= 2^-16 + 2^-17); wp from
+ *             maua_pack_weight_sbf16_f32.  Not used unless the caller asks for it; the default path computes in fp32.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
  * floats used for split-K partial sums on small feature maps and, for up == 6, for the exported last input column [B, cin, H]

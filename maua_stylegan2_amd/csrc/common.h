@@ -41,3 +41,10 @@ const char* maua_up2d_last_instance();
 int64_t maua_up2d_ws_floats(int batch, int cin, int h);
 int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
                      int cout, int h, int w, float wscale, void* stream);
+
+// modconv_sbf16.hip (mode 7 of maua_modconv3x3_f32; side measurement, off by default): plain 3x3 convolution with split-bf16 products
+int maua_sbf16_ok(int cin, int cout, int h, int w);
+const char* maua_sbf16_last_instance();
+int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin, int cout,
+                      int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                      const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream);

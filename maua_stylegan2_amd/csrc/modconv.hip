@@ -1353,6 +1353,13 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
         if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
         return rc;
     }
+    if (up == 7) {  // plain conv with split-bf16 products (side measurement), modconv_sbf16.hip
+        if (rgb) return MAUA_ENOSYS;
+        const int rc = maua_sbf16_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, fuse_act, noise, noise_batch_stride,
+                                         noise_w, bias, src, noise_slot, stream);
+        if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_sbf16_last_instance());
+        return rc;
+    }
     if (up == 6) {  // transposed conv, F(2,2) on both axes, modconv_up2d.hip: raw output only (the blur kernel applies the tail)
         if (fuse_act || rgb) return MAUA_EINVAL;
         const int rc = maua_up2d_launch(x, wp, s, s_stride, d, y, ws, batch, cin, cout, h, w, wscale, stream);

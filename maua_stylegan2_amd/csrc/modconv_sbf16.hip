@@ -1,0 +1,318 @@
+// SIDE MEASUREMENT, never the headline path: plain 3x3 modulated convolution with SPLIT-bf16 products on the
+// bf16 matrix cores (mode 7 of maua_modconv3x3_f32), fp32 accumulation.
+//
+// Behavioural contract: /root/reference/models/stylegan2.py:217-254 (plain branch :248-252) + the StyledConv tail :338-343, in the
+// input-scale -> shared-weight contraction -> output-demod formulation of modconv.hip.  What changes is the arithmetic of the
+// contraction: every fp32 operand is split into two bf16 terms, a = a_h + a_l (a_h = bf16(a), a_l = bf16(a - a_h)), and
+//
+//     a b  ~=  a_h b_h + a_h b_l + a_l b_h          (the a_l b_l term, <= 2^-16 |a b|, is dropped; products and sums in fp32)
+//
+// i.e. three v_mfma_f32_32x32x16_bf16 per K slice instead of one fp32 MFMA.  The bf16 matrix pipe is 16 x the fp32 one
+// (MI355X_MICROARCH.md: 2.5 PFLOP/s vs 157.3 TFLOP/s), so the DIRECT 9-tap form costs 9 x 3 / 16 = 1.7 fp32-MFMA units per MAC
+// against 3 for the 2-D Winograd kernel — without its input transforms, weight-tile DMA and exchange epilogue.  The relative error
+// of a product is <= 2^-16 + 2^-17 (dropped term + the rounding of the two low halves), of the same order as the fp32 Winograd
+// forms (measured in tests/test_layers_gpu.py::test_modconv_split_bf16_vs_oracle and reported by bench.py next to the time).
+// The headline dtype stays f32: this mode is OFF unless ModulatedConv2d.split_bf16_min_cout is lowered (bench.py side_configs).
+//
+// Work decomposition: a workgroup owns 128 output channels x (8 rows x 32 columns) pixels; wave (wm, wn) takes 64 channels (two
+// 32-row m-tiles) x 4 rows (four 32-column n-tiles): 8 accumulator tiles of 32 x 32 = 128 registers.  K runs over chunks of 16
+// input channels x 9 taps.
+//   B operand: the 10 x 34 halo patch of a chunk is fetched with buffer loads (lane = pixel, scalar channel offset), scaled by the
+//     style, split, and written to LDS as 16-byte records [hi | lo][k half][row][col][8 channels]; a tap is a shifted view of the
+//     patch (no im2col), one conflict-free ds_read_b128 per (n-tile, hi | lo).  Double buffered: the next chunk's loads are in
+//     flight under the nine taps of the current one.
+//   A operand: the packed weight (maua_pack_weight_sbf16_f32) is stored in HBM in MFMA lane order, [m-tile][chunk][tap][hi | lo]
+//     [lane][8], and goes straight to registers (one 16-byte load per lane, m-tile and half, one tap ahead): no LDS, no DMA.
+#include "common.h"
+
+#include <cstdio>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAUA_DEVICE_PASS 1
+#endif
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SB_BM = 128;   // output channels per workgroup
+constexpr int SB_KC = 16;    // input channels per K chunk = K of v_mfma_f32_32x32x16_bf16
+constexpr int SB_TH = 8, SB_TW = 32;
+constexpr int SB_PH = SB_TH + 2, SB_PW = SB_TW + 2;
+constexpr int SB_ITEMS = 2 * SB_PH * SB_PW;             // (k half, row, col) records per chunk and hi | lo plane
+constexpr int SB_PER_THREAD = (SB_ITEMS + 255) / 256;   // 3
+constexpr int SB_PLANE_BYTES = SB_ITEMS * 16;           // one hi (or lo) plane of a chunk
+constexpr int SB_BUF_BYTES = 2 * SB_PLANE_BYTES;
+constexpr unsigned SB_OOB = 0x80000000u;
+
+struct SbArgs {
+    const float* x;
+    const bf16x8* wq;
+    const float* s;
+    const float* d;
+    const float* noise;
+    const float* noise_w;
+    const float* bias;
+    float* y;
+    int B, Cin, Cout, H, W;
+    int s_stride;
+    float wscale;
+    int fuse_act;
+    int64_t noise_batch_stride;
+    int tiles_x, tiles_y, m_tiles, n_chunks;
+    const maua_frame_source_t* src;
+    int noise_slot;
+};
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const bf16x2 l = __builtin_convertvector(f32x2{a - hf.x, b - hf.y}, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h), lo = __builtin_bit_cast(unsigned, l);
+}
+
+__global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // LDS: patch[2 buffers][hi | lo][k half][PH][PW] 16-byte records | Ss[Cin] | Eg[128] | Eb[128]
+    float* Ss = reinterpret_cast<float*>(lds_raw + 2 * SB_BUF_BYTES);
+    float* Eg = Ss + p.Cin;
+    float* Eb = Eg + SB_BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, hi32 = lane >> 5;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt_id = t % p.m_tiles;
+    t /= p.m_tiles;
+    const int tile_x = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tile_y = t % p.tiles_y;
+    const int b0 = t / p.tiles_y;
+    const int ty0 = tile_y * SB_TH, tx0 = tile_x * SB_TW;
+    const int m0 = mt_id * SB_BM;
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned plane_bytes = (unsigned)plane * 4u;
+
+    const bool act = p.fuse_act != 0;
+    const float act_gain = act ? 1.41421356237309515f : 1.f;
+    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    for (int i = tid; i < SB_BM; i += 256) {
+        float gain = p.wscale * act_gain;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
+        Eg[i] = gain;
+        Eb[i] = (act && p.bias) ? p.bias[m0 + i] * act_gain : 0.f;
+    }
+
+    // ---- staging map of this thread: items it, it + 256, it + 512 of (k half, row, col); lane = consecutive columns
+    unsigned item_voff[SB_PER_THREAD];   // byte offset of the item's pixel in channel (8 * k half) of the chunk, or out of range
+    unsigned item_lds[SB_PER_THREAD];    // byte offset of its record inside a plane
+    int item_kb[SB_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < SB_PER_THREAD; ++q) {
+        const int idx = tid + 256 * q;
+        const int kb = idx / (SB_PH * SB_PW), rem = idx % (SB_PH * SB_PW);
+        const int row = rem / SB_PW, col = rem % SB_PW;
+        const int yy = ty0 - 1 + row, xx = tx0 - 1 + col;
+        const bool ok = idx < SB_ITEMS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        item_voff[q] = ok ? (unsigned)kb * 8u * plane_bytes + ((unsigned)yy * (unsigned)p.W + (unsigned)xx) * 4u : SB_OOB;
+        item_lds[q] = (unsigned)idx * 16u;
+        item_kb[q] = idx < SB_ITEMS ? kb : -1;
+    }
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + (size_t)b0 * p.Cin * plane, 0, (int)((unsigned)p.Cin * plane_bytes), 0x00020000);
+#endif
+    float stage[SB_PER_THREAD][8];
+    auto fetch = [&](int chunk) {
+#ifdef MAUA_DEVICE_PASS
+#pragma unroll
+        for (int q = 0; q < SB_PER_THREAD; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                stage[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                            x_rsrc, item_voff[q], (unsigned)(chunk * SB_KC + e) * plane_bytes, 0));
+#else
+        (void)chunk;
+#endif
+    };
+    auto commit = [&](int chunk, int buf) {  // style, split, 16-byte records into the hi and lo planes of buffer `buf`
+#pragma unroll
+        for (int q = 0; q < SB_PER_THREAD; ++q) {
+            if (item_kb[q] < 0) continue;
+            const float* sp = Ss + chunk * SB_KC + item_kb[q] * 8;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            unsigned h[4], l[4];
+            split2(stage[q][0] * s0[0], stage[q][1] * s0[1], h[0], l[0]);
+            split2(stage[q][2] * s0[2], stage[q][3] * s0[3], h[1], l[1]);
+            split2(stage[q][4] * s1[0], stage[q][5] * s1[1], h[2], l[2]);
+            split2(stage[q][6] * s1[2], stage[q][7] * s1[3], h[3], l[3]);
+            unsigned char* dst = lds_raw + buf * SB_BUF_BYTES + item_lds[q];
+            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(dst + SB_PLANE_BYTES) = u32x4{l[0], l[1], l[2], l[3]};
+        }
+    };
+
+    // ---- accumulators [m-tile][n-tile]
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.f;
+
+    // B records of this lane: k half hi32, patch row 4 wn + n + ky, column l31 + kx
+    const unsigned b_base = (unsigned)((hi32 * SB_PH + 4 * wn) * SB_PW + l31) * 16u;
+    // A records: [m-tile][chunk][tap][hi | lo][lane] of 16 bytes
+    const bf16x8* wq = p.wq + ((size_t)(mt_id * 4 + wm * 2) * p.n_chunks * 9 * 2) * 64 + lane;
+    const size_t a_mt_stride = (size_t)p.n_chunks * 9 * 2 * 64;
+    auto load_a = [&](bf16x8(&a)[2][2], int chunk, int tap) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) a[m][hl] = wq[m * a_mt_stride + ((size_t)(chunk * 9 + tap) * 2 + hl) * 64];
+    };
+
+    __syncthreads();  // styles and gains are in LDS
+    fetch(0);
+    commit(0, 0);
+    __syncthreads();
+    bf16x8 a_cur[2][2], a_nxt[2][2];
+    load_a(a_cur, 0, 0);
+    int cur = 0;
+    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+        const bool more = chunk + 1 < p.n_chunks;
+        if (more) fetch(chunk + 1);
+        const unsigned char* pb = lds_raw + cur * SB_BUF_BYTES + b_base;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            if (tap < 8) load_a(a_nxt, chunk, tap + 1);
+            else if (more) load_a(a_nxt, chunk + 1, 0);
+            // n-tile by n-tile: two records (hi, lo) feed six matrix instructions; the small terms go first
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const unsigned char* rec = pb + ((n + ky) * SB_PW + kx) * 16;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rec);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rec + SB_PLANE_BYTES);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][1], bh, acc[m][n], 0, 0, 0);  // a_l b_h
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][0], bl, acc[m][n], 0, 0, 0);  // a_h b_l
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][0], bh, acc[m][n], 0, 0, 0);  // a_h b_h
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) a_cur[m][hl] = a_nxt[m][hl];
+        }
+        if (more) commit(chunk + 1, cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: gain (wscale * demod), noise, bias, leaky ReLU * sqrt2 as max(t, 0.2 t) on pre-scaled operands; a lane holds
+    // 16 output channels of one pixel column per tile: rows (j & 3) + 8 (j >> 2) + 4 hi32 of the 32 x 32 result tile
+    const float* noise_base = p.noise;
+    int64_t noise_bstride = p.noise_batch_stride;
+    if (p.src) {
+        noise_bstride = p.src->noise_stride[p.noise_slot];
+        noise_base = p.src->noise[p.noise_slot];
+        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
+    }
+    const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
+    const float slope = act ? 0.2f : 1.f;
+    float* yimg = p.y + ((size_t)b0 * p.Cout + m0 + wm * 64) * plane;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int oy = ty0 + 4 * wn + n, ox = tx0 + l31;
+        const size_t pix = (size_t)oy * p.W + ox;
+        const float nz = nw != 0.f ? noise_base[(size_t)b0 * noise_bstride + pix] * nw : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ol = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hi32;
+                const float tt = fmaf(acc[m][n][j], Eg[wm * 64 + ol], nz + Eb[wm * 64 + ol]);
+                yimg[(size_t)ol * plane + pix] = fmaxf(tt, tt * slope);
+            }
+    }
+}
+
+// wq: [cout / 32][cin / 16][9 taps][hi | lo][64 lanes][8] bf16 — lane l of an m-tile holds row l % 32, input channels 8 (l / 32) .. + 7
+__global__ __launch_bounds__(256) void pack_weight_sbf16_kernel(const float* __restrict__ w, unsigned* __restrict__ wq, int cout, int cin) {
+    const int n_chunks = cin / SB_KC;
+    const int64_t total = (int64_t)(cout / 32) * n_chunks * 9 * 64 * 4;  // one thread per (m-tile, chunk, tap, lane, channel pair)
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx;
+        const int pr = (int)(r % 4);
+        r /= 4;
+        const int l = (int)(r % 64);
+        r /= 64;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int chunk = (int)(r % n_chunks);
+        const int mt = (int)(r / n_chunks);
+        const int o = mt * 32 + (l & 31), c = chunk * SB_KC + 8 * (l >> 5) + 2 * pr;
+        unsigned hi, lo;
+        split2(w[((size_t)o * cin + c) * 9 + tap], w[((size_t)o * cin + c + 1) * 9 + tap], hi, lo);
+        const size_t base = ((((size_t)mt * n_chunks + chunk) * 9 + tap) * 2) * 64;
+        wq[(base + l) * 4 + pr] = hi;
+        wq[(base + 64 + l) * 4 + pr] = lo;
+    }
+}
+
+char g_sbf16_instance[48] = "";
+
+}  // namespace
+
+int maua_sbf16_ok(int cin, int cout, int h, int w) {
+    return cin > 0 && cout > 0 && cin % SB_KC == 0 && cout % SB_BM == 0 && h % SB_TH == 0 && w % SB_TW == 0;
+}
+
+const char* maua_sbf16_last_instance() { return g_sbf16_instance; }
+
+int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin, int cout,
+                      int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                      const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream) {
+    if (!maua_sbf16_ok(cin, cout, h, w)) return MAUA_EINVAL;
+    if ((int64_t)cin * h * w * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor range / 32-bit offsets
+    SbArgs a{};
+    a.x = x, a.wq = static_cast<const bf16x8*>(wq), a.s = s, a.d = d, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.y = y;
+    a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale, a.fuse_act = fuse_act;
+    a.noise_batch_stride = noise_batch_stride, a.src = src, a.noise_slot = noise_slot;
+    a.tiles_x = w / SB_TW, a.tiles_y = h / SB_TH, a.m_tiles = cout / SB_BM, a.n_chunks = cin / SB_KC;
+    const size_t lds_bytes = (size_t)2 * SB_BUF_BYTES + sizeof(float) * ((size_t)cin + 2 * SB_BM);
+    static int attr_rc = -1;
+    if (attr_rc < 0)
+        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_sbf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc) return attr_rc;
+    snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_kernel");
+    const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
+    hipLaunchKernelGGL(modconv_sbf16_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t maua_pack_weight_sbf16_bytes(int cout, int cin) { return maua_sbf16_ok(cin, cout, SB_TH, SB_TW) ? (int64_t)cout * cin * 9 * 2 * 2 : 0; }
+
+extern "C" int maua_pack_weight_sbf16_f32(const float* w, void* wq, int cout, int cin, void* stream) {
+    if (!w || !wq || !maua_sbf16_ok(cin, cout, SB_TH, SB_TW)) return MAUA_EINVAL;
+    const int64_t total = (int64_t)(cout / 32) * (cin / SB_KC) * 9 * 64 * 4;
+    const int64_t blocks = ceil_div64(total, 256);
+    hipLaunchKernelGGL(pack_weight_sbf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<unsigned*>(wq), cout, cin);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_modconv_sbf16_ok(int cin, int cout, int h, int w) { return maua_sbf16_ok(cin, cout, h, w); }

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     for (int i = 0; i < NR; ++i) {
         const int rr = ty + i * WY;  // (scalar)
         const int iy = iy0 + rr;
+        (void)iy;
         v[i] = 0.f;
 #ifdef MAUA_DEVICE_PASS
         if (rr < RH && iy >= 0 && iy < in_h)  // uniform over the wave: a scalar branch
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
         const int hr = e / (KW - 1), hc = TW + (e - hr * (KW - 1));
         const int iy = iy0 + hr, ix = ix0 + hc;
         const bool ok = e < (KW - 1) * RH && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
+        (void)ok;
         vh[h] = 0.f;
 #ifdef MAUA_DEVICE_PASS
         vh[h] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(

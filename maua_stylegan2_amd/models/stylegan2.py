@@ -182,6 +182,10 @@ class ModulatedConv2d(nn.Module):
     # transposed layers whose shape csrc/modconv_up2d.hip accepts (mode 6: F(2,2) on both axes of the polyphase form, 25 instead of
     # 30 (mode 4) / 36 (mode 1) products per 2x2 positions) with at least this many output channels; a huge value turns it off
     upwino2d_min_cout = 32
+    # SIDE MEASUREMENT, off by default (a huge value): plain layers with at least this many output channels whose shape
+    # csrc/modconv_sbf16.hip accepts run the direct 9-tap form with split-bf16 products on the bf16 matrix cores (mode 7) instead of the
+    # fp32 2-D Winograd kernel.  bench.py lowers it for its `split_bf16` side figure; the headline path computes in fp32.
+    split_bf16_min_cout = 1 << 30
 
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 / 4 / 6 transposed, 2 Winograd F(2,3), 3 Winograd
@@ -198,6 +202,8 @@ class ModulatedConv2d(nn.Module):
             if self.upconv_winograd and w % 2 == 0 and tiles >= 256:
                 return 4
             return 1
+        if self.out_channel >= self.split_bf16_min_cout and _lib.load().maua_modconv_sbf16_ok(self.in_channel, self.out_channel, h, w):
+            return 7
         # (the Winograd kernels want at least one full 128-position tile per image; shorter maps would pack several images
         # into a tile, which only the direct mode implements)
         if (self.out_channel >= self.winograd2d_min_cout
@@ -225,6 +231,14 @@ class ModulatedConv2d(nn.Module):
                 _lib.check(_lib.load().maua_pack_weight_up2d_f32(wd.data_ptr(), wq.data_ptr(), self.out_channel,
                                                                  self.in_channel, _lib.stream_ptr(w.device)),
                            "maua_pack_weight_up2d_f32")
+            self._packed_wino[mode] = wq
+        if mode == 7 and mode not in self._packed_wino:
+            w = self.weight
+            wd = _lib.require_cuda(w.detach(), "weight")
+            wq = th.empty(_lib.load().maua_pack_weight_sbf16_bytes(self.out_channel, self.in_channel), dtype=th.uint8, device=w.device)
+            with th.cuda.device(w.device):
+                _lib.check(_lib.load().maua_pack_weight_sbf16_f32(wd.data_ptr(), wq.data_ptr(), self.out_channel, self.in_channel,
+                                                                  _lib.stream_ptr(w.device)), "maua_pack_weight_sbf16_f32")
             self._packed_wino[mode] = wq
         if mode == 5 and mode not in self._packed_wino:
             w = self.weight
