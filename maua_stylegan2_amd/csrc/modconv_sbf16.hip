@@ -14,9 +14,10 @@
 // forms (measured in tests/test_layers_gpu.py::test_modconv_split_bf16_vs_oracle and reported by bench.py next to the time).
 // The headline dtype stays f32: this mode is OFF unless ModulatedConv2d.split_bf16_min_cout is lowered (bench.py side_configs).
 //
-// Work decomposition: a workgroup owns 128 output channels x (8 rows x 32 columns) pixels; wave (wm, wn) takes 64 channels (two
-// 32-row m-tiles) x 4 rows (four 32-column n-tiles): 8 accumulator tiles of 32 x 32 = 128 registers.  K runs over chunks of 16
-// input channels x 9 taps.
+// Work decomposition: a workgroup owns 128 output channels x (8 rows x 32 columns) pixels; wave w takes channels 32 w .. 32 w + 31
+// (one 32-row m-tile) x all 8 rows (eight 32-column n-tiles): 8 accumulator tiles of 32 x 32 = 128 registers — every wave streams
+// only ITS quarter of the packed weight (the first version split 2 x 2: two waves fetched the same weight records, 6.4 TB/s of L2
+// reads at 0.38 ms per 256-channel layer).  K runs over chunks of 16 input channels x 9 taps.
 //   B operand: the 10 x 34 halo patch of a chunk is fetched with buffer loads (lane = pixel, scalar channel offset), scaled by the
 //     style, split, and written to LDS as 16-byte records [hi | lo][k half][row][col][8 channels]; a tap is a shifted view of the
 //     patch (no im2col), one conflict-free ds_read_b128 per (n-tile, hi | lo).  Double buffered: the next chunk's loads are in
@@ -26,6 +27,7 @@
 #include "common.h"
 
 #include <cstdio>
+#include <type_traits>
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAUA_DEVICE_PASS 1
@@ -69,6 +71,14 @@ struct SbArgs {
     int noise_slot;
 };
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
     const f32x2 hf = __builtin_convertvector(h, f32x2);
@@ -86,7 +96,6 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
     const int l31 = lane & 31, hi32 = lane >> 5;
 
     int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -130,92 +139,107 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x) + (size_t)b0 * p.Cin * plane, 0, (int)((unsigned)p.Cin * plane_bytes), 0x00020000);
 #endif
-    float stage[SB_PER_THREAD][8];
-    auto fetch = [&](int chunk) {
+    // one item (8 channels of one patch pixel) is in flight at a time: item q of the next chunk is requested at tap 3 q and written to
+    // LDS three taps later — 8 staging registers instead of 24
+    float stage[8];
+    auto fetch = [&](int chunk, int q) {
 #ifdef MAUA_DEVICE_PASS
 #pragma unroll
-        for (int q = 0; q < SB_PER_THREAD; ++q)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                stage[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                            x_rsrc, item_voff[q], (unsigned)(chunk * SB_KC + e) * plane_bytes, 0));
+        for (int e = 0; e < 8; ++e)
+            stage[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, item_voff[q],
+                                                                                      (unsigned)(chunk * SB_KC + e) * plane_bytes, 0));
 #else
-        (void)chunk;
+        (void)chunk, (void)q;
 #endif
     };
-    auto commit = [&](int chunk, int buf) {  // style, split, 16-byte records into the hi and lo planes of buffer `buf`
-#pragma unroll
-        for (int q = 0; q < SB_PER_THREAD; ++q) {
-            if (item_kb[q] < 0) continue;
-            const float* sp = Ss + chunk * SB_KC + item_kb[q] * 8;
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-            unsigned h[4], l[4];
-            split2(stage[q][0] * s0[0], stage[q][1] * s0[1], h[0], l[0]);
-            split2(stage[q][2] * s0[2], stage[q][3] * s0[3], h[1], l[1]);
-            split2(stage[q][4] * s1[0], stage[q][5] * s1[1], h[2], l[2]);
-            split2(stage[q][6] * s1[2], stage[q][7] * s1[3], h[3], l[3]);
-            unsigned char* dst = lds_raw + buf * SB_BUF_BYTES + item_lds[q];
-            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<u32x4*>(dst + SB_PLANE_BYTES) = u32x4{l[0], l[1], l[2], l[3]};
-        }
+    auto commit = [&](int chunk, int buf, int q) {  // style, split, 16-byte records into the hi and lo planes of buffer `buf`
+        if (item_kb[q] < 0) return;
+        const float* sp = Ss + chunk * SB_KC + item_kb[q] * 8;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        unsigned h[4], l[4];
+        split2(stage[0] * s0[0], stage[1] * s0[1], h[0], l[0]);
+        split2(stage[2] * s0[2], stage[3] * s0[3], h[1], l[1]);
+        split2(stage[4] * s1[0], stage[5] * s1[1], h[2], l[2]);
+        split2(stage[6] * s1[2], stage[7] * s1[3], h[3], l[3]);
+        unsigned char* dst = lds_raw + buf * SB_BUF_BYTES + item_lds[q];
+        *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(dst + SB_PLANE_BYTES) = u32x4{l[0], l[1], l[2], l[3]};
     };
 
-    // ---- accumulators [m-tile][n-tile]
-    f32x16 acc[2][4];
+    // ---- accumulators [n-tile = tile row]
+    f32x16 acc[8];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < 8; ++n)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[m][n][j] = 0.f;
+        for (int j = 0; j < 16; ++j) acc[n][j] = 0.f;
 
-    // B records of this lane: k half hi32, patch row 4 wn + n + ky, column l31 + kx
-    const unsigned b_base = (unsigned)((hi32 * SB_PH + 4 * wn) * SB_PW + l31) * 16u;
-    // A records: [m-tile][chunk][tap][hi | lo][lane] of 16 bytes
-    const bf16x8* wq = p.wq + ((size_t)(mt_id * 4 + wm * 2) * p.n_chunks * 9 * 2) * 64 + lane;
-    const size_t a_mt_stride = (size_t)p.n_chunks * 9 * 2 * 64;
-    auto load_a = [&](bf16x8(&a)[2][2], int chunk, int tap) {
+    // B records of this lane: k half hi32, patch row n + ky, column l31 + kx
+    const unsigned b_base = (unsigned)(hi32 * SB_PH * SB_PW + l31) * 16u;
+    // A records: [m-tile][chunk][tap][hi | lo][lane] of 16 bytes; this wave's m-tile
+    const bf16x8* wq = p.wq + ((size_t)(mt_id * 4 + wave) * p.n_chunks * 9 * 2) * 64 + lane;
+    auto load_a = [&](bf16x8(&a)[2], int chunk, int tap) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) a[m][hl] = wq[m * a_mt_stride + ((size_t)(chunk * 9 + tap) * 2 + hl) * 64];
+        for (int hl = 0; hl < 2; ++hl) a[hl] = wq[((size_t)(chunk * 9 + tap) * 2 + hl) * 64];
     };
 
     __syncthreads();  // styles and gains are in LDS
-    fetch(0);
-    commit(0, 0);
+#pragma unroll
+    for (int q = 0; q < SB_PER_THREAD; ++q) {
+        fetch(0, q);
+        commit(0, 0, q);
+    }
     __syncthreads();
-    bf16x8 a_cur[2][2], a_nxt[2][2];
-    load_a(a_cur, 0, 0);
+    // Explicitly software-pipelined, sched_barrier-pinned (left alone the compiler sinks every load to just in front of its first use —
+    // the weight loads of a tap right before its matrix instructions, a global round trip exposed per tap: 33 % of the wave cycles
+    // parked at s_waitcnt in the first version):
+    //   * weight records are requested TWO taps ahead (3 x 2 x 4 registers);
+    //   * a tap runs as two half-taps of four n-tiles (12 matrix instructions); the eight B records of half-tap h + 1 are read while
+    //     the matrix instructions of half-tap h run (2 x 32 registers); an accumulator is touched every fourth instruction; the small
+    //     terms go first.
+    bf16x8 a0[2], a1[2], a2[2];
+    load_a(a0, 0, 0);
+    load_a(a1, 0, 1);
     int cur = 0;
+    static_assert(SB_PER_THREAD == 3, "the tap loop stages one item per three taps");
+    bf16x8 bh[2][4], bl[2][4];
+    auto read_b = [&](const unsigned char* pb, auto h_c, bf16x8(&dh)[4], bf16x8(&dl)[4]) {
+        constexpr int h = decltype(h_c)::value, tap = h / 2, nq = h % 2, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned char* rec = pb + ((4 * nq + i + ky) * SB_PW + kx) * 16;
+            dh[i] = *reinterpret_cast<const bf16x8*>(rec);
+            dl[i] = *reinterpret_cast<const bf16x8*>(rec + SB_PLANE_BYTES);
+        }
+    };
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
         const bool more = chunk + 1 < p.n_chunks;
-        if (more) fetch(chunk + 1);
         const unsigned char* pb = lds_raw + cur * SB_BUF_BYTES + b_base;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            if (tap < 8) load_a(a_nxt, chunk, tap + 1);
-            else if (more) load_a(a_nxt, chunk + 1, 0);
-            // n-tile by n-tile: two records (hi, lo) feed six matrix instructions; the small terms go first
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const unsigned char* rec = pb + ((n + ky) * SB_PW + kx) * 16;
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(rec);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(rec + SB_PLANE_BYTES);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][1], bh, acc[m][n], 0, 0, 0);  // a_l b_h
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][0], bl, acc[m][n], 0, 0, 0);  // a_h b_l
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[m][0], bh, acc[m][n], 0, 0, 0);  // a_h b_h
+        read_b(pb, std::integral_constant<int, 0>{}, bh[0], bl[0]);
+        static_for<0, 18>([&](auto h_c) {
+            constexpr int h = decltype(h_c)::value, tap = h / 2, nq = h % 2, slot = h % 2;
+            if constexpr (nq == 0) {
+                if (more && tap % 3 == 0) {
+                    if (tap) commit(chunk + 1, cur ^ 1, tap / 3 - 1);
+                    fetch(chunk + 1, tap / 3);
+                }
+                if (tap < 7) load_a(a2, chunk, tap + 2);
+                else if (more) load_a(a2, chunk + 1, tap - 7);
             }
+            if constexpr (h + 1 < 18) read_b(pb, std::integral_constant<int, h + 1>{}, bh[slot ^ 1], bl[slot ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int i = 0; i < 4; ++i) acc[4 * nq + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], bh[slot][i], acc[4 * nq + i], 0, 0, 0);  // a_l b_h
 #pragma unroll
-                for (int hl = 0; hl < 2; ++hl) a_cur[m][hl] = a_nxt[m][hl];
-        }
-        if (more) commit(chunk + 1, cur ^ 1);
+            for (int i = 0; i < 4; ++i) acc[4 * nq + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], bl[slot][i], acc[4 * nq + i], 0, 0, 0);  // a_h b_l
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * nq + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], bh[slot][i], acc[4 * nq + i], 0, 0, 0);  // a_h b_h
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (nq == 1) {
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) a0[hl] = a1[hl], a1[hl] = a2[hl];
+            }
+        });
+        if (more) commit(chunk + 1, cur ^ 1, SB_PER_THREAD - 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -231,20 +255,18 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     }
     const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
     const float slope = act ? 0.2f : 1.f;
-    float* yimg = p.y + ((size_t)b0 * p.Cout + m0 + wm * 64) * plane;
+    float* yimg = p.y + ((size_t)b0 * p.Cout + m0 + wave * 32) * plane;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int oy = ty0 + 4 * wn + n, ox = tx0 + l31;
+    for (int n = 0; n < 8; ++n) {
+        const int oy = ty0 + n, ox = tx0 + l31;
         const size_t pix = (size_t)oy * p.W + ox;
         const float nz = nw != 0.f ? noise_base[(size_t)b0 * noise_bstride + pix] * nw : 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int ol = m * 32 + (j & 3) + 8 * (j >> 2) + 4 * hi32;
-                const float tt = fmaf(acc[m][n][j], Eg[wm * 64 + ol], nz + Eb[wm * 64 + ol]);
-                yimg[(size_t)ol * plane + pix] = fmaxf(tt, tt * slope);
-            }
+        for (int j = 0; j < 16; ++j) {
+            const int ol = (j & 3) + 8 * (j >> 2) + 4 * hi32;
+            const float tt = fmaf(acc[n][j], Eg[wave * 32 + ol], nz + Eb[wave * 32 + ol]);
+            yimg[(size_t)ol * plane + pix] = fmaxf(tt, tt * slope);
+        }
     }
 }
 

@@ -408,3 +408,48 @@ def test_upconv_two_axis_f22_matches_polyphase_and_oracle(gpu, cin, cout, h, w, 
     ref = F.conv_transpose2d((torch.from_numpy(x) * styles.cpu()[:, :, None, None]), torch.from_numpy(wgt[0]).transpose(0, 1).contiguous(),
                              stride=2).numpy() * m.scale
     np.testing.assert_allclose(raws[6], ref, atol=3e-5 * scale, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [
+    (128, 128, 16, 64, 2),    # one weight tile, 2 x 2 position tiles, 8 K chunks
+    (256, 256, 32, 32, 1),    # two weight tiles
+    (512, 128, 8, 32, 1),     # deep K (32 chunks), a single tile
+    (48, 384, 24, 96, 2),     # three K chunks, three weight tiles, 3 x 3 tiles: image borders on every side
+])
+def test_modconv_split_bf16_vs_oracle(gpu, cin, cout, h, w, batch):
+    """SIDE MEASUREMENT (mode 7, csrc/modconv_sbf16.hip; off by default): the plain 3x3 modulated convolution in its direct 9-tap
+    form with split-bf16 products on the bf16 matrix cores (a b ~= a_h b_h + a_h b_l + a_l b_h, fp32 accumulation).  Same bounds
+    as the fp32 Winograd modes — 5e-4 against the oracle, 2e-4 against the fp32 direct kernel — with and without the fused tail;
+    the measured maxima are printed."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(7 * cin + cout + h + w)
+    m = StyledConv(cin, cout, 3, 512, upsample=False)
+    m.conv.split_bf16_min_cout = 128
+    assert m.conv.conv_mode(h, w) == 7
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.31]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((batch, 1, h, w)).astype(np.float32))
+    want = so.styled_conv(sd, "L", x, s, nz, False).numpy()
+    got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    raw = m.conv(x.to(gpu), s.to(gpu)).cpu().numpy()  # no tail: demodulated convolution only
+    want_raw = so.modulated_conv2d(x, s, sd["L.conv.weight"], sd["L.conv.modulation.weight"], sd["L.conv.modulation.bias"]).numpy()
+    m.conv.split_bf16_min_cout = m.conv.winograd_min_cout = m.conv.winograd43_min_cout = m.conv.winograd2d_min_cout = 1 << 30
+    assert m.conv.conv_mode(h, w) == 0
+    direct = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    print(f"[split-bf16 {cin}->{cout} @{h}x{w}] max |mode 7 - oracle| = {np.abs(got - want).max():.2e} (output std {want.std():.2f}), "
+          f"raw {np.abs(raw - want_raw).max():.2e}, vs fp32 direct kernel {np.abs(got - direct).max():.2e}; "
+          f"fp32 direct vs oracle {np.abs(direct - want).max():.2e}")
+    np.testing.assert_allclose(got, want, atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(raw, want_raw, atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(got, direct, atol=2e-4, rtol=1e-4)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--no-up-wino", action="store_true", help="transposed layers use the plain polyphase kernel (mode 1)")
     ap.add_argument("--wino43-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd43_min_cout")
     ap.add_argument("--wino2d-min-cout", type=int, default=None, help="override ModulatedConv2d.winograd2d_min_cout (huge = mode 3)")
+    ap.add_argument("--split-bf16-min-cout", type=int, default=None, help="side measurement: plain layers from this many channels run mode 7 (split-bf16 products)")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     if args.lib:
@@ -98,6 +99,8 @@ def main():
                 ModulatedConv2d.winograd43_min_cout = args.wino43_min_cout
             if args.wino2d_min_cout is not None:
                 ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
+            if args.split_bf16_min_cout is not None:
+                ModulatedConv2d.split_bf16_min_cout = args.split_bf16_min_cout
             for name, cin, cout, h, up in [("plain32@1024", 32, 32, 1024, 0), ("plain64@512", 64, 64, 512, 0),
                                            ("plain128@256", 128, 128, 256, 0), ("plain256@128", 256, 256, 128, 0),
                                            ("plain512@64", 512, 512, 64, 0), ("up64-32@512", 64, 32, 512, 1),
