@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-end extras on the GPU box (through gpurun): the measured maxima of the whole-frame parity tests (pytest -s), bench.py with its side
+# configurations, PMC of the split-bf16 side kernel.  Outputs under gpurun_out/r4i/.
 mkdir -p gpurun_out/r4i
 python -m pytest tests/test_render_gpu.py -q -m gpu -s -k "bench_configuration or config5_bends_1024 or config3_900 or captured_bends_equal" 2>&1 | grep "^\[\|passed\|failed" > gpurun_out/r4i/parity_full_frames.txt
 python -m pytest tests/test_layers_gpu.py -q -m gpu -s -k "split_bf16" 2>&1 | grep "^\[\|^\.\[\|passed\|failed" >> gpurun_out/r4i/parity_full_frames.txt
