@@ -168,6 +168,8 @@ int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w);
  *   up == 7 : SIDE MEASUREMENT — the plain convolution in its direct 9-tap form with split-bf16 products on the bf16 matrix cores
  *             (a b ~= a_h b_h + a_h b_l + a_l b_h, fp32 accumulation; relative error of a product <= 2^-16 + 2^-17); wp from
  *             maua_pack_weight_sbf16_f32.  Not used unless the caller asks for it; the default path computes in fp32.
+ *   up == 8 : SIDE MEASUREMENT — the transposed convolution of up == 1 with split-bf16 products (four polyphase phase launches of the
+ *             up == 7 kernel + fp32 edge lines), same packed weight as up == 7, fuse_act == 0, ws as for up == 6.
  * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
  * floats used for split-K partial sums on small feature maps and, for up == 6, for the exported last input column [B, cin, H]

@@ -45,6 +45,8 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
 // modconv_sbf16.hip (mode 7 of maua_modconv3x3_f32; side measurement, off by default): plain 3x3 convolution with split-bf16 products
 int maua_sbf16_ok(int cin, int cout, int h, int w);
 const char* maua_sbf16_last_instance();
-int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin, int cout,
-                      int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
-                      const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream);
+int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
+                      int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
+                      const float* noise_w, const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream);
+int maua_up2d_edge_launch(const float* x, const float* edge_taps, const float* s, int s_stride, const float* d, float* y, const float* xcol,
+                          int batch, int cin, int cout, int h, int w, float wscale, void* stream);

@@ -1316,8 +1316,8 @@ extern "C" int maua_pack_weight_wino43_f32(const float* w, float* wq, int cout, 
 }
 
 extern "C" int64_t maua_modconv_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
-    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || up == 5) return 0;
-    if (up == 6) return maua_up2d_ws_floats(batch, cin, h);  // the exported last input column
+    if (batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || up == 5 || up == 7) return 0;
+    if (up == 6 || up == 8) return maua_up2d_ws_floats(batch, cin, h);  // the exported last input column
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     return pl.g.splits > 1 ? pl.g.ws_slab * pl.g.splits : 0;
 }
@@ -1353,10 +1353,10 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
         if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
         return rc;
     }
-    if (up == 7) {  // plain conv with split-bf16 products (side measurement), modconv_sbf16.hip
+    if (up == 7 || up == 8) {  // plain (7) / transposed (8) conv with split-bf16 products (side measurement), modconv_sbf16.hip
         if (rgb) return MAUA_ENOSYS;
-        const int rc = maua_sbf16_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, fuse_act, noise, noise_batch_stride,
-                                         noise_w, bias, src, noise_slot, stream);
+        const int rc = maua_sbf16_launch(x, wp, s, s_stride, d, y, ws, batch, cin, cout, h, w, up == 8, wscale, fuse_act, noise,
+                                         noise_batch_stride, noise_w, bias, src, noise_slot, stream);
         if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_sbf16_last_instance());
         return rc;
     }

@@ -86,7 +86,25 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     hi = __builtin_bit_cast(unsigned, h), lo = __builtin_bit_cast(unsigned, l);
 }
 
+// Tap tables.  PHASE -1: the plain convolution, 9 taps, tap (ky, kx) reads patch record (n + ky, l + kx) (patch origin = (ty0 - 1,
+// tx0 - 1)).  PHASE 0..3: the four output phases (even / odd row) x (even / odd column) of the stride-2 TRANSPOSED convolution
+// (models/stylegan2.py:229-237; conv_transpose2d: y[i] += x[p] g[i - 2 p]) in its polyphase form on the INPUT grid — position (p, q)
+// owns outputs (2 p + a', 2 q + b'):  even = g0 x[p] + g2 x[p - 1],  odd = g1 x[p]  per axis, i.e. 4 + 2 + 2 + 1 = 9 taps in all,
+// the same packed weight records, each phase its own launch with 8 accumulator tiles (all four phases at once would need 512 registers).
+struct SbTap { int wt, ro, co; };  // packed weight tap (ky * 3 + kx), patch row / column offset of the record
+template <int PHASE> struct SbTaps;
+template <> struct SbTaps<-1> { static constexpr int NT = 9; static constexpr SbTap t[9] = {{0, 0, 0}, {1, 0, 1}, {2, 0, 2}, {3, 1, 0}, {4, 1, 1}, {5, 1, 2}, {6, 2, 0}, {7, 2, 1}, {8, 2, 2}}; };
+template <> struct SbTaps<0> { static constexpr int NT = 4; static constexpr SbTap t[4] = {{0, 1, 1}, {2, 1, 0}, {6, 0, 1}, {8, 0, 0}}; };  // (even, even)
+template <> struct SbTaps<1> { static constexpr int NT = 2; static constexpr SbTap t[2] = {{1, 1, 1}, {7, 0, 1}}; };                        // (even row, odd column)
+template <> struct SbTaps<2> { static constexpr int NT = 2; static constexpr SbTap t[2] = {{3, 1, 1}, {5, 1, 0}}; };                        // (odd row, even column)
+template <> struct SbTaps<3> { static constexpr int NT = 1; static constexpr SbTap t[1] = {{4, 1, 1}}; };                                   // (odd, odd)
+
+template <int PHASE>
 __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
+    using Taps = SbTaps<PHASE>;
+    constexpr int NT = Taps::NT;
+    constexpr int STEPS = 2 * NT;        // half-taps of a chunk: four n-tiles (12 matrix instructions) each
+    constexpr bool UP = PHASE >= 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // LDS: patch[2 buffers][hi | lo][k half][PH][PW] 16-byte records | Ss[Cin] | Eg[128] | Eb[128]
     float* Ss = reinterpret_cast<float*>(lds_raw + 2 * SB_BUF_BYTES);
@@ -139,15 +157,16 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x) + (size_t)b0 * p.Cin * plane, 0, (int)((unsigned)p.Cin * plane_bytes), 0x00020000);
 #endif
-    // one item (8 channels of one patch pixel) is in flight at a time: item q of the next chunk is requested at tap 3 q and written to
-    // LDS three taps later — 8 staging registers instead of 24
-    float stage[8];
+    // plain form: one item (8 channels of one patch pixel) is in flight at a time — item q of the next chunk is requested at tap 3 q and
+    // written to LDS three taps later, so the three staging sets share 8 registers; the short chunks of the transposed phases request
+    // all three items at their first step and write them behind their last one
+    float stage[UP ? SB_PER_THREAD : 1][8];
     auto fetch = [&](int chunk, int q) {
 #ifdef MAUA_DEVICE_PASS
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            stage[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, item_voff[q],
-                                                                                      (unsigned)(chunk * SB_KC + e) * plane_bytes, 0));
+            stage[UP ? q : 0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, item_voff[q],
+                                                                                         (unsigned)(chunk * SB_KC + e) * plane_bytes, 0));
 #else
         (void)chunk, (void)q;
 #endif
@@ -157,10 +176,11 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
         const float* sp = Ss + chunk * SB_KC + item_kb[q] * 8;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
         unsigned h[4], l[4];
-        split2(stage[0] * s0[0], stage[1] * s0[1], h[0], l[0]);
-        split2(stage[2] * s0[2], stage[3] * s0[3], h[1], l[1]);
-        split2(stage[4] * s1[0], stage[5] * s1[1], h[2], l[2]);
-        split2(stage[6] * s1[2], stage[7] * s1[3], h[3], l[3]);
+        const float(&v)[8] = stage[UP ? q : 0];
+        split2(v[0] * s0[0], v[1] * s0[1], h[0], l[0]);
+        split2(v[2] * s0[2], v[3] * s0[3], h[1], l[1]);
+        split2(v[4] * s1[0], v[5] * s1[1], h[2], l[2]);
+        split2(v[6] * s1[2], v[7] * s1[3], h[3], l[3]);
         unsigned char* dst = lds_raw + buf * SB_BUF_BYTES + item_lds[q];
         *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
         *reinterpret_cast<u32x4*>(dst + SB_PLANE_BYTES) = u32x4{l[0], l[1], l[2], l[3]};
@@ -177,9 +197,9 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     const unsigned b_base = (unsigned)(hi32 * SB_PH * SB_PW + l31) * 16u;
     // A records: [m-tile][chunk][tap][hi | lo][lane] of 16 bytes; this wave's m-tile
     const bf16x8* wq = p.wq + ((size_t)(mt_id * 4 + wave) * p.n_chunks * 9 * 2) * 64 + lane;
-    auto load_a = [&](bf16x8(&a)[2], int chunk, int tap) {
+    auto load_a = [&](bf16x8(&a)[2], int chunk, int wt) {
 #pragma unroll
-        for (int hl = 0; hl < 2; ++hl) a[hl] = wq[((size_t)(chunk * 9 + tap) * 2 + hl) * 64];
+        for (int hl = 0; hl < 2; ++hl) a[hl] = wq[((size_t)(chunk * 9 + wt) * 2 + hl) * 64];
     };
 
     __syncthreads();  // styles and gains are in LDS
@@ -192,21 +212,25 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     // Explicitly software-pipelined, sched_barrier-pinned (left alone the compiler sinks every load to just in front of its first use —
     // the weight loads of a tap right before its matrix instructions, a global round trip exposed per tap: 33 % of the wave cycles
     // parked at s_waitcnt in the first version):
-    //   * weight records are requested TWO taps ahead (3 x 2 x 4 registers);
+    //   * weight records are requested TWO taps ahead (3 x 2 x 4 registers), across chunk boundaries;
     //   * a tap runs as two half-taps of four n-tiles (12 matrix instructions); the eight B records of half-tap h + 1 are read while
     //     the matrix instructions of half-tap h run (2 x 32 registers); an accumulator is touched every fourth instruction; the small
     //     terms go first.
+    auto load_a_ahead = [&](bf16x8(&a)[2], int chunk, auto tap_c) {  // tap number `tap` (may run past NT: into the following chunks)
+        constexpr int tap = decltype(tap_c)::value, dc = tap / NT, tt = tap % NT;
+        if (chunk + dc < p.n_chunks) load_a(a, chunk + dc, Taps::t[tt].wt);
+    };
     bf16x8 a0[2], a1[2], a2[2];
-    load_a(a0, 0, 0);
-    load_a(a1, 0, 1);
+    load_a_ahead(a0, 0, std::integral_constant<int, 0>{});
+    load_a_ahead(a1, 0, std::integral_constant<int, 1>{});
     int cur = 0;
-    static_assert(SB_PER_THREAD == 3, "the tap loop stages one item per three taps");
+    static_assert(SB_PER_THREAD == 3, "the tap loop stages three items per thread");
     bf16x8 bh[2][4], bl[2][4];
     auto read_b = [&](const unsigned char* pb, auto h_c, bf16x8(&dh)[4], bf16x8(&dl)[4]) {
-        constexpr int h = decltype(h_c)::value, tap = h / 2, nq = h % 2, ky = tap / 3, kx = tap % 3;
+        constexpr int h = decltype(h_c)::value, tap = h / 2, nq = h % 2, ro = Taps::t[tap].ro, co = Taps::t[tap].co;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned char* rec = pb + ((4 * nq + i + ky) * SB_PW + kx) * 16;
+            const unsigned char* rec = pb + ((4 * nq + i + ro) * SB_PW + co) * 16;
             dh[i] = *reinterpret_cast<const bf16x8*>(rec);
             dl[i] = *reinterpret_cast<const bf16x8*>(rec + SB_PLANE_BYTES);
         }
@@ -215,17 +239,23 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
         const bool more = chunk + 1 < p.n_chunks;
         const unsigned char* pb = lds_raw + cur * SB_BUF_BYTES + b_base;
         read_b(pb, std::integral_constant<int, 0>{}, bh[0], bl[0]);
-        static_for<0, 18>([&](auto h_c) {
+        static_for<0, STEPS>([&](auto h_c) {
             constexpr int h = decltype(h_c)::value, tap = h / 2, nq = h % 2, slot = h % 2;
             if constexpr (nq == 0) {
-                if (more && tap % 3 == 0) {
-                    if (tap) commit(chunk + 1, cur ^ 1, tap / 3 - 1);
-                    fetch(chunk + 1, tap / 3);
+                if (more) {
+                    if constexpr (!UP) {
+                        if constexpr (tap % 3 == 0) {
+                            if constexpr (tap > 0) commit(chunk + 1, cur ^ 1, tap / 3 - 1);
+                            fetch(chunk + 1, tap / 3);
+                        }
+                    } else if constexpr (tap == 0) {
+#pragma unroll
+                        for (int q = 0; q < SB_PER_THREAD; ++q) fetch(chunk + 1, q);
+                    }
                 }
-                if (tap < 7) load_a(a2, chunk, tap + 2);
-                else if (more) load_a(a2, chunk + 1, tap - 7);
+                load_a_ahead(a2, chunk, std::integral_constant<int, tap + 2>{});
             }
-            if constexpr (h + 1 < 18) read_b(pb, std::integral_constant<int, h + 1>{}, bh[slot ^ 1], bl[slot ^ 1]);
+            if constexpr (h + 1 < STEPS) read_b(pb, std::integral_constant<int, h + 1>{}, bh[slot ^ 1], bl[slot ^ 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[4 * nq + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], bh[slot][i], acc[4 * nq + i], 0, 0, 0);  // a_l b_h
@@ -239,7 +269,14 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
                 for (int hl = 0; hl < 2; ++hl) a0[hl] = a1[hl], a1[hl] = a2[hl];
             }
         });
-        if (more) commit(chunk + 1, cur ^ 1, SB_PER_THREAD - 1);
+        if (more) {
+            if constexpr (UP) {
+#pragma unroll
+                for (int q = 0; q < SB_PER_THREAD; ++q) commit(chunk + 1, cur ^ 1, q);
+            } else {
+                commit(chunk + 1, cur ^ 1, SB_PER_THREAD - 1);
+            }
+        }
         __syncthreads();
         cur ^= 1;
     }
@@ -255,6 +292,22 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     }
     const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
     const float slope = act ? 0.2f : 1.f;
+    if constexpr (UP) {  // raw map [B, Cout, 2 H + 1, 2 W + 1]: this phase's outputs (2 p + a', 2 q + b'); the blur kernel applies the tail
+        constexpr int ar = PHASE >> 1, bc = PHASE & 1;
+        const int OW = 2 * p.W + 1;
+        const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
+        float* yup = p.y + ((size_t)b0 * p.Cout + m0 + wave * 32) * plane_out;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const size_t pix = (size_t)(2 * (ty0 + n) + ar) * OW + 2 * (tx0 + l31) + bc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ol = (j & 3) + 8 * (j >> 2) + 4 * hi32;
+                yup[(size_t)ol * plane_out + pix] = acc[n][j] * Eg[wave * 32 + ol];
+            }
+        }
+        return;
+    }
     float* yimg = p.y + ((size_t)b0 * p.Cout + m0 + wave * 32) * plane;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -268,6 +321,12 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
             yimg[(size_t)ol * plane + pix] = fmaxf(tt, tt * slope);
         }
     }
+}
+
+// the last input column x[b][c][:, W - 1] -> xcol[b][c][:] for the edge lines of the transposed form (modconv_up2d.hip's edge kernel reads
+// it with unit stride)
+__global__ __launch_bounds__(256) void export_last_column_kernel(const float* __restrict__ x, float* __restrict__ xcol, int64_t rows, int w) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) xcol[i] = x[i * w + (w - 1)];
 }
 
 // wq: [cout / 32][cin / 16][9 taps][hi | lo][64 lanes][8] bf16 — lane l of an m-tile holds row l % 32, input channels 8 (l / 32) .. + 7
@@ -293,6 +352,18 @@ __global__ __launch_bounds__(256) void pack_weight_sbf16_kernel(const float* __r
     }
 }
 
+// edge tap matrices [5][cin][cout] of the transposed form: g20, g21, g22 (the kernel's last row), g02, g12 (the rest of its last column) —
+// the layout modconv_up2d.hip's edge kernel reads
+__global__ __launch_bounds__(256) void pack_edge_taps_kernel(const float* __restrict__ w, float* __restrict__ edge, int cout, int cin) {
+    const int64_t total = (int64_t)cout * cin, tsz = total;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int o = (int)(idx % cout), i = (int)(idx / cout);
+        const float* g = w + ((size_t)o * cin + i) * 9;
+        float* ed = edge + (size_t)i * cout + o;
+        ed[0] = g[6], ed[tsz] = g[7], ed[2 * tsz] = g[8], ed[3 * tsz] = g[2], ed[4 * tsz] = g[5];
+    }
+}
+
 char g_sbf16_instance[48] = "";
 
 }  // namespace
@@ -303,29 +374,59 @@ int maua_sbf16_ok(int cin, int cout, int h, int w) {
 
 const char* maua_sbf16_last_instance() { return g_sbf16_instance; }
 
-int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stride, const float* d, float* y, int batch, int cin, int cout,
-                      int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
-                      const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream) {
+namespace {
+template <int PHASE>
+int sbf16_launch_phase(const SbArgs& a, size_t lds_bytes, hipStream_t st) {
+    static int attr_rc = -1;
+    if (attr_rc < 0)
+        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_sbf16_kernel<PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+    if (attr_rc) return attr_rc;
+    const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
+    hipLaunchKernelGGL(modconv_sbf16_kernel<PHASE>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+// up = 0: the plain convolution (+ tail when fuse_act).  up = 1: the stride-2 transposed convolution, raw map [B, Cout, 2H+1, 2W+1]:
+// four phase launches over the positions p < H, q < W, then the edge lines (output row 2H, column 2W) by modconv_up2d.hip's fp32 edge
+// kernel on the edge tap matrices stored behind the bf16 records; ws = [B, cin, H] floats (the exported last input column).
+int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
+                      int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
+                      const float* noise_w, const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream) {
     if (!maua_sbf16_ok(cin, cout, h, w)) return MAUA_EINVAL;
     if ((int64_t)cin * h * w * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor range / 32-bit offsets
+    if (up && (fuse_act || !ws)) return MAUA_EINVAL;
     SbArgs a{};
     a.x = x, a.wq = static_cast<const bf16x8*>(wq), a.s = s, a.d = d, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.y = y;
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale, a.fuse_act = fuse_act;
     a.noise_batch_stride = noise_batch_stride, a.src = src, a.noise_slot = noise_slot;
     a.tiles_x = w / SB_TW, a.tiles_y = h / SB_TH, a.m_tiles = cout / SB_BM, a.n_chunks = cin / SB_KC;
     const size_t lds_bytes = (size_t)2 * SB_BUF_BYTES + sizeof(float) * ((size_t)cin + 2 * SB_BM);
-    static int attr_rc = -1;
-    if (attr_rc < 0)
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_sbf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_rc) return attr_rc;
-    snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_kernel");
-    const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
-    hipLaunchKernelGGL(modconv_sbf16_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (!up) {
+        snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_kernel<-1>");
+        return sbf16_launch_phase<-1>(a, lds_bytes, st);
+    }
+    snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_kernel<0..3>");
+    int rc = sbf16_launch_phase<0>(a, lds_bytes, st);
+    if (!rc) rc = sbf16_launch_phase<1>(a, lds_bytes, st);
+    if (!rc) rc = sbf16_launch_phase<2>(a, lds_bytes, st);
+    if (!rc) rc = sbf16_launch_phase<3>(a, lds_bytes, st);
+    if (rc) return rc;
+    const int64_t rows = (int64_t)batch * cin * h;
+    const int64_t blocks = ceil_div64(rows, 256);
+    hipLaunchKernelGGL(export_last_column_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, x, ws, rows, w);
     MAUA_LAUNCH_CHECK();
-    return 0;
+    const float* edge = reinterpret_cast<const float*>(static_cast<const unsigned char*>(wq) + (size_t)cout * cin * 9 * 2 * 2);
+    return maua_up2d_edge_launch(x, edge, s, s_stride, d, y, ws, batch, cin, cout, h, w, wscale, stream);
 }
 
-extern "C" int64_t maua_pack_weight_sbf16_bytes(int cout, int cin) { return maua_sbf16_ok(cin, cout, SB_TH, SB_TW) ? (int64_t)cout * cin * 9 * 2 * 2 : 0; }
+// bf16 records (cout * cin * 9 * 2 * 2 bytes), then the five fp32 edge tap matrices [5][cin][cout] of the transposed form
+extern "C" int64_t maua_pack_weight_sbf16_bytes(int cout, int cin) {
+    return maua_sbf16_ok(cin, cout, SB_TH, SB_TW) ? (int64_t)cout * cin * 9 * 2 * 2 + (int64_t)5 * cin * cout * 4 : 0;
+}
 
 extern "C" int maua_pack_weight_sbf16_f32(const float* w, void* wq, int cout, int cin, void* stream) {
     if (!w || !wq || !maua_sbf16_ok(cin, cout, SB_TH, SB_TW)) return MAUA_EINVAL;
@@ -333,6 +434,10 @@ extern "C" int maua_pack_weight_sbf16_f32(const float* w, void* wq, int cout, in
     const int64_t blocks = ceil_div64(total, 256);
     hipLaunchKernelGGL(pack_weight_sbf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, w,
                        static_cast<unsigned*>(wq), cout, cin);
+    MAUA_LAUNCH_CHECK();
+    float* edge = reinterpret_cast<float*>(static_cast<unsigned char*>(wq) + (size_t)cout * cin * 9 * 2 * 2);
+    const int64_t eb = ceil_div64((int64_t)cout * cin, 256);
+    hipLaunchKernelGGL(pack_edge_taps_kernel, dim3((unsigned)(eb < 4096 ? eb : 4096)), dim3(256), 0, (hipStream_t)stream, w, edge, cout, cin);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

@@ -471,6 +471,21 @@ extern "C" int maua_pack_weight_up2d_f32(const float* w, float* wq, int cout, in
 
 const char* maua_up2d_last_instance() { return g_up2d_instance; }
 
+// The edge lines alone (output row 2H, column 2W of the transposed convolution) from the five fp32 edge tap matrices [5][cin][cout] and the
+// exported last input column xcol [B, cin, H]: used by the split-bf16 side path (modconv_sbf16.hip), whose phase kernels cover p < H, q < W.
+int maua_up2d_edge_launch(const float* x, const float* edge_taps, const float* s, int s_stride, const float* d, float* y, const float* xcol,
+                          int batch, int cin, int cout, int h, int w, float wscale, void* stream) {
+    if (!x || !edge_taps || !s || !y || !xcol || cout % 16) return MAUA_EINVAL;
+    Up2dArgs a{};
+    a.x = x, a.wq = nullptr, a.s = s, a.d = d, a.y = y, a.xcol = const_cast<float*>(xcol);
+    a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
+    const int nt0 = ceil_div(w + 1, 16), nt1 = ceil_div(h, 16);
+    const int64_t eblocks = (int64_t)batch * (cout / 16) * (nt0 + nt1);
+    hipLaunchKernelGGL(up2d_edge_kernel, dim3((unsigned)eblocks), dim3(256), 0, (hipStream_t)stream, a, edge_taps, nt0, nt1);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 int64_t maua_up2d_ws_floats(int batch, int cin, int h) { return (int64_t)batch * cin * h; }
 
 int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,

@@ -186,10 +186,16 @@ class ModulatedConv2d(nn.Module):
     # csrc/modconv_sbf16.hip accepts run the direct 9-tap form with split-bf16 products on the bf16 matrix cores (mode 7) instead of the
     # fp32 2-D Winograd kernel.  bench.py lowers it for its `split_bf16` side figure; the headline path computes in fp32.
     split_bf16_min_cout = 1 << 30
+    # ... and the same for the transposed layers (mode 8: the four polyphase output phases as four launches of the same kernel + the
+    # fp32 edge lines)
+    split_bf16_up_min_cout = 1 << 30
 
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 / 4 / 6 transposed, 2 Winograd F(2,3), 3 Winograd
-        F(4,3), 5 2-D Winograd F(2x4,3x3), 0 direct."""
+        F(4,3), 5 2-D Winograd F(2x4,3x3), 0 direct; 7 / 8 = the split-bf16 side measurement (plain / transposed), off by default."""
+        if self.upsample and self.out_channel >= self.split_bf16_up_min_cout and _lib.load().maua_modconv_sbf16_ok(
+                self.in_channel, self.out_channel, h, w):
+            return 8
         if self.upsample and self.out_channel >= self.upwino2d_min_cout and _lib.load().maua_modconv_up2d_ok(
                 self.in_channel, self.out_channel, h, w):
             return 6
@@ -232,6 +238,8 @@ class ModulatedConv2d(nn.Module):
                                                                  self.in_channel, _lib.stream_ptr(w.device)),
                            "maua_pack_weight_up2d_f32")
             self._packed_wino[mode] = wq
+        if mode == 8:
+            mode = 7  # (one packed weight serves the plain and the transposed form)
         if mode == 7 and mode not in self._packed_wino:
             w = self.weight
             wd = _lib.require_cuda(w.detach(), "weight")

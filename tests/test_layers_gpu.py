@@ -453,3 +453,67 @@ def test_modconv_split_bf16_vs_oracle(gpu, cin, cout, h, w, batch):
     np.testing.assert_allclose(got, want, atol=5e-4, rtol=1e-4)
     np.testing.assert_allclose(raw, want_raw, atol=5e-4, rtol=1e-4)
     np.testing.assert_allclose(got, direct, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch", [
+    (128, 128, 16, 32, 2),    # one weight tile, 2 x 1 position tiles
+    (256, 256, 8, 64, 1),     # two weight tiles, 1 x 2 position tiles
+    (48, 384, 24, 96, 1),     # three K chunks, three weight tiles, 3 x 3 tiles
+])
+def test_upconv_split_bf16_matches_polyphase_and_oracle(gpu, cin, cout, h, w, batch):
+    """SIDE MEASUREMENT (mode 8, csrc/modconv_sbf16.hip; off by default): the stride-2 transposed convolution (models/stylegan2.py:229-237)
+    as four polyphase output phases on the bf16 matrix cores with split-bf16 products + the fp32 edge lines, written into a NaN-prefilled
+    raw map: every element of [B, Cout, 2H+1, 2W+1] must be written and agree with the fp32 polyphase kernel (mode 1) within 2e-4; then
+    the whole StyledConv (blur + noise + bias + act) against the oracle within 5e-4."""
+    from maua_stylegan2_amd import _lib
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv, _style_table
+    from oracle import stylegan2_oracle as so
+
+    r = np.random.default_rng(11 * cin + cout + h + w)
+    m = StyledConv(cin, cout, 3, 512, upsample=True)
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.blur.kernel": torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.27]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((batch, 1, 2 * h, 2 * w)).astype(np.float32))
+    lib = _lib.load()
+
+    def raw_map(mode_switch):
+        m.conv.split_bf16_up_min_cout = mode_switch
+        mode = m.conv.conv_mode(h, w)
+        xs, ss = x.to(gpu), s.to(gpu)
+        st = torch.empty((batch, cin), device=gpu)
+        dm = torch.empty((batch, cout), device=gpu)
+        table = _style_table([m.conv.table_entry(0, 0, 0)], gpu)
+        lat = ss.reshape(batch, 1, -1)
+        _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), batch, 1, 512, None, None, table.data_ptr(), 1, cin, st.data_ptr(), cin, None,
+                                             _lib.stream_ptr(gpu)), "affine")
+        _lib.check(lib.maua_demod_f32(table.data_ptr(), 1, cout, st.data_ptr(), cin, dm.data_ptr(), batch, _lib.stream_ptr(gpu)), "demod")
+        out = torch.full((batch, cout, 2 * h + 1, 2 * w + 1), float("nan"), device=gpu)
+        n_ws = lib.maua_modconv_ws_floats(batch, cin, cout, h, w, mode)
+        ws = torch.empty(max(n_ws, 1), device=gpu)
+        m.conv.run(xs, st, 0, dm, out, ws if n_ws else None)
+        return mode, out.cpu().numpy()
+
+    mode8, got = raw_map(128)
+    assert mode8 == 8 and np.isfinite(got).all(), "an element of the raw map was not written"
+    m.conv.upwino2d_min_cout = 1 << 30
+    m.conv.upconv_winograd = False
+    mode1, ref = raw_map(1 << 30)
+    assert mode1 == 1
+    print(f"[split-bf16 transposed {cin}->{cout} @{h}x{w}] max |mode 8 - mode 1 (fp32 polyphase)| = {np.abs(got - ref).max():.2e} "
+          f"(raw std {ref.std():.2f})")
+    np.testing.assert_allclose(got, ref, atol=2e-4, rtol=1e-4)
+    m.conv.split_bf16_up_min_cout = 128
+    full = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    want = so.styled_conv(sd, "L", x, s, nz, True).numpy()
+    print(f"[split-bf16 transposed {cin}->{cout} @{h}x{w}] StyledConv: max |hip - oracle| = {np.abs(full - want).max():.2e} (std {want.std():.2f})")
+    np.testing.assert_allclose(full, want, atol=5e-4, rtol=1e-4)
