@@ -197,6 +197,7 @@ def crop_resize_for_delivery(u8, out_size, scratch):
 
 
 _LANE_STREAMS = {}
+_PINNED_RING = {}  # device index -> pinned staging slots of the single-GPU render loop (reallocated when the frame shape changes)
 
 
 def _lane_stream(dev, k):
@@ -418,7 +419,7 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
             # hands it back through `free` (the launch thread blocks here only when the sink is `n_slots` batches behind)
             n_lanes, n_slots = 3, 6
             copy_stream = th.cuda.Stream(dev)
-            pinned = [None] * n_slots
+            pinned = _PINNED_RING.setdefault(dev.index, [None] * n_slots)  # kept across renders: pinning 6 x 25 MB is ~40 ms
             free = queue.Queue()
             for i in range(n_slots):
                 free.put(i)
