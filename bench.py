@@ -510,34 +510,41 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # a side measurement must not take the headline down
                 sides[name] = {"error": repr(exc)}
-        # SIDE MEASUREMENT, never the headline: the plain >= 128-channel layers (convs.5 / 7 / 9 / 11) on the bf16
-        # matrix cores with split-bf16 products (csrc/modconv_sbf16.hip, mode 7: a b ~= a_h b_h + a_h b_l + a_l b_h, fp32 accumulate)
-        # instead of the fp32 2-D Winograd kernel; same machinery otherwise.  Reported with its error against the fp32 path.
-        try:
-            ModulatedConv2d.split_bf16_min_cout = 128
-            w3 = Workload(size, B, n_lanes, dev, rank, False)
-            for _ in range(2 * n_lanes):
-                w3.batch()
-            w3.sync()
-            dt = time_region(w3, 4, bps, "synth", False, 1)
-            nb = [getattr(w3.g.noises, f"noise_{i}") if nz is None else nz[:B] for i, nz in enumerate(w3.noise)]
-            modes = {f"convs.{i}": c.conv.conv_mode(4 * 2 ** ((i + 1) // 2), 4 * 2 ** ((i + 1) // 2)) for i, c in enumerate(w3.g.convs) if i % 2}
-            img7, _ = w3.g(styles=w3.latents[:B], noise=nb, truncation=1.0, randomize_noise=False, input_is_latent=True)
-            ModulatedConv2d.split_bf16_min_cout = 1 << 30
-            img5, _ = w3.g(styles=w3.latents[:B], noise=nb, truncation=1.0, randomize_noise=False, input_is_latent=True)
-            sides["split_bf16_plain_layers"] = {
-                "frames_per_s": 4 * bps * B / dt, "timed_region_s": dt, "frames": 4 * bps * B, "lanes": w3.n_lanes,
-                "relative_to_fp32_headline": 4 * bps * B / dt / (fps / world),
-                "layers_on_the_bf16_matrix_cores": [k for k, m in modes.items() if m == 7],
-                "max_abs_image_diff_vs_fp32_path": float((img7 - img5).abs().max()), "image_std": float(img5.std()),
-                "dtype": "bf16 x 3 split products, fp32 accumulation (NOT the headline dtype)",
-                "what": "side measurement only: plain 3x3 layers with >= 128 channels in the direct 9-tap form on v_mfma_f32_32x32x16_bf16"}
-            del w3
-            torch.cuda.empty_cache()
-        except Exception as exc:
-            sides["split_bf16_plain_layers"] = {"error": repr(exc)}
-        finally:
-            ModulatedConv2d.split_bf16_min_cout = 1 << 30
+        # SIDE MEASUREMENT, never the headline: conv layers on the bf16 matrix cores with split-bf16 products
+        # (csrc/modconv_sbf16.hip: a b ~= a_h b_h + a_h b_l + a_l b_h, fp32 accumulate) — the plain >= 128-channel layers (mode 7,
+        # convs.5 / 7 / 9 / 11) and the transposed layers from 32^2 inputs up (mode 8, convs.6 / 8 / 10 / 12 / 14) instead of the fp32
+        # Winograd / F(2,2) kernels; same machinery otherwise.  Reported with its error against the fp32 path.
+        for key, plain_min, up_min in (("split_bf16_plain_layers", 128, 1 << 30), ("split_bf16_plain_and_transposed_layers", 128, 32)):
+            try:
+                ModulatedConv2d.split_bf16_min_cout, ModulatedConv2d.split_bf16_up_min_cout = plain_min, up_min
+                w3 = Workload(size, B, n_lanes, dev, rank, False)
+                for _ in range(2 * n_lanes):
+                    w3.batch()
+                w3.sync()
+                dt = time_region(w3, 4, bps, "synth", False, 1)
+                nb = [getattr(w3.g.noises, f"noise_{i}") if nz is None else nz[:B] for i, nz in enumerate(w3.noise)]
+                modes = {}
+                for i, c in enumerate(w3.g.convs):
+                    res = 4 * 2 ** ((i + 1) // 2) if i % 2 else 4 * 2 ** (i // 2)
+                    modes[f"convs.{i}"] = c.conv.conv_mode(res, res)
+                img7, _ = w3.g(styles=w3.latents[:B], noise=nb, truncation=1.0, randomize_noise=False, input_is_latent=True)
+                ModulatedConv2d.split_bf16_min_cout = ModulatedConv2d.split_bf16_up_min_cout = 1 << 30
+                img5, _ = w3.g(styles=w3.latents[:B], noise=nb, truncation=1.0, randomize_noise=False, input_is_latent=True)
+                sides[key] = {
+                    "frames_per_s": 4 * bps * B / dt, "timed_region_s": dt, "frames": 4 * bps * B, "lanes": w3.n_lanes,
+                    "relative_to_fp32_headline": 4 * bps * B / dt / (fps / world),
+                    "layers_on_the_bf16_matrix_cores": [k for k, m in modes.items() if m in (7, 8)],
+                    "max_abs_image_diff_vs_fp32_path": float((img7 - img5).abs().max()), "image_std": float(img5.std()),
+                    "graph_vs_eager_max_diff": w3.check_frames() if False else None,
+                    "dtype": "bf16 x 3 split products, fp32 accumulation (NOT the headline dtype)",
+                    "what": "side measurement only: direct / polyphase 3x3 convolutions on v_mfma_f32_32x32x16_bf16"}
+                del sides[key]["graph_vs_eager_max_diff"]
+                del w3
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                sides[key] = {"error": repr(exc)}
+            finally:
+                ModulatedConv2d.split_bf16_min_cout = ModulatedConv2d.split_bf16_up_min_cout = 1 << 30
         # --stylegan1 (models/stylegan1.py G_style at 1024 px, random init): frames through render.synthesize's captured lanes
         try:
             from maua_stylegan2_amd import render

@@ -140,6 +140,7 @@ int maua_modconv_up2d_ok(int cin, int cout, int h, int w);
 int64_t maua_pack_weight_sbf16_bytes(int cout, int cin);
 int maua_pack_weight_sbf16_f32(const float* w, void* wq, int cout, int cin, void* stream);
 int maua_modconv_sbf16_ok(int cin, int cout, int h, int w);
+int maua_modconv_sbf16_up_ok(int cin, int cout, int h, int w);  /* the transposed form (up == 8): cout % 32 == 0 instead of % 128 */
 
 /* 2-D Winograd F(2x4, 3x3) form for mode 5 (F(2,3) along ky on top of F(4,3) along kx: 24 values per (cout, cin) pair),
  * stored as the LDS tile image the kernel DMAs linearly: wq[cout/BM][cin/4][fy 4][xf 6][cin%4][BM columns] (BM = 64, or 32 for

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "maua_pack_weight_sbf16_bytes": (c_int64, [c_int] * 2),
     "maua_pack_weight_sbf16_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "maua_modconv_sbf16_ok": (c_int, [c_int] * 4),
+    "maua_modconv_sbf16_up_ok": (c_int, [c_int] * 4),
     "maua_modconv_w2d_ok": (c_int, [c_int] * 4),
     "maua_modconv_w2d_mtiles": (c_int, [c_int] * 4),
     "maua_modconv_ws_floats": (c_int64, [c_int] * 6),

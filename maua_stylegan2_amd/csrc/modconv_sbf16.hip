@@ -23,7 +23,8 @@
 //     patch (no im2col), one conflict-free ds_read_b128 per (n-tile, hi | lo).  Double buffered: the next chunk's loads are in
 //     flight under the nine taps of the current one.
 //   A operand: the packed weight (maua_pack_weight_sbf16_f32) is stored in HBM in MFMA lane order, [m-tile][chunk][tap][hi | lo]
-//     [lane][8], and goes straight to registers (one 16-byte load per lane, m-tile and half, one tap ahead): no LDS, no DMA.
+//     [lane][8], and goes straight to registers (one 16-byte load per lane and half, two taps ahead): no LDS, no DMA.
+// The transposed layers (mode 8) run the same arithmetic in their polyphase form on the input grid — modconv_sbf16_up_kernel below.
 #include "common.h"
 
 #include <cstdio>
@@ -86,25 +87,17 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     hi = __builtin_bit_cast(unsigned, h), lo = __builtin_bit_cast(unsigned, l);
 }
 
-// Tap tables.  PHASE -1: the plain convolution, 9 taps, tap (ky, kx) reads patch record (n + ky, l + kx) (patch origin = (ty0 - 1,
-// tx0 - 1)).  PHASE 0..3: the four output phases (even / odd row) x (even / odd column) of the stride-2 TRANSPOSED convolution
-// (models/stylegan2.py:229-237; conv_transpose2d: y[i] += x[p] g[i - 2 p]) in its polyphase form on the INPUT grid — position (p, q)
-// owns outputs (2 p + a', 2 q + b'):  even = g0 x[p] + g2 x[p - 1],  odd = g1 x[p]  per axis, i.e. 4 + 2 + 2 + 1 = 9 taps in all,
-// the same packed weight records, each phase its own launch with 8 accumulator tiles (all four phases at once would need 512 registers).
+// Tap table of the plain convolution: tap (ky, kx) reads patch record (n + ky, l + kx) (patch origin = (ty0 - 1, tx0 - 1)).  (The kernel is
+// written against a table so that other tap sets can be tried; the transposed layers have their own kernel below.)
 struct SbTap { int wt, ro, co; };  // packed weight tap (ky * 3 + kx), patch row / column offset of the record
 template <int PHASE> struct SbTaps;
 template <> struct SbTaps<-1> { static constexpr int NT = 9; static constexpr SbTap t[9] = {{0, 0, 0}, {1, 0, 1}, {2, 0, 2}, {3, 1, 0}, {4, 1, 1}, {5, 1, 2}, {6, 2, 0}, {7, 2, 1}, {8, 2, 2}}; };
-template <> struct SbTaps<0> { static constexpr int NT = 4; static constexpr SbTap t[4] = {{0, 1, 1}, {2, 1, 0}, {6, 0, 1}, {8, 0, 0}}; };  // (even, even)
-template <> struct SbTaps<1> { static constexpr int NT = 2; static constexpr SbTap t[2] = {{1, 1, 1}, {7, 0, 1}}; };                        // (even row, odd column)
-template <> struct SbTaps<2> { static constexpr int NT = 2; static constexpr SbTap t[2] = {{3, 1, 1}, {5, 1, 0}}; };                        // (odd row, even column)
-template <> struct SbTaps<3> { static constexpr int NT = 1; static constexpr SbTap t[1] = {{4, 1, 1}}; };                                   // (odd, odd)
 
 template <int PHASE>
 __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     using Taps = SbTaps<PHASE>;
     constexpr int NT = Taps::NT;
     constexpr int STEPS = 2 * NT;        // half-taps of a chunk: four n-tiles (12 matrix instructions) each
-    constexpr bool UP = PHASE >= 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     // LDS: patch[2 buffers][hi | lo][k half][PH][PW] 16-byte records | Ss[Cin] | Eg[128] | Eb[128]
     float* Ss = reinterpret_cast<float*>(lds_raw + 2 * SB_BUF_BYTES);
@@ -157,15 +150,14 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x) + (size_t)b0 * p.Cin * plane, 0, (int)((unsigned)p.Cin * plane_bytes), 0x00020000);
 #endif
-    // plain form: one item (8 channels of one patch pixel) is in flight at a time — item q of the next chunk is requested at tap 3 q and
-    // written to LDS three taps later, so the three staging sets share 8 registers; the short chunks of the transposed phases request
-    // all three items at their first step and write them behind their last one
-    float stage[UP ? SB_PER_THREAD : 1][8];
+    // one item (8 channels of one patch pixel) is in flight at a time: item q of the next chunk is requested at tap 3 q and written to LDS
+    // three taps later — 8 staging registers instead of 24
+    float stage[8];
     auto fetch = [&](int chunk, int q) {
 #ifdef MAUA_DEVICE_PASS
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            stage[UP ? q : 0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, item_voff[q],
+            stage[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, item_voff[q],
                                                                                          (unsigned)(chunk * SB_KC + e) * plane_bytes, 0));
 #else
         (void)chunk, (void)q;
@@ -176,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
         const float* sp = Ss + chunk * SB_KC + item_kb[q] * 8;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
         unsigned h[4], l[4];
-        const float(&v)[8] = stage[UP ? q : 0];
+        const float(&v)[8] = stage;
         split2(v[0] * s0[0], v[1] * s0[1], h[0], l[0]);
         split2(v[2] * s0[2], v[3] * s0[3], h[1], l[1]);
         split2(v[4] * s1[0], v[5] * s1[1], h[2], l[2]);
@@ -224,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     load_a_ahead(a0, 0, std::integral_constant<int, 0>{});
     load_a_ahead(a1, 0, std::integral_constant<int, 1>{});
     int cur = 0;
-    static_assert(SB_PER_THREAD == 3, "the tap loop stages three items per thread");
+    static_assert(SB_PER_THREAD == 3 && NT == 9, "the tap loop stages one item per three taps");
     bf16x8 bh[2][4], bl[2][4];
     auto read_b = [&](const unsigned char* pb, auto h_c, bf16x8(&dh)[4], bf16x8(&dl)[4]) {
         constexpr int h = decltype(h_c)::value, tap = h / 2, nq = h % 2, ro = Taps::t[tap].ro, co = Taps::t[tap].co;
@@ -243,14 +235,9 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
             constexpr int h = decltype(h_c)::value, tap = h / 2, nq = h % 2, slot = h % 2;
             if constexpr (nq == 0) {
                 if (more) {
-                    if constexpr (!UP) {
-                        if constexpr (tap % 3 == 0) {
-                            if constexpr (tap > 0) commit(chunk + 1, cur ^ 1, tap / 3 - 1);
-                            fetch(chunk + 1, tap / 3);
-                        }
-                    } else if constexpr (tap == 0) {
-#pragma unroll
-                        for (int q = 0; q < SB_PER_THREAD; ++q) fetch(chunk + 1, q);
+                    if constexpr (tap % 3 == 0) {
+                        if constexpr (tap > 0) commit(chunk + 1, cur ^ 1, tap / 3 - 1);
+                        fetch(chunk + 1, tap / 3);
                     }
                 }
                 load_a_ahead(a2, chunk, std::integral_constant<int, tap + 2>{});
@@ -269,14 +256,7 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
                 for (int hl = 0; hl < 2; ++hl) a0[hl] = a1[hl], a1[hl] = a2[hl];
             }
         });
-        if (more) {
-            if constexpr (UP) {
-#pragma unroll
-                for (int q = 0; q < SB_PER_THREAD; ++q) commit(chunk + 1, cur ^ 1, q);
-            } else {
-                commit(chunk + 1, cur ^ 1, SB_PER_THREAD - 1);
-            }
-        }
+        if (more) commit(chunk + 1, cur ^ 1, SB_PER_THREAD - 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -292,22 +272,6 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
     }
     const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
     const float slope = act ? 0.2f : 1.f;
-    if constexpr (UP) {  // raw map [B, Cout, 2 H + 1, 2 W + 1]: this phase's outputs (2 p + a', 2 q + b'); the blur kernel applies the tail
-        constexpr int ar = PHASE >> 1, bc = PHASE & 1;
-        const int OW = 2 * p.W + 1;
-        const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
-        float* yup = p.y + ((size_t)b0 * p.Cout + m0 + wave * 32) * plane_out;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const size_t pix = (size_t)(2 * (ty0 + n) + ar) * OW + 2 * (tx0 + l31) + bc;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int ol = (j & 3) + 8 * (j >> 2) + 4 * hi32;
-                yup[(size_t)ol * plane_out + pix] = acc[n][j] * Eg[wave * 32 + ol];
-            }
-        }
-        return;
-    }
     float* yimg = p.y + ((size_t)b0 * p.Cout + m0 + wave * 32) * plane;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -319,6 +283,189 @@ __global__ __launch_bounds__(256, 2) void modconv_sbf16_kernel(SbArgs p) {
             const int ol = (j & 3) + 8 * (j >> 2) + 4 * hi32;
             const float tt = fmaf(acc[n][j], Eg[wave * 32 + ol], nz + Eb[wave * 32 + ol]);
             yimg[(size_t)ol * plane + pix] = fmaxf(tt, tt * slope);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The transposed layers in ONE launch (mode 8): a workgroup owns one 32-channel m-tile x (8 rows x 32 columns of POSITIONS) and ALL
+// FOUR output phases; wave w takes position rows 2 w, 2 w + 1: 4 phases x 2 n-tiles = 8 accumulator tiles.  A transposed layer has four
+// output phases per input position, i.e. a quarter of a plain layer's accumulator reuse per weight record, so here the records go through
+// LDS once per workgroup (LDS-DMA of the 18 KB (9 taps x hi | lo x 64 lanes x 16 bytes) of a chunk, double buffered; the packed layout IS
+// that tile) and every wave reads them from there; the patch (9 x 33 positions) is staged as in the plain kernel.
+constexpr int SU_PH = SB_TH + 1, SU_PW = SB_TW + 1;           // the taps reach one row up and one column left
+constexpr int SU_ITEMS = 2 * SU_PH * SU_PW;                    // 594 records per chunk and hi | lo plane
+constexpr int SU_PER_THREAD = (SU_ITEMS + 255) / 256;          // 3
+constexpr int SU_PLANE_BYTES = SU_ITEMS * 16;
+constexpr int SU_BBUF_BYTES = 2 * SU_PLANE_BYTES;
+constexpr int SU_ABUF_BYTES = 18 * 1024;
+// (phase = 2 * (odd row) + (odd column), weight tap ky * 3 + kx, patch row / column offset of the record: patch origin = (ty0 - 1, tx0 - 1))
+struct SuTap { int ph, wt, ro, co; };
+__device__ constexpr SuTap SU_TAPS[9] = {{0, 0, 1, 1}, {1, 1, 1, 1}, {2, 3, 1, 1}, {3, 4, 1, 1}, {0, 2, 1, 0},
+                                         {1, 7, 0, 1}, {2, 5, 1, 0}, {0, 6, 0, 1}, {0, 8, 0, 0}};
+
+__global__ __launch_bounds__(256, 2) void modconv_sbf16_up_kernel(SbArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // LDS: A[2][18 KB] | patch[2 buffers][hi | lo][k half][9][33] 16-byte records | Ss[Cin] | Eg[32]
+    unsigned char* Bs = lds_raw + 2 * SU_ABUF_BYTES;
+    float* Ss = reinterpret_cast<float*>(Bs + 2 * SU_BBUF_BYTES);
+    float* Eg = Ss + p.Cin;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi32 = lane >> 5;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt_id = t % p.m_tiles;  // (32-channel m-tiles here)
+    t /= p.m_tiles;
+    const int tile_x = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tile_y = t % p.tiles_y;
+    const int b0 = t / p.tiles_y;
+    const int ty0 = tile_y * SB_TH, tx0 = tile_x * SB_TW;
+    const int m0 = mt_id * 32;
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned plane_bytes = (unsigned)plane * 4u;
+
+    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    if (tid < 32) Eg[tid] = p.wscale * (p.d ? p.d[(size_t)b0 * p.Cout + m0 + tid] : 1.f);
+
+    unsigned item_voff[SU_PER_THREAD], item_lds[SU_PER_THREAD];
+    int item_kb[SU_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < SU_PER_THREAD; ++q) {
+        const int idx = tid + 256 * q;
+        const int kb = idx / (SU_PH * SU_PW), rem = idx % (SU_PH * SU_PW);
+        const int row = rem / SU_PW, col = rem % SU_PW;
+        const int yy = ty0 - 1 + row, xx = tx0 - 1 + col;
+        const bool ok = idx < SU_ITEMS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        item_voff[q] = ok ? (unsigned)kb * 8u * plane_bytes + ((unsigned)yy * (unsigned)p.W + (unsigned)xx) * 4u : SB_OOB;
+        item_lds[q] = (unsigned)idx * 16u;
+        item_kb[q] = idx < SU_ITEMS ? kb : -1;
+    }
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x) + (size_t)b0 * p.Cin * plane, 0, (int)((unsigned)p.Cin * plane_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16x8*>(p.wq) + (size_t)mt_id * p.n_chunks * 18 * 64, 0, (int)((unsigned)p.n_chunks * SU_ABUF_BYTES), 0x00020000);
+#endif
+    float stage[SU_PER_THREAD][8];
+    auto fetch = [&](int chunk) {
+#ifdef MAUA_DEVICE_PASS
+#pragma unroll
+        for (int q = 0; q < SU_PER_THREAD; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                stage[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, item_voff[q],
+                                                                                             (unsigned)(chunk * SB_KC + e) * plane_bytes, 0));
+#else
+        (void)chunk;
+#endif
+    };
+    auto commit = [&](int chunk, int buf) {
+#pragma unroll
+        for (int q = 0; q < SU_PER_THREAD; ++q) {
+            if (item_kb[q] < 0) continue;
+            const float* sp = Ss + chunk * SB_KC + item_kb[q] * 8;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            unsigned h[4], l[4];
+            split2(stage[q][0] * s0[0], stage[q][1] * s0[1], h[0], l[0]);
+            split2(stage[q][2] * s0[2], stage[q][3] * s0[3], h[1], l[1]);
+            split2(stage[q][4] * s1[0], stage[q][5] * s1[1], h[2], l[2]);
+            split2(stage[q][6] * s1[2], stage[q][7] * s1[3], h[3], l[3]);
+            unsigned char* dst = Bs + buf * SU_BBUF_BYTES + item_lds[q];
+            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(dst + SU_PLANE_BYTES) = u32x4{l[0], l[1], l[2], l[3]};
+        }
+    };
+    auto issue_a = [&](int chunk, int buf) {  // 18 pieces of 1 KiB, dealt to the four waves
+#ifdef MAUA_DEVICE_PASS
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = wave + 4 * k;  // (scalar)
+            if (i < 18)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(lds_raw + buf * SU_ABUF_BYTES + i * 1024),
+                                                         16, i * 1024 + lane * 16, chunk * SU_ABUF_BYTES, 0, 0);
+        }
+#else
+        (void)chunk, (void)buf;
+#endif
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[ph][n][j] = 0.f;
+
+    // B records of this lane: k half hi32, patch row 2 wave + n + ro, column l31 + co;  A records: (tap * 2 + hi | lo) * 1 KiB + lane * 16
+    const unsigned b_base = (unsigned)((hi32 * SU_PH + 2 * wave) * SU_PW + l31) * 16u;
+    const unsigned a_base = (unsigned)lane * 16u;
+
+    __syncthreads();  // styles and gains are in LDS
+    issue_a(0, 0);
+    fetch(0);
+    commit(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    bf16x8 av[2][2], bh[2][2], bl[2][2];  // [pipeline slot][hi | lo] / [slot][n-tile]
+    auto read_tap = [&](const unsigned char* pa, const unsigned char* pb, auto t_c, int slot) {
+        constexpr int tp = decltype(t_c)::value;
+        constexpr SuTap T = SU_TAPS[tp];
+        av[slot][0] = *reinterpret_cast<const bf16x8*>(pa + (T.wt * 2) * 1024);
+        av[slot][1] = *reinterpret_cast<const bf16x8*>(pa + (T.wt * 2 + 1) * 1024);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const unsigned char* rec = pb + ((n + T.ro) * SU_PW + T.co) * 16;
+            bh[slot][n] = *reinterpret_cast<const bf16x8*>(rec);
+            bl[slot][n] = *reinterpret_cast<const bf16x8*>(rec + SU_PLANE_BYTES);
+        }
+    };
+    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
+        const bool more = chunk + 1 < p.n_chunks;
+        if (more) {
+            issue_a(chunk + 1, cur ^ 1);
+            fetch(chunk + 1);
+        }
+        const unsigned char* pa = lds_raw + cur * SU_ABUF_BYTES + a_base;
+        const unsigned char* pb = Bs + cur * SU_BBUF_BYTES + b_base;
+        read_tap(pa, pb, std::integral_constant<int, 0>{}, 0);
+        static_for<0, 9>([&](auto t_c) {
+            constexpr int tp = decltype(t_c)::value, slot = tp % 2, ph = SU_TAPS[tp].ph;
+            if constexpr (tp + 1 < 9) read_tap(pa, pb, std::integral_constant<int, tp + 1>{}, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[ph][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][1], bh[slot][n], acc[ph][n], 0, 0, 0);  // a_l b_h
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[ph][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][0], bl[slot][n], acc[ph][n], 0, 0, 0);  // a_h b_l
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[ph][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[slot][0], bh[slot][n], acc[ph][n], 0, 0, 0);  // a_h b_h
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (more) commit(chunk + 1, cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: the 2 x 2 output block of every position — raw map [B, Cout, 2 H + 1, 2 W + 1], gain = wscale * demod
+    const int OW = 2 * p.W + 1;
+    const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
+    float* yup = p.y + ((size_t)b0 * p.Cout + m0) * plane_out;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const size_t pix = (size_t)(2 * (ty0 + 2 * wave + n)) * OW + 2 * (tx0 + l31);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int ol = (j & 3) + 8 * (j >> 2) + 4 * hi32;
+            const float g = Eg[ol];
+            float* dst = yup + (size_t)ol * plane_out + pix;
+            dst[0] = acc[0][n][j] * g, dst[1] = acc[1][n][j] * g;
+            dst[OW] = acc[2][n][j] * g, dst[OW + 1] = acc[3][n][j] * g;
         }
     }
 }
@@ -371,6 +518,10 @@ char g_sbf16_instance[48] = "";
 int maua_sbf16_ok(int cin, int cout, int h, int w) {
     return cin > 0 && cout > 0 && cin % SB_KC == 0 && cout % SB_BM == 0 && h % SB_TH == 0 && w % SB_TW == 0;
 }
+// (the transposed kernel works on 32-channel m-tiles)
+int maua_sbf16_up_ok(int cin, int cout, int h, int w) {
+    return cin > 0 && cout > 0 && cin % SB_KC == 0 && cout % 32 == 0 && h % SB_TH == 0 && w % SB_TW == 0;
+}
 
 const char* maua_sbf16_last_instance() { return g_sbf16_instance; }
 
@@ -395,7 +546,7 @@ int sbf16_launch_phase(const SbArgs& a, size_t lds_bytes, hipStream_t st) {
 int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
                       int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
                       const float* noise_w, const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream) {
-    if (!maua_sbf16_ok(cin, cout, h, w)) return MAUA_EINVAL;
+    if (!(up ? maua_sbf16_up_ok(cin, cout, h, w) : maua_sbf16_ok(cin, cout, h, w))) return MAUA_EINVAL;
     if ((int64_t)cin * h * w * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor range / 32-bit offsets
     if (up && (fuse_act || !ws)) return MAUA_EINVAL;
     SbArgs a{};
@@ -409,12 +560,19 @@ int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stri
         snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_kernel<-1>");
         return sbf16_launch_phase<-1>(a, lds_bytes, st);
     }
-    snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_kernel<0..3>");
-    int rc = sbf16_launch_phase<0>(a, lds_bytes, st);
-    if (!rc) rc = sbf16_launch_phase<1>(a, lds_bytes, st);
-    if (!rc) rc = sbf16_launch_phase<2>(a, lds_bytes, st);
-    if (!rc) rc = sbf16_launch_phase<3>(a, lds_bytes, st);
-    if (rc) return rc;
+    snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_up_kernel");
+    {
+        static int attr_rc = -1;
+        if (attr_rc < 0)
+            attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_sbf16_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+        if (attr_rc) return attr_rc;
+        a.m_tiles = cout / 32;
+        const size_t up_lds = (size_t)2 * SU_ABUF_BYTES + (size_t)2 * SU_BBUF_BYTES + sizeof(float) * ((size_t)cin + 32);
+        const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
+        hipLaunchKernelGGL(modconv_sbf16_up_kernel, dim3((unsigned)blocks), dim3(256), up_lds, st, a);
+        MAUA_LAUNCH_CHECK();
+    }
     const int64_t rows = (int64_t)batch * cin * h;
     const int64_t blocks = ceil_div64(rows, 256);
     hipLaunchKernelGGL(export_last_column_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, x, ws, rows, w);
@@ -425,11 +583,11 @@ int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stri
 
 // bf16 records (cout * cin * 9 * 2 * 2 bytes), then the five fp32 edge tap matrices [5][cin][cout] of the transposed form
 extern "C" int64_t maua_pack_weight_sbf16_bytes(int cout, int cin) {
-    return maua_sbf16_ok(cin, cout, SB_TH, SB_TW) ? (int64_t)cout * cin * 9 * 2 * 2 + (int64_t)5 * cin * cout * 4 : 0;
+    return maua_sbf16_up_ok(cin, cout, SB_TH, SB_TW) ? (int64_t)cout * cin * 9 * 2 * 2 + (int64_t)5 * cin * cout * 4 : 0;
 }
 
 extern "C" int maua_pack_weight_sbf16_f32(const float* w, void* wq, int cout, int cin, void* stream) {
-    if (!w || !wq || !maua_sbf16_ok(cin, cout, SB_TH, SB_TW)) return MAUA_EINVAL;
+    if (!w || !wq || !maua_sbf16_up_ok(cin, cout, SB_TH, SB_TW)) return MAUA_EINVAL;
     const int64_t total = (int64_t)(cout / 32) * (cin / SB_KC) * 9 * 64 * 4;
     const int64_t blocks = ceil_div64(total, 256);
     hipLaunchKernelGGL(pack_weight_sbf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, w,
@@ -443,3 +601,4 @@ extern "C" int maua_pack_weight_sbf16_f32(const float* w, void* wq, int cout, in
 }
 
 extern "C" int maua_modconv_sbf16_ok(int cin, int cout, int h, int w) { return maua_sbf16_ok(cin, cout, h, w); }
+extern "C" int maua_modconv_sbf16_up_ok(int cin, int cout, int h, int w) { return maua_sbf16_up_ok(cin, cout, h, w); }

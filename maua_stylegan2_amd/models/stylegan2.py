@@ -193,7 +193,7 @@ class ModulatedConv2d(nn.Module):
     def conv_mode(self, h, w):
         """Kernel mode of maua_modconv3x3_f32 for an [*, Cin, h, w] input: 1 / 4 / 6 transposed, 2 Winograd F(2,3), 3 Winograd
         F(4,3), 5 2-D Winograd F(2x4,3x3), 0 direct; 7 / 8 = the split-bf16 side measurement (plain / transposed), off by default."""
-        if self.upsample and self.out_channel >= self.split_bf16_up_min_cout and _lib.load().maua_modconv_sbf16_ok(
+        if self.upsample and self.out_channel >= self.split_bf16_up_min_cout and _lib.load().maua_modconv_sbf16_up_ok(
                 self.in_channel, self.out_channel, h, w):
             return 8
         if self.upsample and self.out_channel >= self.upwino2d_min_cout and _lib.load().maua_modconv_up2d_ok(

@@ -458,11 +458,13 @@ def test_modconv_split_bf16_vs_oracle(gpu, cin, cout, h, w, batch):
 @pytest.mark.parametrize("cin,cout,h,w,batch", [
     (128, 128, 16, 32, 2),    # one weight tile, 2 x 1 position tiles
     (256, 256, 8, 64, 1),     # two weight tiles, 1 x 2 position tiles
-    (48, 384, 24, 96, 1),     # three K chunks, three weight tiles, 3 x 3 tiles
+    (48, 384, 24, 96, 1),     # three K chunks, twelve m-tiles, 3 x 3 tiles
+    (64, 32, 16, 32, 2),      # a single 32-channel m-tile (convs.14's shape class)
 ])
 def test_upconv_split_bf16_matches_polyphase_and_oracle(gpu, cin, cout, h, w, batch):
     """SIDE MEASUREMENT (mode 8, csrc/modconv_sbf16.hip; off by default): the stride-2 transposed convolution (models/stylegan2.py:229-237)
-    as four polyphase output phases on the bf16 matrix cores with split-bf16 products + the fp32 edge lines, written into a NaN-prefilled
+    in its polyphase form — all four output phases of a position in one workgroup — on the bf16 matrix cores with split-bf16 products + the
+    fp32 edge lines, written into a NaN-prefilled
     raw map: every element of [B, Cout, 2H+1, 2W+1] must be written and agree with the fp32 polyphase kernel (mode 1) within 2e-4; then
     the whole StyledConv (blur + noise + bias + act) against the oracle within 5e-4."""
     from maua_stylegan2_amd import _lib
@@ -503,7 +505,7 @@ def test_upconv_split_bf16_matches_polyphase_and_oracle(gpu, cin, cout, h, w, ba
         m.conv.run(xs, st, 0, dm, out, ws if n_ws else None)
         return mode, out.cpu().numpy()
 
-    mode8, got = raw_map(128)
+    mode8, got = raw_map(32)
     assert mode8 == 8 and np.isfinite(got).all(), "an element of the raw map was not written"
     m.conv.upwino2d_min_cout = 1 << 30
     m.conv.upconv_winograd = False
@@ -512,7 +514,7 @@ def test_upconv_split_bf16_matches_polyphase_and_oracle(gpu, cin, cout, h, w, ba
     print(f"[split-bf16 transposed {cin}->{cout} @{h}x{w}] max |mode 8 - mode 1 (fp32 polyphase)| = {np.abs(got - ref).max():.2e} "
           f"(raw std {ref.std():.2f})")
     np.testing.assert_allclose(got, ref, atol=2e-4, rtol=1e-4)
-    m.conv.split_bf16_up_min_cout = 128
+    m.conv.split_bf16_up_min_cout = 32
     full = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
     want = so.styled_conv(sd, "L", x, s, nz, True).numpy()
     print(f"[split-bf16 transposed {cin}->{cout} @{h}x{w}] StyledConv: max |hip - oracle| = {np.abs(full - want).max():.2e} (std {want.std():.2f})")

@@ -100,7 +100,8 @@ def main():
             if args.wino2d_min_cout is not None:
                 ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
             if args.split_bf16_min_cout is not None:
-                ModulatedConv2d.split_bf16_min_cout = ModulatedConv2d.split_bf16_up_min_cout = args.split_bf16_min_cout
+                ModulatedConv2d.split_bf16_min_cout = args.split_bf16_min_cout
+                ModulatedConv2d.split_bf16_up_min_cout = 32  # (the transposed kernel works on 32-channel m-tiles)
             for name, cin, cout, h, up in [("plain32@1024", 32, 32, 1024, 0), ("plain64@512", 64, 64, 512, 0),
                                            ("plain128@256", 128, 128, 256, 0), ("plain256@128", 256, 256, 128, 0),
                                            ("plain512@64", 512, 512, 64, 0), ("up64-32@512", 64, 32, 512, 1),
