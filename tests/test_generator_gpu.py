@@ -311,3 +311,36 @@ def test_surplus_latent_rows_are_ignored_as_in_the_reference(gpu):
     assert np.array_equal(frames(lat18), frames(lat10))
     with pytest.raises(RuntimeError, match="do not match"):
         g(styles=lat18[:bs, :9].to(gpu), noise=None, randomize_noise=False, input_is_latent=True)
+
+
+@pytest.mark.parametrize("size", [256, 1024])
+def test_generator_with_split_bf16_conv_layers_matches_reference_golden(gpu, golden, size):
+    """SIDE MEASUREMENT switched ON (ModulatedConv2d.split_bf16_min_cout = 128, split_bf16_up_min_cout = 32: the wide plain layers and the
+    transposed layers from 32^2 inputs up run split-bf16 products on the bf16 matrix cores, csrc/modconv_sbf16.hip): the generator must
+    still reproduce the REFERENCE's own image within the north_star tolerance of 1e-3; the measured error and the number of switched
+    layers are printed."""
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+
+    gold = golden(f"gen_{size}.npz")
+    batch, stride = int(gold["batch"]), int(gold["stride"])
+    s_sd, s_lat, s_noise, s_tl = (int(v) for v in gold["seeds"])
+    g = build(size, gpu, s_sd)
+    lat = seeding.seeded_latents(batch, g.n_latent, seed=s_lat).to(gpu)
+    noise = [n.to(gpu) for n in seeding.seeded_noise(batch, size, seed=s_noise)]
+    g.truncation_latent = torch.from_numpy(seeding.seeded_array(s_tl, "truncation_latent", (1, 512))).to(gpu)
+    trunc = torch.full((batch,), float(gold["truncation"]), device=gpu)
+    keep = ModulatedConv2d.split_bf16_min_cout, ModulatedConv2d.split_bf16_up_min_cout
+    try:
+        fp32, _ = g(styles=lat, noise=noise, truncation=trunc, randomize_noise=False, input_is_latent=True)
+        ModulatedConv2d.split_bf16_min_cout, ModulatedConv2d.split_bf16_up_min_cout = 128, 32
+        switched = sum(c.conv.conv_mode(4 * 2 ** ((i + 1) // 2) if i % 2 else 4 * 2 ** (i // 2),
+                                        4 * 2 ** ((i + 1) // 2) if i % 2 else 4 * 2 ** (i // 2)) in (7, 8) for i, c in enumerate(g.convs))
+        img, _ = g(styles=lat, noise=noise, truncation=trunc, randomize_noise=False, input_is_latent=True)
+    finally:
+        ModulatedConv2d.split_bf16_min_cout, ModulatedConv2d.split_bf16_up_min_cout = keep
+    assert switched >= (5 if size == 256 else 9), switched
+    err = np.abs(img.cpu().numpy()[:, :, ::stride, ::stride] - gold["image"]).max()
+    err32 = np.abs(fp32.cpu().numpy()[:, :, ::stride, ::stride] - gold["image"]).max()
+    print(f"[split-bf16 generator {size}] {switched} conv layers on the bf16 cores: max |image - reference| = {err:.2e} "
+          f"(fp32 path: {err32:.2e}; image std {float(fp32.std()):.2f}), max |split - fp32| = {float((img - fp32).abs().max()):.2e}")
+    assert err < TOL, f"{size}: max abs err {err}"
