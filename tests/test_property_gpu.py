@@ -127,6 +127,42 @@ def test_upconv2d_random_shapes_vs_oracle(gpu, cin, cout, hb, wb, batch, seed):
     np.testing.assert_allclose(got, want, atol=5e-4, rtol=2e-4)
 
 
+@settings(max_examples=30, **COMMON)
+@given(cin=st.sampled_from([16, 32, 48, 80, 128, 256]), cout=st.sampled_from([32, 64, 96, 128, 256, 384]), hb=st.integers(1, 4),
+       wb=st.integers(1, 3), batch=st.integers(1, 3), up=st.booleans(), shared_noise=st.booleans(), seed=st.integers(0, 1 << 16))
+def test_split_bf16_random_shapes_vs_oracle(gpu, cin, cout, hb, wb, batch, up, shared_noise, seed):
+    """SIDE MEASUREMENT kernels (csrc/modconv_sbf16.hip, off by default) on random qualifying shapes — Cin % 16 == 0, H a multiple of 8, W of
+    32; plain (mode 7): Cout % 128 == 0; transposed (mode 8): Cout % 32 == 0 — through the whole StyledConv (tail, and blur for the
+    transposed form) against the oracle, same bound as the fp32 kernels."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+
+    if not up:
+        cout = 128 * max(1, cout // 128)
+    h, w = hb * 8, wb * 32
+    r = np.random.default_rng(seed)
+    m = StyledConv(cin, cout, 3, 512, upsample=up)
+    m.conv.split_bf16_min_cout, m.conv.split_bf16_up_min_cout = 128, 32
+    assert m.conv.conv_mode(h, w) == (8 if up else 7)
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.27]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    if up:
+        sd["L.conv.blur.kernel"] = m.conv.blur.kernel.clone()
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    oh, ow = (2 * h, 2 * w) if up else (h, w)
+    nz = torch.from_numpy(r.standard_normal((1 if shared_noise else batch, 1, oh, ow)).astype(np.float32))
+    want = so.styled_conv(sd, "L", x, s, nz, up).numpy()
+    got = m(x.to(gpu), s.to(gpu), noise=nz.to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-4, rtol=2e-4)
+
+
 @settings(max_examples=25, **COMMON)
 @given(cin=st.sampled_from([3, 16, 32, 40, 64, 128]), h=st.integers(2, 40), w=st.sampled_from([2, 4, 6, 10, 16, 30, 32, 64, 72]),
        batch=st.integers(1, 3), skip=st.booleans(), seed=st.integers(0, 1 << 16))
