@@ -411,14 +411,21 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MAUA_DIST_BACKEND=gloo (debug): run the N > 1 code path with several ranks SHARING one GPU — RCCL wants one GPU per rank, gloo moves
+    # device tensors for the collectives this path uses; the rate measured that way is meaningless, the code path is the real one
+    backend = os.environ.get("MAUA_DIST_BACKEND", "nccl")
+    device_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torch.distributed.run
     if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     torch.set_grad_enabled(False)
 
     from maua_stylegan2_amd import _lib, seeding
