@@ -198,6 +198,7 @@ def crop_resize_for_delivery(u8, out_size, scratch):
 
 _LANE_STREAMS = {}
 _PINNED_RING = {}  # device index -> pinned staging slots of the single-GPU render loop (reallocated when the frame shape changes)
+_DEVICE_RING = {}  # device index -> their device-side twins (a batch leaves its lane's frame buffer before it crosses PCIe)
 
 
 def _lane_stream(dev, k):
@@ -420,6 +421,7 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
             n_lanes, n_slots = 3, 6
             copy_stream = th.cuda.Stream(dev)
             pinned = _PINNED_RING.setdefault(dev.index, [None] * n_slots)  # kept across renders: pinning 6 x 25 MB is ~40 ms
+            staged = _DEVICE_RING.setdefault(dev.index, [None] * n_slots)
             free = queue.Queue()
             for i in range(n_slots):
                 free.put(i)
@@ -428,18 +430,25 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
                                         randomize_noise, lanes=n_lanes):
                 u8 = crop_resize_for_delivery(u8, out_size, resized)  # 2048-px frames leave the device as 1920x1080 already
                 slot = free.get()
-                if pinned[slot] is None or pinned[slot].shape != u8.shape:
-                    pinned[slot] = th.empty(u8.shape, dtype=th.uint8).pin_memory()
+                count = u8.shape[0]
+                # slots hold a FULL batch; the tail batch of a render uses a prefix (re-pinning per shape cost 2 x 6.5 ms per render)
+                if pinned[slot] is None or pinned[slot].shape[1:] != u8.shape[1:] or pinned[slot].shape[0] < max(count, batch_size):
+                    shape = (max(count, batch_size),) + tuple(u8.shape[1:])
+                    pinned[slot] = th.empty(shape, dtype=th.uint8).pin_memory()
+                    staged[slot] = th.empty(shape, dtype=th.uint8, device=dev)
+                host, held = pinned[slot][:count], staged[slot][:count]
+                # the lane's frame buffer is overwritten by its next replay: the batch moves to a device-side slot on the lane's own
+                # stream (25 MB inside HBM: ~20 us) and crosses PCIe from there, so that no lane ever waits for a host copy
+                # (waiting for it — 0.5 ms per batch on the lane — cost the render loop the whole gain of the three lanes)
+                held.copy_(u8, non_blocking=True)
                 produced = th.cuda.Event()
                 produced.record(th.cuda.current_stream(dev))
                 with th.cuda.stream(copy_stream):
                     copy_stream.wait_event(produced)
-                    pinned[slot].copy_(u8, non_blocking=True)
+                    host.copy_(held, non_blocking=True)
                     copied = th.cuda.Event()
                     copied.record(copy_stream)
-                # the producer must not overwrite u8 before the copy has read it
-                th.cuda.current_stream(dev).wait_event(copied)
-                worker.submit(copied.synchronize, pinned[slot].numpy(), u8.shape[0], lambda s=slot: free.put(s))
+                worker.submit(copied.synchronize, host.numpy(), count, lambda s=slot: free.put(s))
         elif transport == "host":
             # every rank copies its rounds to a pinned shared-memory segment over its own PCIe link; rank 0's sink thread reads the
             # segments in global order (sharding.HostFrameStore) — no xGMI traffic, no funnel through rank 0's link
