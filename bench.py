@@ -700,9 +700,10 @@ def main():
             ach = byts / ms / 1e6
             # HBM bytes per launch from the newest PMC passes (FETCH_SIZE x2 correction, WRITE_SIZE exact), scaled to this launch's planes
             table, table_path = pmc_traffic_table()
-            fir_name = "fir_tile_kernel<4, 4, 4, false>"
+            fir_name = "fir_tile_kernel<4, 4, 4, false, 24>"
             kernels = (table or {}).get("kernels", {})
-            rec = kernels.get(fir_name) or kernels.get("fir_strip_kernel<4, 4, 4>")  # (rounds 1-3: the plain op was a kernel of its own)
+            # (older tables: the instance had no strip-height argument; rounds 1-3: the plain op was a kernel of its own)
+            rec = kernels.get(fir_name) or kernels.get("fir_tile_kernel<4, 4, 4, false>") or kernels.get("fir_strip_kernel<4, 4, 4>")
             traffic = None
             if rec is not None and table.get("size") == size and rec.get("planes"):
                 traffic = (rec["read_bytes"] + rec["write_bytes"]) * major / rec["planes"]  # scaled to this launch's planes

@@ -36,7 +36,12 @@ struct FirTail {
 
 // output rows per wave: 32 with the fused tail; 24 for the plain op (27 KB of LDS: five workgroups per CU instead of four — measured
 // 5.51 vs 5.33 TB/s on [8,32,1025,1025], 16 rows 5.46; with the tail 24 and 16 measure the same as 32)
-__host__ __device__ constexpr int fir_tile_rows(bool tail) { return tail ? 32 : 24; }
+// Output rows per wave strip (TH).  Plain: 24.  With the tail 32 on the 1024-row maps and 16 below: a 16-row strip needs 57 registers
+// instead of 106 (19 staged rows + 16 noise values in flight instead of 35 + 32), the launches of the 8^2..512^2 layers measure
+// 0.027 -> 0.017 ms (8^2..64^2), 0.057 -> 0.054 (128^2), 0.152 -> 0.150 (256^2), ~0.23 (512^2: unchanged); the 1024^2 launch is 7 % slower with
+// it (0.427 -> 0.457: more halo rows per output row) and keeps 32.
+constexpr int FIR_ROWS_PLAIN = 24, FIR_ROWS_TAIL = 32, FIR_ROWS_TAIL_SMALL = 16;
+constexpr int FIR_TAIL_SMALL_MAX_H = 512;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAUA_DEVICE_PASS 1
@@ -51,13 +56,12 @@ constexpr unsigned FIR_OOB = 0x80000000u;  // a voffset beyond every descriptor 
 // per access, a zero-initialising move per staged value): 4 waves per SIMD x 4 cycles made the VALU 70-80 % busy at the rates
 // they reached, i.e. they were as much issue-bound as HBM-bound.  Here out-of-range columns are an out-of-range voffset (the
 // descriptor returns 0 / drops the store), out-of-range rows a scalar branch.
-template <int KH, int KW, int WX, bool TAIL>
+template <int KH, int KW, int WX, bool TAIL, int TH>
 __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                        float* __restrict__ y, int planes, int in_h, int in_w,
                                                        int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
                                                        int tiles_y, FirTail tail) {
     constexpr int WY = 4 / WX;
-    constexpr int TH = fir_tile_rows(TAIL);
     constexpr int TW = 64 * WX;
     constexpr int RH = WY * TH + KH - 1;  // staged rows
     constexpr int RW = TW + KW - 1;       // staged cols
@@ -311,25 +315,30 @@ int launch_fir_typed(const void* x, const void* k, void* y, int major, int in_h,
 template <int KH, int KW, bool TAIL>
 int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
                     int pad_x0, int pad_y0, const FirTail& tail, hipStream_t st) {
-    auto go = [&](auto wx_tag) -> int {
-        constexpr int WX = decltype(wx_tag)::value;
+    auto go = [&](auto wx_tag, auto th_tag) -> int {
+        constexpr int WX = decltype(wx_tag)::value, TH = decltype(th_tag)::value;
         constexpr int WY = 4 / WX;
-        constexpr int RH = WY * fir_tile_rows(TAIL) + KH - 1, RW = 64 * WX + KW - 1;
-        const int tiles_x = ceil_div(out_w, 64 * WX), tiles_y = ceil_div(out_h, WY * fir_tile_rows(TAIL));
+        constexpr int RH = WY * TH + KH - 1, RW = 64 * WX + KW - 1;
+        const int tiles_x = ceil_div(out_w, 64 * WX), tiles_y = ceil_div(out_h, WY * TH);
         const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
         if (nblocks <= 0) return 0;
         if (nblocks > 0x7fffffff) return MAUA_EINVAL;
         const size_t lds_bytes = (size_t)RH * RW * sizeof(float);
-        hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y, planes,
+        hipLaunchKernelGGL((fir_tile_kernel<KH, KW, WX, TAIL, TH>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y, planes,
                            in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, tail);
         MAUA_LAUNCH_CHECK();
         return 0;
     };
+    auto go_wx = [&](auto wx_tag) -> int {
+        if (!TAIL) return go(wx_tag, std::integral_constant<int, FIR_ROWS_PLAIN>{});
+        if (out_h <= FIR_TAIL_SMALL_MAX_H) return go(wx_tag, std::integral_constant<int, FIR_ROWS_TAIL_SMALL>{});
+        return go(wx_tag, std::integral_constant<int, FIR_ROWS_TAIL>{});
+    };
     // (the kernel addresses a plane through 32-bit buffer offsets)
     if ((int64_t)in_h * in_w * 4 >= 0x7fffffffLL || (int64_t)out_h * out_w * 4 >= 0x7fffffffLL) return MAUA_ENOSYS;
-    if (out_w <= 64) return go(std::integral_constant<int, 1>{});
-    if (out_w <= 128) return go(std::integral_constant<int, 2>{});
-    return go(std::integral_constant<int, 4>{});
+    if (out_w <= 64) return go_wx(std::integral_constant<int, 1>{});
+    if (out_w <= 128) return go_wx(std::integral_constant<int, 2>{});
+    return go_wx(std::integral_constant<int, 4>{});
 }
 
 template <bool TAIL>

@@ -150,7 +150,7 @@ duration; "non-MFMA VALU per MFMA" = (SQ_INSTS_VALU - MOPS / 4) / (MOPS / 4).
             continue
         rec = {"read_bytes": 2.0 * t["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0, "dispatches": t["n"],
                "avg_us": t["us"], "dispatches_per_step": t["n"] / steps_in_run if t["n"] % steps_in_run == 0 else None}
-        if n.startswith("fir_strip_kernel") or n == "fir_tile_kernel<4, 4, 4, false>":  # (the plain op: only bench.py's standalone leg launches it)
+        if n.startswith("fir_strip_kernel") or n in ("fir_tile_kernel<4, 4, 4, false>", "fir_tile_kernel<4, 4, 4, false, 24>"):  # (the plain op: only bench.py's standalone leg launches it)
             rec["planes"] = 256  # bench.py's standalone upfirdn2d leg: [8, 32, 1025, 1025]
         kernels[n] = rec
     bench = last_json(f"{O}/bench_default.json")
