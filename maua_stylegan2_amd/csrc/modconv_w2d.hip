@@ -700,6 +700,384 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(rgb_img + (size_t)c * rgb_plane + pix_off) = outc[c];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 32-output-channel workgroups in which every wave keeps ALL 24 frequencies of its own 16 positions (modconv_w2dw_kernel).
+//
+// The y-frequency split above buys its small accumulator footprint with an epilogue in which the four waves' partial rows meet in
+// LDS (two barriers and an exchange pass per 16 channels) and every thread then handles 4 pixels of 16 / CG channels: on the 32-channel
+// layers (8 K steps) that epilogue costs as many VALU issue cycles as the whole K loop costs matrix cycles, and fp32 VALU and fp32
+// matrix instructions share the datapath (MFMA-busy 45 %).  Here a workgroup is 32 channels x 4 n-tiles (16 rows x 32 pixels) and WAVE w
+// OWNS n-tile w: 4 x 6 frequencies x 2 m-tiles = 48 accumulator tiles (192 registers, two workgroups per CU).  Per K step a wave forms
+// all four row combinations of its window itself (64 VALU for 48 MFMAs: the same 1.33 per MFMA as the split kernel's 16 for 12) and reads
+// the whole 12 KB weight tile; the window rows are fetched lazily into two register slots (rows 0, 2 -> f0; row 1 -> f1, f2; row 3 ->
+// f3), each fetch hidden behind the previous frequency's 12 MFMAs.  The epilogue runs entirely in registers: A_x^T and A_y^T per lane,
+// tail, the ToRGB products of the lane's 8 channels, a two-step butterfly over the four K lane groups, then bias / up-sampled skip /
+// uint8 frames by the lanes of groups 0 and 1 (one output row of the position each) — no barrier after the K loop.  Same packed weight
+// (TM = 2 layout), same staged patch and DMA scheme as modconv_w2d_kernel<2, 4>.
+constexpr int WW_TN = 4, WW_BM = 32;
+constexpr int WW_A_FLOATS = 24 * W2D_CC * WW_BM;
+
+template <bool PLUS>
+__device__ __forceinline__ void ww_transform(const f32x2 (&a)[4], const f32x2 (&b)[4], float sc, float m5, float (&bv)[6]) {
+    // D = a +- b (the F(2,3) row combination), then B_x^T of F(4,3) on register pairs exactly as in modconv_w2d_kernel
+    f32x2 D12, D34, ba, ec, b12, b34;
+    float d0, d5, t0, t5, u0, u5;
+    const f32x2 sc2 = f32x2{sc, sc};
+    if constexpr (PLUS) {
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(D12) : "v"(a[1]), "v"(b[1]));
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(D34) : "v"(a[2]), "v"(b[2]));
+        d0 = a[0].y + b[0].y, d5 = a[3].x + b[3].x;
+    } else {
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(D12) : "v"(a[1]), "v"(b[1]));
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(D34) : "v"(a[2]), "v"(b[2]));
+        d0 = a[0].y - b[0].y, d5 = a[3].x - b[3].x;
+    }
+    asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(ba) : "v"(D12), "v"(D34));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ec) : "v"(D34), "v"(D12));
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(b12) : "v"(ba));
+    asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(b34) : "v"(ec));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(m5), "v"(D12.y), "v"(D34.y));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t5) : "v"(m5), "v"(D34.x), "v"(d5));
+    asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u0) : "v"(d0), "v"(t0));
+    asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u5) : "v"(D12.x), "v"(t5));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b12) : "v"(b12), "v"(sc2));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b34) : "v"(b34), "v"(sc2));
+    bv[0] = u0 * sc, bv[5] = u5 * sc;
+    bv[1] = b12.x, bv[2] = b12.y, bv[3] = b34.x, bv[4] = b34.y;
+}
+
+__global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
+    constexpr int dbg = MAUA_W2D_ABL;  // (ablation masks as in modconv_w2d_kernel: 1 no MFMA, 2 no DMA after the first chunk, 8 no epilogue)
+    constexpr int TN = WW_TN, BM = WW_BM;
+    constexpr int TH = 4 * TN, PH = TH + 2;
+    constexpr int PSTRIDE = w2d_pstride(TN);
+    constexpr int NQ = w2d_dma_per_channel(TN);
+    constexpr int A_FLOATS = WW_A_FLOATS;
+    constexpr int A_PER_WAVE = A_FLOATS / 256 / 4;
+    constexpr int PBUF = w2d_pbuf(TN);
+    static_assert(NQ == 4 && A_FLOATS % 1024 == 0, "one patch row group and whole weight pieces per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    float* lds = lds_all;
+    float* Ps = lds + 2 * A_FLOATS;       // [2][PBUF]
+    float* Ss = Ps + 2 * PBUF;            // [Cin] styles of this image
+    float* E = Ss + ((p.Cin + 3) & ~3);   // [BM][8] epilogue constants
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's n-tile
+    const int j = lane & 15, kq = lane >> 4;
+    const int jx = j & 7, jy = j >> 3;
+
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt_id = t % p.m_tiles;
+    t /= p.m_tiles;
+    const int tile_x = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tile_y = t % p.tiles_y;
+    const int b0 = t / p.tiles_y;
+    const int ty0 = tile_y * TH, tx0 = tile_x * 32;
+    const int m0 = mt_id * BM;
+    const size_t plane = (size_t)p.H * p.W;
+
+    // patch DMA of this lane: wave w issues row group w of every channel (see modconv_w2d_kernel)
+    unsigned rel_bytes;
+    {
+        const int pr = W2D_ROWS_PER_DMA * wv + lane / 12, sg = lane % 12;
+        const int yy = ty0 + pr - 1, xx = tx0 - 4 + 4 * sg;
+        const bool ok = sg < W2D_SEGS && pr < PH && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        rel_bytes = ok ? (unsigned)(yy * p.W + xx) * 4u : 0x80000000u;
+    }
+    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
+    const size_t plane_bytes = plane * sizeof(float);
+    (void)ximg, (void)plane_bytes, (void)rel_bytes;
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wq), 0, 0x7fffffff, 0x00020000);
+#endif
+    auto issue = [&](int chunk, int buf) {
+#ifdef MAUA_DEVICE_PASS
+        const int wbase = (int)(((size_t)mt_id * p.n_chunks + chunk) * A_FLOATS * sizeof(float));
+#pragma unroll
+        for (int k = 0; k < A_PER_WAVE; ++k) {
+            const int i = wv + 4 * k;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(lds + buf * A_FLOATS + i * 256), 16,
+                                                     (i * 256 + lane * 4) * 4, wbase, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < W2D_CC; ++c) {
+            float* dst = Ps + buf * PBUF + c * PSTRIDE + (c & 1) * W2D_ODD_SHIFT + wv * (W2D_ROWS_PER_DMA * W2D_PWS);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)rel_bytes,
+                                                     (int)((size_t)(chunk * W2D_CC + c) * plane_bytes), 0, 0);
+        }
+#else
+        (void)chunk, (void)buf;
+#endif
+    };
+
+    const bool act = p.fuse_act != 0;
+    const float act_gain = act ? 1.41421356237309515f : 1.f;
+    const float* noise_base = p.noise;
+    int64_t noise_bstride = p.noise_batch_stride;
+    if (p.src) {
+        noise_bstride = p.src->noise_stride[p.noise_slot];
+        noise_base = p.src->noise[p.noise_slot];
+        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
+    }
+    const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
+    for (int i = tid; i < BM; i += 256) {
+        const int o = m0 + i;
+        float gain = p.wscale * act_gain;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
+        f32x4 e = f32x4{gain, (act && p.bias) ? p.bias[o] * act_gain : 0.f, 0.f, 0.f};
+        float r2 = 0.f;
+        if (p.rgb) {
+            const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
+            e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
+        }
+        *reinterpret_cast<f32x4*>(E + 8 * i) = e;
+        E[8 * i + 4] = r2;
+    }
+
+    f32x4 acc[4][6][2];  // [y-frequency][x-frequency][m-tile]; the first K step runs with C = 0
+    float m5 = -5.f;
+    asm("" : "+v"(m5));
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    // window of position (2 wv + jy, jx), channel kq: patch rows 2 (2 wv + jy) .. + 3, read as aligned 8-byte pairs from row float 4 jx + 2
+    const unsigned w_addr = lds0 + (unsigned)(2 * A_FLOATS + kq * PSTRIDE + (kq & 1) * W2D_ODD_SHIFT + (2 * (2 * wv + jy)) * W2D_PWS + 4 * jx + 2) * 4u;
+    const unsigned a_addr = lds0 + (unsigned)(kq * BM + 2 * j) * 4u;  // weight rows: ((fy * 6 + xf) * 4 + kq) * BM + (i16 * 2 + m-tile)
+    unsigned s_addr = lds0 + (unsigned)(2 * A_FLOATS + 2 * PBUF + kq) * 4u;
+    constexpr unsigned A_BUF_BYTES = A_FLOATS * 4u, P_BUF_BYTES = PBUF * 4u;
+    constexpr int XF_BYTES = W2D_CC * BM * 4;
+    constexpr int ROW_BYTES = W2D_PWS * 4;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase)
+    for (int chunk = phase; chunk < (phase ? p.n_chunks : 1); ++chunk) {
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+        const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u), pw = w_addr + (cur ? P_BUF_BYTES : 0u);
+        float sc = lds_read32(s_addr);
+        s_addr += W2D_CC * 4u;
+        f32x2 SA[4], SB[4], a2[2];
+        float bv[6];
+        auto read_row = [&](f32x2(&dst)[4], auto r_c) {
+            constexpr int o = decltype(r_c)::value * ROW_BYTES;
+            dst[0] = lds_read64<o>(pw), dst[1] = lds_read64<o + 8>(pw), dst[2] = lds_read64<o + 16>(pw), dst[3] = lds_read64<o + 24>(pw);
+        };
+        // the 12 matrix instructions of y-frequency f; the weight row of the next (f, xf) is read one step ahead.  FIRST_BEHIND: LDS
+        // operations issued behind this block's first weight row before its wait (4 when a window row went out in between)
+        auto block = [&](auto f_c, auto first_c) {
+            constexpr int f = decltype(f_c)::value, first_behind = decltype(first_c)::value;
+            static_for<0, 6>([&](auto xf_c) {
+                constexpr int xf = decltype(xf_c)::value, idx = f * 6 + xf;
+                if constexpr (idx + 1 < 24) a2[(idx + 1) & 1] = lds_read64<(idx + 1) * XF_BYTES>(ap);
+                constexpr int behind = (idx + 1 < 24 ? 1 : 0) + (xf == 0 ? first_behind : 0);
+                lds_wait<behind>(a2[idx & 1]);
+                if constexpr ((dbg & 1) != 0) {
+                    if (!phase) acc[f][xf][0] = acc[f][xf][1] = zero4;
+                    asm volatile("" : "+v"(acc[f][xf][0]), "+v"(acc[f][xf][1]) : "v"(a2[idx & 1]), "v"(bv[xf]));
+                } else {
+                    acc[f][xf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[idx & 1].x, bv[xf], phase ? acc[f][xf][0] : zero4, 0, 0, 0);
+                    acc[f][xf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[idx & 1].y, bv[xf], phase ? acc[f][xf][1] : zero4, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>;
+        read_row(SA, I0{});
+        read_row(SB, I2{});
+        a2[0] = lds_read64<0>(ap);
+        asm volatile("s_waitcnt lgkmcnt(1)"
+                     : "+v"(sc), "+v"(SA[0]), "+v"(SA[1]), "+v"(SA[2]), "+v"(SA[3]), "+v"(SB[0]), "+v"(SB[1]), "+v"(SB[2]), "+v"(SB[3]));
+        ww_transform<false>(SA, SB, sc, m5, bv);  // f0: d0 - d2
+        __builtin_amdgcn_sched_barrier(0);
+        read_row(SA, I1{});                        // (row 0 is dead)
+        block(I0{}, I4{});
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(SA[0]), "+v"(SA[1]), "+v"(SA[2]), "+v"(SA[3]));
+        ww_transform<true>(SA, SB, sc, m5, bv);   // f1: d1 + d2
+        __builtin_amdgcn_sched_barrier(0);
+        block(I1{}, I0{});
+        ww_transform<false>(SB, SA, sc, m5, bv);  // f2: d2 - d1
+        __builtin_amdgcn_sched_barrier(0);
+        read_row(SB, I3{});                        // (row 2 is dead)
+        block(I2{}, I4{});
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(SB[0]), "+v"(SB[1]), "+v"(SB[2]), "+v"(SB[3]));
+        ww_transform<false>(SA, SB, sc, m5, bv);  // f3: d1 - d3
+        __builtin_amdgcn_sched_barrier(0);
+        block(I3{}, I0{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (dbg & 8) {
+        if (p.B < 0) {  // never true: keeps the accumulators alive in builds without the epilogue
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) sum += acc[f][a][0] + acc[f][a][1];
+            *reinterpret_cast<f32x4*>(p.y + tid * 4) = sum;
+        }
+        return;
+    }
+    // ---- epilogue, in registers.  This lane: position (2 wv + jy, jx) = output rows oy0, oy0 + 1, columns ox .. ox + 3; channels
+    // 16 m + 4 kq + v of the workgroup's 32
+    const int oy0 = ty0 + 2 * (2 * wv + jy), ox = tx0 + 4 * jx;
+    const unsigned pix0 = (unsigned)oy0 * (unsigned)p.W + (unsigned)ox;
+    f32x4 nzw[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (nw != 0.f) {
+        const float* nb = noise_base + (size_t)b0 * noise_bstride + pix0;
+        nzw[0] = *reinterpret_cast<const f32x4*>(nb) * nw;
+        nzw[1] = *reinterpret_cast<const f32x4*>(nb + p.W) * nw;
+    }
+    const float slope = act ? 0.2f : 1.f;
+    const bool store_feat = p.rgb != 2;
+    const unsigned plane_b = (unsigned)plane * 4u;
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.y + ((size_t)b0 * p.Cout + m0) * plane, 0, 0x7fffffff, 0x00020000);
+#endif
+    const unsigned y_voff = pix0 * 4u + (unsigned)(4 * kq) * plane_b;
+    (void)y_voff;
+    const float* Elane = E + 8 * (4 * kq);
+    f32x4 rgbacc[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgbacc[c][0] = rgbacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // 2x FIR-upsampled skip image (see modconv_w2d_kernel): fetched by the lanes that finish the pixels (K lane groups 0 and 1: output
+    // row oy0 + kq), once the first m-tile's accumulators are dead
+    const int cr = kq & 1;
+    const int oy = oy0 + cr;
+    const int sh = p.H >> 1, sw = p.W >> 1;
+    const bool finisher = kq < 2;
+    const bool want_skip = (p.rgb == 1 || p.rgb == 2) && p.rgb_skip && finisher;
+    float sv[3][2][4], wy[2], wx[4];
+    auto load_skip = [&]() {
+        const float* skip_img = p.rgb_skip + (size_t)b0 * 3 * sh * sw;
+        const int iy0 = (oy - 1) >> 1;
+        int rowc[2], colc[4];
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy) {
+            const int yy = iy0 + qy;
+            wy[qy] = (yy >= 0 && yy < sh) ? 1.f : 0.f;
+            rowc[qy] = min(max(yy, 0), sh - 1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = (ox >> 1) - 1 + k;
+            wx[k] = (xx >= 0 && xx < sw) ? 1.f : 0.f;
+            colc[k] = min(max(xx, 0), sw - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[c][qy][k] = skip_img[(unsigned)((c * sh + rowc[qy]) * sw + colc[k])];
+    };
+
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m == 1 && want_skip) load_skip();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            f32x4 Z[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float m0_ = acc[f][0][m][v], m1_ = acc[f][1][m][v], m2_ = acc[f][2][m][v];
+                const float m3_ = acc[f][3][m][v], m4_ = acc[f][4][m][v], m5_ = acc[f][5][m][v];
+                const float s12 = m1_ + m2_, d12 = m1_ - m2_, s34 = m3_ + m4_, d34 = m3_ - m4_;
+                Z[f] = f32x4{(m0_ + s12) + s34, fmaf(2.f, d34, d12), fmaf(4.f, s34, s12), fmaf(8.f, d34, d12) + m5_};
+            }
+            // A_y^T of F(2,3): row 0 = Z0 + Z1 + Z2, row 1 = Z1 - Z2 - Z3
+            const f32x4 raw0 = (Z[0] + Z[2]) + Z[1], raw1 = Z[1] - (Z[2] + Z[3]);
+            const int ol = 16 * m + v;  // + 4 kq through Elane / y_voff
+            const f32x4 e = *reinterpret_cast<const f32x4*>(Elane + 8 * ol);
+            const float r2 = Elane[8 * ol + 4];
+            const f32x4 t0 = raw0 * e[0] + (nzw[0] + e[1]), t1 = raw1 * e[0] + (nzw[1] + e[1]);
+            const f32x4 v0 = __builtin_elementwise_max(t0, t0 * slope), v1 = __builtin_elementwise_max(t1, t1 * slope);
+            if (p.rgb) {
+                rgbacc[0][0] = v0 * e[2] + rgbacc[0][0], rgbacc[0][1] = v1 * e[2] + rgbacc[0][1];
+                rgbacc[1][0] = v0 * e[3] + rgbacc[1][0], rgbacc[1][1] = v1 * e[3] + rgbacc[1][1];
+                rgbacc[2][0] = v0 * r2 + rgbacc[2][0], rgbacc[2][1] = v1 * r2 + rgbacc[2][1];
+            }
+#ifdef MAUA_DEVICE_PASS
+            if (store_feat) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), y_rsrc, y_voff, (unsigned)ol * plane_b, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), y_rsrc, y_voff + (unsigned)p.W * 4u, (unsigned)ol * plane_b, 0);
+            }
+#endif
+        }
+    }
+    if (!p.rgb) return;
+    // ---- fused ToRGB: lanes j, j + 16, j + 32, j + 48 hold disjoint channels of one position.  Step 1 (xor 32) sums both rows of the
+    // pairs (kq, kq ^ 2); step 2 (xor 16) is a reduce-scatter: a lane keeps the row it will finish (row kq & 1) and sends the other
+    f32x4 outc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float a = rgbacc[c][0][px], b = rgbacc[c][1][px];
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            const float mine = cr ? b : a, other = cr ? a : b;
+            outc[c][px] = mine + __shfl_xor(other, 16) + p.rgb_bias[c];
+        }
+    if (!finisher) return;
+    const unsigned pix_off = pix0 + (unsigned)cr * (unsigned)p.W;
+    const size_t rgb_plane = plane;
+    if (p.rgb_skip) {
+        const int ty_ = (oy & 1) ? 2 : 3;
+        float kt[2][4];
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) kt[qy][t4] = p.rgb_k4[(ty_ - 2 * qy) * 4 + t4] * wy[qy];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const int k0 = (px + 1) >> 1;
+            const int t0 = (px & 1) ? 2 : 3;
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy) {
+                const float w0 = kt[qy][t0] * wx[k0], w1 = kt[qy][t0 - 2] * wx[k0 + 1];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) outc[c][px] = fmaf(w0, sv[c][qy][k0], fmaf(w1, sv[c][qy][k0 + 1], outc[c][px]));
+            }
+        }
+    }
+    if (p.rgb_u8) {
+        uint32_t pix[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            pix[px] = 0u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pix[px] |= (uint32_t)((fminf(fmaxf(outc[c][px], -1.f), 1.f) + 1.f) * 127.5f) << (8 * c);
+        }
+        uint32_t* fw = reinterpret_cast<uint32_t*>(p.rgb_u8 + ((size_t)b0 * rgb_plane + pix_off) * 3);
+        fw[0] = pix[0] | (pix[1] << 24);
+        fw[1] = (pix[1] >> 8) | (pix[2] << 16);
+        fw[2] = (pix[2] >> 16) | (pix[3] << 8);
+        if (!p.rgb_out) return;
+    }
+    float* rgb_img = p.rgb_out + (size_t)b0 * 3 * rgb_plane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4*>(rgb_img + (size_t)c * rgb_plane + pix_off) = outc[c];
+}
+
+size_t w2dw_lds_bytes(int cin) {
+    return sizeof(float) * ((size_t)2 * WW_A_FLOATS + (size_t)2 * w2d_pbuf(WW_TN) + (size_t)((cin + 3) & ~3) + (size_t)8 * WW_BM);
+}
+
 // wq (the LDS tile image): [m_tile][chunk][fy 4][xf 6][kq 4][BM physical column]
 __global__ __launch_bounds__(256) void pack_weight_wino2d_kernel(const float* __restrict__ w, float* __restrict__ wq, int cout,
                                                                  int cin, int tm) {
@@ -767,6 +1145,18 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
     return 0;
 }
 
+int w2dw_launch(const W2dArgs& a, hipStream_t st) {
+    static int attr_rc = -1;
+    if (attr_rc < 0)
+        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_w2dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc) return attr_rc;
+    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2dw_kernel");
+    const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
+    hipLaunchKernelGGL(modconv_w2dw_kernel, dim3((unsigned)blocks), dim3(256), w2dw_lds_bytes(a.Cin), st, a);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 // Tile shape for a layer: TM (16-channel m-tiles per workgroup) and TN (16-position n-tiles); 0 = the layer does not qualify.
@@ -807,6 +1197,12 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
     } else if (rgb_mode && (a.m_tiles != 1 || !fuse_act || !rgb_w || !rgb_s || !rgb_bias || (!rgb_out && !rgb_u8) || (rgb_skip && (!rgb_k4 || (h & 1) || (w & 1)))))
         return MAUA_ENOSYS;
     hipStream_t st = (hipStream_t)stream;
+#ifndef MAUA_W2D_NO_WW
+    if (tm == 2 && h % (4 * WW_TN) == 0 && rgb_mode != 3) {  // 32 output channels: the wave-complete kernel (16-row tiles)
+        a.tiles_y = h / (4 * WW_TN);
+        return w2dw_launch(a, st);
+    }
+#endif
     return tm == 4 ? w2d_launch_t<4, 2>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32>(a, st);
 }
 
