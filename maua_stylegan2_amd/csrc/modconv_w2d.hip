@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     float* lds = lds_all;
     float* Ps = lds + 2 * A_FLOATS;       // [2][PBUF]
     float* Ss = Ps + 2 * PBUF;            // [Cin] styles of this image
-    float* E = Ss + ((p.Cin + 3) & ~3);   // [BM][8] epilogue constants
+    float* E = Ss + ((p.Cin + 3) & ~3);   // [BM / 2][12] epilogue constants of channel pairs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -835,8 +835,9 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
             const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
             e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
         }
-        *reinterpret_cast<f32x4*>(E + 8 * i) = e;
-        E[8 * i + 4] = r2;
+        // channel PAIRS side by side (the epilogue works on register pairs): [pair][gain x2 | bias x2 | rgb0 x2 | rgb1 x2 | rgb2 x2 | pad x2]
+        float* ep = E + 12 * (i >> 1) + (i & 1);
+        ep[0] = e[0], ep[2] = e[1], ep[4] = e[2], ep[6] = e[3], ep[8] = r2;
     }
 
     f32x4 acc[4][6][2];  // [y-frequency][x-frequency][m-tile]; the first K step runs with C = 0
@@ -949,10 +950,15 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
 #endif
     const unsigned y_voff = pix0 * 4u + (unsigned)(4 * kq) * plane_b;
     (void)y_voff;
-    const float* Elane = E + 8 * (4 * kq);
-    f32x4 rgbacc[3][2];
+    const float* Elane = E + 12 * (2 * kq);
+    // The arithmetic runs on CHANNEL PAIRS (v = 2 vp, 2 vp + 1 of an accumulator tile are neighbouring registers): v_pk_* instructions do
+    // two channels per issue slot.  ToRGB partial sums per pair member; the members are added before the butterfly.
+    f32x2 nzp[2][4];  // noise * weight of this lane's 2 x 4 pixels, duplicated into pairs
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rgbacc[c][0] = rgbacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) nzp[r][px] = f32x2{nzw[r][px], nzw[r][px]};
+    f32x2 rgb2[3][2][4];  // [colour][row][pixel], first written by the first channel pair
 
     // 2x FIR-upsampled skip image (see modconv_w2d_kernel): fetched by the lanes that finish the pixels (K lane groups 0 and 1: output
     // row oy0 + kq), once the first m-tile's accumulators are dead
@@ -986,35 +992,68 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
                 for (int k = 0; k < 4; ++k) sv[c][qy][k] = skip_img[(unsigned)((c * sh + rowc[qy]) * sw + colc[k])];
     };
 
+    const f32x2 slope2 = f32x2{slope, slope};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         if (m == 1 && want_skip) load_skip();
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            f32x4 Z[4];
+        for (int vp = 0; vp < 2; ++vp) {
+            auto pair_of = [&](const f32x4& a) { return vp ? f32x2{a[2], a[3]} : f32x2{a[0], a[1]}; };
+            // A_x^T per y-frequency (y0 = m0+m1+m2+m3+m4, y1 = (m1-m2) + 2(m3-m4), y2 = (m1+m2) + 4(m3+m4), y3 = (m1-m2) + 8(m3-m4) + m5)
+            // accumulated straight into A_y^T of F(2,3): row 0 = Z0 + Z1 + Z2, row 1 = Z1 - Z2 - Z3
+            f32x2 raw0[4], raw1[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                const float m0_ = acc[f][0][m][v], m1_ = acc[f][1][m][v], m2_ = acc[f][2][m][v];
-                const float m3_ = acc[f][3][m][v], m4_ = acc[f][4][m][v], m5_ = acc[f][5][m][v];
-                const float s12 = m1_ + m2_, d12 = m1_ - m2_, s34 = m3_ + m4_, d34 = m3_ - m4_;
-                Z[f] = f32x4{(m0_ + s12) + s34, fmaf(2.f, d34, d12), fmaf(4.f, s34, s12), fmaf(8.f, d34, d12) + m5_};
+                const f32x2 M0 = pair_of(acc[f][0][m]), M1 = pair_of(acc[f][1][m]), M2 = pair_of(acc[f][2][m]);
+                const f32x2 M3 = pair_of(acc[f][3][m]), M4 = pair_of(acc[f][4][m]), M5 = pair_of(acc[f][5][m]);
+                const f32x2 s12 = M1 + M2, d12 = M1 - M2, s34 = M3 + M4, d34 = M3 - M4;
+                const f32x2 Zf[4] = {(M0 + s12) + s34, d34 * 2.f + d12, s34 * 4.f + s12, (d34 * 8.f + d12) + M5};
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    if (f == 0) raw0[px] = Zf[px];
+                    if (f == 1) raw0[px] += Zf[px], raw1[px] = Zf[px];
+                    if (f == 2) raw0[px] += Zf[px], raw1[px] -= Zf[px];
+                    if (f == 3) raw1[px] -= Zf[px];
+                }
             }
-            // A_y^T of F(2,3): row 0 = Z0 + Z1 + Z2, row 1 = Z1 - Z2 - Z3
-            const f32x4 raw0 = (Z[0] + Z[2]) + Z[1], raw1 = Z[1] - (Z[2] + Z[3]);
-            const int ol = 16 * m + v;  // + 4 kq through Elane / y_voff
-            const f32x4 e = *reinterpret_cast<const f32x4*>(Elane + 8 * ol);
-            const float r2 = Elane[8 * ol + 4];
-            const f32x4 t0 = raw0 * e[0] + (nzw[0] + e[1]), t1 = raw1 * e[0] + (nzw[1] + e[1]);
-            const f32x4 v0 = __builtin_elementwise_max(t0, t0 * slope), v1 = __builtin_elementwise_max(t1, t1 * slope);
+            const float* ep = Elane + 12 * (8 * m + vp);
+            const f32x4 gb = *reinterpret_cast<const f32x4*>(ep), r01 = *reinterpret_cast<const f32x4*>(ep + 4);
+            const f32x2 r2p = *reinterpret_cast<const f32x2*>(ep + 8);
+            const f32x2 gain2 = f32x2{gb[0], gb[1]}, bias2 = f32x2{gb[2], gb[3]};
+            const f32x2 w0 = f32x2{r01[0], r01[1]}, w1 = f32x2{r01[2], r01[3]};
+            f32x2 val[2][4];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const f32x2 t0 = raw0[px] * gain2 + (nzp[0][px] + bias2), t1 = raw1[px] * gain2 + (nzp[1][px] + bias2);
+                val[0][px] = __builtin_elementwise_max(t0, t0 * slope2);
+                val[1][px] = __builtin_elementwise_max(t1, t1 * slope2);
+            }
             if (p.rgb) {
-                rgbacc[0][0] = v0 * e[2] + rgbacc[0][0], rgbacc[0][1] = v1 * e[2] + rgbacc[0][1];
-                rgbacc[1][0] = v0 * e[3] + rgbacc[1][0], rgbacc[1][1] = v1 * e[3] + rgbacc[1][1];
-                rgbacc[2][0] = v0 * r2 + rgbacc[2][0], rgbacc[2][1] = v1 * r2 + rgbacc[2][1];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        if (m == 0 && vp == 0) {
+                            rgb2[0][r][px] = val[r][px] * w0, rgb2[1][r][px] = val[r][px] * w1, rgb2[2][r][px] = val[r][px] * r2p;
+                        } else {
+                            rgb2[0][r][px] = val[r][px] * w0 + rgb2[0][r][px];
+                            rgb2[1][r][px] = val[r][px] * w1 + rgb2[1][r][px];
+                            rgb2[2][r][px] = val[r][px] * r2p + rgb2[2][r][px];
+                        }
+                    }
             }
 #ifdef MAUA_DEVICE_PASS
             if (store_feat) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), y_rsrc, y_voff, (unsigned)ol * plane_b, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), y_rsrc, y_voff + (unsigned)p.W * 4u, (unsigned)ol * plane_b, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ol = 16 * m + 2 * vp + h;  // + 4 kq through y_voff
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const f32x4 row = f32x4{val[r][0][h], val[r][1][h], val[r][2][h], val[r][3][h]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, row), y_rsrc, y_voff + (unsigned)(r * p.W) * 4u,
+                                                               (unsigned)ol * plane_b, 0);
+                    }
+                }
             }
 #endif
         }
@@ -1027,7 +1066,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-            float a = rgbacc[c][0][px], b = rgbacc[c][1][px];
+            float a = rgb2[c][0][px].x + rgb2[c][0][px].y, b = rgb2[c][1][px].x + rgb2[c][1][px].y;
             a += __shfl_xor(a, 32);
             b += __shfl_xor(b, 32);
             const float mine = cr ? b : a, other = cr ? a : b;
