@@ -787,7 +787,6 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
         const bool ok = sg < W2D_SEGS && pr < PH && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
         rel_bytes = ok ? (unsigned)(yy * p.W + xx) * 4u : 0x80000000u;
     }
-    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
     const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
     const size_t plane_bytes = plane * sizeof(float);
     (void)ximg, (void)plane_bytes, (void)rel_bytes;
@@ -815,6 +814,10 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
 #endif
     };
 
+    // the first chunk's operands are requested BEFORE the per-image tables below are fetched: their global round trip (styles, demod,
+    // bias, ToRGB weights) then runs under the DMA's instead of in front of it
+    issue(0, 0);
+    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
     const bool act = p.fuse_act != 0;
     const float act_gain = act ? 1.41421356237309515f : 1.f;
     const float* noise_base = p.noise;
@@ -852,7 +855,6 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     constexpr int XF_BYTES = W2D_CC * BM * 4;
     constexpr int ROW_BYTES = W2D_PWS * 4;
 
-    issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
