@@ -214,7 +214,9 @@ def test_modconv_winograd43_vs_oracle(gpu, cin, cout, h, w, batch):
 @pytest.mark.parametrize("cin,cout,h,w,batch", [
     (64, 64, 32, 32, 2),      # one m-tile group (BM 64), 1 x 4 tiles per image
     (128, 128, 16, 64, 1),    # two weight tiles per position tile, 2 x 2 tiles
-    (32, 32, 32, 64, 2),      # 32-channel layer: BM 32, 64-position tiles (16 rows)
+    (32, 32, 32, 64, 2),      # 32-channel layer: the wave-complete kernel (16-row tiles, one n-tile per wave)
+    (32, 32, 24, 32, 1),      # 32-channel layer whose height is not a multiple of 16: the y-frequency-split <2, 2, 3> instance
+    (16, 32, 16, 32, 3),      # wave-complete kernel, 4 K steps, a single tile per image
     (512, 256, 8, 32, 1),     # deep K (128 chunks), a single 8-row tile
     (64, 192, 24, 96, 1),     # three weight tiles, 3 x 3 position tiles
     (36, 64, 40, 32, 3),      # Cin = 9 chunks, ragged nothing: H % 8 == 0, three images
@@ -259,7 +261,7 @@ def test_modconv_winograd2d_vs_oracle(gpu, cin, cout, h, w, batch):
 
 @pytest.mark.parametrize("cin,cout,h,w,with_skip", [(64, 64, 32, 64, True), (32, 32, 32, 32, True), (128, 64, 16, 32, False),
                                                      (32, 32, 48, 64, True), (64, 128, 32, 32, True), (128, 256, 16, 64, False),
-                                                     (32, 512, 8, 32, True)])
+                                                     (32, 512, 8, 32, True), (32, 32, 40, 32, True), (64, 32, 16, 64, False)])
 def test_fused_torgb_epilogue_equals_separate_launches(gpu, cin, cout, h, w, with_skip):
     """StyledConv + ToRGB folded into one launch (maua_styledconv_torgb_f32: <= 64-channel plain layers, every kernel mode that
     the layer shape selects — 2-D Winograd here) against the same two layers run as separate launches and against the oracle;
