@@ -320,8 +320,8 @@ def time_region(wl, steps, bps, mode, use_dist, world):
     """Time ``steps`` steps of ``bps`` batches.  mode "synth": replay + uint8 epilogue only.  "gathered" (N > 1): every batch's
     frames also travel to rank 0 through sharding.FrameStream (one asynchronous RCCL gather per batch, as render() issues them);
     the clock stops when the last round has landed in rank 0's HBM — SURVEY.md 8d's definition of the metric ("uint8 frames
-    gathered to rank 0").  "pcie": every batch's frames also go to the host through the pinned staging ring on a copy stream
-    exactly as render() does (null sink)."""
+    gathered to rank 0").  "pcie": every batch's frames also go to the host exactly as render() sends them (device-side ring slot on
+    the lane's stream, then the pinned ring on a copy stream; null sink)."""
     import torch.distributed as dist
 
     dev, B, size = wl.dev, wl.B, wl.size
@@ -330,8 +330,9 @@ def time_region(wl, steps, bps, mode, use_dist, world):
         from maua_stylegan2_amd import sharding
 
         fs = sharding.FrameStream(world * steps * bps * B, B, (size, size, 3), dev)
-    n_slots = 3
+    n_slots = 6
     pinned = [torch.empty((B, size, size, 3), dtype=torch.uint8).pin_memory() for _ in range(n_slots)] if mode == "pcie" else None
+    staged = [torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)] if mode == "pcie" else None
     copy_stream = torch.cuda.Stream(dev) if mode == "pcie" else None
     copied = [None] * n_slots
     wl.sync()
@@ -350,14 +351,15 @@ def time_region(wl, steps, bps, mode, use_dist, world):
                 slot = k % n_slots
                 if copied[slot] is not None:
                     copied[slot].synchronize()  # the host consumed this slot (null sink) before it is overwritten
+                with torch.cuda.stream(stream):
+                    staged[slot].copy_(lane.u8, non_blocking=True)  # the batch leaves the lane's frame buffer inside HBM (render.py)
                 produced = torch.cuda.Event()
                 produced.record(stream)
                 with torch.cuda.stream(copy_stream):
                     copy_stream.wait_event(produced)
-                    pinned[slot].copy_(lane.u8, non_blocking=True)
+                    pinned[slot].copy_(staged[slot], non_blocking=True)
                     copied[slot] = torch.cuda.Event()
                     copied[slot].record(copy_stream)
-                stream.wait_event(copied[slot])  # the producer must not overwrite u8 before the copy read it
             k += 1
     if fs is not None:
         fs.wait_all()
@@ -466,8 +468,8 @@ def main():
         extra["frames_per_sec_synth_only"] = world * side * bps * B / time_region(wl, side, bps, "synth", use_dist, world)
     if world == 1 and not args.no_pcie_side:
         extra["frames_per_sec_pcie_inclusive"] = side * bps * B / time_region(wl, side, bps, "pcie", use_dist, world)
-        extra["pcie_inclusive_note"] = (f"{side} steps; uint8 frames copied to pinned host memory through a 3-slot staging "
-                                        "ring on a copy stream, as render() does; null sink (no encoder)")
+        extra["pcie_inclusive_note"] = (f"{side} steps; every batch moves to a device-side ring slot on its lane's stream and from there to "
+                                        "pinned host memory on a copy stream (6 slots), as render() does; null sink (no encoder)")
 
     result = None
     if rank == 0:

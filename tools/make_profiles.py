@@ -10,7 +10,7 @@ import sqlite3
 import sys
 
 O = "gpurun_out/prof_final"
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def table(db, keep=("modconv_mfma", "modconv_w2d", "modconv_up2d", "up2d_edge", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel",

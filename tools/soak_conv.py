@@ -19,7 +19,7 @@ cases = [  # cin, cout, h, w, up, batch
     (64, 64, 512, 512, False, 2), (64, 32, 512, 512, True, 2), (32, 32, 1024, 1024, False, 2), (32, 32, 96, 68, False, 3),
     (64, 64, 40, 34, False, 3), (24, 40, 20, 38, False, 2), (72, 24, 33, 20, True, 3), (16, 16, 128, 128, False, 2),
     # mode 5 (2-D Winograd) incl. its 32-channel tile config, forced below the generator's 128-channel threshold
-    ("w2d", 64, 64, 64, 96, 3), ("w2d", 32, 32, 64, 64, 3), ("w2d", 128, 192, 24, 32, 2),
+    ("w2d", 64, 64, 64, 96, 3), ("w2d", 32, 32, 64, 64, 3), ("w2d", 128, 192, 24, 32, 2), ("w2d", 32, 32, 40, 64, 2),
 ]
 _empty = torch.empty
 
