@@ -1205,6 +1205,10 @@ int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
     if (cin % W2D_CC || w % 32 || cin <= 0 || cout <= 0) return 0;
     int m, n;
     // (the tile shape depends on the channel counts only: the packed weight of a layer serves every map size)
+#ifdef MAUA_W2D_TM2_64  // (experiment: 64-channel layers as two 32-channel workgroups per tile on the wave-complete kernel)
+    if (cout == 64) m = 2, n = MAUA_W2D_TN32;
+    else
+#endif
     if (cout % 64 == 0) m = 4, n = 2;
     else if (cout == 32) m = 2, n = MAUA_W2D_TN32;
     else return 0;
