@@ -359,6 +359,7 @@ class HostFrameStore:
             self._copy_stream = th.cuda.Stream(device)
         self.pushed = 0
         self._events = []
+        self._dev_ring, self._dev_done = [None] * 3, [None] * 3  # device-side slots between the producer's frame buffer and PCIe
         self._published = 0
         self._lock = threading.Lock()
         self._peers = {}
@@ -375,14 +376,25 @@ class HostFrameStore:
         if u8 is not None:
             dst = self._frames[k, : u8.shape[0]]
             if self._on_gpu:
+                # the round leaves the producer's frame buffer inside HBM first (a device-side ring slot, on the producer's stream) and
+                # crosses PCIe from there: the producer never waits for a host copy before its next replay (render.render_shard does the
+                # same in its single-GPU loop); a slot is re-used once the host copy that read it three rounds ago is done
+                producer = th.cuda.current_stream(u8.device)
+                slot = k % len(self._dev_ring)
+                if self._dev_ring[slot] is None or self._dev_ring[slot].shape[1:] != u8.shape[1:] or self._dev_ring[slot].shape[0] < u8.shape[0]:
+                    self._dev_ring[slot] = th.empty((max(self.batch, u8.shape[0]),) + tuple(u8.shape[1:]), dtype=th.uint8, device=u8.device)
+                if self._dev_done[slot] is not None:
+                    producer.wait_event(self._dev_done[slot])
+                held = self._dev_ring[slot][: u8.shape[0]]
+                held.copy_(u8, non_blocking=True)
                 produced = th.cuda.Event()
-                produced.record(th.cuda.current_stream(u8.device))
+                produced.record(producer)
                 with th.cuda.stream(self._copy_stream):
                     self._copy_stream.wait_event(produced)
-                    dst.copy_(u8, non_blocking=True)
+                    dst.copy_(held, non_blocking=True)
                     done = th.cuda.Event()
                     done.record(self._copy_stream)
-                th.cuda.current_stream(u8.device).wait_event(done)  # the producer must not overwrite u8 before the copy has read it
+                self._dev_done[slot] = done
                 self._events.append(done)
             else:
                 dst.copy_(u8)
