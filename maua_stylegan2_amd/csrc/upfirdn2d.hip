@@ -32,6 +32,7 @@ struct FirTail {
     int channels;
     const maua_frame_source_t* src;  // when set: noise / noise_batch_stride come from src->noise[noise_slot] at frame src->frame0
     int noise_slot;
+    int plane_major;  // block order: 1 = plane by plane (sequential HBM rows), 0 = channel fastest (planes sharing a noise tile back to back)
 };
 
 // output rows per wave: 32 with the fused tail; 24 for the plain op (27 KB of LDS: five workgroups per CU instead of four — measured
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     const int nblocks = gridDim.x;
     int t = xcd_remap(blockIdx.x, nblocks);
     int plane, tile_x, tile_y;
-    if (TAIL) {  // channel fastest: the planes that share one noise tile run back-to-back on one XCD (L2 hits)
+    if (TAIL && !tail.plane_major) {  // channel fastest: the planes that share one noise tile run back-to-back on one XCD (L2 hits)
         const int c = t % tail.channels;
         t /= tail.channels;
         tile_y = t % tiles_y;
@@ -386,7 +387,14 @@ extern "C" int maua_blur_noise_act_f32(const float* x, const float* k, float* y,
     if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     const int out_h = in_h + pad0 + pad1 - kh + 1, out_w = in_w + pad0 + pad1 - kw + 1;
     if (out_h <= 0 || out_w <= 0) return MAUA_EINVAL;
-    FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels, src, noise_slot};
+    // Block order.  Channel-fastest (planes that share a noise tile back to back: the tile stays in one XCD's L2) pays on the 1024-row maps,
+    // whose noise maps (4 MB per frame) exceed an L2; up to 512 rows the batch's noise maps fit and plane-by-plane order — sequential HBM
+    // rows, as the plain op walks them — is faster: 256^2 x 128 channels 0.147 -> 0.122 ms, 512^2 0.235 -> 0.228, 1024^2 unchanged
+    // (alternating A/B in bench.py, profiles/r04_probes.md)
+#ifndef MAUA_FIR_PLANE_MAJOR_MAX_H
+#define MAUA_FIR_PLANE_MAJOR_MAX_H 512
+#endif
+    FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels, src, noise_slot, out_h <= MAUA_FIR_PLANE_MAJOR_MAX_H ? 1 : 0};
     return dispatch_fir_tile<true>(x, k, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, pad0, pad0, tail,
                                    (hipStream_t)stream);
 }
