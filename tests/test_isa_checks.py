@@ -57,3 +57,38 @@ def test_hot_kernels_use_no_scratch_memory(device_asm, name):
     as a spill: the first build of the wave-complete 32-channel kernel carried 112 bytes of it in its epilogue."""
     sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", device_asm[name])]
     assert sizes and max(sizes) == 0, sizes
+
+
+def _kernel_body(asm, mangled_fragment):
+    lines = asm.split("\n")
+    start = next(i for i, line in enumerate(lines) if line.startswith("_Z") and mangled_fragment in line.split(":")[0])
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return lines[start + 1:end]
+
+
+def _main_loop(body):
+    """(first, last) line index of the backward-branch loop that holds the most matrix instructions."""
+    labels = {m.group(1): i for i, line in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", line))}
+    loops = []
+    for i, line in enumerate(body):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", line)
+        if m and labels.get(m.group(1), len(body)) < i:
+            loops.append((labels[m.group(1)], i))
+    return max(loops, key=lambda ab: sum("v_mfma" in line for line in body[ab[0]:ab[1]]))
+
+
+def test_wave_complete_kernel_k_step_composition(device_asm):
+    """modconv_w2dw_kernel: one K step = 48 matrix instructions (4 y-frequencies x 6 x-frequencies x 2 m-tiles) around <= 72 VALU
+    instructions (the four window transforms: fp32 VALU and fp32 matrix instructions share the datapath, every extra one is matrix time
+    lost), 16 window + 24 weight + 1 style LDS reads, ONE barrier, and no full vmcnt drain except the one in front of that barrier."""
+    body = _kernel_body(device_asm["modconv_w2d"], "modconv_w2dw_kernel")
+    lo, hi = _main_loop(body)
+    ops = [line.split()[0] for line in body[lo:hi + 1] if line.strip() and not line.strip().startswith((".", ";")) and not line.strip().endswith(":")]
+    assert sum(op.startswith("v_mfma") for op in ops) == 48
+    valu = sum(op.startswith("v_") and not op.startswith("v_mfma") for op in ops)
+    assert valu <= 72, valu
+    assert sum(op.startswith("ds_read") for op in ops) == 41
+    assert sum(op == "s_barrier" for op in ops) == 1
+    drains = [i for i, line in enumerate(body[lo:hi + 1]) if "s_waitcnt" in line and "vmcnt(0)" in line]
+    barrier = next(i for i, line in enumerate(body[lo:hi + 1]) if "s_barrier" in line)
+    assert drains and all(0 < barrier - d < 12 for d in drains), (drains, barrier)
