@@ -817,7 +817,8 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     // the first chunk's operands are requested BEFORE the per-image tables below are fetched: their global round trip (styles, demod,
     // bias, ToRGB weights) then runs under the DMA's instead of in front of it
     issue(0, 0);
-    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    // (styles: the first 256 channels' load goes out here and is written below, next to the table — one round trip for both)
+    const float s_first = *(tid < p.Cin ? p.s + (size_t)b0 * p.s_stride + tid : p.s);
     const bool act = p.fuse_act != 0;
     const float act_gain = act ? 1.41421356237309515f : 1.f;
     const float* noise_base = p.noise;
@@ -828,20 +829,25 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
         if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
     }
     const float nw = (act && noise_base) ? p.noise_w[0] * act_gain : 0.f;
-    for (int i = tid; i < BM; i += 256) {
-        const int o = m0 + i;
-        float gain = p.wscale * act_gain;
-        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + o];
-        f32x4 e = f32x4{gain, (act && p.bias) ? p.bias[o] * act_gain : 0.f, 0.f, 0.f};
-        float r2 = 0.f;
-        if (p.rgb) {
-            const float ms = p.rgb_wscale * p.rgb_s[(size_t)b0 * p.s_stride + o];
-            e[2] = ms * p.rgb_w[0 * p.Cout + o], e[3] = ms * p.rgb_w[1 * p.Cout + o], r2 = ms * p.rgb_w[2 * p.Cout + o];
-        }
+    if (tid < BM) {
+        // ALL table loads go out together, unconditionally: absent operands (no demodulation, no bias, no ToRGB) read a valid dummy
+        // address and are masked by a wave-uniform select.  Written as `if (p.d) gain *= p.d[..]` etc. the compiler emitted a branch and
+        // a full wait per operand: four dependent global round trips (~3 us) in front of every workgroup's K loop.
+        const int i = tid, o = m0 + i;
+        const float* dummy = p.s;
+        const float dv = *(p.d ? p.d + (size_t)b0 * p.Cout + o : dummy);
+        const float bv_ = *((act && p.bias) ? p.bias + o : dummy);
+        const float sv_ = *(p.rgb ? p.rgb_s + (size_t)b0 * p.s_stride + o : dummy);
+        const float w0 = *(p.rgb ? p.rgb_w + 0 * p.Cout + o : dummy), w1 = *(p.rgb ? p.rgb_w + 1 * p.Cout + o : dummy);
+        const float w2 = *(p.rgb ? p.rgb_w + 2 * p.Cout + o : dummy);
+        const float gain = p.wscale * act_gain * (p.d ? dv : 1.f);
+        const float ms = p.rgb ? p.rgb_wscale * sv_ : 0.f;
         // channel PAIRS side by side (the epilogue works on register pairs): [pair][gain x2 | bias x2 | rgb0 x2 | rgb1 x2 | rgb2 x2 | pad x2]
         float* ep = E + 12 * (i >> 1) + (i & 1);
-        ep[0] = e[0], ep[2] = e[1], ep[4] = e[2], ep[6] = e[3], ep[8] = r2;
+        ep[0] = gain, ep[2] = (act && p.bias) ? bv_ * act_gain : 0.f, ep[4] = ms * w0, ep[6] = ms * w1, ep[8] = ms * w2;
     }
+    if (tid < p.Cin) Ss[tid] = s_first;
+    for (int e = tid + 256; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
 
     f32x4 acc[4][6][2];  // [y-frequency][x-frequency][m-tile]; the first K step runs with C = 0
     float m5 = -5.f;
