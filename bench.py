@@ -329,7 +329,10 @@ def time_region(wl, steps, bps, mode, use_dist, world):
     if mode == "gathered":
         from maua_stylegan2_amd import sharding
 
-        fs = sharding.FrameStream(world * steps * bps * B, B, (size, size, 3), dev)
+        # two streams of SEG rounds used alternately: rank 0's HBM store stays at 2 x world x SEG x B frames whatever --steps is (one
+        # stream for the whole region would be world x steps x 15 x 8 frames: 90 GB on rank 0 at 8 GPUs and 30 steps)
+        SEG = 60  # (a multiple of every lane count up to 6: a slot of a stream is always written on the same lane's stream)
+        fs = [sharding.FrameStream(world * SEG * B, B, (size, size, 3), dev) for _ in range(2)]
     n_slots = 6
     pinned = [torch.empty((B, size, size, 3), dtype=torch.uint8).pin_memory() for _ in range(n_slots)] if mode == "pcie" else None
     staged = [torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev) for _ in range(n_slots)] if mode == "pcie" else None
@@ -345,8 +348,11 @@ def time_region(wl, steps, bps, mode, use_dist, world):
         for _ in range(bps):
             stream, lane = wl.batch()
             if fs is not None:
+                seg, r = divmod(k, SEG)
+                if r == 0 and seg >= 2:
+                    fs[seg % 2].reset()  # (its gathers were issued 60 .. 120 rounds ago: nothing left to wait for in practice)
                 with torch.cuda.stream(stream):
-                    fs.push(k, lane.u8)
+                    fs[seg % 2].push(r, lane.u8)
             if mode == "pcie":
                 slot = k % n_slots
                 if copied[slot] is not None:
@@ -362,7 +368,8 @@ def time_region(wl, steps, bps, mode, use_dist, world):
                     copied[slot].record(copy_stream)
             k += 1
     if fs is not None:
-        fs.wait_all()
+        for f in fs:
+            f.wait_all()
     if copy_stream is not None:
         copy_stream.synchronize()
     wl.sync()

@@ -16,6 +16,7 @@ tests):
 ``broadcast_tensor`` makes it identical on every rank.
 """
 import queue
+import time
 
 import torch as th
 import torch.distributed as dist
@@ -218,6 +219,16 @@ class FrameStream:
         for w in self.works:
             if w is not None:
                 w.wait()
+
+    def reset(self):
+        """Start over at round 0 in the same buffers (every collective of the previous pass is waited for first).  For callers that
+        stream more rounds than they want to hold — bench.py's gathered region walks two streams of a fixed number of rounds
+        alternately, so that rank 0's store stays bounded whatever --steps is."""
+        for w in self.works:  # completion as seen from the HOST (Work.wait() would only order the current stream behind the collective,
+            while w is not None and not w.is_completed():  # and the next pass's pushes run on other streams)
+                time.sleep(0.0002)
+        self.works, self.pushed, self._cursor = [], 0, (0, 0)
+        self._pushed_events, self._inflight = [], []
 
     def _landed(self, k, block):
         if k >= len(self.works):

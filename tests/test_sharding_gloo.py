@@ -207,6 +207,27 @@ def _stream_worker(rank, world, port, n_frames, batch, out_dir):
             if stream.rounds >= 3:
                 assert first_peer_frame_at is not None and first_peer_frame_at < float(stamps[1][0]), (
                     first_peer_frame_at, float(stamps[1][0]))
+        # ---- reset(): a second pass through the SAME buffers (bench.py's gathered region re-uses two streams alternately) delivers
+        # the second pass's frames, not the first's
+        stream.reset()
+        assert stream.pushed == 0
+        k = 0
+        for first in range(lo, hi, batch):
+            count = min(batch, hi - first)
+            u8 = torch.zeros((count, 4, 5, 3), dtype=torch.uint8)
+            for i in range(count):
+                u8[i] = (first + i + 100) % 251
+            stream.push(k, u8)
+            k += 1
+        stream.finish()
+        if rank == 0:
+            again = list(stream.drain(block=True))
+            assert [i for i, _ in again] == list(range(n_frames))
+            for i, f in again:
+                assert int(f.min()) == int(f.max()) == (i + 100) % 251
+        else:
+            stream.wait_all()
+        if rank == 0:
             np.save(os.path.join(out_dir, "stream_ok.npy"), np.array([n_frames]))
     finally:
         dist.destroy_process_group()
