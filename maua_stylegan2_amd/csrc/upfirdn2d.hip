@@ -41,7 +41,10 @@ struct FirTail {
 // instead of 106 (19 staged rows + 16 noise values in flight instead of 35 + 32), the launches of the 8^2..512^2 layers measure
 // 0.027 -> 0.017 ms (8^2..64^2), 0.057 -> 0.054 (128^2), 0.152 -> 0.150 (256^2), ~0.23 (512^2: unchanged); the 1024^2 launch is 7 % slower with
 // it (0.427 -> 0.457: more halo rows per output row) and keeps 32.
-constexpr int FIR_ROWS_PLAIN = 24, FIR_ROWS_TAIL = 32, FIR_ROWS_TAIL_SMALL = 16;
+#ifndef MAUA_FIR_ROWS_TAIL_SMALL
+#define MAUA_FIR_ROWS_TAIL_SMALL 16
+#endif
+constexpr int FIR_ROWS_PLAIN = 24, FIR_ROWS_TAIL = 32, FIR_ROWS_TAIL_SMALL = MAUA_FIR_ROWS_TAIL_SMALL;
 constexpr int FIR_TAIL_SMALL_MAX_H = 512;
 
 #if defined(__HIP_DEVICE_COMPILE__)
