@@ -35,9 +35,8 @@ struct FirTail {
     int plane_major;  // block order: 1 = plane by plane (sequential HBM rows), 0 = channel fastest (planes sharing a noise tile back to back)
 };
 
-// output rows per wave: 32 with the fused tail; 24 for the plain op (27 KB of LDS: five workgroups per CU instead of four — measured
-// 5.51 vs 5.33 TB/s on [8,32,1025,1025], 16 rows 5.46; with the tail 24 and 16 measure the same as 32)
-// Output rows per wave strip (TH).  Plain: 24.  With the tail 32 on the 1024-row maps and 16 below: a 16-row strip needs 57 registers
+// Output rows per wave strip (TH).  Plain: 24 (27 KB of LDS: five workgroups per CU instead of four — 5.51 vs 5.33 TB/s on [8,32,1025,1025]
+// with 32 rows, 16 rows 5.46).  With the tail 32 on the 1024-row maps and 16 below: a 16-row strip needs 57 registers
 // instead of 106 (19 staged rows + 16 noise values in flight instead of 35 + 32), the launches of the 8^2..512^2 layers measure
 // 0.027 -> 0.017 ms (8^2..64^2), 0.057 -> 0.054 (128^2), 0.152 -> 0.150 (256^2), ~0.23 (512^2: unchanged); the 1024^2 launch is 7 % slower with
 // it (0.427 -> 0.457: more halo rows per output row) and keeps 32.
