@@ -246,19 +246,48 @@ class Workload:
 
         self.size, self.B, self.dev = size, batch, dev
         g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
-        g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
+        if rank == 0:  # only rank 0 holds the "checkpoint" (generate_audiovisual.load_generator): the other ranks keep their own random
+            g.load_state_dict(seeding.seeded_state_dict(size, seed=0))  # initialisation until the flat broadcast below overwrites it
         self.g = g = g.to(dev).eval()
-        if use_dist:  # weights: rank 0 is the source of truth
-            from maua_stylegan2_amd import sharding
-
-            sharding.broadcast_module(g)
+        self.collectives = {"broadcast_bytes": 0, "scatter_bytes": 0}
         # synthetic sequences resident in HBM: POOL * B frames of latents; noise maps for scales <= 256 are per-frame
         # (audio-reactive in the default plugin), 512/1024 use the checkpoint buffers (get_noise -> None)
         self.n_frames = n = POOL * batch
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1000 + rank)
-        self.latents = torch.randn(n, g.n_latent, 512, device=dev, generator=gen)
-        self.noise = [torch.randn(n, 1, r, r, device=dev, generator=gen) if r <= 256 else None for r in seeding.noise_sizes(size)]
+        sizes = seeding.noise_sizes(size)
+
+        def sequences(r):  # rank r's block of the job's per-frame inputs
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1000 + r)
+            lat = torch.randn(n, g.n_latent, 512, device=dev, generator=gen)
+            return gen, lat, [torch.randn(n, 1, side, side, device=dev, generator=gen) if side <= 256 else None for side in sizes]
+
+        if use_dist:
+            # weights: rank 0 is the source of truth - ONE flat broadcast; per-frame inputs: rank 0 "ran the front end" for
+            # the whole job and every rank receives only its contiguous block (sharding.scatter_frames, one dist.scatter per sequence),
+            # exactly the hand-over of generate(); a group of one rank issues the same collectives (sharding.grouped)
+            import torch.distributed as dist
+
+            from maua_stylegan2_amd import sharding
+
+            world = dist.get_world_size()
+            sharding.broadcast_module(g)
+            self.collectives["broadcast_bytes"] = sum(t.numel() * t.element_size() for t in list(g.parameters()) + list(g.buffers()))
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1000 + rank)
+            full_lat, full_noise = None, [None] * len(sizes)
+            if rank == 0:
+                blocks = [sequences(r) for r in range(world)]
+                gen = blocks[0][0]
+                full_lat = torch.cat([b[1] for b in blocks])
+                full_noise = [None if blocks[0][2][i] is None else torch.cat([b[2][i] for b in blocks]) for i in range(len(sizes))]
+                del blocks
+            self.latents = sharding.scatter_frames(full_lat, world * n, device=dev)
+            self.noise = [sharding.scatter_frames(nz, world * n, device=dev) for nz in full_noise]
+            assert self.latents.shape[0] == n and [nz is None for nz in self.noise] == [side > 256 for side in sizes]
+            self.collectives["scatter_bytes"] = sum(t.numel() * 4 for t in [self.latents] + [nz for nz in self.noise if nz is not None])
+            del full_lat, full_noise
+        else:
+            gen, self.latents, self.noise = sequences(rank)
         self.bend_spec = []
         if bends:  # BASELINE config 5: a modulated Translate at layer id 4 and a modulated Zoom at layer id 5 (16 x 16 features)
             from maua_stylegan2_amd.audioreactive import bend
@@ -383,7 +412,63 @@ def time_region(wl, steps, bps, mode, use_dist, world):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    if fs is not None and k:
+        # evidence for the `rccl` block (outside the clock): what the gathers moved, and whether the LAST round of every rank arrived in rank
+        # 0's store intact (byte sums of the round on its producer against the sums of rank 0's slots)
+        seg, r = divmod(k - 1, SEG)
+        f = fs[seg % 2]
+        mine = f.mine[r * B: (r + 1) * B].long().sum().reshape(1)
+        if use_dist and dist.get_backend() != "nccl":
+            mine = mine.cpu()  # (the gloo debug backend: small bookkeeping tensors travel from the host)
+        sums = [mine.clone() for _ in range(world)]
+        if use_dist:
+            dist.all_gather(sums, mine)
+        landed = [int(f.store[p, r * B: (r + 1) * B].long().sum()) for p in range(world)] if f.store is not None else None
+        GATHER_EVIDENCE.update(
+            rounds_per_rank=k, gather_calls_per_rank=k if f.grouped else 0, bytes_per_round_per_rank=B * size * size * 3,
+            bytes_into_rank0=k * B * size * size * 3 * world if f.grouped else 0,
+            transport="dist.gather(async_op=True) per batch-round (sharding.FrameStream)" if f.grouped else "local copy (no process group)",
+            last_round_byte_sums_on_producers=[int(x) for x in sums], last_round_byte_sums_in_rank0_store=landed,
+            payload_check=None if landed is None else ("ok" if landed == [int(x) for x in sums] else "FAILED"))
     return dt
+
+
+GATHER_EVIDENCE = {}
+
+
+def rccl_block(dev, rank, world, backend, wl):
+    """Who took part in the job and what the collectives moved — so that a SCALE record proves N ranks on N devices.
+    Every rank reports its process, host, device (index, name, UUID, PCI address); rank 0 also checks that the flat weight broadcast left
+    every rank with the same parameters (fp64 checksums)."""
+    import socket
+
+    import torch.distributed as dist
+
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "pid": os.getpid(), "host": socket.gethostname(), "device_index": dev.index, "device_name": props.name,
+          "device_uuid": str(getattr(props, "uuid", "")) or None,
+          "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+          "hbm_gib": round(props.total_memory / 2 ** 30, 1)}
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    check = torch.stack([t.detach().double().sum() for t in wl.g.parameters()]).sum().reshape(1)
+    if backend != "nccl":
+        check = check.cpu()
+    sums = [check.clone() for _ in range(world)]
+    dist.all_gather(sums, check)
+    sums = [float(x) for x in sums]
+    try:
+        version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        version = None
+    uuids = [r["device_uuid"] or r["pci"] for r in ranks]
+    return {"backend": backend, "backend_is": "RCCL (torch.distributed 'nccl' on ROCm)" if backend == "nccl" else backend,
+            "rccl_version": version, "world_size": world, "ranks": ranks, "distinct_devices": len(set(zip((r["host"] for r in ranks), uuids))),
+            "weights": {"collective": "dist.broadcast of one flat fp32 buffer (sharding.broadcast_module); ranks != 0 started from their own random init",
+                        "bytes": wl.collectives["broadcast_bytes"], "param_checksums_equal_after_broadcast": len(set(sums)) == 1},
+            "inputs": {"collective": "dist.scatter per sequence (sharding.scatter_frames): rank 0 produced every rank's latents / noise block",
+                       "bytes_received_per_rank": wl.collectives["scatter_bytes"]},
+            "frames": dict(GATHER_EVIDENCE)}
 
 
 def main():
@@ -483,6 +568,7 @@ def main():
         extra["pcie_inclusive_note"] = (f"median of three regions of {side} steps; every batch moves to a device-side ring slot on its lane's stream and from there to "
                                         "pinned host memory on a copy stream (6 slots), as render() does; null sink (no encoder)")
 
+    rccl = rccl_block(dev, rank, world, backend, wl) if use_dist else None  # (collective: every rank calls it)
     result = None
     if rank == 0:
         frames = world * args.steps * bps * B
@@ -511,6 +597,11 @@ def main():
                             "what": "uint8 frames of the last replay of every lane vs the eager (un-captured) forward of the same frames"},
             "device": _lib.device_info(),
         }
+        if rccl is not None:
+            result["rccl"] = rccl
+            if rccl["frames"].get("payload_check") == "FAILED" or not rccl["weights"]["param_checksums_equal_after_broadcast"]:
+                print("bench.py: a collective delivered wrong bytes (see the rccl block)", file=sys.stderr)
+                result["rccl"]["FAILED"] = True
         if frame_err != 0:
             print(f"bench.py: captured frames differ from the eager forward by {frame_err} grey levels", file=sys.stderr)
             result["frame_check"]["FAILED"] = True

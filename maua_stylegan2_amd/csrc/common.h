@@ -11,6 +11,22 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that uses more than the default 64 KB of LDS.  The attribute belongs to
+// (function, device): SUCCESS is remembered per device in the caller's `done` bit mask (one static per launcher), a failure is
+// returned as the launch's hipError_t (> 0, the contract of include/maua_hip.h) and retried by the next call instead of being cached
+// for the life of the process.  Relaxed atomics: two threads racing on the first call both set the attribute, which is harmless.
+static inline int maua_allow_full_lds(const void* kern, unsigned long long* done, int bytes = 160 * 1024) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done, __ATOMIC_RELAXED) & bit) return 0;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+    return 0;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -85,8 +85,10 @@ struct ConvGeom {
     int flat;         // transposed mode: tiles are runs of BN consecutive positions of the row-major (H+1)x(W+1) grid
     int rgb;          // fused ToRGB epilogue: 0 off, 1 on, 2 on and the feature map itself is not stored
     float rgb_wscale;
-    int debug;        // MAUA_EXPERIMENTS builds only (maua_tuning_set key 1): 1 skip stores, 2 skip MFMA, 4 skip loads, 32 skip weight
-                      // DMA, 64 skip patch loads, 128 fold the patch loads onto 4 KB per channel (always cache hits; wrong results)
+#ifdef MAUA_EXPERIMENTS
+    int debug;        // (maua_tuning_set key 1) 1 skip stores, 2 skip MFMA, 4 skip loads, 32 skip weight DMA, 64 skip patch loads,
+                      // 128 fold the patch loads onto 4 KB per channel (always cache hits; wrong results).  Not a member of the product's struct.
+#endif
 };
 
 struct ConvPtrs {
@@ -1240,9 +1242,8 @@ int launch_conv_impl2(const Plan& pl, const ConvPtrs& ptrs, hipStream_t st) {
     auto kern = modconv_mfma_kernel<BM, BN, WM, UP, MULTI, FAST, MAXP>;
     snprintf(g_last_instance, sizeof(g_last_instance), "modconv_mfma_kernel<%d, %d, %d, %d, %s, %s, %d>", BM, BN, WM, UP,
              MULTI ? "true" : "false", FAST ? "true" : "false", MAXP);
-    static int attr_rc = -1;  // (per instantiation; a failure is returned by every launch instead of being swallowed)
-    if (attr_rc < 0) attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_rc) return attr_rc;
+    static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(kern), &lds_ok, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(256), pl.lds_bytes, st, pl.g, ptrs);
     MAUA_LAUNCH_CHECK();
     return 0;

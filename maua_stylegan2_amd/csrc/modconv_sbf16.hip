@@ -528,11 +528,8 @@ const char* maua_sbf16_last_instance() { return g_sbf16_instance; }
 namespace {
 template <int PHASE>
 int sbf16_launch_phase(const SbArgs& a, size_t lds_bytes, hipStream_t st) {
-    static int attr_rc = -1;
-    if (attr_rc < 0)
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_sbf16_kernel<PHASE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-    if (attr_rc) return attr_rc;
+    static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_sbf16_kernel<PHASE>), &lds_ok, 160 * 1024)) return rc;
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
     hipLaunchKernelGGL(modconv_sbf16_kernel<PHASE>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     MAUA_LAUNCH_CHECK();
@@ -562,11 +559,8 @@ int maua_sbf16_launch(const float* x, const void* wq, const float* s, int s_stri
     }
     snprintf(g_sbf16_instance, sizeof(g_sbf16_instance), "modconv_sbf16_up_kernel");
     {
-        static int attr_rc = -1;
-        if (attr_rc < 0)
-            attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_sbf16_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               160 * 1024);
-        if (attr_rc) return attr_rc;
+        static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
+        if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_sbf16_up_kernel), &lds_ok, 160 * 1024)) return rc;
         a.m_tiles = cout / 32;
         const size_t up_lds = (size_t)2 * SU_ABUF_BYTES + (size_t)2 * SU_BBUF_BYTES + sizeof(float) * ((size_t)cin + 32);
         const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;

@@ -501,13 +501,10 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM);
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
-    static int attr_rc = -1;  // (a failure is returned by every launch instead of being swallowed)
-    if (attr_rc < 0) {
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (!attr_rc)
-            attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_up2d_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    if (attr_rc) return attr_rc;
+    static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
+    static unsigned long long lds_ok1 = 0;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<4>), &lds_ok, 160 * 1024)) return rc;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8>), &lds_ok1, 160 * 1024)) return rc;
     snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<%d>", cc);
     if (cc == 8) hipLaunchKernelGGL(modconv_up2d_kernel<8>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     else hipLaunchKernelGGL(modconv_up2d_kernel<4>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);

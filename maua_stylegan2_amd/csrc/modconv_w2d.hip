@@ -41,9 +41,14 @@
 // stores, 8 no epilogue, 16 no K-step barrier, 32 no input transform (raw window values feed the MFMAs), 64 no window reads, 128 half the weight DMA pieces, 1024 no patch DMA,
 // 256 no ToRGB tail after the passes, 512 no combine phase (barriers and the A_x^T / exchange writes stay, so the accumulators
 // remain live).  0 in the product, which carries no run-time switch of any kind.
+#if !defined(MAUA_EXPERIMENTS)
+#undef MAUA_W2D_ABL  // the product ignores the mask even when somebody passes it
+#endif
 #ifndef MAUA_W2D_ABL
 #define MAUA_W2D_ABL 0
 #endif
+// W2D_ABL(bits): true only in an experiments build whose mask has one of `bits` (a compile-time constant: `if (W2D_ABL(..))` folds away)
+#define W2D_ABL(bits) ((MAUA_W2D_ABL & (bits)) != 0)
 
 namespace {
 
@@ -174,7 +179,6 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
 
 template <int TM, int TN, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
-    constexpr int dbg = MAUA_W2D_ABL;
     constexpr int BM = 16 * TM;
     constexpr int NPOS = 16 * TN;
     constexpr int TH = 4 * TN;  // output rows per tile
@@ -246,14 +250,14 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
 #pragma unroll
         for (int k = 0; k < A_PER_WAVE; ++k) {
             const int i = fy + 4 * k;
-            if ((dbg & 128) && (k & 1) && chunk) continue;  // (ablation: half the weight pieces)
+            if (W2D_ABL(128) && (k & 1) && chunk) continue;  // (ablation: half the weight pieces)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(As + buf * A_FLOATS + i * 256),
                                                      16, (i * 256 + lane * 4) * 4, wbase, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < (4 * NQ + 3) / 4; ++k) {
             const int id = fy + 4 * k;  // (scalar) instruction id = channel * NQ + row group
-            if (id < W2D_CC * NQ && !((dbg & 1024) && chunk)) {  // (ablation 1024: no patch DMA after the first chunk)
+            if (id < W2D_CC * NQ && !(W2D_ABL(1024) && chunk)) {  // (ablation 1024: no patch DMA after the first chunk)
                 const int c = id / NQ, q = id % NQ;
                 float* dst = Ps + buf * PBUF + c * PSTRIDE + (c & 1) * W2D_ODD_SHIFT + q * (W2D_ROWS_PER_DMA * W2D_PWS);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     for (int chunk = phase; chunk < (phase ? p.n_chunks : 1); ++chunk) {
         const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #if !MAUA_W2D_READ_FIRST
-        if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+        if (chunk + 1 < p.n_chunks && !W2D_ABL(2)) issue(chunk + 1, cur ^ 1);
 #endif
         // ---- operand reads of this chunk: style, raw window rows, first weight row
         const unsigned a_off = cur ? A_BUF_BYTES : 0u, p_off = cur ? P_BUF_BYTES : 0u;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         const unsigned pa = b_addr[0] + p_off - 4u, pb = b_addr[1] + p_off - 4u;
         auto read_window = [&](auto n_c, int slot) {
             constexpr int o = decltype(n_c)::value * NT_BYTES;
-            if constexpr ((dbg & 64) != 0) {  // (ablation: the registers keep whatever they held)
+            if constexpr (W2D_ABL(64)) {  // (ablation: the registers keep whatever they held)
                 asm volatile("" : "=v"(wa0[slot]), "=v"(wa5[slot]), "=v"(wb0[slot]), "=v"(wb5[slot]), "=v"(wa[slot][0]), "=v"(wa[slot][1]),
                              "=v"(wb[slot][0]), "=v"(wb[slot][1]));
                 return;
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             wb5[slot] = lds_read64<o + 24>(pb);
         };
         auto transform = [&](int n, int slot) {
-            if constexpr ((dbg & 32) != 0) {  // (ablation: raw window values feed the matrix instructions)
+            if constexpr (W2D_ABL(32)) {  // (ablation: raw window values feed the matrix instructions)
                 bv[n][0] = wa0[slot].y, bv[n][1] = wa[slot][0].x, bv[n][2] = wa[slot][0].y, bv[n][3] = wb[slot][1].x, bv[n][4] = wb[slot][1].y;
                 bv[n][5] = wb5[slot].x + sc;
                 return;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             read_window(std::integral_constant<int, 0>{}, 0);
             if constexpr (TN > 1 && WSLOTS > 1) read_window(std::integral_constant<int, 1>{}, 1);
 #if MAUA_W2D_READ_FIRST
-            if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+            if (chunk + 1 < p.n_chunks && !W2D_ABL(2)) issue(chunk + 1, cur ^ 1);
 #endif
             static_for<0, TN>([&](auto n_c) {
                 constexpr int n = decltype(n_c)::value;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
                 transform(0, slot);
                 if constexpr (n + WSLOTS < TN) read_window(std::integral_constant<int, n + WSLOTS>{}, slot);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(dbg & 1)) {
+                if (!W2D_ABL(1)) {
 #pragma unroll
                     for (int xf = 0; xf < 6; ++xf)
 #pragma unroll
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         read_window(std::integral_constant<int, 0>{}, 0);
         if constexpr (TN > 1 && WSLOTS > 1) read_window(std::integral_constant<int, 1>{}, 1);
 #if MAUA_W2D_READ_FIRST
-        if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+        if (chunk + 1 < p.n_chunks && !W2D_ABL(2)) issue(chunk + 1, cur ^ 1);
 #endif
         static_for<0, TN>([&](auto n_c) {
             constexpr int n = decltype(n_c)::value;
@@ -490,13 +494,13 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             constexpr int pending = xf < 5 ? TM / 2 : 0;
             if constexpr (TM == 4) lds_wait<pending>(a2[xf & 1][0], a2[xf & 1][1]);
             else lds_wait<pending>(a2[xf & 1][0]);
-            if ((dbg & 1) && !phase) {
+            if (W2D_ABL(1) && !phase) {
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
                     for (int n = 0; n < TN; ++n) acc[xf][m][n] = zero4;
             }
-            if (!(dbg & 1)) {
+            if (!W2D_ABL(1)) {
 #pragma unroll
                 for (int h = 0; h < TM / 2; ++h)
 #pragma unroll
@@ -509,11 +513,11 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (!(dbg & 16)) __syncthreads();
+        if constexpr (!W2D_ABL(16)) __syncthreads();
         cur ^= 1;
     }
 
-    if (dbg & 8) {
+    if (W2D_ABL(8)) {
         if (p.B < 0) {  // never true: keeps the accumulators alive in builds without the epilogue
             f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     f32x4 rgbv[3];  // this thread's share of the ToRGB sums, [rgb channel][pixel]
 #pragma unroll
     for (int c = 0; c < 3; ++c) rgbv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool store_feat = p.rgb != 2 && !(dbg & 4);
+    const bool store_feat = p.rgb != 2 && !W2D_ABL(4);
     const unsigned pix_off = (unsigned)oy * (unsigned)p.W + (unsigned)ox;
     // the channel a thread combines in step q of a pass is uniform over its wave (cg = tid / (2 NPOS), 2 NPOS >= 64): per-channel
     // constants come from one broadcast LDS read, and the feature store is a buffer store whose channel offset is a scalar
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             }
         __syncthreads();
         if (mt == TM - 1 && want_skip) load_skip();
-        if constexpr (!(MAUA_W2D_ABL & 512))
+        if constexpr (!W2D_ABL(512))
 #pragma unroll
         for (int q = 0; q < CPG; ++q) {
             const int ch16 = cg_s * CPG + q;
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
 #endif
         }
     }
-    if (!p.rgb || (MAUA_W2D_ABL & 256)) return;
+    if (!p.rgb || W2D_ABL(256)) return;
     // ---- fused ToRGB: sum the channel groups through LDS, add bias and the 2x FIR-upsampled skip image, store
     __syncthreads();
     {
@@ -747,7 +751,6 @@ __device__ __forceinline__ void ww_transform(const f32x2 (&a)[4], const f32x2 (&
 }
 
 __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
-    constexpr int dbg = MAUA_W2D_ABL;  // (ablation masks as in modconv_w2d_kernel: 1 no MFMA, 2 no DMA after the first chunk, 8 no epilogue)
     constexpr int TN = WW_TN, BM = WW_BM;
     constexpr int TH = 4 * TN, PH = TH + 2;
     constexpr int PSTRIDE = w2d_pstride(TN);
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     for (int phase = 0; phase < 2; ++phase)
     for (int chunk = phase; chunk < (phase ? p.n_chunks : 1); ++chunk) {
         const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (chunk + 1 < p.n_chunks && !(dbg & 2)) issue(chunk + 1, cur ^ 1);
+        if (chunk + 1 < p.n_chunks && !W2D_ABL(2)) issue(chunk + 1, cur ^ 1);
         const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u), pw = w_addr + (cur ? P_BUF_BYTES : 0u);
         float sc = lds_read32(s_addr);
         s_addr += W2D_CC * 4u;
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
                 if constexpr (idx + 1 < 24) a2[(idx + 1) & 1] = lds_read64<(idx + 1) * XF_BYTES>(ap);
                 constexpr int behind = (idx + 1 < 24 ? 1 : 0) + (xf == 0 ? first_behind : 0);
                 lds_wait<behind>(a2[idx & 1]);
-                if constexpr ((dbg & 1) != 0) {
+                if constexpr (W2D_ABL(1)) {
                     if (!phase) acc[f][xf][0] = acc[f][xf][1] = zero4;
                     asm volatile("" : "+v"(acc[f][xf][0]), "+v"(acc[f][xf][1]) : "v"(a2[idx & 1]), "v"(bv[xf]));
                 } else {
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
         cur ^= 1;
     }
 
-    if (dbg & 8) {
+    if (W2D_ABL(8)) {
         if (p.B < 0) {  // never true: keeps the accumulators alive in builds without the epilogue
             f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1176,10 +1179,8 @@ char g_w2d_instance[64] = "";
 template <int TM, int TN, int MINB = 2>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
     auto kern = modconv_w2d_kernel<TM, TN, MINB>;
-    static int attr_rc = -1;  // (set once per instantiation; a failure is returned by every launch instead of being swallowed)
-    if (attr_rc < 0)
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_rc) return attr_rc;
+    static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(kern), &lds_ok, 160 * 1024)) return rc;
     snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %d>", TM, TN, MINB);
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
 #ifdef MAUA_EXPERIMENTS  // occupancy probe (MAUA_W2D_LDS_PAD with an experiments build): extra dynamic LDS so that a CU holds one workgroup instead of two
@@ -1193,10 +1194,8 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
 }
 
 int w2dw_launch(const W2dArgs& a, hipStream_t st) {
-    static int attr_rc = -1;
-    if (attr_rc < 0)
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(modconv_w2dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr_rc) return attr_rc;
+    static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_w2dw_kernel), &lds_ok, 160 * 1024)) return rc;
     snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2dw_kernel");
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
     hipLaunchKernelGGL(modconv_w2dw_kernel, dim3((unsigned)blocks), dim3(256), w2dw_lds_bytes(a.Cin), st, a);

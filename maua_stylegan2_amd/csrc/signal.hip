@@ -738,15 +738,10 @@ extern "C" int maua_nn_median_f32(const float* ch, float* out, int n_bins, int n
         return MAUA_EINVAL;
     const size_t small = (size_t)k * sizeof(int) + (size_t)n_bins * k * sizeof(float);
     const size_t lds = (size_t)n_frames * sizeof(double) + small;
-    static int attr_rc = -1;  // (a failure is returned by every call instead of being swallowed)
-    if (attr_rc < 0) {
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024);
-        if (!attr_rc)
-            attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(nn_median_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    }
-    if (attr_rc) return attr_rc;
+    static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
+    static unsigned long long lds_ok1 = 0;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(nn_median_kernel<true>), &lds_ok, 150 * 1024)) return rc;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(nn_median_kernel<false>), &lds_ok1, 150 * 1024)) return rc;
     if (!ws) {
         if (lds > 150 * 1024) return MAUA_EINVAL;  // long track: the caller must supply the workspace
         hipLaunchKernelGGL(nn_median_kernel<true>, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, ch, out, n_bins, n_frames, k,

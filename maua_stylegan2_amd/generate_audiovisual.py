@@ -171,14 +171,15 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
     ar.set_SMF(args.fps / 30)  # temporal smoothing independent of the frame rate
 
     rank, world = sharding.rank_world()
+    grouped = sharding.grouped()  # a process group of ANY size (one rank included) takes the collective order of operations
     # One process per GPU: the audio front end and the latent / noise / truncation callbacks run on rank 0 only and their
     # per-frame results are scattered.  Bends and rewrites are closures, so a plugin that defines them is run on every rank;
     # every rank re-seeds its torch / numpy / python generators from one broadcast seed IMMEDIATELY before get_bends and before
     # get_rewrites (rank 0 has consumed draws in the latent / noise callbacks by then, the others have not), so that random
     # draws inside them — e.g. AddNoise(0.025 * th.randn(...)) in examples/kelp.py, tauceti.py — agree across shards.
-    everywhere = world > 1 and (get_bends is not None or get_rewrites is not None)
+    everywhere = grouped and (get_bends is not None or get_rewrites is not None)
     front_end = rank == 0 or everywhere
-    if world > 1:
+    if grouped:
         seed = int(sharding.broadcast_object(random.randrange(2 ** 31) if rank == 0 else None))
         if everywhere:
             _seed_all(seed)
@@ -200,7 +201,7 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
     # order (generator after the preprocessing, :215-224), so the callbacks see the same random stream as there.
     generator = None
     will_bend = get_bends is not None or get_rewrites is not None
-    if world > 1:
+    if grouped:
         generator = load()
         if rank != 0:
             render.prepare(generator, batch, bends=will_bend)
@@ -233,12 +234,12 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
 
     if front_end and get_bends is not None:
         print("generating network bends...")
-        if world > 1:
+        if grouped:
             _seed_all(seed + 1)
         bends = get_bends(args=args)
     if front_end and get_rewrites is not None:
         print("generating model rewrites...")
-        if world > 1:
+        if grouped:
             _seed_all(seed + 2)
         rewrites = get_rewrites(args=args)
     if rank == 0:
@@ -249,7 +250,7 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
             truncation = float(truncation)
 
     shard = None
-    if world > 1:
+    if grouped:
         latents, noise, truncation = _scatter_from_rank0(latents, noise, truncation, bends, rewrites, n_frames)
         lo, hi = sharding.shard_bounds(n_frames, rank, world)
         shard = (lo, hi, n_frames)
@@ -257,7 +258,7 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
     gc.collect()
     if generator is None:
         generator = load()
-    if world > 1 and not stylegan1 and not (isinstance(truncation, float) and truncation == 1.0):
+    if grouped and not stylegan1 and not (isinstance(truncation, float) and truncation == 1.0):
         # the truncation centre is a random draw (mean_latent(2**14), reference models/stylegan2.py:539-540): one draw, on rank
         # 0, for every shard — otherwise neighbouring shards are truncated toward slightly different centres
         centre = generator.mean_latent(2 ** 14) if rank == 0 else th.empty(1, latent_dim, device=render.device_of(generator))

@@ -148,6 +148,17 @@ class SinkWorker:
         self._check()
         self._work.put((wait, frames, count, release))
 
+    def feed(self, wait, frames, count, release=None):
+        """``submit`` for a HELPER thread (the host transport's reader): never raises and never takes the sink's error off the worker —
+        the error stays where the launch thread's next ``submit`` / ``close`` finds it.  Returns False once the sink has failed (the
+        batch is dropped and its slot released: the helper can stop feeding)."""
+        if self.error is not None:
+            if release is not None:
+                release()
+            return False
+        self._work.put((wait, frames, count, release))
+        return True
+
     def close(self):
         """Wait until everything submitted has been written (or dropped after an error), then re-raise a sink error."""
         if self._thread.is_alive():
@@ -197,8 +208,20 @@ def crop_resize_for_delivery(u8, out_size, scratch):
 
 
 _LANE_STREAMS = {}
+_RING_LOCKS = {}  # device index -> lock held by the single-GPU render loop while it uses that device's rings (two renders in two threads)
 _PINNED_RING = {}  # device index -> pinned staging slots of the single-GPU render loop (reallocated when the frame shape changes)
 _DEVICE_RING = {}  # device index -> their device-side twins (a batch leaves its lane's frame buffer before it crosses PCIe)
+
+
+def release_rings(device=None):
+    """Free the pinned / device staging rings of the single-GPU render loop (6 x batch frames each, kept across renders by default) for
+    ``device`` (index or torch.device; default: every device)."""
+    index = None if device is None else (th.device(device).index if not isinstance(device, int) else device)
+    for ring in (_PINNED_RING, _DEVICE_RING):
+        for key in list(ring):
+            if index is None or key == index:
+                with _RING_LOCKS.setdefault(key, threading.Lock()):
+                    del ring[key]
 
 
 def _lane_stream(dev, k):
@@ -414,14 +437,19 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
         sink = FrameSink(output_file, width, height, n_frames / duration, audio_file, offset, duration, ffmpeg_preset)
 
     worker = SinkWorker(sink) if sink is not None else None
+    locked = False
     try:
-        if world == 1:
+        if not sharding.grouped():
             # pinned staging ring: the D2H of batch k overlaps the replays of the next batches; the sink thread writes a slot and
             # hands it back through `free` (the launch thread blocks here only when the sink is `n_slots` batches behind)
             n_lanes, n_slots = 3, 6
             copy_stream = th.cuda.Stream(dev)
-            pinned = _PINNED_RING.setdefault(dev.index, [None] * n_slots)  # kept across renders: pinning 6 x 25 MB is ~40 ms
-            staged = _DEVICE_RING.setdefault(dev.index, [None] * n_slots)
+            index = dev.index if dev.index is not None else th.cuda.current_device()  # torch.device("cuda") carries no index
+            ring_lock = _RING_LOCKS.setdefault(index, threading.Lock())
+            ring_lock.acquire()  # the rings are per device, not per render: a second render on this device (another thread) waits
+            locked = True
+            pinned = _PINNED_RING.setdefault(index, [None] * n_slots)  # kept across renders: pinning 6 x 25 MB is ~40 ms
+            staged = _DEVICE_RING.setdefault(index, [None] * n_slots)
             free = queue.Queue()
             for i in range(n_slots):
                 free.put(i)
@@ -458,10 +486,15 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
             k = 0
             resized = {}
 
+            stop_reader = threading.Event()  # set when this rank's launch loop fails: the reader must not outlive the store
+
             def start_reader():
                 def run():
-                    for _, count, host in store.rounds_in_order():
-                        worker.submit(None, host.numpy(), count, None)
+                    # (worker.feed, not submit: a sink error must stay on the worker for the LAUNCH thread — popped here it would end
+                    # this thread, clear itself, and the render would return a truncated video without an exception)
+                    for _, count, host in store.rounds_in_order(stop=stop_reader.is_set):
+                        if not worker.feed(None, host.numpy(), count, None):
+                            return
 
                 t = threading.Thread(target=run, name="maua-host-gather", daemon=True)
                 t.start()
@@ -484,8 +517,11 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
                 store.finish()
                 if reader is not None:
                     reader.join()
-                    worker.close()
+                    worker.close()  # re-raises a sink error on the launch thread
             finally:
+                if reader is not None and reader.is_alive():  # the launch loop failed: stop the reader BEFORE its segments go away
+                    stop_reader.set()
+                    reader.join()
                 if store is not None:
                     store.close()
         else:
@@ -521,9 +557,11 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
     finally:  # the encoder process / output file must not outlive a failed render
         if worker is not None:
             try:
-                worker.close()
+                worker.close()  # (also: every ring slot has been written before the rings are handed to the next render)
             except BaseException:  # noqa: BLE001 - (a second failure while unwinding must not mask the first)
                 pass
+        if locked:
+            ring_lock.release()
         if sink is not None:
             sink.close()
     return sink.count if sink is not None else 0

@@ -28,6 +28,14 @@ def rank_world():
     return 0, 1
 
 
+def grouped():
+    """True when a process group exists — whatever its size.  Every helper below takes its REAL collective branch then, also in a
+    group of one rank: `torchrun --nproc-per-node 1` on the nccl backend issues the same dist.broadcast / dist.scatter / asynchronous
+    dist.gather sequence as an 8-rank job (round 4 returned early for world == 1, so a one-rank RCCL run proved nothing about the
+    collectives).  Without a process group there is nothing to call and the local short cuts apply."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def max_shard(n_frames, world):
     return (n_frames + world - 1) // world
 
@@ -43,7 +51,7 @@ def broadcast_module(module, src=0):
     """Make every rank's parameters and buffers equal rank ``src``'s: ONE broadcast per dtype of a flat staging buffer (the
     1024^2 generator is 171 tensors / 133 MB; per-tensor broadcasts were 171 collectives, most of them latency-bound)."""
     rank, world = rank_world()
-    if world == 1:
+    if not grouped():
         return module
     by_dtype = {}
     # (the tensors themselves, not .data: copy_ below then advances their version counters, which is what the packed-weight cache,
@@ -67,8 +75,7 @@ def broadcast_module(module, src=0):
 
 
 def broadcast_tensor(t, src=0):
-    rank, world = rank_world()
-    if world > 1:
+    if grouped():
         dist.broadcast(t, src)
     return t
 
@@ -79,7 +86,7 @@ def gather_frames(shard, n_frames, dst=0, chunk=64):
     blocks stay on ``dst``'s device (3 MiB per 1024^2 frame) and are brought to the host ``chunk`` frames at a time while
     the iterator is consumed, so host memory does not grow with the length of the video."""
     rank, world = rank_world()
-    if world == 1:
+    if not grouped():
         blocks = [(shard, min(n_frames, shard.shape[0]))]
     else:
         bufs = [th.empty_like(shard) for _ in range(world)] if rank == dst else None
@@ -104,7 +111,7 @@ def gather_frames(shard, n_frames, dst=0, chunk=64):
 def broadcast_object(obj, src=0):
     """Small picklable metadata (shapes, which noise scales are None) from ``src`` to every rank."""
     rank, world = rank_world()
-    if world == 1:
+    if not grouped():
         return obj
     box = [obj if rank == src else None]
     dist.broadcast_object_list(box, src=src)
@@ -116,7 +123,7 @@ def scatter_frames(t, n_frames, src=0, device=None):
     ``t[shard_bounds(n_frames, rank, world)]`` on ``device`` and nothing else.  ``None`` on ``src`` stays ``None`` everywhere
     (a noise scale served by the checkpoint's buffer)."""
     rank, world = rank_world()
-    if world == 1:
+    if not grouped():
         return t if t is None or device is None else t.to(device)
     meta = broadcast_object(None if t is None else (tuple(t.shape[1:]), str(t.dtype).replace("torch.", "")), src)
     if meta is None:
@@ -159,6 +166,7 @@ class FrameStream:
 
     def __init__(self, n_frames, batch_size, frame_shape, device, dst=0, ring_slots=6):
         self.rank, self.world = rank_world()
+        self.grouped = grouped()  # a group of ONE rank still gathers for real (into its own store)
         self.n_frames, self.batch, self.dst = int(n_frames), int(batch_size), dst
         self.per = max_shard(n_frames, self.world)
         self.rounds = (self.per + self.batch - 1) // self.batch
@@ -173,6 +181,7 @@ class FrameStream:
         self.store = th.empty((self.world, slots) + self.shape, dtype=th.uint8, device=device) if self.rank == dst else None
         self.works = []
         self.pushed = 0
+        self.bytes_gathered = 0  # bytes this rank has handed to / received from dist.gather (bench.py's `rccl` block)
         self._cursor = (0, 0)  # (rank, round) of the next frames to hand out on dst
         # dst's way to the host: a ring of pinned staging buffers filled by asynchronous copies on a copy stream, so that
         # fetching round k overlaps the Python thread launching the next replays (as render() does on one GPU); on a CPU
@@ -201,9 +210,10 @@ class FrameStream:
             ev = th.cuda.Event()
             ev.record(th.cuda.current_stream(self.mine.device))
             self._pushed_events.append(ev)
-        if self.world > 1:
+        if self.grouped:
             into = [self.store[p, k * self.batch: (k + 1) * self.batch] for p in range(self.world)] if self.rank == self.dst else None
             self.works.append(dist.gather(slot, into, dst=self.dst, async_op=True))
+            self.bytes_gathered += slot.numel() * (self.world if self.rank == self.dst else 1)
         elif self.store is not None:
             self.store[0, k * self.batch: (k + 1) * self.batch].copy_(slot)
             self.works.append(None)
@@ -356,6 +366,19 @@ class HostFrameStore:
         self.token = str(token)
         self.round_bytes = self.batch * int(np.prod(self.shape))
         size = self.HEADER + max(self.rounds, 1) * self.round_bytes
+        # tmpfs reserves nothing at ftruncate: a segment larger than what /dev/shm can still hold dies with SIGBUS on first touch,
+        # not with a Python error (64 MB is the container default) — check first
+        try:
+            import os
+
+            vfs = os.statvfs("/dev/shm")
+            free_bytes = vfs.f_bavail * vfs.f_frsize
+        except OSError:
+            free_bytes = None
+        if free_bytes is not None and size > free_bytes:
+            raise RuntimeError(f"MAUA_FRAME_TRANSPORT=host: rank {self.rank} needs a {size / 2**20:.0f} MiB shared-memory segment for its "
+                               f"{max(self.rounds, 1) * self.batch} frames but /dev/shm has {free_bytes / 2**20:.0f} MiB free — enlarge "
+                               f"/dev/shm (docker --shm-size) or use the default gather transport")
         self._mine = shared_memory.SharedMemory(name=self._name(self.rank), create=True, size=size)
         self._header = np.ndarray((2,), dtype=np.int64, buffer=self._mine.buf)
         self._header[:] = 0
@@ -374,7 +397,7 @@ class HostFrameStore:
         self._published = 0
         self._lock = threading.Lock()
         self._peers = {}
-        if self.world > 1:
+        if grouped():
             dist.barrier()  # every segment exists before anybody attaches
 
     def _name(self, rank):
@@ -439,16 +462,23 @@ class HostFrameStore:
         if p not in self._peers:
             np = self._np
             shm = self._shm_mod.SharedMemory(name=self._name(p))
+            try:  # Python < 3.13 registers ATTACHED segments with this process's resource tracker as well: the owner unlinks them,
+                from multiprocessing import resource_tracker  # a second unlink at exit only prints warnings
+
+                resource_tracker.unregister(shm._name, "shared_memory")
+            except Exception:  # noqa: BLE001 - bookkeeping only
+                pass
             header = np.ndarray((2,), dtype=np.int64, buffer=shm.buf)
             frames = th.from_numpy(np.ndarray((max(self.rounds, 1), self.batch) + self.shape, dtype=np.uint8, buffer=shm.buf,
                                               offset=self.HEADER))
             self._peers[p] = (shm, header, frames)
         return self._peers[p][1], self._peers[p][2]
 
-    def rounds_in_order(self, poll_s=0.0005, own_progress=None):
+    def rounds_in_order(self, poll_s=0.0005, own_progress=None, stop=None):
         """Rank 0: yield (first_frame_index, count, uint8 host tensor [count, H, W, 3]) for every round in global frame order
         (rank-major), waiting for each to be published.  ``own_progress()`` is called while waiting on rank 0's OWN rounds (its
-        publisher runs on the thread that pushes)."""
+        publisher runs on the thread that pushes).  ``stop()`` returning True ends the iteration (the launch loop failed: the reader
+        thread must leave before the segments are closed)."""
         import time
 
         for p in range(self.world):
@@ -457,6 +487,8 @@ class HostFrameStore:
             k = 0
             while lo + k * self.batch < hi:
                 while int(header[0]) <= k:
+                    if stop is not None and stop():
+                        return
                     if p == self.rank:
                         self.publish(block=False)
                         if own_progress is not None:
@@ -469,7 +501,7 @@ class HostFrameStore:
 
     def close(self):
         """Collective: every rank keeps its segment until rank 0 has read it."""
-        if self.world > 1:
+        if grouped():
             dist.barrier()
         for shm, _, _ in self._peers.values():
             shm.close()

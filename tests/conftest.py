@@ -6,6 +6,8 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+if os.path.join(REPO, "tests") not in sys.path:  # tests/played_world.py (spawned workers import test modules by name as well)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 

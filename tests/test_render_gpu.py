@@ -632,6 +632,7 @@ def test_render_rank_shards_on_device_equal_single_rank(gpu, tmp_path, monkeypat
     monkeypatch.setattr(sharding, "FrameStream", Recording)
     for rank in (0, 1):
         monkeypatch.setattr(sharding, "rank_world", lambda r=rank: (r, 2))
+        monkeypatch.setattr(sharding, "grouped", lambda: True)  # (the collective branches are taken whenever a process group exists)
         lo, hi = sharding.shard_bounds(n, rank, 2)
         out = str(tmp_path / f"rank{rank}.mp4")
         written = render.render(g, lat, noise, 0, n / 30, 2, 512, out)
