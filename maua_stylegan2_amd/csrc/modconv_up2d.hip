@@ -101,9 +101,22 @@ struct Up2dArgs {
     int s_stride;
     float wscale;
     int tiles_x, tiles_y, m_tiles, n_chunks;
+#ifdef MAUA_EXPERIMENTS
+    // FUSE = 1 (tools/fuse_probe.py, profiles/r05_fused_upconv_blur.md): the Blur + noise + bias + leaky ReLU of the StyledConv run in THIS
+    // kernel's epilogue on the accumulators; yb [B, Cout, 2H, 2W] receives the activated map and the raw (2H+1) x (2W+1) map is never
+    // written.  The halo a tile needs from its neighbours is taken as ZERO here (wrong by construction in the 3 rows / 3 columns at every
+    // tile seam): the launch measures the epilogue's cost in this matrix-bound kernel before the exact halo handling is paid for.
+    float* yb;
+    const float* k4;       // [4][4] blur taps (separable: row sums x column sums / total)
+    const float* noise;    // [B or 1, 1, 2H, 2W] or null
+    const float* noise_w;  // [1]
+    const float* bias;     // [Cout] or null
+    int64_t noise_batch_stride;
+    int real_blocks;       // blocks beyond this number repeat earlier tiles (emulates the extra tiles an overlapped tiling launches)
+#endif
 };
 
-template <int CC>
+template <int CC, int FUSE = 0>
 __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     constexpr int U2_A_FLOATS = u2_a_floats(CC), U2_PBUF = u2_pbuf(CC), U2_P_INSTR = u2_p_instr(CC);
     constexpr int A_PER_WAVE = 2 * CC / 4;                 // weight DMA instructions per wave and K step
@@ -119,6 +132,9 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     const int j = lane & 15, kq = lane >> 4;
 
     int t = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef MAUA_EXPERIMENTS
+    if (FUSE && t >= p.real_blocks) t -= p.real_blocks;  // (redundant tiles: see real_blocks)
+#endif
     const int mt_id = t % p.m_tiles;
     t /= p.m_tiles;
     const int tile_x = t % p.tiles_x;
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     // The right-edge tiles of the first m-tile export the last input column from their staged patch (row float 35 = image column
     // tx0 + 31 = W - 1) into xcol[b][c][row]: the edge kernel then reads that column with unit stride (gathering it from x costs
     // one 128-byte line per element: 32 of the edge launch's 45 us)
-    const bool export_col = mt_id == 0 && tx0 + 32 == p.W && wv == 3 && lane < CC * 8;
+    const bool export_col = FUSE == 0 && mt_id == 0 && tx0 + 32 == p.W && wv == 3 && lane < CC * 8;
     const int ex_c = lane >> 3, ex_r = lane & 7;
     int cur = 0;
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
@@ -292,6 +308,133 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         cur ^= 1;
     }
 
+#ifdef MAUA_EXPERIMENTS
+    if constexpr (FUSE != 0) {
+        // ---- fused epilogue (experiment): raw 4 x 4 patches -> separable 4-tap blur -> noise / bias / leaky ReLU -> [B, Cout, 2H, 2W].
+        // out[Y][X] = sum_ij K[i][j] raw[Y - 1 + i][X - 1 + j] (upfirdn2d with pad (1, 1), reference models/stylegan2.py:229-238).
+        // This lane: raw rows R0 .. R0 + 3 (R0 = 2 ty0 + 4 wv), raw columns C0 .. C0 + 3 (C0 = 2 tx0 + 4 j), channels 16 m + 4 kq + v.
+        //   horizontal pass: the lane's 4 columns need raw columns C0 - 1 .. C0 + 5: column 3 of lane j - 1 and columns 0, 1 of lane j + 1
+        //     (DPP row shifts inside the 16-lane row of one K lane group; the row ends read 0);
+        //   vertical pass: wave w emits output rows R0 - 2 .. R0 + 1 from the h-rows R0 - 3 .. R0 + 3: its own four and rows 1 .. 3 of the
+        //     wave above (through LDS, in the operand buffers the K loop has released; wave 0: zero — the tile above in the exact form).
+        // All arithmetic on channel PAIRS (registers 2 vp, 2 vp + 1 of an accumulator tile): v_pk_* instructions.
+        float kx[4], ky[4];
+        {
+            float kk[4][4], total = 0.f, rs[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) kk[a][b] = p.k4[(3 - a) * 4 + (3 - b)], rs[a] += kk[a][b], cs[b] += kk[a][b], total += kk[a][b];
+            const float inv = 1.f / total;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ky[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rs[a] * inv)));
+                kx[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cs[a])));
+            }
+        }
+        const float act_gain = 1.41421356237309515f;
+        const int OHb = 2 * p.H, OWb = 2 * p.W;
+        const int Y0 = 2 * ty0 + 4 * wv - 2, X0 = 2 * tx0 + 4 * j;
+        const float nw = p.noise ? p.noise_w[0] * act_gain : 0.f;
+        const float* nzp = p.noise ? p.noise + (size_t)b0 * p.noise_batch_stride + (size_t)(Y0 < 0 ? 0 : Y0) * OWb + X0 : p.k4;
+        const int nzs = p.noise ? OWb : 0;
+        float* xch = lds;  // exchange region [parity 2][wave 4][row 3][lane 64][8 floats] = 48 KB over the weight / patch buffers
+        float* ybimg = p.yb + ((size_t)b0 * p.Cout + m0) * ((size_t)OHb * OWb);
+        auto shr1 = [](f32x2 v) {  // value of lane j - 1 (0 at j = 0)
+            return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x111, 0xf, 0xf, true)),
+                         __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0x111, 0xf, 0xf, true))};
+        };
+        auto shl1 = [](f32x2 v) {  // value of lane j + 1 (0 at j = 15)
+            return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x101, 0xf, 0xf, true)),
+                         __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0x101, 0xf, 0xf, true))};
+        };
+        // phase sums first, for all eight channels: 200 accumulator registers become 128 raw values before the blur's temporaries exist
+        f32x2 Rall[4][4][4];  // [channel pair][row][col]
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = it >> 1, vp = it & 1;
+            auto pr = [&](const f32x4& a) { return vp ? f32x2{a[2], a[3]} : f32x2{a[0], a[1]}; };
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x2 ee00 = pr(acc_ee[i][0][m]), ee01 = pr(acc_ee[i][1][m]), ee02 = pr(acc_ee[i][2][m]);
+                const f32x2 ee10 = pr(acc_ee[i + 1][0][m]), ee11 = pr(acc_ee[i + 1][1][m]), ee12 = pr(acc_ee[i + 1][2][m]);
+                const f32x2 mid = ee01 + ee11;
+                Rall[it][2 * i][0] = (ee00 + ee10) + mid;
+                Rall[it][2 * i][2] = mid + (ee02 + ee12);
+                Rall[it][2 * i][1] = pr(acc_eo[i][0][m]) + pr(acc_eo[i + 1][0][m]);
+                Rall[it][2 * i][3] = pr(acc_eo[i][1][m]) + pr(acc_eo[i + 1][1][m]);
+                const f32x2 oe1 = pr(acc_oe[i][1][m]);
+                Rall[it][2 * i + 1][0] = pr(acc_oe[i][0][m]) + oe1;
+                Rall[it][2 * i + 1][2] = oe1 + pr(acc_oe[i][2][m]);
+                Rall[it][2 * i + 1][1] = pr(acc_oo[i][0][m]);
+                Rall[it][2 * i + 1][3] = pr(acc_oo[i][1][m]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = it >> 1, vp = it & 1;
+            const f32x2(&R)[4][4] = Rall[it];
+            // horizontal pass
+            f32x2 Hh[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 left = shr1(R[r][3]), right0 = shl1(R[r][0]), right1 = shl1(R[r][1]);
+                const f32x2 e[7] = {left, R[r][0], R[r][1], R[r][2], R[r][3], right0, right1};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Hh[r][c] = ((e[c] * kx[0] + e[c + 1] * kx[1]) + e[c + 2] * kx[2]) + e[c + 3] * kx[3];
+            }
+            // rows 1 .. 3 to the wave below
+            float* mine = xch + (size_t)(((it & 1) * 4 + wv) * 3) * 64 * 8 + lane * 8;
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+                *reinterpret_cast<f32x4*>(mine + (r - 1) * 64 * 8) = f32x4{Hh[r][0].x, Hh[r][0].y, Hh[r][1].x, Hh[r][1].y};
+                *reinterpret_cast<f32x4*>(mine + (r - 1) * 64 * 8 + 4) = f32x4{Hh[r][2].x, Hh[r][2].y, Hh[r][3].x, Hh[r][3].y};
+            }
+            __syncthreads();
+            f32x2 S[7][4];
+            const float* above = xch + (size_t)(((it & 1) * 4 + (wv ? wv - 1 : 0)) * 3) * 64 * 8 + lane * 8;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) S[r][c] = f32x2{0.f, 0.f};  // (wave 0: the tile above, zero in this experiment)
+            if (wv != 0) {  // (uniform)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(above + r * 64 * 8), hi = *reinterpret_cast<const f32x4*>(above + r * 64 * 8 + 4);
+                    S[r][0] = f32x2{lo[0], lo[1]}, S[r][1] = f32x2{lo[2], lo[3]}, S[r][2] = f32x2{hi[0], hi[1]}, S[r][3] = f32x2{hi[2], hi[3]};
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) S[3 + r][c] = Hh[r][c];
+            // vertical pass + tail + stores
+            const int ol = 16 * m + 4 * kq + 2 * vp;
+            const f32x2 gain2 = f32x2{Eg[ol] * act_gain, Eg[ol + 1] * act_gain};
+            const f32x2 bias2 = p.bias ? f32x2{p.bias[m0 + ol] * act_gain, p.bias[m0 + ol + 1] * act_gain} : f32x2{0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x2 val[4];
+                const f32x4 nzq = *reinterpret_cast<const f32x4*>(nzp + (Y0 < 0 ? (q >= 2 ? q - 2 : 0) : q) * nzs) * nw;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x2 bl = ((S[q][c] * ky[0] + S[q + 1][c] * ky[1]) + S[q + 2][c] * ky[2]) + S[q + 3][c] * ky[3];
+                    const f32x2 tt = bl * gain2 + (f32x2{nzq[c], nzq[c]} + bias2);
+                    val[c] = __builtin_elementwise_max(tt, tt * 0.2f);
+                }
+                const int Y = Y0 + q;
+                if (Y >= 0 && Y < OHb) {
+                    float* dst = ybimg + ((size_t)ol * OHb + Y) * OWb + X0;
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{val[0].x, val[1].x, val[2].x, val[3].x};
+                    *reinterpret_cast<f32x4*>(dst + (size_t)OHb * OWb) = f32x4{val[0].y, val[1].y, val[2].y, val[3].y};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+#endif
     // ---- epilogue: phase sums, per-channel gain, 16-byte stores of the 4 x 4 output patch
     const int OW = 2 * p.W + 1;
     const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
@@ -485,6 +628,35 @@ int maua_up2d_edge_launch(const float* x, const float* edge_taps, const float* s
     MAUA_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef MAUA_EXPERIMENTS
+// Experiment entry (tools/fuse_probe.py): the transposed convolution with the Blur + noise + bias + activation in its epilogue, tile halos
+// taken as zero; `extra_pct` launches that many per cent of redundant tiles on top (the price of an overlapped tiling).
+extern "C" int maua_exp_upconv_blur_fused_f32(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* yb,
+                                              const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                              const float* bias, int batch, int cin, int cout, int h, int w, float wscale, int extra_pct,
+                                              void* stream) {
+    if (!maua_modconv_up2d_ok(cin, cout, h, w) || !yb || !k4) return MAUA_EINVAL;
+    const int cc = u2_cc(cin);
+    if (cc != 8) return MAUA_ENOSYS;
+    Up2dArgs a{};
+    a.x = x, a.wq = wq, a.s = s, a.d = d, a.y = nullptr, a.xcol = nullptr;
+    a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
+    a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
+    a.yb = yb, a.k4 = k4, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.noise_batch_stride = noise_batch_stride;
+    const size_t k_loop = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM);
+    const size_t lds_bytes = k_loop > 49152 + 4096 ? k_loop : 49152 + 4096;
+    if ((size_t)2 * u2_a_floats(cc) * 4 + (size_t)2 * u2_pbuf(cc) * 4 < 49152) return MAUA_ENOSYS;  // the exchange region must end below the styles / gains
+    const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
+    a.real_blocks = (int)blocks;
+    const int64_t launched = blocks + blocks * extra_pct / 100;
+    static unsigned long long lds_ok = 0;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 1>), &lds_ok, 160 * 1024)) return rc;
+    hipLaunchKernelGGL((modconv_up2d_kernel<8, 1>), dim3((unsigned)launched), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+#endif
 
 int64_t maua_up2d_ws_floats(int batch, int cin, int h) { return (int64_t)batch * cin * h; }
 

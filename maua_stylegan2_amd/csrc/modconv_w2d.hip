@@ -176,6 +176,15 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
 #ifndef MAUA_W2D_MINB32
 #define MAUA_W2D_MINB32 3
 #endif
+//   MAUA_W2D_TN64 / MAUA_W2D_MINB64  the same for the layers of 64 and more output channels (TM = 4).  2 n-tiles at two workgroups per CU
+//       (247 VGPRs); the round-5 experiment is 4 n-tiles at ONE workgroup per CU = one wave per SIMD with a 512-register budget, twice the
+//       outputs per transformed window and per weight piece (VERDICT r4 item 4 i; profiles/r05_w2d_one_wave_per_simd.md)
+#ifndef MAUA_W2D_TN64
+#define MAUA_W2D_TN64 2
+#endif
+#ifndef MAUA_W2D_MINB64
+#define MAUA_W2D_MINB64 2
+#endif
 
 template <int TM, int TN, int MINB = 2>
 __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
@@ -1214,7 +1223,7 @@ int maua_w2d_tiles(int cin, int cout, int h, int w, int* tm, int* tn) {
     if (cout == 64) m = 2, n = MAUA_W2D_TN32;
     else
 #endif
-    if (cout % 64 == 0) m = 4, n = 2;
+    if (cout % 64 == 0) m = 4, n = MAUA_W2D_TN64;
     else if (cout == 32) m = 2, n = MAUA_W2D_TN32;
     else return 0;
     if (h % (4 * n)) return 0;
@@ -1253,7 +1262,7 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
         return w2dw_launch(a, st);
     }
 #endif
-    return tm == 4 ? w2d_launch_t<4, 2>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32>(a, st);
+    return tm == 4 ? w2d_launch_t<4, MAUA_W2D_TN64, MAUA_W2D_MINB64>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32>(a, st);
 }
 
 extern "C" int maua_pack_weight_wino2d_f32(const float* w, float* wq, int cout, int cin, void* stream) {

@@ -498,9 +498,11 @@ def nn_filter_median(ch, width=1):
     return out
 
 
-def chroma(y, sr, n_frames, margin=16, notes=12, type="stft", nearest_neighbor=False):
+def chroma(y, sr, n_frames, margin=16, notes=12, type="stft", nearest_neighbor=False, return_order=False):
     """signal.py:136-156: harmonic separation (:150) -> raw_chroma (:102-133; "stft" chromagram, optionally CENS
-    post-processed and nearest-neighbour median filtered) -> resample -> note selection -> per-frame normalisation."""
+    post-processed and nearest-neighbour median filtered) -> resample -> note selection -> per-frame normalisation.
+    ``return_order``: also return (pitch class of every output column, the medians the columns were ordered by) — the
+    tests compare column for column and allow a swap only between columns whose medians are closer than their tolerance."""
     if margin:
         y = hpss(y, margin)[0]
     raw = chroma_stft(y, sr) if type == "stft" else chroma_cqt(y, sr)
@@ -510,9 +512,11 @@ def chroma(y, sr, n_frames, margin=16, notes=12, type="stft", nearest_neighbor=F
         raw = np.minimum(raw, nn_filter_median(raw))
     ch = raw.T
     ch = resample(ch, n_frames)
-    keep = np.argsort(np.median(ch, axis=0))[:notes]
+    medians = np.median(ch, axis=0)
+    keep = np.argsort(medians)[:notes]
     ch = ch[:, keep]
-    return torch.from_numpy(ch / ch.sum(1)[:, None]).float()
+    out = torch.from_numpy(ch / ch.sum(1)[:, None]).float()
+    return (out, keep, medians[keep]) if return_order else out
 
 
 def perlin_noise(shape, res, theta, phi, tileable=(True, False, False)):

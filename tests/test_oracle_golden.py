@@ -142,45 +142,37 @@ def test_oracle_audio_features_are_sane():
     assert int(np.argmax(signal_oracle.chroma_stft(tone, sr).mean(axis=1))) == 9
 
 
-def test_c_restatement_matches_golden(golden):
+def test_c_restatement_matches_golden():
     """oracle/c/ops_ref.c (scalar loops, independent of the conv2d-based oracle) against the reference's outputs."""
-    import ctypes
     import os
     import subprocess
 
+    from c_oracle_check import check_c_oracle
     from conftest import REPO
 
     subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=True, capture_output=True)
-    lib = ctypes.CDLL(os.path.join(REPO, "oracle", "c", "libops_ref.so"))
-    fp = ctypes.POINTER(ctypes.c_float)
-    g = golden("ops_upfirdn2d.npz")
-    for name in g["cases"]:
-        up, down, p0, p1 = (int(v) for v in g[f"{name}.cfg"])
-        x = np.ascontiguousarray(g[f"{name}.x"], dtype=np.float32)
-        k = np.ascontiguousarray(g[f"{name}.k"], dtype=np.float32)
-        want = g[f"{name}.y"]
-        n, c, h, w = x.shape
-        y = np.zeros(want.shape, np.float32)
-        rc = lib.ref_upfirdn2d(x.ctypes.data_as(fp), k.ctypes.data_as(fp), y.ctypes.data_as(fp), n * c, h, w, 1,
-                               k.shape[0], k.shape[1], up, up, down, down, p0, p1, p0, p1)
-        assert rc == 0
-        np.testing.assert_allclose(y, want, atol=1e-5, err_msg=str(name))
-    g = golden("ops_fused_leaky_relu.npz")
-    lib.ref_fused_bias_act.argtypes = [fp, fp, fp, fp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                       ctypes.c_int, ctypes.c_float, ctypes.c_float]
-    for name in g["cases"]:
-        x = np.ascontiguousarray(g[f"{name}.x"], dtype=np.float32)
-        b = np.ascontiguousarray(g[f"{name}.b"], dtype=np.float32)
-        y = np.zeros_like(x)
-        step = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
-        lib.ref_fused_bias_act(x.ctypes.data_as(fp), b.ctypes.data_as(fp), None, y.ctypes.data_as(fp), x.size, b.size,
-                               step, 3, 0, 0.2, 2 ** 0.5)
-        np.testing.assert_allclose(y, g[f"{name}.y"], atol=1e-6)
-    g = golden("postprocess.npz")
-    x = np.ascontiguousarray(g["x"], dtype=np.float32)
-    out = np.zeros(g["y"].shape, np.uint8)
-    lib.ref_frames_to_u8(x.ctypes.data_as(fp), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 1, 4, 8)
-    assert (out == g["y"]).all()
+    check_c_oracle(os.path.join(REPO, "oracle", "c", "libops_ref.so"))
+
+
+def test_c_restatement_under_asan_and_ubsan():
+    """SURVEY.md 5 row 2 (sanitizers), VERDICT r4 item 6: the same golden check with oracle/c/ops_ref.c built with
+    -fsanitize=address,undefined -fno-sanitize-recover=all (`make -C oracle san`), in a subprocess that pre-loads gcc's ASAN runtime: any
+    out-of-bounds access, signed overflow, misaligned or invalid shift in the scalar restatement aborts the run."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle"), "san"], check=True, capture_output=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], check=True, capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan):
+        pytest.skip("gcc has no shared ASAN runtime here")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "c_oracle_check.py"), os.path.join(REPO, "oracle", "c", "libops_ref_san.so")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "c oracle ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
 
 
 # ---------------------------------------------------------------------------------------------------------------------

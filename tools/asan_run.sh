@@ -1,0 +1,34 @@
+#!/bin/bash
+# Sanitizer runs of the native library on the GPU box.  Builds come from
+# `python -m maua_stylegan2_amd.build --asan-host` / `--asan` (hipcc cross-compiles them without a GPU; they travel with the snapshot).
+#   leg 1  host ASAN + UBSan (launchers, argument checks, host-side tables; device code uninstrumented): the ops / property suites with the
+#          clang ASAN runtime pre-loaded into python and MAUA_TEST_LIB pointing at the build (tests/conftest.py).
+#   leg 2  device ASAN (gfx950:xnack+, HSA_XNACK=1): the ops suite, under a hard timeout — complete device reports need the ASAN build of
+#          the ROCm runtime (/opt/rocm/lib/asan), which this image does not ship; whatever the stock runtime makes of it is recorded.
+# Output: gpurun_out/asan/{host,device}.log + summary.txt
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/asan
+mkdir -p "$O"
+cd "$R"
+RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:detect_odr_violation=0:log_path=$O/asan_report
+export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$O/ubsan_report
+TESTS="tests/test_ops_gpu.py tests/test_property_gpu.py"
+{
+  echo "== leg 1: host ASAN + UBSan build, $TESTS"
+  LD_PRELOAD=$RT MAUA_TEST_LIB=maua_stylegan2_amd/csrc/san/libmaua_hip_hostasan.so timeout 900 python -m pytest $TESTS -q -m gpu -x -p no:cacheprovider 2>&1 | tail -15
+  echo "rc=${PIPESTATUS[0]}"
+} > "$O/host.log" 2>&1
+{
+  echo "== leg 2: device ASAN build (gfx950:xnack+), HSA_XNACK=1, tests/test_ops_gpu.py"
+  HSA_XNACK=1 LD_PRELOAD=$RT MAUA_TEST_LIB=maua_stylegan2_amd/csrc/san/libmaua_hip_asan.so timeout 300 python -m pytest tests/test_ops_gpu.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -25
+  echo "rc=${PIPESTATUS[0]}"
+} > "$O/device.log" 2>&1
+{
+  echo "sanitizer runs on $(python -c 'import torch;print(torch.cuda.get_device_name(0))' 2>/dev/null), $(date -u +%FT%TZ)"
+  echo "--- host ASAN + UBSan"; tail -4 "$O/host.log"
+  echo "--- device ASAN"; tail -8 "$O/device.log"
+  echo "--- sanitizer report files:"; ls "$O" | grep -c "_report" ; for f in "$O"/*_report*; do [ -f "$f" ] && { echo "## $f"; head -40 "$f"; }; done
+} > "$O/summary.txt" 2>&1
+cat "$O/summary.txt" | head -80

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Fused transposed-convolution + blur: measurement harness for the experiment build.
+
+    tools/build_exp.sh fuse && python tools/fuse_probe.py --lib tools/bin/libmaua_fuse.so
+
+For the up-sampling layers of the 1024^2 generator it runs, on the same inputs,
+  (a) the product pair: maua_modconv3x3_f32 (mode 6: raw (2H+1) x (2W+1) map + edge lines) -> maua_blur_noise_act_f32, and
+  (b) the experiment kernel maua_exp_upconv_blur_fused_f32 (blur + noise + bias + leaky ReLU in the up-conv's epilogue, tile halos = 0),
+checks (b) against (a) on every pixel whose 4 x 4 blur footprint lies inside one workgroup tile (the seam rows / columns are wrong by
+construction in the experiment), and times (a)'s two launches, (b), and (b) with 12 / 20 % redundant tiles — the work an exact
+overlapped tiling (x: 60 of 64 columns per tile kept, y: a warm-up tile per vertical segment) adds.  Prints one JSON object."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maua_stylegan2_amd import _lib, seeding  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", required=True)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=3)
+    args = ap.parse_args()
+    torch.set_grad_enabled(False)
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    fused = raw.maua_exp_upconv_blur_fused_f32
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    fused.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, i64, vp, vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, vp]
+    fused.restype = ctypes.c_int
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(dev)
+    sp = stream.cuda_stream
+    B = args.batch
+    out = {}
+    k4 = torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)).to(dev)
+    with torch.cuda.stream(stream):
+        for name, cin, cout, h in [("convs.14 64->32 @512", 64, 32, 512), ("convs.12 128->64 @256", 128, 64, 256),
+                                   ("convs.10 256->128 @128", 256, 128, 128), ("convs.8 512->256 @64", 512, 256, 64)]:
+            m = ModulatedConv2d(cin, cout, 3, 512, upsample=True).to(dev)
+            assert m.conv_mode(h, h) == 6
+            x = torch.randn(B, cin, h, h, device=dev)
+            s = torch.randn(B, cin, device=dev)
+            d = torch.rand(B, cout, device=dev) + 0.5
+            raw_map = torch.empty(B, cout, 2 * h + 1, 2 * h + 1, device=dev)
+            ref = torch.empty(B, cout, 2 * h, 2 * h, device=dev)
+            got = torch.full((B, cout, 2 * h, 2 * h), float("nan"), device=dev)
+            nz = torch.randn(B, 1, 2 * h, 2 * h, device=dev)
+            nw = torch.full((1,), 0.3, device=dev)
+            bias = torch.randn(cout, device=dev)
+            nws = lib.maua_modconv_ws_floats(B, cin, cout, h, h, 6)
+            ws = torch.empty(max(nws, 1), device=dev)
+            wq = m.packed_wino(6)
+
+            def pair_up():
+                m.run(x, s, 0, d, raw_map, ws)
+
+            def pair_tail():
+                _lib.check(lib.maua_blur_noise_act_f32(raw_map.data_ptr(), k4.data_ptr(), ref.data_ptr(), B, cout, 2 * h + 1, 2 * h + 1, 4, 4,
+                                                       1, 1, None, nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, sp),
+                           "maua_blur_noise_act_f32")
+
+            def run_fused(extra):
+                rc = fused(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), got.data_ptr(), k4.data_ptr(), nz.data_ptr(),
+                           4 * h * h, nw.data_ptr(), bias.data_ptr(), B, cin, cout, h, h, float(m.scale), extra, sp)
+                _lib.check(rc, "maua_exp_upconv_blur_fused_f32")
+
+            pair_up(), pair_tail(), run_fused(0)
+            stream.synchronize()
+            # pixels the experiment computes exactly: rows 16 t + 1 .. 16 t + 13, columns 64 u + 1 .. 64 u + 61
+            yy = torch.arange(2 * h, device=dev) % 16
+            xx = torch.arange(2 * h, device=dev) % 64
+            mask = ((yy >= 1) & (yy <= 13))[:, None] & ((xx >= 1) & (xx <= 61))[None, :]
+            diff = (got - ref).abs()
+            inner = diff[:, :, mask]
+            written = ~torch.isnan(got)
+            rec = {"interior_max_abs_err": float(inner.max()), "interior_share": float(mask.float().mean()),
+                   "ref_abs_mean": float(ref.abs().mean()), "rows_never_written": int((~written[0, 0].any(1)).sum()),
+                   "seam_max_abs_err": float(torch.nan_to_num(diff[:, :, ~mask], nan=0.0).max())}
+
+            def timed(fn):
+                e0, e1 = _lib.HipEvent(), _lib.HipEvent()
+                fn()
+                e0.record(sp)
+                for _ in range(args.iters):
+                    fn()
+                e1.record(sp)
+                return e0.elapsed_ms(e1) / args.iters
+
+            rows = {"pair_upconv_ms": [], "pair_tail_ms": [], "fused_ms": [], "fused_plus12_ms": [], "fused_plus20_ms": []}
+            for _ in range(args.rounds):  # alternating rounds: the chip's clock drifts with load
+                rows["pair_upconv_ms"].append(timed(pair_up))
+                rows["pair_tail_ms"].append(timed(pair_tail))
+                rows["fused_ms"].append(timed(lambda: run_fused(0)))
+                rows["fused_plus12_ms"].append(timed(lambda: run_fused(12)))
+                rows["fused_plus20_ms"].append(timed(lambda: run_fused(20)))
+            for key, vals in rows.items():
+                rec[key] = float(np.median(vals))
+            rec["pair_ms"] = rec["pair_upconv_ms"] + rec["pair_tail_ms"]
+            out[name] = rec
+        stream.synchronize()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
