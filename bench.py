@@ -498,6 +498,9 @@ def main():
     ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
+    ap.add_argument("--fused-blur-min-width", type=int, default=None,
+                    help="A/B switch: override StyledConv.fused_blur_min_width (narrowest up-sampling layer input that runs transposed conv + blur + "
+                         "noise + activation as ONE kernel; a huge value = always the two-launch path)")
     ap.add_argument("--up2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.upwino2d_min_cout (smallest transposed layer on the 2-D F(2,2) kernel)")
     args = ap.parse_args()
@@ -534,6 +537,8 @@ def main():
         ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
     if args.up2d_min_cout is not None:
         ModulatedConv2d.upwino2d_min_cout = args.up2d_min_cout
+    if args.fused_blur_min_width is not None:
+        StyledConv.fused_blur_min_width = args.fused_blur_min_width
 
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)

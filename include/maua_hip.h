@@ -20,7 +20,7 @@ extern "C" {
 #define MAUA_ENOSYS (-38)
 
 /* ABI version of this header; bumped on any signature change. */
-int maua_abi_version(void);  /* 2: frame source (maua_frame_source_t) arguments; no tuning entry */
+int maua_abi_version(void);  /* 3: + maua_upconv_blur_f32 (round 5); 2: frame source (maua_frame_source_t) arguments; no tuning entry */
 /* Number of compute units / name of device 0 (diagnostics for bench.py). */
 int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
 
@@ -84,6 +84,23 @@ int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch,
                             int kh, int kw, int pad0, int pad1, const float* gain, const float* noise,
                             int64_t noise_batch_stride, const float* noise_w, const float* bias,
                             const maua_frame_source_t* src, int noise_slot, void* stream);
+
+/* The WHOLE up-sampling StyledConv in one pass (round 5): transposed 3x3 modulated convolution (stride 2) -> Blur (4x4 SEPARABLE taps, pad
+ * (1, 1)) -> NoiseInjection -> FusedLeakyReLU — models/stylegan2.py:229-238,262-266,338-343 — without the raw (2H+1) x (2W+1) map that
+ * maua_modconv3x3_f32 (mode 6) writes and maua_blur_noise_act_f32 reads back (548 MB per 1024^2 frame each way):
+ *   y[b,o] = lrelu_0.2( blur( conv_transpose2d(x[b] * s[b], W)[o] ) * wscale * d[b,o] + noise_w * noise[b,0] + bias[o] ) * sqrt(2),  y [B,Cout,2H,2W].
+ * The blur runs on the accumulators of csrc/modconv_up2d.hip (F(2,2) on both axes of the polyphase form): horizontal pass across the lanes
+ * of a wave, vertical pass across the waves of a workgroup through LDS; a workgroup walks a vertical segment of tiles and keeps the three
+ * halo rows in LDS; the rows either side of a segment boundary go through `ws` to a small second launch.  `wq` = maua_pack_weight_up2d_f32.
+ * `k4`: the [4][4] tap matrix in DEVICE memory; it MUST be separable (outer product, as make_kernel([1,3,3,1]) is) — the caller checks.
+ * `ws`: maua_upconv_blur_ws_floats(...) floats.  Shapes: maua_upconv_blur_ok (cin % 8 == 0, cin <= 256, cout % 32 == 0, h % 8 == 0,
+ * w % 32 == 0); MAUA_ENOSYS otherwise (the two-launch path serves every shape). */
+int maua_upconv_blur_ok(int cin, int cout, int h, int w);
+int64_t maua_upconv_blur_ws_floats(int batch, int cin, int cout, int h, int w);
+int maua_upconv_blur_f32(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws,
+                         const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
+                         const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w, float wscale,
+                         void* stream);
 
 /* All style affines and demodulation factors of one forward, two launches in total, table-driven.
  *  affine (EqualLinear, models/stylegan2.py:140-146,207,220), with the truncation lerp of Generator.forward

@@ -35,6 +35,7 @@
 #include "common.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -45,6 +46,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4u __attribute__((aligned(4)));
 typedef f32x2 f32x2u __attribute__((aligned(4)));
 
@@ -101,28 +103,60 @@ struct Up2dArgs {
     int s_stride;
     float wscale;
     int tiles_x, tiles_y, m_tiles, n_chunks;
-#ifdef MAUA_EXPERIMENTS
-    // FUSE = 1 (tools/fuse_probe.py, profiles/r05_fused_upconv_blur.md): the Blur + noise + bias + leaky ReLU of the StyledConv run in THIS
-    // kernel's epilogue on the accumulators; yb [B, Cout, 2H, 2W] receives the activated map and the raw (2H+1) x (2W+1) map is never
-    // written.  The halo a tile needs from its neighbours is taken as ZERO here (wrong by construction in the 3 rows / 3 columns at every
-    // tile seam): the launch measures the epilogue's cost in this matrix-bound kernel before the exact halo handling is paid for.
+    // ---- FUSE != 0: the Blur + noise + bias + leaky ReLU of the up-sampling StyledConv (reference models/stylegan2.py:229-238, :310-343) run
+    // in this kernel's epilogue; yb [B, Cout, 2H, 2W] receives the activated map and the raw (2H+1) x (2W+1) map is never written.
     float* yb;
-    const float* k4;       // [4][4] blur taps (separable: row sums x column sums / total)
+    const float* k4;       // [4][4] blur taps, SEPARABLE (row sums x column sums / total; checked by the launcher's caller)
     const float* noise;    // [B or 1, 1, 2H, 2W] or null
     const float* noise_w;  // [1]
     const float* bias;     // [Cout] or null
     int64_t noise_batch_stride;
-    int real_blocks;       // blocks beyond this number repeat earlier tiles (emulates the extra tiles an overlapped tiling launches)
+    const maua_frame_source_t* src;  // frame source: noise from src->noise[noise_slot] at frame src->frame0
+    int noise_slot;
+    // FUSE == 2 (exact): tiles_y counts vertical SEGMENTS of seg_tiles tiles, walked by one workgroup (tiles_total_y = H / 8 + 1 tiles: the
+    // last one holds raw row 2H only); x tiles step 28 positions (56 of a tile's 64 raw columns are kept); hbuf [B][Cout][n_seg - 1][6][2W]
+    // receives the h-rows either side of a segment boundary for up2d_seam_kernel
+    float* hbuf;
+    int seg_tiles, tiles_total_y;
+#ifdef MAUA_EXPERIMENTS
+    int real_blocks;       // FUSE == 1 (tools/fuse_probe.py): blocks beyond this number repeat earlier tiles (the price of an overlapped tiling)
 #endif
 };
 
+// Compile-time ablation mask of the fused kernel, experiments builds only (results wrong by construction): 1 no second barrier / saved rows,
+// 2 no seam exports, 4 no output stores, 16 aligned 64-column tiles that keep every lane (the halo-free tiling, with everything else of FUSE == 2)
+#if !defined(MAUA_EXPERIMENTS)
+#undef MAUA_FUSE_ABL
+#endif
+#ifndef MAUA_FUSE_ABL
+#define MAUA_FUSE_ABL 0
+#endif
+#define FUSE_ABL(bits) ((MAUA_FUSE_ABL & (bits)) != 0)
+
+// Separable factors of the 4 x 4 blur: K[a][b] (flipped taps: out[Y][X] = sum K[a][b] raw[Y - 1 + a][X - 1 + b]) = ky[a] * kx[b]
+__device__ __forceinline__ void u2_blur_taps(const float* k4, float (&kx)[4], float (&ky)[4]) {
+    float kk[4][4], total = 0.f, rs[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) kk[a][b] = k4[(3 - a) * 4 + (3 - b)], rs[a] += kk[a][b], cs[b] += kk[a][b], total += kk[a][b];
+    const float inv = 1.f / total;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        ky[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rs[a] * inv)));
+        kx[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cs[a])));
+    }
+}
+
+// FUSE: 0 = the raw (2H+1) x (2W+1) map (mode 6 of maua_modconv3x3_f32); 2 = the whole up-sampling StyledConv, exact (maua_upconv_blur_f32);
+// 1 = experiments builds only: the fused epilogue with the tile halos taken as zero (the measurement that preceded the exact form)
 template <int CC, int FUSE = 0>
 __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     constexpr int U2_A_FLOATS = u2_a_floats(CC), U2_PBUF = u2_pbuf(CC), U2_P_INSTR = u2_p_instr(CC);
     constexpr int A_PER_WAVE = 2 * CC / 4;                 // weight DMA instructions per wave and K step
     constexpr int P_PER_WAVE = (U2_P_INSTR + 3) / 4;       // patch DMA instructions per wave and K step (the last ones may be idle)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // LDS: As[2][A_FLOATS] | Ps[2][PBUF] | Ss[Cin]
+    // LDS: As[2][A_FLOATS] | Ps[2][PBUF] | Ss[Cin] | Eg[32] | (FUSE == 2) SV[4][3][64][8]: the h-rows the next tile of the segment needs
     float* Ps = lds + 2 * U2_A_FLOATS;
     float* Ss = Ps + 2 * U2_PBUF;
 
@@ -133,36 +167,25 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 
     int t = xcd_remap(blockIdx.x, gridDim.x);
 #ifdef MAUA_EXPERIMENTS
-    if (FUSE && t >= p.real_blocks) t -= p.real_blocks;  // (redundant tiles: see real_blocks)
+    if (FUSE == 1 && t >= p.real_blocks) t -= p.real_blocks;  // (redundant tiles: see real_blocks)
 #endif
     const int mt_id = t % p.m_tiles;
     t /= p.m_tiles;
     const int tile_x = t % p.tiles_x;
     t /= p.tiles_x;
-    const int tile_y = t % p.tiles_y;
+    const int tile_y = t % p.tiles_y;                  // FUSE == 2: the vertical segment
     const int b0 = t / p.tiles_y;
-    const int ty0 = tile_y * 8, tx0 = tile_x * 32;   // first position row / column of the tile
+    const int tx0 = tile_x * ((FUSE == 2 && !FUSE_ABL(16)) ? 28 : 32);    // first position column of the tile
+    const int first_tile = FUSE == 2 ? tile_y * p.seg_tiles : tile_y;
+    const int n_tiles = (FUSE == 2 && !FUSE_ABL(32)) ? min(p.seg_tiles, p.tiles_total_y - first_tile) : 1;  // (ablation 32: one tile per workgroup, known at compile time; run with MAUA_FUSE_SEG=1)
     const int m0 = mt_id * U2_BM;
     const size_t plane = (size_t)p.H * p.W;
 
-    // ---- patch DMA of this lane (decoded once).  Slot s = 64 i + lane of instruction i is 16-byte slot s of the buffer:
-    // channel s / 88, then row (s % 88) / 9 and segment (s % 88) % 9 (slots 81..87 of a channel are padding).  Rows above / below
-    // the image, the segment left of column 0 and the padding get an offset beyond the buffer descriptor's range, for which a
-    // raw buffer load returns 0: the DMA itself writes the zero padding.  Wave w issues instructions w, w + 4, ...
-    unsigned rel_bytes[P_PER_WAVE];
-#pragma unroll
-    for (int g = 0; g < P_PER_WAVE; ++g) {
-        const int s = 64 * (wv + 4 * g) + lane;
-        const int c = s / (U2_PLANE / 4), rem = s % (U2_PLANE / 4);
-        const int pr = rem / U2_PSEGS, sg = rem % U2_PSEGS;
-        const int yy = ty0 - 1 + pr, xx = tx0 - 4 + 4 * sg;
-        const bool ok = c < CC && rem < U2_PROWS * U2_PSEGS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        rel_bytes[g] = ok ? (unsigned)((size_t)c * plane + (size_t)yy * p.W + xx) * 4u : 0x80000000u;
-    }
     for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
 
     const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
     const size_t plane_bytes = plane * sizeof(float);
+    unsigned rel_bytes[P_PER_WAVE];
     (void)ximg, (void)plane_bytes, (void)rel_bytes;
 #ifdef MAUA_DEVICE_PASS
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
@@ -190,6 +213,63 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 #endif
     };
 
+    // LDS byte addresses (buffer 0) of this lane's operands; the second buffer is a constant distance away.
+    // window of block j, channel kq: staged rows 2 w .. 2 w + 2, floats 2 j + 3 .. 2 j + 5 of a row (float 3 = image column
+    // tx0 - 1), read as two aligned 8-byte pairs (2 j + 2, 2 j + 3) and (2 j + 4, 2 j + 5)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    // weight row of entry u, channel c of the K step: (u * CC + c) * 32 + 2 * j (m-tile pair interleaved: one 8-byte read feeds
+    // both m-tiles)
+    constexpr unsigned A_BUF_BYTES = U2_A_FLOATS * 4u, P_BUF_BYTES = U2_PBUF * 4u;
+    constexpr int U_BYTES = CC * U2_BM * 4;     // distance between transformed-kernel entries in the weight tile
+    constexpr int KG_A_BYTES = 4 * U2_BM * 4;   // ... between the MFMA K groups (4 channels) of one entry
+    constexpr int KG_P_BYTES = 4 * U2_PLANE * 4;  // ... between the K groups' channel planes in the patch
+    constexpr int ROW_BYTES = U2_PWS * 4;
+
+    // per-channel gain (wscale * demod) of the epilogue: fetched under the first DMA wait into LDS behind the styles (loaded after
+    // the main loop, its round trip was exposed in every workgroup)
+    float* Eg = lds + 2 * U2_A_FLOATS + 2 * U2_PBUF + ((p.Cin + 3) & ~3);
+    for (int i = tid; i < U2_BM; i += 256) {
+        float gain = p.wscale;
+        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
+        Eg[i] = gain;
+    }
+    float* SV = Eg + U2_BM;
+    if constexpr (FUSE == 2) {
+        // h-rows above the segment's first tile: zero — exact at the top of the image (raw rows -3 .. -1 are padding); below a segment
+        // boundary the three output rows that would need them are left to up2d_seam_kernel
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(SV + (i * 256 + tid) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#if defined(MAUA_EXPERIMENTS) && defined(MAUA_FUSE_STAGGER)
+    // (experiment: the two workgroups of a CU start in lock-step and, with equal work, stay there — K loops together, epilogues together;
+    // delaying every other workgroup by part of a tile time puts one's latency-bound epilogue under the other's matrix-bound K loop)
+    if (FUSE == 2 && (blockIdx.x & 1))
+        for (int i = 0; i < MAUA_FUSE_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    for (int tile = 0; tile < n_tiles; ++tile) {
+    const int ty0 = (first_tile + tile) * 8;   // first position row of the tile
+    // (FUSE == 2: everything derived from the lane id is re-derived per tile behind an opaque copy — hoisted out of the tile loop these
+    // values would have to survive a K loop that uses 238 registers, i.e. live in scratch)
+    int lane_t = lane;
+    if constexpr (FUSE == 2) asm volatile("" : "+v"(lane_t));
+    const int j_t = lane_t & 15, kq_t = lane_t >> 4;
+    const unsigned b_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + kq_t * U2_PLANE + (2 * wv) * U2_PWS + 2 * j_t + 2) * 4u;
+    const unsigned a_addr = lds0 + (unsigned)(kq_t * U2_BM + 2 * j_t) * 4u;
+    // ---- patch DMA of this lane.  Slot s = 64 i + lane of instruction i is 16-byte slot s of the buffer:
+    // channel s / 88, then row (s % 88) / 9 and segment (s % 88) % 9 (slots 81..87 of a channel are padding).  Rows above / below
+    // the image, segments left / right of it and the padding get an offset beyond the buffer descriptor's range, for which a
+    // raw buffer load returns 0: the DMA itself writes the zero padding.  Wave w issues instructions w, w + 4, ...
+#pragma unroll
+    for (int g = 0; g < P_PER_WAVE; ++g) {
+        const int s = 64 * (wv + 4 * g) + lane_t;
+        const int c = s / (U2_PLANE / 4), rem = s % (U2_PLANE / 4);
+        const int pr = rem / U2_PSEGS, sg = rem % U2_PSEGS;
+        const int yy = ty0 - 1 + pr, xx = tx0 - 4 + 4 * sg;
+        const bool ok = c < CC && rem < U2_PROWS * U2_PSEGS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        rel_bytes[g] = ok ? ((unsigned)c * (unsigned)plane + (unsigned)yy * (unsigned)p.W + (unsigned)xx) * 4u : 0x80000000u;  // (< 2^31: checked by the launcher)
+    }
+
     // ---- accumulators (one 16 x 16 tile = 4 registers each; [.][m-tile]): 25 products x 2 m-tiles = 200 registers
     // (zeroed here: a peeled first K group with C = 0, as in modconv_w2d.hip, spills 20 registers in the CC = 8 instance)
     f32x4 acc_ee[3][3][2], acc_eo[3][2][2], acc_oe[2][3][2], acc_oo[2][2][2];
@@ -210,30 +290,8 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 for (int b = 0; b < 2; ++b) acc_oo[a][b][m] = z4;
         }
     }
+    unsigned s_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + 2 * U2_PBUF + kq_t) * 4u;
 
-    // LDS byte addresses (buffer 0) of this lane's operands; the second buffer is a constant distance away.
-    // window of block j, channel kq: staged rows 2 w .. 2 w + 2, floats 2 j + 3 .. 2 j + 5 of a row (float 3 = image column
-    // tx0 - 1), read as two aligned 8-byte pairs (2 j + 2, 2 j + 3) and (2 j + 4, 2 j + 5)
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
-    const unsigned b_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + kq * U2_PLANE + (2 * wv) * U2_PWS + 2 * j + 2) * 4u;
-    // weight row of entry u, channel c of the K step: (u * CC + c) * 32 + 2 * j (m-tile pair interleaved: one 8-byte read feeds
-    // both m-tiles)
-    const unsigned a_addr = lds0 + (unsigned)(kq * U2_BM + 2 * j) * 4u;
-    unsigned s_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + 2 * U2_PBUF + kq) * 4u;
-    constexpr unsigned A_BUF_BYTES = U2_A_FLOATS * 4u, P_BUF_BYTES = U2_PBUF * 4u;
-    constexpr int U_BYTES = CC * U2_BM * 4;     // distance between transformed-kernel entries in the weight tile
-    constexpr int KG_A_BYTES = 4 * U2_BM * 4;   // ... between the MFMA K groups (4 channels) of one entry
-    constexpr int KG_P_BYTES = 4 * U2_PLANE * 4;  // ... between the K groups' channel planes in the patch
-    constexpr int ROW_BYTES = U2_PWS * 4;
-
-    // per-channel gain (wscale * demod) of the epilogue: fetched under the first DMA wait into LDS behind the styles (loaded after
-    // the main loop, its round trip was exposed in every workgroup)
-    float* Eg = lds + 2 * U2_A_FLOATS + 2 * U2_PBUF + ((p.Cin + 3) & ~3);
-    for (int i = tid; i < U2_BM; i += 256) {
-        float gain = p.wscale;
-        if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
-        Eg[i] = gain;
-    }
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -308,45 +366,64 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         cur ^= 1;
     }
 
-#ifdef MAUA_EXPERIMENTS
     if constexpr (FUSE != 0) {
-        // ---- fused epilogue (experiment): raw 4 x 4 patches -> separable 4-tap blur -> noise / bias / leaky ReLU -> [B, Cout, 2H, 2W].
-        // out[Y][X] = sum_ij K[i][j] raw[Y - 1 + i][X - 1 + j] (upfirdn2d with pad (1, 1), reference models/stylegan2.py:229-238).
+        // ---- fused epilogue: raw 4 x 4 patches -> separable 4-tap blur -> noise / bias / leaky ReLU -> [B, Cout, 2H, 2W].
+        // out[Y][X] = sum_ab K[a][b] raw[Y - 1 + a][X - 1 + b] (upfirdn2d with pad (1, 1), reference models/stylegan2.py:229-238).
         // This lane: raw rows R0 .. R0 + 3 (R0 = 2 ty0 + 4 wv), raw columns C0 .. C0 + 3 (C0 = 2 tx0 + 4 j), channels 16 m + 4 kq + v.
         //   horizontal pass: the lane's 4 columns need raw columns C0 - 1 .. C0 + 5: column 3 of lane j - 1 and columns 0, 1 of lane j + 1
-        //     (DPP row shifts inside the 16-lane row of one K lane group; the row ends read 0);
+        //     (DPP row shifts inside the 16-lane row of one K lane group; the row ends read 0: lane 0 is exact only at the image's left
+        //     edge, lane 15 never — FUSE == 2 keeps lanes 1 .. 14 of a tile, the tiles step 56 raw columns);
         //   vertical pass: wave w emits output rows R0 - 2 .. R0 + 1 from the h-rows R0 - 3 .. R0 + 3: its own four and rows 1 .. 3 of the
-        //     wave above (through LDS, in the operand buffers the K loop has released; wave 0: zero — the tile above in the exact form).
+        //     wave above, through LDS (in the operand buffers the K loop has released); wave 0 takes them from the PREVIOUS tile of its
+        //     segment (SV, written by wave 3), so a workgroup walking down a segment never recomputes or re-reads a halo row.
         // All arithmetic on channel PAIRS (registers 2 vp, 2 vp + 1 of an accumulator tile): v_pk_* instructions.
+        // The kernel arguments the epilogue needs are RE-READ from the kernarg segment per tile (scalar loads through an opaque pointer):
+        // taken from `p` they are loop invariants that the compiler keeps in ~50 SGPRs across the K loop, i.e. spills to vector lanes.
+        typedef const __attribute__((address_space(4))) Up2dArgs* KernargPtr;
+        KernargPtr pk = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        if constexpr (FUSE == 2) asm volatile("" : "+s"(pk));
+        // (per-tile copies of the lane's coordinates behind an opaque barrier: without it the compiler hoists the epilogue's address arithmetic
+        // out of the tile loop and carries ~90 registers across the K loop — as spills)
+        int lane_e = lane_t;
+        asm volatile("" : "+v"(lane_e));
+        const int j_e = lane_e & 15, kq_e = lane_e >> 4;
         float kx[4], ky[4];
-        {
-            float kk[4][4], total = 0.f, rs[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) kk[a][b] = p.k4[(3 - a) * 4 + (3 - b)], rs[a] += kk[a][b], cs[b] += kk[a][b], total += kk[a][b];
-            const float inv = 1.f / total;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                ky[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rs[a] * inv)));
-                kx[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cs[a])));
-            }
-        }
+        u2_blur_taps(pk->k4, kx, ky);
         const float act_gain = 1.41421356237309515f;
-        const int OHb = 2 * p.H, OWb = 2 * p.W;
-        const int Y0 = 2 * ty0 + 4 * wv - 2, X0 = 2 * tx0 + 4 * j;
-        const float nw = p.noise ? p.noise_w[0] * act_gain : 0.f;
-        const float* nzp = p.noise ? p.noise + (size_t)b0 * p.noise_batch_stride + (size_t)(Y0 < 0 ? 0 : Y0) * OWb + X0 : p.k4;
-        const int nzs = p.noise ? OWb : 0;
+        const int OHb = 2 * pk->H, OWb = 2 * pk->W;
+        const int Y0 = 2 * ty0 + 4 * wv - 2, X0 = 2 * tx0 + 4 * j_e;
+        const float* noise_base = pk->noise;
+        int64_t noise_bstride = pk->noise_batch_stride;
+        if (pk->src) {  // (uniform scalar loads)
+            noise_bstride = pk->src->noise_stride[pk->noise_slot];
+            noise_base = pk->src->noise[pk->noise_slot];
+            if (noise_base) noise_base += (int64_t)pk->src->frame0 * noise_bstride;
+        }
+        const float nw = noise_base ? pk->noise_w[0] * act_gain : 0.f;
+        // which of this lane's outputs are kept: FUSE == 2: lanes 1 .. 14 (+ lane 0 of the first tile column), inside the map
+        const bool x_keep = ((FUSE == 2 && !FUSE_ABL(16)) ? ((j_e >= 1 && j_e <= 14) || (j_e == 0 && tile_x == 0)) : true) && X0 < OWb;
+        const bool seam_above = FUSE == 2 && tile == 0 && tile_y > 0;  // the three rows above this tile's first kept row go to the seam kernel
+        const bool seam_below = FUSE == 2 && tile == n_tiles - 1 && first_tile + tile + 1 < pk->tiles_total_y;
+        const int Yx = Y0 < 0 ? 0 : (Y0 + 3 < OHb ? Y0 : (OHb >= 4 ? OHb - 4 : 0));  // (clamped row base of the noise loads: always inside the map)
+        const float* nzp = noise_base ? noise_base + (size_t)b0 * noise_bstride + (size_t)Yx * OWb + (X0 < OWb ? X0 : 0) : pk->k4;
+        const int nzs = noise_base ? OWb : 0;
         float* xch = lds;  // exchange region [parity 2][wave 4][row 3][lane 64][8 floats] = 48 KB over the weight / patch buffers
-        float* ybimg = p.yb + ((size_t)b0 * p.Cout + m0) * ((size_t)OHb * OWb);
-        auto shr1 = [](f32x2 v) {  // value of lane j - 1 (0 at j = 0)
-            return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x111, 0xf, 0xf, true)),
-                         __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0x111, 0xf, 0xf, true))};
+        float* ybimg = pk->yb + ((size_t)b0 * pk->Cout + m0) * ((size_t)OHb * OWb);
+        // neighbour lanes of the 16-lane row (one K lane group): DPP row shifts, 0 beyond the row ends.  (Scalar helpers on purpose:
+        // __builtin_bit_cast applied to the .y ELEMENT of an ext-vector gave poison in this compiler and the second lane's move vanished.)
+        auto dpp_from_left = [](float a) {
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x111, 0xf, 0xf, true));  // row_shr:1: lane j - 1
         };
-        auto shl1 = [](f32x2 v) {  // value of lane j + 1 (0 at j = 15)
-            return f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x101, 0xf, 0xf, true)),
-                         __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0x101, 0xf, 0xf, true))};
+        auto dpp_from_right = [](float a) {
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x101, 0xf, 0xf, true));  // row_shl:1: lane j + 1
+        };
+        auto shr1 = [&](f32x2 v) {
+            const float a = v.x, b = v.y;
+            return f32x2{dpp_from_left(a), dpp_from_left(b)};
+        };
+        auto shl1 = [&](f32x2 v) {
+            const float a = v.x, b = v.y;
+            return f32x2{dpp_from_right(a), dpp_from_right(b)};
         };
         // phase sums first, for all eight channels: 200 accumulator registers become 128 raw values before the blur's temporaries exist
         f32x2 Rall[4][4][4];  // [channel pair][row][col]
@@ -372,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < (FUSE_ABL(64) ? 1 : 4); ++it) {  // (ablation 64: one channel pair of four)
             const int m = it >> 1, vp = it & 1;
             const f32x2(&R)[4][4] = Rall[it];
             // horizontal pass
@@ -384,21 +461,39 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) Hh[r][c] = ((e[c] * kx[0] + e[c + 1] * kx[1]) + e[c + 2] * kx[2]) + e[c + 3] * kx[3];
             }
+            const int ol = 16 * m + 4 * kq_e + 2 * vp;   // first channel of the pair inside the m-tile pair
             // rows 1 .. 3 to the wave below
-            float* mine = xch + (size_t)(((it & 1) * 4 + wv) * 3) * 64 * 8 + lane * 8;
+            float* mine = xch + (size_t)(((it & 1) * 4 + wv) * 3) * 64 * 8 + lane_e * 8;
 #pragma unroll
             for (int r = 1; r < 4; ++r) {
                 *reinterpret_cast<f32x4*>(mine + (r - 1) * 64 * 8) = f32x4{Hh[r][0].x, Hh[r][0].y, Hh[r][1].x, Hh[r][1].y};
                 *reinterpret_cast<f32x4*>(mine + (r - 1) * 64 * 8 + 4) = f32x4{Hh[r][2].x, Hh[r][2].y, Hh[r][3].x, Hh[r][3].y};
             }
+            if constexpr (FUSE == 2) {
+                // the h-rows either side of a segment boundary go to hbuf [B][Cout][n_seg - 1][6][2W] (rows 0 .. 2: above, 3 .. 5: below)
+                if (!FUSE_ABL(2) && ((seam_above && wv == 0) || (seam_below && wv == 3))) {
+                    if (x_keep) {
+                        const int bnd = wv == 0 ? tile_y - 1 : tile_y;
+                        float* hb = pk->hbuf + ((((size_t)b0 * pk->Cout + m0 + ol) * (pk->tiles_y - 1) + bnd) * 6 + (wv == 0 ? 3 : 0)) * (size_t)OWb + X0;
+                        const size_t chs = (size_t)(pk->tiles_y - 1) * 6 * OWb;  // floats between channels
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const f32x2(&row)[4] = Hh[wv == 0 ? r : r + 1];
+                            *reinterpret_cast<f32x4*>(hb + (size_t)r * OWb) = f32x4{row[0].x, row[1].x, row[2].x, row[3].x};
+                            *reinterpret_cast<f32x4*>(hb + (size_t)r * OWb + chs) = f32x4{row[0].y, row[1].y, row[2].y, row[3].y};
+                        }
+                    }
+                }
+            }
             __syncthreads();
             f32x2 S[7][4];
-            const float* above = xch + (size_t)(((it & 1) * 4 + (wv ? wv - 1 : 0)) * 3) * 64 * 8 + lane * 8;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) S[r][c] = f32x2{0.f, 0.f};  // (wave 0: the tile above, zero in this experiment)
-            if (wv != 0) {  // (uniform)
+                for (int c = 0; c < 4; ++c) S[r][c] = f32x2{0.f, 0.f};  // (FUSE == 1: the tile above, zero in the experiment)
+            if (wv != 0 || FUSE == 2) {  // (uniform)
+                const float* above = wv != 0 ? xch + (size_t)(((it & 1) * 4 + (wv - 1)) * 3) * 64 * 8 + lane_e * 8
+                                             : SV + (size_t)(it * 3) * 64 * 8 + lane_e * 8;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(above + r * 64 * 8), hi = *reinterpret_cast<const f32x4*>(above + r * 64 * 8 + 4);
@@ -410,13 +505,12 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) S[3 + r][c] = Hh[r][c];
             // vertical pass + tail + stores
-            const int ol = 16 * m + 4 * kq + 2 * vp;
             const f32x2 gain2 = f32x2{Eg[ol] * act_gain, Eg[ol + 1] * act_gain};
-            const f32x2 bias2 = p.bias ? f32x2{p.bias[m0 + ol] * act_gain, p.bias[m0 + ol + 1] * act_gain} : f32x2{0.f, 0.f};
+            const f32x2 bias2 = pk->bias ? f32x2{pk->bias[m0 + ol] * act_gain, pk->bias[m0 + ol + 1] * act_gain} : f32x2{0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x2 val[4];
-                const f32x4 nzq = *reinterpret_cast<const f32x4*>(nzp + (Y0 < 0 ? (q >= 2 ? q - 2 : 0) : q) * nzs) * nw;
+                const f32x4 nzq = *reinterpret_cast<const f32x4*>(nzp + (Y0 + q - Yx < 0 ? 0 : (Y0 + q - Yx > 3 ? 3 : Y0 + q - Yx)) * nzs) * nw;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f32x2 bl = ((S[q][c] * ky[0] + S[q + 1][c] * ky[1]) + S[q + 2][c] * ky[2]) + S[q + 3][c] * ky[3];
@@ -424,43 +518,108 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                     val[c] = __builtin_elementwise_max(tt, tt * 0.2f);
                 }
                 const int Y = Y0 + q;
-                if (Y >= 0 && Y < OHb) {
+                const bool row_keep = Y >= 0 && Y < OHb && !(seam_above && wv == 0 && q < 3);  // (uniform)
+                if (row_keep && x_keep && !FUSE_ABL(4)) {
                     float* dst = ybimg + ((size_t)ol * OHb + Y) * OWb + X0;
                     *reinterpret_cast<f32x4*>(dst) = f32x4{val[0].x, val[1].x, val[2].x, val[3].x};
                     *reinterpret_cast<f32x4*>(dst + (size_t)OHb * OWb) = f32x4{val[0].y, val[1].y, val[2].y, val[3].y};
                 }
             }
+            if constexpr (FUSE == 2 && !FUSE_ABL(1)) {
+                // wave 3's rows 1 .. 3 are the next tile's rows above: written once every wave has read this tile's SV[it]
+                __syncthreads();
+                if (wv == 3) {
+                    float* sv = SV + (size_t)(it * 3) * 64 * 8 + lane_e * 8;
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) {
+                        *reinterpret_cast<f32x4*>(sv + (r - 1) * 64 * 8) = f32x4{Hh[r][0].x, Hh[r][0].y, Hh[r][1].x, Hh[r][1].y};
+                        *reinterpret_cast<f32x4*>(sv + (r - 1) * 64 * 8 + 4) = f32x4{Hh[r][2].x, Hh[r][2].y, Hh[r][3].x, Hh[r][3].y};
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        return;
-    }
-#endif
-    // ---- epilogue: phase sums, per-channel gain, 16-byte stores of the 4 x 4 output patch
-    const int OW = 2 * p.W + 1;
-    const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
-    float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane_out;
-    const unsigned pix_off = (unsigned)(2 * (ty0 + 2 * wv)) * (unsigned)OW + (unsigned)(2 * (tx0 + 2 * j));
+        if constexpr (FUSE == 2) __syncthreads();  // (the next tile's operand DMA overwrites the exchange region)
+    } else {
+        // ---- epilogue: phase sums, per-channel gain, 16-byte stores of the 4 x 4 output patch
+        const int OW = 2 * p.W + 1;
+        const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
+        float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane_out;
+        const unsigned pix_off = (unsigned)(2 * (ty0 + 2 * wv)) * (unsigned)OW + (unsigned)(2 * (tx0 + 2 * j));
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int ol = m * 16 + 4 * kq + v;  // row of the 16 x 16 result tile held in register v
-            const float gain = Eg[ol];
-            float* dst = yimg + (size_t)ol * plane_out + pix_off;
+            for (int v = 0; v < 4; ++v) {
+                const int ol = m * 16 + 4 * kq + v;  // row of the 16 x 16 result tile held in register v
+                const float gain = Eg[ol];
+                float* dst = yimg + (size_t)ol * plane_out + pix_off;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                // even output row of position row i: (ee, eo, ee, eo);  odd one: (oe, oo, oe, oo)
-                const float e0 = (acc_ee[i][0][m][v] + acc_ee[i][1][m][v]) + (acc_ee[i + 1][0][m][v] + acc_ee[i + 1][1][m][v]);
-                const float e1 = (acc_ee[i][1][m][v] + acc_ee[i][2][m][v]) + (acc_ee[i + 1][1][m][v] + acc_ee[i + 1][2][m][v]);
-                const float o0 = acc_eo[i][0][m][v] + acc_eo[i + 1][0][m][v];
-                const float o1 = acc_eo[i][1][m][v] + acc_eo[i + 1][1][m][v];
-                *reinterpret_cast<f32x4u*>(dst + (size_t)(2 * i) * OW) = f32x4{e0 * gain, o0 * gain, e1 * gain, o1 * gain};
-                const float f0 = acc_oe[i][0][m][v] + acc_oe[i][1][m][v];
-                const float f1 = acc_oe[i][1][m][v] + acc_oe[i][2][m][v];
-                *reinterpret_cast<f32x4u*>(dst + (size_t)(2 * i + 1) * OW) =
-                    f32x4{f0 * gain, acc_oo[i][0][m][v] * gain, f1 * gain, acc_oo[i][1][m][v] * gain};
+                for (int i = 0; i < 2; ++i) {
+                    // even output row of position row i: (ee, eo, ee, eo);  odd one: (oe, oo, oe, oo)
+                    const float e0 = (acc_ee[i][0][m][v] + acc_ee[i][1][m][v]) + (acc_ee[i + 1][0][m][v] + acc_ee[i + 1][1][m][v]);
+                    const float e1 = (acc_ee[i][1][m][v] + acc_ee[i][2][m][v]) + (acc_ee[i + 1][1][m][v] + acc_ee[i + 1][2][m][v]);
+                    const float o0 = acc_eo[i][0][m][v] + acc_eo[i + 1][0][m][v];
+                    const float o1 = acc_eo[i][1][m][v] + acc_eo[i + 1][1][m][v];
+                    *reinterpret_cast<f32x4u*>(dst + (size_t)(2 * i) * OW) = f32x4{e0 * gain, o0 * gain, e1 * gain, o1 * gain};
+                    const float f0 = acc_oe[i][0][m][v] + acc_oe[i][1][m][v];
+                    const float f1 = acc_oe[i][1][m][v] + acc_oe[i][2][m][v];
+                    *reinterpret_cast<f32x4u*>(dst + (size_t)(2 * i + 1) * OW) =
+                        f32x4{f0 * gain, acc_oo[i][0][m][v] * gain, f1 * gain, acc_oo[i][1][m][v] * gain};
+                }
             }
         }
+
+    }
+    }  // tiles of the segment
+}
+
+// The three output rows either side of every segment boundary of the exact fused kernel: vertical pass + tail over the six h-rows
+// modconv_up2d_kernel<., 2> left in hbuf [B][Cout][n_bnd][6][OW].  Boundary g lies above raw row R = 16 seg_tiles (g + 1): outputs R - 2, R - 1, R.
+__global__ __launch_bounds__(256) void up2d_seam_kernel(Up2dArgs p, int n_bnd) {
+    const int OHb = 2 * p.H, OWb = 2 * p.W;
+    const int xq = OWb / 4;  // 16-byte column groups per row
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.Cout * n_bnd * xq;
+    if (t >= total) return;
+    const int x4 = (int)(t % xq);
+    t /= xq;
+    const int g = (int)(t % n_bnd);
+    t /= n_bnd;
+    const int c = (int)(t % p.Cout), b = (int)(t / p.Cout);
+    float kx[4], ky[4];
+    u2_blur_taps(p.k4, kx, ky);
+    (void)kx;
+    const float act_gain = 1.41421356237309515f;
+    const float* noise_base = p.noise;
+    int64_t noise_bstride = p.noise_batch_stride;
+    if (p.src) {
+        noise_bstride = p.src->noise_stride[p.noise_slot];
+        noise_base = p.src->noise[p.noise_slot];
+        if (noise_base) noise_base += (int64_t)p.src->frame0 * noise_bstride;
+    }
+    const float nw = noise_base ? p.noise_w[0] * act_gain : 0.f;
+    float gain = p.wscale * act_gain;
+    if (p.d) gain *= p.d[(size_t)b * p.Cout + c];
+    const float bias = p.bias ? p.bias[c] * act_gain : 0.f;
+    const float* hb = p.hbuf + (((size_t)b * p.Cout + c) * n_bnd + g) * 6 * (size_t)OWb + 4 * x4;
+    f32x4 h[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) h[r] = *reinterpret_cast<const f32x4*>(hb + (size_t)r * OWb);
+    const int R = 16 * p.seg_tiles * (g + 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int Y = R - 2 + k;
+        if (Y < 0 || Y >= OHb) continue;
+        f32x4 nz = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (noise_base) nz = *reinterpret_cast<const f32x4*>(noise_base + (size_t)b * noise_bstride + (size_t)Y * OWb + 4 * x4) * nw;
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bl = ((h[k][e] * ky[0] + h[k + 1][e] * ky[1]) + h[k + 2][e] * ky[2]) + h[k + 3][e] * ky[3];
+            const float tt = bl * gain + (nz[e] + bias);
+            out[e] = fmaxf(tt, tt * 0.2f);
+        }
+        *reinterpret_cast<f32x4*>(p.yb + (((size_t)b * p.Cout + c) * OHb + Y) * (size_t)OWb + 4 * x4) = out;
     }
 }
 
@@ -629,6 +788,99 @@ int maua_up2d_edge_launch(const float* x, const float* edge_taps, const float* s
     return 0;
 }
 
+// ---- the whole up-sampling StyledConv in one pass over the accumulators (FUSE == 2) -------------------------------------------------------
+namespace {
+struct FusePlan {
+    int tiles_x, tiles_total_y, seg_tiles, n_seg;
+};
+// x: tiles step 28 positions = 56 raw columns (a tile keeps lanes 1 .. 14 of its 16 block columns; the first one also lane 0);
+// y: H / 8 tiles + one for raw row 2H, walked in segments of seg_tiles by one workgroup each.  seg_tiles balances two costs: every segment
+// boundary sends 6 h-rows through HBM to the seam kernel, and few long segments leave the last round of workgroups half empty.
+FusePlan fuse_plan(int batch, int cout, int h, int w) {
+    FusePlan f{};
+    f.tiles_x = 2 * w <= 60 ? 1 : (2 * w - 60 + 55) / 56 + 1;
+    if (FUSE_ABL(16)) f.tiles_x = w / 32;
+    f.tiles_total_y = h / 8 + 1;
+    static int slots = 0;
+    if (!slots) {
+        int cus = 0, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+    }
+    const int64_t strips = (int64_t)batch * f.tiles_x * (cout / U2_BM);
+    double best = 1e30;
+#ifdef MAUA_EXPERIMENTS
+    if (const char* force = getenv("MAUA_FUSE_SEG")) {  // (A/B: a fixed segment length)
+        f.seg_tiles = atoi(force) > 0 ? atoi(force) : 1;
+        f.n_seg = (f.tiles_total_y + f.seg_tiles - 1) / f.seg_tiles;
+        return f;
+    }
+#endif
+    for (int sg = 2; sg <= 16; ++sg) {
+        const int n_seg = (f.tiles_total_y + sg - 1) / sg;
+        const int64_t rounds = (strips * n_seg + slots - 1) / slots;
+        const double cost = (double)rounds * sg * slots / (double)(strips * f.tiles_total_y) + 0.25 / sg;  // launched / useful tile slots + seam share
+        if (cost < best - 1e-9) best = cost, f.seg_tiles = sg, f.n_seg = n_seg;
+    }
+    return f;
+}
+}  // namespace
+
+extern "C" int maua_upconv_blur_ok(int cin, int cout, int h, int w) {
+    return maua_modconv_up2d_ok(cin, cout, h, w) && u2_cc(cin) == 8 && cin <= 256;  // (LDS: operand buffers + styles + the 24 KB of saved rows)
+}
+
+extern "C" int64_t maua_upconv_blur_ws_floats(int batch, int cin, int cout, int h, int w) {
+    if (!maua_upconv_blur_ok(cin, cout, h, w)) return 0;
+    const FusePlan f = fuse_plan(batch, cout, h, w);
+    return (int64_t)batch * cout * (f.n_seg - 1) * 6 * 2 * w + 4;
+}
+
+extern "C" int maua_upconv_blur_f32(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws,
+                                    const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                    const float* bias, const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h,
+                                    int w, float wscale, void* stream) {
+    if (!x || !wq || !s || !y || !k4 || batch <= 0) return MAUA_EINVAL;
+    if (!maua_upconv_blur_ok(cin, cout, h, w)) return MAUA_ENOSYS;
+    if ((noise || src) && !noise_w) return MAUA_EINVAL;
+    if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
+    if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)U2_NU * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
+    const FusePlan f = fuse_plan(batch, cout, h, w);
+    if (f.n_seg > 1 && !ws) return MAUA_EINVAL;
+    constexpr int cc = 8;
+    Up2dArgs a{};
+    a.x = x, a.wq = wq, a.s = s, a.d = d, a.y = nullptr, a.xcol = nullptr;
+    a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
+    a.tiles_x = f.tiles_x, a.tiles_y = f.n_seg, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
+    a.seg_tiles = f.seg_tiles, a.tiles_total_y = f.tiles_total_y;
+    a.yb = y, a.hbuf = ws, a.k4 = k4, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.noise_batch_stride = noise_batch_stride;
+    a.src = src, a.noise_slot = noise_slot;
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM + 4 * 3 * 64 * 8);
+    static_assert((size_t)2 * u2_a_floats(8) + (size_t)2 * u2_pbuf(8) >= 2 * 4 * 3 * 64 * 8, "the exchange region lives in the operand buffers");
+    if (lds_bytes > 80 * 1024) return MAUA_ENOSYS;  // two workgroups per CU
+    const int64_t blocks = (int64_t)batch * f.n_seg * f.tiles_x * a.m_tiles;
+    static unsigned long long lds_ok = 0;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 2>), &lds_ok, 160 * 1024)) return rc;
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<8, 2>");
+    hipStream_t st = (hipStream_t)stream;
+#ifdef MAUA_EXPERIMENTS
+    if (getenv("MAUA_FUSE_DEBUG")) {
+        int occ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(modconv_up2d_kernel<8, 2>), 256, lds_bytes);
+        fprintf(stderr, "[maua_upconv_blur] %d->%d @%dx%d B=%d: x tiles %d, y tiles %d in %d segments of %d, %lld workgroups, LDS %zu B, occupancy %d WG/CU\n",
+                cin, cout, h, w, batch, f.tiles_x, f.tiles_total_y, f.n_seg, f.seg_tiles, (long long)blocks, lds_bytes, occ);
+    }
+#endif
+    hipLaunchKernelGGL((modconv_up2d_kernel<8, 2>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    MAUA_LAUNCH_CHECK();
+    if (f.n_seg > 1) {
+        const int64_t threads = (int64_t)batch * cout * (f.n_seg - 1) * (2 * w / 4);
+        hipLaunchKernelGGL(up2d_seam_kernel, dim3((unsigned)ceil_div64(threads, 256)), dim3(256), 0, st, a, f.n_seg - 1);
+        MAUA_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 #ifdef MAUA_EXPERIMENTS
 // Experiment entry (tools/fuse_probe.py): the transposed convolution with the Blur + noise + bias + activation in its epilogue, tile halos
 // taken as zero; `extra_pct` launches that many per cent of redundant tiles on top (the price of an overlapped tiling).
@@ -646,7 +898,6 @@ extern "C" int maua_exp_upconv_blur_fused_f32(const float* x, const float* wq, c
     a.yb = yb, a.k4 = k4, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.noise_batch_stride = noise_batch_stride;
     const size_t k_loop = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM);
     const size_t lds_bytes = k_loop > 49152 + 4096 ? k_loop : 49152 + 4096;
-    if ((size_t)2 * u2_a_floats(cc) * 4 + (size_t)2 * u2_pbuf(cc) * 4 < 49152) return MAUA_ENOSYS;  // the exchange region must end below the styles / gains
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
     a.real_blocks = (int)blocks;
     const int64_t launched = blocks + blocks * extra_pct / 100;

@@ -222,6 +222,22 @@ class ModulatedConv2d(nn.Module):
             return 2
         return 0
 
+    def blur_is_separable(self):
+        """True when the Blur's tap matrix is 4 x 4 and an outer product (make_kernel of 1-D taps always is; a checkpoint could carry
+        anything): what maua_upconv_blur_f32 requires.  One host read per (buffer, version), made by the eager warm-up forward — never
+        inside a capture."""
+        k = self.blur.kernel
+        key = (k.data_ptr(), k._version, str(k.device))
+        cached = self.__dict__.get("_blur_sep")
+        if cached is None or cached[0] != key:
+            kk = k.detach().double().cpu()
+            ok = tuple(kk.shape) == (4, 4) and float(kk.sum()) != 0.0
+            if ok:
+                outer = kk.sum(1)[:, None] * kk.sum(0)[None, :] / kk.sum()
+                ok = bool((outer - kk).abs().max() <= 1e-6 * kk.abs().max())
+            self.__dict__["_blur_sep"] = cached = (key, ok)
+        return cached[1]
+
     def packed_wino(self, mode=2):
         """Winograd-domain weight [(ky*F+xi), Cin, Cout_pad], F = 4 for mode 2 (maua_pack_weight_wino_f32) and mode 4
         (maua_pack_weight_upwino_f32), 6 for mode 3 (maua_pack_weight_wino43_f32); cached like ``packed()``."""
@@ -453,6 +469,10 @@ class StyledConv(nn.Module):
 
     # layers wider than one weight tile on the 2-D Winograd kernel leave per-tile partial ToRGB sums (A/B switch)
     partial_rgb_fusion = True
+    # up-sampling layers whose INPUT is at least this wide run transposed convolution + blur + noise + bias + activation as one kernel
+    # (maua_upconv_blur_f32, round 5); below, the extra tiles of its overlapped tiling cost more than the raw map's round trip saves
+    # (profiles/r05_fused_upconv_blur.md).  A huge value = always the two-launch path.
+    fused_blur_min_width = 512
 
     def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None, src=None, slot=0):
         """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers.
@@ -528,10 +548,22 @@ class StyledConv(nn.Module):
                     return out
             return conv.run(x, s, s_off, d, out, ws, fuse_act=True, noise=noise, noise_w=self.noise.weight,
                             bias=self.activate.bias, src=src, slot=slot)
-        raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
-        conv.run(x, s, s_off, d, raw, ws)
         k = conv.blur.kernel
         pad0, pad1 = conv.blur.pad
+        if (self.fused_blur_min_width <= w and conv.conv_mode(h, w) == 6 and (pad0, pad1) == (1, 1) and conv.blur_is_separable()
+                and lib.maua_upconv_blur_ok(cin, conv.out_channel, h, w)):
+            # the whole layer in one pass over the transposed convolution's accumulators: no raw (2H+1) x (2W+1) map (csrc/modconv_up2d.hip)
+            out = bufs(tag, (b, conv.out_channel, 2 * h, 2 * w))
+            n_seam = lib.maua_upconv_blur_ws_floats(b, cin, conv.out_channel, h, w)
+            seam = bufs(tag + ".seam", (n_seam,)) if n_seam else None
+            nstride = 0 if noise is None or noise.shape[0] == 1 else 4 * h * w
+            _lib.check(lib.maua_upconv_blur_f32(
+                x.data_ptr(), conv.packed_wino(6).data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(),
+                _lib.ptr(seam), k.data_ptr(), _lib.ptr(noise), nstride, self.noise.weight.data_ptr(), self.activate.bias.data_ptr(),
+                src, slot, b, cin, conv.out_channel, h, w, float(conv.scale), _lib.stream_ptr(x.device)), "maua_upconv_blur_f32")
+            return out
+        raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
+        conv.run(x, s, s_off, d, raw, ws)
         oh, ow = raw.shape[2] + pad0 + pad1 - k.shape[0] + 1, raw.shape[3] + pad0 + pad1 - k.shape[1] + 1
         out = bufs(tag, (b, conv.out_channel, oh, ow))
         nstride = 0 if noise is None or noise.shape[0] == 1 else oh * ow

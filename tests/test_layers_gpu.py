@@ -521,3 +521,127 @@ def test_upconv_split_bf16_matches_polyphase_and_oracle(gpu, cin, cout, h, w, ba
     want = so.styled_conv(sd, "L", x, s, nz, True).numpy()
     print(f"[split-bf16 transposed {cin}->{cout} @{h}x{w}] StyledConv: max |hip - oracle| = {np.abs(full - want).max():.2e} (std {want.std():.2f})")
     np.testing.assert_allclose(full, want, atol=5e-4, rtol=1e-4)
+
+
+# ---- round 5: the whole up-sampling StyledConv as one kernel (maua_upconv_blur_f32, csrc/modconv_up2d.hip FUSE == 2) --------------------
+
+
+def _styled_up(cin, cout, seed, dev):
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+
+    r = np.random.default_rng(seed)
+    m = StyledConv(cin, cout, 3, 512, upsample=True)
+    sd = {
+        "L.conv.weight": torch.from_numpy(r.standard_normal((1, cout, cin, 3, 3)).astype(np.float32)),
+        "L.conv.blur.kernel": m.conv.blur.kernel.clone(),
+        "L.conv.modulation.weight": torch.from_numpy(r.standard_normal((cin, 512)).astype(np.float32)),
+        "L.conv.modulation.bias": torch.from_numpy((1 + 0.1 * r.standard_normal(cin)).astype(np.float32)),
+        "L.noise.weight": torch.tensor([0.41]),
+        "L.activate.bias": torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32)),
+    }
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    return m.to(dev), sd, r
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch,noise_batch", [
+    (64, 32, 8, 32, 1, 1),       # one x tile pair, two y tiles (the second holds raw row 2H only)
+    (64, 32, 32, 32, 3, 3),      # several vertical segments: seam rows through the second launch
+    (128, 64, 64, 64, 2, 1),     # two m-tiles, shared noise map (a checkpoint buffer)
+    (32, 32, 40, 96, 2, 2),      # tile counts that are not powers of two, wide map: four x tiles
+    (256, 64, 24, 64, 1, 0),     # long K loop, no noise map
+    (64, 32, 256, 256, 1, 1),    # generator-sized grid (convs.12's shape class): 10 x 33 tiles
+])
+def test_upconv_blur_fused_equals_two_launches_and_oracle(gpu, cin, cout, h, w, batch, noise_batch):
+    """reference models/stylegan2.py:229-238,262-266,338-343 — transposed conv -> blur -> noise -> bias -> leaky ReLU — as ONE kernel against
+    (a) the two-launch path (mode-6 transposed convolution writing the raw (2H+1) x (2W+1) map, then maua_blur_noise_act_f32) on a
+    NaN-prefilled output: every element written, agreement to 1e-5 of the output scale (the separable blur sums in another order);
+    (b) the oracle's StyledConv (3e-4)."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+    from oracle import stylegan2_oracle as so
+
+    m, sd, r = _styled_up(cin, cout, cin + cout + h + w, gpu)
+    x = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s = torch.from_numpy(r.standard_normal((batch, 512)).astype(np.float32))
+    nz = torch.from_numpy(r.standard_normal((noise_batch, 1, 2 * h, 2 * w)).astype(np.float32)) if noise_batch else None
+    keep = StyledConv.fused_blur_min_width
+    outs = {}
+    try:
+        for name, width in (("fused", 32), ("pair", 1 << 30)):
+            StyledConv.fused_blur_min_width = width
+            launches = []
+            real = m.conv.run
+            m.conv.run = lambda *a, _real=real, **k: (launches.append("conv.run"), _real(*a, **k))[1]
+            noise = torch.zeros(1, 1, 2 * h, 2 * w, device=gpu) if nz is None else nz.to(gpu)
+            outs[name] = m(x.to(gpu), s.to(gpu), noise=noise).cpu().numpy()
+            m.conv.run = real
+            assert (launches == []) == (name == "fused"), (name, launches)  # the fused path never runs the raw-map convolution
+    finally:
+        StyledConv.fused_blur_min_width = keep
+    assert np.isfinite(outs["fused"]).all()
+    scale = np.abs(outs["pair"]).max()
+    np.testing.assert_allclose(outs["fused"], outs["pair"], atol=1e-5 * scale, rtol=0)
+    want = so.styled_conv(sd, "L", x, s, torch.zeros(1, 1, 2 * h, 2 * w) if nz is None else nz, True).numpy()
+    np.testing.assert_allclose(outs["fused"], want, atol=3e-4, rtol=1e-4)
+
+
+def test_upconv_blur_fused_c_abi_contract(gpu):
+    """maua_upconv_blur_f32 through the C ABI: unwritten elements would stay NaN; noise through a frame source (the captured forward's
+    way) equals noise through the argument; shapes outside maua_upconv_blur_ok are refused with MAUA_ENOSYS, missing operands with
+    MAUA_EINVAL; a non-separable blur kernel keeps the layer on the two-launch path."""
+    import ctypes
+
+    from maua_stylegan2_amd import _lib
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+
+    lib = _lib.load()
+    cin, cout, h, w, b = 64, 32, 32, 64, 2
+    m, sd, r = _styled_up(cin, cout, 77, gpu)
+    conv = m.conv
+    x = torch.from_numpy(r.standard_normal((b, cin, h, w)).astype(np.float32)).to(gpu)
+    s = torch.from_numpy(r.standard_normal((b, cin)).astype(np.float32)).to(gpu)
+    d = (torch.rand(b, cout) + 0.5).to(gpu)
+    frames = 5
+    nz_seq = torch.from_numpy(r.standard_normal((frames, 1, 2 * h, 2 * w)).astype(np.float32)).to(gpu)
+    wq = conv.packed_wino(6)
+    k = conv.blur.kernel
+    n_ws = lib.maua_upconv_blur_ws_floats(b, cin, cout, h, w)
+    ws = torch.empty(max(n_ws, 1), device=gpu)
+    st = _lib.stream_ptr(gpu)
+
+    def call(out, noise, nstride, src=None, slot=0, cin_=cin, ws_=ws, k_=k):
+        return lib.maua_upconv_blur_f32(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), out.data_ptr(), _lib.ptr(ws_), k_.data_ptr(),
+                                        _lib.ptr(noise), nstride, m.noise.weight.data_ptr(), m.activate.bias.data_ptr(), src, slot, b, cin_, cout,
+                                        h, w, float(conv.scale), st)
+
+    frame0 = 2
+    direct = torch.full((b, cout, 2 * h, 2 * w), float("nan"), device=gpu)
+    assert call(direct, nz_seq[frame0: frame0 + b].contiguous(), 4 * h * w) == 0
+    src = _lib.FrameSource()
+    src.frame0 = frame0
+    src.noise[3] = nz_seq.data_ptr()
+    src.noise_stride[3] = 4 * h * w
+    dev_src = torch.frombuffer(bytearray(bytes(src)), dtype=torch.uint8).to(gpu)
+    via_src = torch.full_like(direct, float("nan"))
+    assert call(via_src, None, 0, src=dev_src.data_ptr(), slot=3) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(direct).all() and torch.equal(direct, via_src)
+    assert lib.maua_upconv_blur_ok(cin, cout, h, w) == 1 and lib.maua_upconv_blur_ok(512, 256, 64, 64) == 0  # (cin <= 256: LDS budget)
+    assert lib.maua_upconv_blur_ok(60, 32, 32, 64) == 0 and lib.maua_upconv_blur_ok(64, 32, 30, 64) == 0
+    assert call(direct, None, 0, cin_=60) == -38   # MAUA_ENOSYS: the two-launch path serves the shape
+    assert n_ws > 0 and call(direct, None, 0, ws_=None) == -22  # MAUA_EINVAL: several segments need their seam workspace
+    # a tap matrix that is not an outer product: StyledConv keeps the two-launch path (and agrees with the generic FIR)
+    odd = k.clone()
+    odd[0, 0] += 0.05
+    conv.blur.kernel.copy_(odd)
+    assert not conv.blur_is_separable()
+    keep = StyledConv.fused_blur_min_width
+    try:
+        StyledConv.fused_blur_min_width = 32
+        launches = []
+        real = conv.run
+        conv.run = lambda *a, _real=real, **kw: (launches.append(1), _real(*a, **kw))[1]
+        m(x, torch.from_numpy(r.standard_normal((b, 512)).astype(np.float32)).to(gpu), noise=nz_seq[:b])
+        conv.run = real
+        assert launches, "a non-separable blur must not reach the fused kernel"
+    finally:
+        StyledConv.fused_blur_min_width = keep

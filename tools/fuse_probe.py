@@ -28,15 +28,19 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--exact", action="store_true", help="the product's exact fused kernel (maua_upconv_blur_f32) against the two-launch pair: whole maps")
+    ap.add_argument("--diag", action="store_true", help="error maps of the experiment for single-tap (shift) kernels: which rows / columns are wrong")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     _lib.LIB_PATH = os.path.abspath(args.lib)
     lib = _lib.load()
-    raw = ctypes.CDLL(_lib.LIB_PATH)
-    fused = raw.maua_exp_upconv_blur_fused_f32
-    vp, i64 = ctypes.c_void_p, ctypes.c_int64
-    fused.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, i64, vp, vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, vp]
-    fused.restype = ctypes.c_int
+    fused = None
+    if not args.exact:  # (the halo-free experiment entry only exists in experiments builds)
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        fused = raw.maua_exp_upconv_blur_fused_f32
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        fused.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, i64, vp, vp] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, vp]
+        fused.restype = ctypes.c_int
     from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
 
     dev = torch.device("cuda:0")
@@ -45,6 +49,102 @@ def main():
     B = args.batch
     out = {}
     k4 = torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)).to(dev)
+    if args.exact:
+        with torch.cuda.stream(stream):
+            for name, cin, cout, h, Bx in [("small 64->32 @32 B=3", 64, 32, 32, 3), ("small 128->64 @64x64 B=2", 128, 64, 64, 2),
+                                           ("convs.14 64->32 @512", 64, 32, 512, B), ("convs.12 128->64 @256", 128, 64, 256, B),
+                                           ("convs.10 256->128 @128", 256, 128, 128, B)]:
+                m = ModulatedConv2d(cin, cout, 3, 512, upsample=True).to(dev)
+                x = torch.randn(Bx, cin, h, h, device=dev)
+                s = torch.randn(Bx, cin, device=dev)
+                d = torch.rand(Bx, cout, device=dev) + 0.5
+                raw_map = torch.empty(Bx, cout, 2 * h + 1, 2 * h + 1, device=dev)
+                ref = torch.empty(Bx, cout, 2 * h, 2 * h, device=dev)
+                got = torch.full((Bx, cout, 2 * h, 2 * h), float("nan"), device=dev)
+                nz = torch.randn(Bx, 1, 2 * h, 2 * h, device=dev)
+                nw = torch.full((1,), 0.3, device=dev)
+                bias = torch.randn(cout, device=dev)
+                ws = torch.empty(max(lib.maua_modconv_ws_floats(Bx, cin, cout, h, h, 6), 1), device=dev)
+                nseam = lib.maua_upconv_blur_ws_floats(Bx, cin, cout, h, h)
+                seam = torch.full((max(nseam, 1),), float("nan"), device=dev)
+                wq = m.packed_wino(6)
+                assert lib.maua_upconv_blur_ok(cin, cout, h, h)
+
+                def pair():
+                    m.run(x, s, 0, d, raw_map, ws)
+                    _lib.check(lib.maua_blur_noise_act_f32(raw_map.data_ptr(), k4.data_ptr(), ref.data_ptr(), Bx, cout, 2 * h + 1, 2 * h + 1, 4, 4,
+                                                           1, 1, None, nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, sp), "tail")
+
+                def exact():
+                    _lib.check(lib.maua_upconv_blur_f32(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), got.data_ptr(), seam.data_ptr(),
+                                                        k4.data_ptr(), nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, Bx, cin, cout, h,
+                                                        h, float(m.scale), sp), "maua_upconv_blur_f32")
+
+                pair(), exact()
+                stream.synchronize()
+                diff = torch.nan_to_num((got - ref).abs(), nan=99.0)
+                rec = {"max_abs_err": float(diff.max()), "unwritten": int(torch.isnan(got).sum()), "ref_abs_mean": float(ref.abs().mean()),
+                       "by_row_mod16": [round(float(v), 6) for v in diff.amax(dim=(0, 1, 3)).reshape(-1, 16).amax(0)],
+                       "by_col_mod56_first8_last8": [round(float(v), 6) for v in torch.cat([diff.amax(dim=(0, 1, 2))[:8], diff.amax(dim=(0, 1, 2))[-8:]])],
+                       "worst_rows": [int(v) for v in torch.topk(diff.amax(dim=(0, 1, 3)), 6).indices], "worst_cols": [int(v) for v in torch.topk(diff.amax(dim=(0, 1, 2)), 6).indices]}
+
+                def timed(fn):
+                    e0, e1 = _lib.HipEvent(), _lib.HipEvent()
+                    fn()
+                    e0.record(sp)
+                    for _ in range(args.iters):
+                        fn()
+                    e1.record(sp)
+                    return e0.elapsed_ms(e1) / args.iters
+
+                tp, te = [], []
+                for _ in range(args.rounds):
+                    tp.append(timed(pair)), te.append(timed(exact))
+                rec["pair_ms"], rec["exact_ms"] = float(np.median(tp)), float(np.median(te))
+                out[name] = rec
+        print(json.dumps(out))
+        return
+    if args.diag:
+        with torch.cuda.stream(stream):
+            cin, cout, h, Bd = 128, 64, 256, 2
+            m = ModulatedConv2d(cin, cout, 3, 512, upsample=True).to(dev)
+            x = torch.randn(Bd, cin, h, h, device=dev)
+            s = torch.randn(Bd, cin, device=dev)
+            d = torch.rand(Bd, cout, device=dev) + 0.5
+            raw_map = torch.empty(Bd, cout, 2 * h + 1, 2 * h + 1, device=dev)
+            ref = torch.empty(Bd, cout, 2 * h, 2 * h, device=dev)
+            nz = torch.randn(Bd, 1, 2 * h, 2 * h, device=dev)
+            nw = torch.full((1,), 0.3, device=dev)
+            bias = torch.randn(cout, device=dev)
+            ws = torch.empty(max(lib.maua_modconv_ws_floats(Bd, cin, cout, h, h, 6), 1), device=dev)
+            wq = m.packed_wino(6)
+            m.run(x, s, 0, d, raw_map, ws)
+            cases = [("delta(1,1)", (1, 1), False), ("delta(1,0)", (1, 0), False), ("delta(1,2)", (1, 2), False), ("delta(1,3)", (1, 3), False), ("delta(0,1)", (0, 1), False),
+                     ("delta(3,1)", (3, 1), False), ("full", None, False), ("full+noise+bias", None, True)]
+            for cname, tap, tail in cases:
+                if tap is None:
+                    k = k4.clone()
+                else:
+                    k = torch.zeros(4, 4, device=dev)
+                    k[3 - tap[0], 3 - tap[1]] = 1.0  # (the kernels flip the tap matrix: this is K[tap] = 1 in out = sum K[i][j] raw[Y-1+i][X-1+j])
+                got = torch.full((Bd, cout, 2 * h, 2 * h), float("nan"), device=dev)
+                _lib.check(lib.maua_blur_noise_act_f32(raw_map.data_ptr(), k.data_ptr(), ref.data_ptr(), Bd, cout, 2 * h + 1, 2 * h + 1, 4, 4, 1, 1,
+                                                       None, nz.data_ptr() if tail else None, 4 * h * h, nw.data_ptr(), bias.data_ptr() if tail else None,
+                                                       None, 0, sp), "tail")
+                _lib.check(fused(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), got.data_ptr(), k.data_ptr(),
+                                 nz.data_ptr() if tail else None, 4 * h * h, nw.data_ptr(), bias.data_ptr() if tail else None, Bd, cin, cout, h, h,
+                                 float(m.scale), 0, sp), "fused")
+                stream.synchronize()
+                diff = torch.nan_to_num((got - ref).abs(), nan=99.0)[:, :, 16:-16]  # (the first / last tile rows: image borders, rows never written)
+                per_row = diff.amax(dim=(0, 1, 3)).reshape(-1, 16).amax(0)
+                inner_rows = diff.reshape(Bd, cout, -1, 16, 2 * h)[:, :, :, 1:14].reshape(Bd, cout, -1, 2 * h)
+                per_col = inner_rows.amax(dim=(0, 1, 2)).reshape(-1, 64).amax(0)
+                per_ch = inner_rows.amax(dim=(0, 2, 3))
+                out[cname] = {"by_row_mod16": [round(float(v), 3) for v in per_row], "by_col_mod64": [round(float(v), 3) for v in per_col],
+                              "by_channel_first8": [round(float(v), 3) for v in per_ch[:8]],
+                              "got_row37_cols0_11": [round(float(v), 3) for v in got[0, 0, 37, :12]], "ref_row37_cols0_11": [round(float(v), 3) for v in ref[0, 0, 37, :12]]}
+        print(json.dumps(out))
+        return
     with torch.cuda.stream(stream):
         for name, cin, cout, h in [("convs.14 64->32 @512", 64, 32, 512), ("convs.12 128->64 @256", 128, 64, 256),
                                    ("convs.10 256->128 @128", 256, 128, 128), ("convs.8 512->256 @64", 512, 256, 64)]:
