@@ -79,7 +79,11 @@ int maua_frame_source_seek(maua_frame_source_t* src, int frame0, void* stream);
  * (models/stylegan2.py:238,262-266,338-343; op/fused_act.py:74-83):
  *   y[b,c] = lrelu_0.2( upfirdn2d(x[b,c], k, pad=(pad0,pad1)) * gain[b,c] + noise_w * noise[b,0] + bias[c] ) * sqrt(2)
  * x [B,C,in_h,in_w] -> y [B,C,out_h,out_w], up = down = 1. gain (may be NULL = 1) carries the demodulation
- * factor of the preceding shared-weight convolution. noise [B or 1,1,out_h,out_w] (noise_batch_stride 0 = broadcast). */
+ * factor of the preceding shared-weight convolution. noise [B or 1,1,out_h,out_w] (noise_batch_stride 0 = broadcast).
+ * Limits (the kernel addresses a plane through 32-bit buffer offsets): kh == kw in 2..4, and planes below 2 GiB — MAUA_ENOSYS otherwise
+ * (there is no generic fallback behind this entry: run maua_upfirdn2d_f32, which has one, and maua_fused_bias_act_f32 instead).  The noise
+ * map is read as exactly out_h * out_w floats per sample from noise + b * noise_batch_stride: the CALLER guarantees that shape (the Python
+ * mirror checks it against the feature map, models/stylegan2.py StyledConv.run; the reference raises a broadcast error there). */
 int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch, int channels, int in_h, int in_w,
                             int kh, int kw, int pad0, int pad1, const float* gain, const float* noise,
                             int64_t noise_batch_stride, const float* noise_w, const float* bias,

@@ -25,10 +25,25 @@ TESTS="tests/test_ops_gpu.py tests/test_property_gpu.py"
   HSA_XNACK=1 LD_PRELOAD=$RT MAUA_TEST_LIB=maua_stylegan2_amd/csrc/san/libmaua_hip_asan.so timeout 300 python -m pytest tests/test_ops_gpu.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -25
   echo "rc=${PIPESTATUS[0]}"
 } > "$O/device.log" 2>&1
+# legs 3 / 4: the torch-free driver (tools/asan_driver.cpp: the two native ops + the fused blur tail on tile-edge shapes against the C oracle),
+# linked against the host-sanitized and against the device-sanitized library
+RTDIR=$(dirname "$RT")
+{
+  echo "== leg 3: tools/bin/asan_driver_host (host ASAN + UBSan library, no python in the process)"
+  LD_LIBRARY_PATH=$RTDIR:${LD_LIBRARY_PATH:-} timeout 300 tools/bin/asan_driver_host 2>&1 | tail -25
+  echo "rc=${PIPESTATUS[0]}"
+} > "$O/driver_host.log" 2>&1
+{
+  echo "== leg 4: tools/bin/asan_driver_device (device ASAN library, gfx950:xnack+, HSA_XNACK=1)"
+  HSA_XNACK=1 LD_LIBRARY_PATH=$RTDIR:${LD_LIBRARY_PATH:-} timeout 300 tools/bin/asan_driver_device 2>&1 | tail -25
+  echo "rc=${PIPESTATUS[0]}"
+} > "$O/driver_device.log" 2>&1
 {
   echo "sanitizer runs on $(python -c 'import torch;print(torch.cuda.get_device_name(0))' 2>/dev/null), $(date -u +%FT%TZ)"
   echo "--- host ASAN + UBSan"; tail -4 "$O/host.log"
   echo "--- device ASAN"; tail -8 "$O/device.log"
+  echo "--- torch-free driver, host ASAN + UBSan library"; tail -22 "$O/driver_host.log"
+  echo "--- torch-free driver, device ASAN library"; tail -22 "$O/driver_device.log"
   echo "--- sanitizer report files:"; ls "$O" | grep -c "_report" ; for f in "$O"/*_report*; do [ -f "$f" ] && { echo "## $f"; head -40 "$f"; }; done
 } > "$O/summary.txt" 2>&1
-cat "$O/summary.txt" | head -80
+cat "$O/summary.txt" | head -120

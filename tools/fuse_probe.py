@@ -80,6 +80,11 @@ def main():
                                                         k4.data_ptr(), nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, Bx, cin, cout, h,
                                                         h, float(m.scale), sp), "maua_upconv_blur_f32")
 
+                def exact_plain():  # (no noise map, no bias: what the tail's global loads cost)
+                    _lib.check(lib.maua_upconv_blur_f32(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), got.data_ptr(), seam.data_ptr(),
+                                                        k4.data_ptr(), None, 0, nw.data_ptr(), None, None, 0, Bx, cin, cout, h,
+                                                        h, float(m.scale), sp), "maua_upconv_blur_f32")
+
                 pair(), exact()
                 stream.synchronize()
                 diff = torch.nan_to_num((got - ref).abs(), nan=99.0)
@@ -97,10 +102,10 @@ def main():
                     e1.record(sp)
                     return e0.elapsed_ms(e1) / args.iters
 
-                tp, te = [], []
+                tp, te, tn = [], [], []
                 for _ in range(args.rounds):
-                    tp.append(timed(pair)), te.append(timed(exact))
-                rec["pair_ms"], rec["exact_ms"] = float(np.median(tp)), float(np.median(te))
+                    tp.append(timed(pair)), te.append(timed(exact)), tn.append(timed(exact_plain))
+                rec["pair_ms"], rec["exact_ms"], rec["exact_no_noise_no_bias_ms"] = float(np.median(tp)), float(np.median(te)), float(np.median(tn))
                 out[name] = rec
         print(json.dumps(out))
         return
