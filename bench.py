@@ -98,6 +98,7 @@ def time_calls(fn, iters, stream_ptr):
 
 
 INSTANCES = {}  # bench row name -> rocprofv3 kernel instance name (filled by layer_breakdown)
+FUSED_OVERLAP = {}  # breakdown row of a fused up-sampling layer -> tiles launched / tiles of the plain tiling (its executed-flops factor)
 
 
 def layer_breakdown(g, batch, noise_batch, stream):
@@ -132,16 +133,25 @@ def layer_breakdown(g, batch, noise_batch, stream):
         e_up, e_pl, e_rgb = ent[li], ent[li + 1], ent[li + 2]
         nz1, nz2 = noise_batch[2 * n + 1], noise_batch[2 * n + 2]
         xin = out
-        # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
-        raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
-        n_ws = _lib.load().maua_modconv_ws_floats(batch, cin, cout, h, h, up.conv.conv_mode(h, h))
-        ws = g._buf(batch, "bench.ws", (max(n_ws, 1),)) if n_ws else None
-        t_up = time_calls(lambda: up.conv.run(xin, s, e_up["s_off"], demod_of(e_up), raw, ws), 10, sp)
-        rows.append((f"convs.{2*n}.upconv", "modconv_up", t_up, 2 * cin * cout * 9 * h * h * batch, 0))
-        INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
         t_all = time_calls(lambda: up.run(xin, s, e_up["s_off"], demod_of(e_up), nz1, bufs, f"u{n}"), 10, sp)
         blur_bytes = 4 * batch * cout * ((2 * h + 1) ** 2 + (2 * h) ** 2)
-        rows.append((f"convs.{2*n}.blur+noise+act", "upfirdn2d_tail", max(t_all - t_up, 1e-6), 16 * 2 * batch * cout * (2 * h) ** 2, blur_bytes))
+        if getattr(up, "last_path", "pair") == "fused":
+            # transposed conv + blur + noise + bias + activation as ONE kernel (maua_upconv_blur_f32) + its seam pass: a single row.  Its
+            # overlapped tiling launches tiles_x * 64 / 2W times the columns and (H / 8 + 1) / (H / 8) times the rows of the plain kernel.
+            tiles_x = 1 if 2 * h <= 60 else (2 * h - 60 + 55) // 56 + 1
+            FUSED_OVERLAP[f"convs.{2*n}.upconv+blur+noise+act (one kernel)"] = (tiles_x * 64.0 / (2 * h)) * ((h // 8 + 1) / (h // 8))
+            rows.append((f"convs.{2*n}.upconv+blur+noise+act (one kernel)", "modconv_up_fused", t_all, 2 * cin * cout * 9 * h * h * batch,
+                         4 * batch * (cin * h * h + cout * (2 * h) ** 2)))
+            INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
+        else:
+            # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
+            raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
+            n_ws = _lib.load().maua_modconv_ws_floats(batch, cin, cout, h, h, up.conv.conv_mode(h, h))
+            ws = g._buf(batch, "bench.ws", (max(n_ws, 1),)) if n_ws else None
+            t_up = time_calls(lambda: up.conv.run(xin, s, e_up["s_off"], demod_of(e_up), raw, ws), 10, sp)
+            rows.append((f"convs.{2*n}.upconv", "modconv_up", t_up, 2 * cin * cout * 9 * h * h * batch, 0))
+            INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
+            rows.append((f"convs.{2*n}.blur+noise+act", "upfirdn2d_tail", max(t_all - t_up, 1e-6), 16 * 2 * batch * cout * (2 * h) ** 2, blur_bytes))
         mid = g._buf(batch, f"convs.{2*n}", (batch, cout, 2 * h, 2 * h))
         img_in = image
         rgb_buf = bufs(f"rgb{n}", (batch, 3, 2 * h, 2 * h))
@@ -751,12 +761,20 @@ def main():
                                             "frac": algo_flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                                             "note": "direct-conv flops as SURVEY 8d / BASELINE.md 3.1 count them; can exceed the peak"}}
 
+                def executed(row_name):
+                    """(executed / algorithmic matrix flops, description) of a breakdown row."""
+                    ratio, text = EXECUTED.get(mode_of(row_name), (1.0, "direct form"))
+                    if row_name in FUSED_OVERLAP:
+                        ratio *= FUSED_OVERLAP[row_name]
+                        text += f"; x {FUSED_OVERLAP[row_name]:.3f} for the overlapped tiling of the fused blur (56 of 64 columns kept per tile, one extra tile row)"
+                    return ratio, text
+
                 conv_rows = [r for r in rows if r[1].startswith("modconv")]
                 # (a) the single launch with the largest device time
                 dom = max(rows, key=lambda r: r[2])
                 if dom[1].startswith("modconv"):
                     inst = INSTANCES.get(dom[0])
-                    ratio, algo = EXECUTED.get(mode_of(dom[0]), (1.0, "direct form"))
+                    ratio, algo = executed(dom[0])
                     result["roofline"] = roof(f"{(inst or 'modconv').split('<')[0]} ({dom[0]})", dom[2], dom[3], ratio, algo)
                     result["roofline"]["kernel_instance"] = inst
                     result["roofline"]["what"] = "the single launch with the largest device time (isolated, HIP events on the launch stream)"
@@ -782,7 +800,7 @@ def main():
                 by_inst = {}
                 for name, family, ms, flops, byts in conv_rows:
                     inst = INSTANCES.get(name) or family
-                    ratio = EXECUTED.get(mode_of(name), (1.0, ""))[0]
+                    ratio = executed(name)[0]
                     acc = by_inst.setdefault(inst, {"ms": 0.0, "algo": 0.0, "exec": 0.0, "layers": []})
                     acc["ms"] += ms
                     acc["algo"] += flops
@@ -796,6 +814,13 @@ def main():
                         "frac": acc["exec"] / acc["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS,
                         "algorithmic": {"achieved": acc["algo"] / acc["ms"] / 1e9, "frac": acc["algo"] / acc["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS},
                         "what": "all launches of this template instance in one forward (isolated launch times summed); achieved = executed flops"}
+                    # the whole forward: matrix flops EXECUTED per batch over the headline's time per batch (three lanes overlapped), as a
+                    # fraction of the fp32-MFMA peak — what the chip's matrix cores are busy with, end to end
+                    exec_per_batch = sum(v["exec"] for v in by_inst.values())
+                    result["whole_forward_executed_tflops"] = exec_per_batch / (result["ms_per_batch"] * 1e-3) / 1e12
+                    result["whole_forward_executed_frac"] = result["whole_forward_executed_tflops"] / MFMA_F32_PEAK_TFLOPS
+                    result["whole_forward_executed_note"] = ("sum over the conv launches of (direct-conv flops x executed ratio of their algorithm) per batch / "
+                                                             "ms_per_batch of the timed region / 157.3 TFLOP/s")
                     result["conv_kernel_instances"] = {
                         k: {"ms_per_batch": v["ms"], "share_of_serial_forward": v["ms"] / total_ms, "executed_tflops": v["exec"] / v["ms"] / 1e9,
                             "executed_frac": v["exec"] / v["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS, "algorithmic_tflops": v["algo"] / v["ms"] / 1e9,

@@ -553,6 +553,7 @@ class StyledConv(nn.Module):
         if (self.fused_blur_min_width <= w and conv.conv_mode(h, w) == 6 and (pad0, pad1) == (1, 1) and conv.blur_is_separable()
                 and lib.maua_upconv_blur_ok(cin, conv.out_channel, h, w)):
             # the whole layer in one pass over the transposed convolution's accumulators: no raw (2H+1) x (2W+1) map (csrc/modconv_up2d.hip)
+            self.last_path = "fused"
             out = bufs(tag, (b, conv.out_channel, 2 * h, 2 * w))
             n_seam = lib.maua_upconv_blur_ws_floats(b, cin, conv.out_channel, h, w)
             seam = bufs(tag + ".seam", (n_seam,)) if n_seam else None
@@ -562,6 +563,7 @@ class StyledConv(nn.Module):
                 _lib.ptr(seam), k.data_ptr(), _lib.ptr(noise), nstride, self.noise.weight.data_ptr(), self.activate.bias.data_ptr(),
                 src, slot, b, cin, conv.out_channel, h, w, float(conv.scale), _lib.stream_ptr(x.device)), "maua_upconv_blur_f32")
             return out
+        self.last_path = "pair"
         raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
         conv.run(x, s, s_off, d, raw, ws)
         oh, ow = raw.shape[2] + pad0 + pad1 - k.shape[0] + 1, raw.shape[3] + pad0 + pad1 - k.shape[1] + 1

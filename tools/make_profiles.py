@@ -10,10 +10,10 @@ import sqlite3
 import sys
 
 O = "gpurun_out/prof_final"
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
-def table(db, keep=("modconv_mfma", "modconv_w2d", "modconv_up2d", "up2d_edge", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel",
+def table(db, keep=("modconv_mfma", "modconv_w2d", "modconv_up2d", "up2d_edge", "up2d_seam", "fir_", "torgb", "frames_to_u8", "style_affine", "demod_kernel",
                      "reduce_tail")):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
