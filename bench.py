@@ -142,7 +142,7 @@ def layer_breakdown(g, batch, noise_batch, stream):
             FUSED_OVERLAP[f"convs.{2*n}.upconv+blur+noise+act (one kernel)"] = (tiles_x * 64.0 / (2 * h)) * ((h // 8 + 1) / (h // 8))
             rows.append((f"convs.{2*n}.upconv+blur+noise+act (one kernel)", "modconv_up_fused", t_all, 2 * cin * cout * 9 * h * h * batch,
                          4 * batch * (cin * h * h + cout * (2 * h) ** 2)))
-            INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
+            INSTANCES[rows[-1][0]] = "modconv_up2d_kernel<8, 2>"  # (maua_upconv_blur_f32 has one instance; the seam pass is up2d_seam_kernel)
         else:
             # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
             raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
@@ -786,6 +786,16 @@ def main():
                         # WRITE_SIZE.  Only used when that instance is launched once per batch, i.e. the average IS this launch.
                         result["roofline"]["traffic"] = rec["read_bytes"] + rec["write_bytes"]
                         result["roofline"]["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}"
+                    if dom[0] in FUSED_OVERLAP:
+                        # the fused up-sampling layer: `frac` counts what the matrix cores executed INCLUDING the redundant tiles of its
+                        # overlapped tiling (PMC-verifiable: SQ_INSTS_VALU_MFMA_MOPS_F32); the same launch without them:
+                        result["roofline"]["redundant_tile_factor"] = FUSED_OVERLAP[dom[0]]
+                        result["roofline"]["frac_without_redundant_tiles"] = result["roofline"]["frac"] / FUSED_OVERLAP[dom[0]]
+                        # input map + activated output map + noise map + packed weight read / written once
+                        result["roofline"]["algorithmic_bytes"] = dom[4] + B * size * size * 4 + 21 * 64 * 32 * 4
+                        result["roofline"]["hbm_frac_of_launch"] = result["roofline"]["algorithmic_bytes"] / (dom[2] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                        result["roofline"]["what"] += ("; this launch is the whole up-sampling StyledConv (transposed conv + blur + noise + bias + leaky ReLU, "
+                                                       "maua_upconv_blur_f32): its blur epilogue is fp32 VALU work inside a matrix kernel")
                     if size == 1024 and dom[0].startswith("convs.15"):
                         # input + skip image + noise map + packed (Winograd-domain) weights, read once; uint8 frames written once
                         result["roofline"]["algorithmic_bytes"] = (B * 32 * size * size * 4 + B * 3 * (size // 2) ** 2 * 4

@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         const int Yx = Y0 < 0 ? 0 : (Y0 + 3 < OHb ? Y0 : (OHb >= 4 ? OHb - 4 : 0));  // (clamped row base of the noise loads: always inside the map)
         const float* nzp = noise_base ? noise_base + (size_t)b0 * noise_bstride + (size_t)Yx * OWb + (X0 < OWb ? X0 : 0) : pk->k4;
         const int nzs = noise_base ? OWb : 0;
-        float* xch = lds;  // exchange region [parity 2][wave 4][row 3][lane 64][8 floats] = 48 KB over the weight / patch buffers
+        float* xch = lds;  // exchange region [parity 2][wave 4][row 3][half 2][lane 64][4 floats] = 48 KB over the weight / patch buffers (a lane's 8
+                           // floats as two 16-byte pieces 1 KB apart: consecutive lanes hit consecutive banks — [lane][8] measured 22.6 % bank conflicts)
         float* ybimg = pk->yb + ((size_t)b0 * pk->Cout + m0) * ((size_t)OHb * OWb);
         // neighbour lanes of the 16-lane row (one K lane group): DPP row shifts, 0 beyond the row ends.  (Scalar helpers on purpose:
         // __builtin_bit_cast applied to the .y ELEMENT of an ext-vector gave poison in this compiler and the second lane's move vanished.)
@@ -463,11 +464,11 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
             }
             const int ol = 16 * m + 4 * kq_e + 2 * vp;   // first channel of the pair inside the m-tile pair
             // rows 1 .. 3 to the wave below
-            float* mine = xch + (size_t)(((it & 1) * 4 + wv) * 3) * 64 * 8 + lane_e * 8;
+            float* mine = xch + (size_t)(((it & 1) * 4 + wv) * 3) * 64 * 8 + lane_e * 4;
 #pragma unroll
             for (int r = 1; r < 4; ++r) {
                 *reinterpret_cast<f32x4*>(mine + (r - 1) * 64 * 8) = f32x4{Hh[r][0].x, Hh[r][0].y, Hh[r][1].x, Hh[r][1].y};
-                *reinterpret_cast<f32x4*>(mine + (r - 1) * 64 * 8 + 4) = f32x4{Hh[r][2].x, Hh[r][2].y, Hh[r][3].x, Hh[r][3].y};
+                *reinterpret_cast<f32x4*>(mine + (r - 1) * 64 * 8 + 256) = f32x4{Hh[r][2].x, Hh[r][2].y, Hh[r][3].x, Hh[r][3].y};
             }
             if constexpr (FUSE == 2) {
                 // the h-rows either side of a segment boundary go to hbuf [B][Cout][n_seg - 1][6][2W] (rows 0 .. 2: above, 3 .. 5: below)
@@ -492,11 +493,11 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) S[r][c] = f32x2{0.f, 0.f};  // (FUSE == 1: the tile above, zero in the experiment)
             if (wv != 0 || FUSE == 2) {  // (uniform)
-                const float* above = wv != 0 ? xch + (size_t)(((it & 1) * 4 + (wv - 1)) * 3) * 64 * 8 + lane_e * 8
-                                             : SV + (size_t)(it * 3) * 64 * 8 + lane_e * 8;
+                const float* above = wv != 0 ? xch + (size_t)(((it & 1) * 4 + (wv - 1)) * 3) * 64 * 8 + lane_e * 4
+                                             : SV + (size_t)(it * 3) * 64 * 8 + lane_e * 4;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(above + r * 64 * 8), hi = *reinterpret_cast<const f32x4*>(above + r * 64 * 8 + 4);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(above + r * 64 * 8), hi = *reinterpret_cast<const f32x4*>(above + r * 64 * 8 + 256);
                     S[r][0] = f32x2{lo[0], lo[1]}, S[r][1] = f32x2{lo[2], lo[3]}, S[r][2] = f32x2{hi[0], hi[1]}, S[r][3] = f32x2{hi[2], hi[3]};
                 }
             }
@@ -529,11 +530,11 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 // wave 3's rows 1 .. 3 are the next tile's rows above: written once every wave has read this tile's SV[it]
                 __syncthreads();
                 if (wv == 3) {
-                    float* sv = SV + (size_t)(it * 3) * 64 * 8 + lane_e * 8;
+                    float* sv = SV + (size_t)(it * 3) * 64 * 8 + lane_e * 4;
 #pragma unroll
                     for (int r = 1; r < 4; ++r) {
                         *reinterpret_cast<f32x4*>(sv + (r - 1) * 64 * 8) = f32x4{Hh[r][0].x, Hh[r][0].y, Hh[r][1].x, Hh[r][1].y};
-                        *reinterpret_cast<f32x4*>(sv + (r - 1) * 64 * 8 + 4) = f32x4{Hh[r][2].x, Hh[r][2].y, Hh[r][3].x, Hh[r][3].y};
+                        *reinterpret_cast<f32x4*>(sv + (r - 1) * 64 * 8 + 256) = f32x4{Hh[r][2].x, Hh[r][2].y, Hh[r][3].x, Hh[r][3].y};
                     }
                 }
             }
