@@ -138,7 +138,7 @@ def layer_breakdown(g, batch, noise_batch, stream):
         if getattr(up, "last_path", "pair") == "fused":
             # transposed conv + blur + noise + bias + activation as ONE kernel (maua_upconv_blur_f32) + its seam pass: a single row.  Its
             # overlapped tiling launches tiles_x * 64 / 2W times the columns and (H / 8 + 1) / (H / 8) times the rows of the plain kernel.
-            tiles_x = 1 if 2 * h <= 60 else (2 * h - 60 + 55) // 56 + 1
+            tiles_x = (2 * h + 59) // 60  # (a tile keeps 60 of its 64 raw columns)
             FUSED_OVERLAP[f"convs.{2*n}.upconv+blur+noise+act (one kernel)"] = (tiles_x * 64.0 / (2 * h)) * ((h // 8 + 1) / (h // 8))
             rows.append((f"convs.{2*n}.upconv+blur+noise+act (one kernel)", "modconv_up_fused", t_all, 2 * cin * cout * 9 * h * h * batch,
                          4 * batch * (cin * h * h + cout * (2 * h) ** 2)))
@@ -766,7 +766,7 @@ def main():
                     ratio, text = EXECUTED.get(mode_of(row_name), (1.0, "direct form"))
                     if row_name in FUSED_OVERLAP:
                         ratio *= FUSED_OVERLAP[row_name]
-                        text += f"; x {FUSED_OVERLAP[row_name]:.3f} for the overlapped tiling of the fused blur (56 of 64 columns kept per tile, one extra tile row)"
+                        text += f"; x {FUSED_OVERLAP[row_name]:.3f} for the overlapped tiling of the fused blur (60 of 64 columns kept per tile, one extra tile row)"
                     return ratio, text
 
                 conv_rows = [r for r in rows if r[1].startswith("modconv")]

@@ -34,8 +34,14 @@
 // (up2d_edge_kernel: direct MFMA, ~1/H of the layer's work).
 #include "common.h"
 
+#include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <queue>
+#include <vector>
 #include <type_traits>
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -114,7 +120,7 @@ struct Up2dArgs {
     const maua_frame_source_t* src;  // frame source: noise from src->noise[noise_slot] at frame src->frame0
     int noise_slot;
     // FUSE == 2 (exact): tiles_y counts vertical SEGMENTS of seg_tiles tiles, walked by one workgroup (tiles_total_y = H / 8 + 1 tiles: the
-    // last one holds raw row 2H only); x tiles step 28 positions (56 of a tile's 64 raw columns are kept); hbuf [B][Cout][n_seg - 1][6][2W]
+    // last one holds raw row 2H only); an x tile keeps 60 of its 64 raw columns (tile column u: [60 u, 60 u + 60)); hbuf [B][Cout][n_seg - 1][6][2W]
     // receives the h-rows either side of a segment boundary for up2d_seam_kernel
     float* hbuf;
     int seg_tiles, tiles_total_y;
@@ -175,7 +181,12 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     t /= p.tiles_x;
     const int tile_y = t % p.tiles_y;                  // FUSE == 2: the vertical segment
     const int b0 = t / p.tiles_y;
-    const int tx0 = tile_x * ((FUSE == 2 && !FUSE_ABL(16)) ? 28 : 32);    // first position column of the tile
+    // first position column of the tile.  FUSE == 2: a tile keeps 60 of its 64 raw columns, [60 u, 60 u + 60): tile column 0 starts at position 0 and keeps its
+    // lanes 0 .. 14 (the image's left padding is a true zero); the others start at the ODD position 30 u - 1 (raw column 60 u - 2) and shift
+    // every lane's outputs right by two columns (its own columns 2, 3 + columns 0, 1 of lane j + 1), which keeps the stores 16-byte aligned;
+    // their operand DMA segments are then only 4-byte aligned in HBM (the LDS-DMA accepts that: tools/dma_align_probe.hip)
+    const bool shifted = FUSE == 2 && !FUSE_ABL(16) && tile_x > 0;
+    const int tx0 = (FUSE == 2 && !FUSE_ABL(16)) ? (tile_x ? 30 * tile_x - 1 : 0) : tile_x * 32;
     const int first_tile = FUSE == 2 ? tile_y * p.seg_tiles : tile_y;
     const int n_tiles = (FUSE == 2 && !FUSE_ABL(32)) ? min(p.seg_tiles, p.tiles_total_y - first_tile) : 1;  // (ablation 32: one tile per workgroup, known at compile time; run with MAUA_FUSE_SEG=1)
     const int m0 = mt_id * U2_BM;
@@ -188,7 +199,10 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     unsigned rel_bytes[P_PER_WAVE];
     (void)ximg, (void)plane_bytes, (void)rel_bytes;
 #ifdef MAUA_DEVICE_PASS
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
+    // (FUSE == 2: the exact size of the image — a segment that straddles its last element must not touch memory behind it; the range check is per dword
+    // and includes the scalar offset: tools/dma_range_probe.hip)
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, FUSE == 2 ? (int)((size_t)p.Cin * plane_bytes) : 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wq), 0, 0x7fffffff, 0x00020000);
 #endif
     auto issue = [&](int chunk, int buf) {
@@ -292,9 +306,21 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     }
     unsigned s_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + 2 * U2_PBUF + kq_t) * 4u;
 
+    // FUSE == 2, tiles with an odd origin that reach the image's right edge: the 16-byte segment that holds column W - 1 also holds the first
+    // floats of the NEXT image row where column W belongs; x[., W] feeds raw columns 2W and 2W + 1 and must be zero (columns beyond feed nothing
+    // that is kept).  One float per staged row and channel, overwritten in LDS behind the DMA's arrival.
+    const int fix_col = p.W - (tx0 - 4);   // row float of image column W
+    const bool fix_edge = FUSE == 2 && shifted && fix_col >= 1 && fix_col <= 35 && (fix_col & 3) != 0;
+    auto zero_edge = [&](int buf) {  // (behind the barrier that follows the DMA wait: every wave waits for its OWN instructions only)
+        if (fix_edge) {              // (workgroup-uniform)
+            if (tid < CC * U2_PROWS) Ps[buf * U2_PBUF + (tid / U2_PROWS) * U2_PLANE + (tid % U2_PROWS) * U2_PWS + fix_col] = 0.f;
+            __syncthreads();
+        }
+    };
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    zero_edge(0);
     // The right-edge tiles of the first m-tile export the last input column from their staged patch (row float 35 = image column
     // tx0 + 31 = W - 1) into xcol[b][c][row]: the edge kernel then reads that column with unit stride (gathering it from x costs
     // one 128-byte line per element: 32 of the edge launch's 45 us)
@@ -363,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (FUSE == 2) zero_edge(cur ^ 1);  // (the chunk that has just landed)
         cur ^= 1;
     }
 
@@ -372,7 +399,9 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         // This lane: raw rows R0 .. R0 + 3 (R0 = 2 ty0 + 4 wv), raw columns C0 .. C0 + 3 (C0 = 2 tx0 + 4 j), channels 16 m + 4 kq + v.
         //   horizontal pass: the lane's 4 columns need raw columns C0 - 1 .. C0 + 5: column 3 of lane j - 1 and columns 0, 1 of lane j + 1
         //     (DPP row shifts inside the 16-lane row of one K lane group; the row ends read 0: lane 0 is exact only at the image's left
-        //     edge, lane 15 never — FUSE == 2 keeps lanes 1 .. 14 of a tile, the tiles step 56 raw columns);
+        //     edge, lane 15 never).  FUSE == 2 keeps 60 columns per tile: tile column 0 its lanes 0 .. 14 as they are; the others start two raw
+        //     columns early and every lane emits its columns 2, 3 and columns 0, 1 of lane j + 1 (four fetches from the right neighbour, none
+        //     from the left), lanes 0 .. 14 again — lane 0's left neighbour and lane 15's right one are never needed;
         //   vertical pass: wave w emits output rows R0 - 2 .. R0 + 1 from the h-rows R0 - 3 .. R0 + 3: its own four and rows 1 .. 3 of the
         //     wave above, through LDS (in the operand buffers the K loop has released); wave 0 takes them from the PREVIOUS tile of its
         //     segment (SV, written by wave 3), so a workgroup walking down a segment never recomputes or re-reads a halo row.
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         u2_blur_taps(pk->k4, kx, ky);
         const float act_gain = 1.41421356237309515f;
         const int OHb = 2 * pk->H, OWb = 2 * pk->W;
-        const int Y0 = 2 * ty0 + 4 * wv - 2, X0 = 2 * tx0 + 4 * j_e;
+        const int Y0 = 2 * ty0 + 4 * wv - 2, X0 = 2 * tx0 + 4 * j_e + (shifted ? 2 : 0);  // (FUSE == 2: 60 tile_x + 4 j either way)
         const float* noise_base = pk->noise;
         int64_t noise_bstride = pk->noise_batch_stride;
         if (pk->src) {  // (uniform scalar loads)
@@ -401,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         }
         const float nw = noise_base ? pk->noise_w[0] * act_gain : 0.f;
         // which of this lane's outputs are kept: FUSE == 2: lanes 1 .. 14 (+ lane 0 of the first tile column), inside the map
-        const bool x_keep = ((FUSE == 2 && !FUSE_ABL(16)) ? ((j_e >= 1 && j_e <= 14) || (j_e == 0 && tile_x == 0)) : true) && X0 < OWb;
+        const bool x_keep = ((FUSE == 2 && !FUSE_ABL(16)) ? j_e <= 14 : true) && X0 < OWb;  // (lane 15 has no right neighbour)
         const bool seam_above = FUSE == 2 && tile == 0 && tile_y > 0;  // the three rows above this tile's first kept row go to the seam kernel
         const bool seam_below = FUSE == 2 && tile == n_tiles - 1 && first_tile + tile + 1 < pk->tiles_total_y;
         const int Yx = Y0 < 0 ? 0 : (Y0 + 3 < OHb ? Y0 : (OHb >= 4 ? OHb - 4 : 0));  // (clamped row base of the noise loads: always inside the map)
@@ -457,10 +486,18 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
             f32x2 Hh[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f32x2 left = shr1(R[r][3]), right0 = shl1(R[r][0]), right1 = shl1(R[r][1]);
-                const f32x2 e[7] = {left, R[r][0], R[r][1], R[r][2], R[r][3], right0, right1};
+                const f32x2 right0 = shl1(R[r][0]), right1 = shl1(R[r][1]);
+                if (!shifted) {  // (uniform) outputs = the lane's own four columns: raw columns C0 - 1 .. C0 + 5
+                    const f32x2 left = shr1(R[r][3]);
+                    const f32x2 e[7] = {left, R[r][0], R[r][1], R[r][2], R[r][3], right0, right1};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) Hh[r][c] = ((e[c] * kx[0] + e[c + 1] * kx[1]) + e[c + 2] * kx[2]) + e[c + 3] * kx[3];
+                    for (int c = 0; c < 4; ++c) Hh[r][c] = ((e[c] * kx[0] + e[c + 1] * kx[1]) + e[c + 2] * kx[2]) + e[c + 3] * kx[3];
+                } else {         // outputs = columns C0 + 2 .. C0 + 5: raw columns C0 + 1 .. C0 + 7
+                    const f32x2 right2 = shl1(R[r][2]), right3 = shl1(R[r][3]);
+                    const f32x2 e[7] = {R[r][1], R[r][2], R[r][3], right0, right1, right2, right3};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Hh[r][c] = ((e[c] * kx[0] + e[c + 1] * kx[1]) + e[c + 2] * kx[2]) + e[c + 3] * kx[3];
+                }
             }
             const int ol = 16 * m + 4 * kq_e + 2 * vp;   // first channel of the pair inside the m-tile pair
             // rows 1 .. 3 to the wave below
@@ -794,22 +831,60 @@ namespace {
 struct FusePlan {
     int tiles_x, tiles_total_y, seg_tiles, n_seg;
 };
-// x: tiles step 28 positions = 56 raw columns (a tile keeps lanes 1 .. 14 of its 16 block columns; the first one also lane 0);
-// y: H / 8 tiles + one for raw row 2H, walked in segments of seg_tiles by one workgroup each.  seg_tiles balances two costs: every segment
-// boundary sends 6 h-rows through HBM to the seam kernel, and few long segments leave the last round of workgroups half empty.
+// x: a tile keeps 60 of its 64 raw columns, ceil(2W / 60) tile columns (see the kernel);
+// y: H / 8 tiles + one for raw row 2H, walked in segments of seg_tiles by one workgroup each.  The segment length decides how the launch ENDS:
+// every XCD takes a contiguous run of the workgroup list (xcd_remap), its CUs hold two workgroups each, a workgroup alone on its CU runs ~1.6 x
+// faster, and a freed slot takes the next workgroup of the run.  fuse_end_time plays that out (a workgroup costs its tiles + 0.2 of a tile for its
+// prologue); fuse_plan keeps the length that ends first.  Fitted on 27 measured (layer, length) points of the 1024^2 generator's three largest
+// up-sampling layers: 2.7 % rms, the measured optimum or its runner-up (within 1 %) chosen in each (profiles/r05_fused_upconv_blur.md).
+double fuse_end_time(const std::vector<float>& cost, int cus_per_xcd) {
+    constexpr int NX = 8;
+    constexpr float ALONE = 1.6f;
+    const int n = (int)cost.size(), q = n / NX, r = n % NX;
+    double worst = 0.0;
+    std::vector<float> left(2 * cus_per_xcd);
+    for (int x = 0, base = 0; x < NX; ++x) {
+        const int count = q + (x < r);
+        std::fill(left.begin(), left.end(), 0.f);
+        int next = base;
+        double now = 0.0;
+        for (;;) {
+            // fill the free slots in order, empty CUs first
+            for (int pass = 0; pass < 2 && next < base + count; ++pass)
+                for (int c = 0; c < cus_per_xcd && next < base + count; ++c) {
+                    const bool a = left[2 * c] > 0.f, b = left[2 * c + 1] > 0.f;
+                    if (pass == 0 ? (!a && !b) : (a != b)) left[2 * c + (a ? 1 : 0)] = cost[next++];
+                }
+            float dt = -1.f;
+            for (int c = 0; c < cus_per_xcd; ++c) {
+                const float a = left[2 * c], b = left[2 * c + 1];
+                const float d = (a > 0.f && b > 0.f) ? std::min(a, b) : std::max(a, b) / ALONE;
+                if (d > 0.f && (dt < 0.f || d < dt)) dt = d;
+            }
+            if (dt < 0.f) break;
+            now += dt;
+            for (int c = 0; c < cus_per_xcd; ++c) {
+                float& a = left[2 * c];
+                float& b = left[2 * c + 1];
+                const float step = (a > 0.f && b > 0.f) ? dt : dt * ALONE;
+                a = a - step > 1e-4f ? a - step : 0.f;
+                b = b - step > 1e-4f ? b - step : 0.f;
+            }
+        }
+        worst = std::max(worst, now);
+        base += count;
+    }
+    return worst;
+}
 FusePlan fuse_plan(int batch, int cout, int h, int w) {
+    static std::mutex lock;
+    static std::map<std::array<int, 4>, FusePlan> cache;
+    const std::array<int, 4> key{batch, cout, h, w};
+    std::lock_guard<std::mutex> guard(lock);
     FusePlan f{};
-    f.tiles_x = 2 * w <= 60 ? 1 : (2 * w - 60 + 55) / 56 + 1;
+    f.tiles_x = (2 * w + 59) / 60;  // a tile keeps 60 of its 64 raw columns
     if (FUSE_ABL(16)) f.tiles_x = w / 32;
     f.tiles_total_y = h / 8 + 1;
-    static int slots = 0;
-    if (!slots) {
-        int cus = 0, dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        slots = 2 * cus;
-    }
-    const int64_t strips = (int64_t)batch * f.tiles_x * (cout / U2_BM);
-    double best = 1e30;
 #ifdef MAUA_EXPERIMENTS
     if (const char* force = getenv("MAUA_FUSE_SEG")) {  // (A/B: a fixed segment length)
         f.seg_tiles = atoi(force) > 0 ? atoi(force) : 1;
@@ -817,12 +892,25 @@ FusePlan fuse_plan(int batch, int cout, int h, int w) {
         return f;
     }
 #endif
-    for (int sg = 2; sg <= 16; ++sg) {
-        const int n_seg = (f.tiles_total_y + sg - 1) / sg;
-        const int64_t rounds = (strips * n_seg + slots - 1) / slots;
-        const double cost = (double)rounds * sg * slots / (double)(strips * f.tiles_total_y) + 0.25 / sg;  // launched / useful tile slots + seam share
-        if (cost < best - 1e-9) best = cost, f.seg_tiles = sg, f.n_seg = n_seg;
+    if (auto it = cache.find(key); it != cache.end()) return it->second;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
     }
+    const int per_seg = f.tiles_x * (cout / U2_BM);   // workgroups of one (image, segment): consecutive in the list
+    double best = 1e30;
+    std::vector<float> cost;
+    for (int sg = 2; sg <= 16 && sg <= f.tiles_total_y; ++sg) {
+        const int n_seg = (f.tiles_total_y + sg - 1) / sg;
+        cost.clear();
+        for (int b = 0; b < batch; ++b)
+            for (int g = 0; g < n_seg; ++g) cost.insert(cost.end(), per_seg, std::min(sg, f.tiles_total_y - g * sg) + 0.2f);
+        const double end = fuse_end_time(cost, cus / 8) + 1e-3 * n_seg;  // (ties: fewer seams)
+        if (end < best) best = end, f.seg_tiles = sg, f.n_seg = n_seg;
+    }
+    if (!f.seg_tiles) f.seg_tiles = f.tiles_total_y, f.n_seg = 1;
+    cache[key] = f;
     return f;
 }
 }  // namespace

@@ -470,9 +470,10 @@ class StyledConv(nn.Module):
     # layers wider than one weight tile on the 2-D Winograd kernel leave per-tile partial ToRGB sums (A/B switch)
     partial_rgb_fusion = True
     # up-sampling layers whose INPUT is at least this wide run transposed convolution + blur + noise + bias + activation as one kernel
-    # (maua_upconv_blur_f32, round 5); below, the extra tiles of its overlapped tiling cost more than the raw map's round trip saves
-    # (profiles/r05_fused_upconv_blur.md).  A huge value = always the two-launch path.
-    fused_blur_min_width = 512
+    # (maua_upconv_blur_f32, round 5): convs.14 (0.82 ms against the pair's 1.01) and convs.12 (level alone, +0.8 % frames/s inside the
+    # overlapped pipeline, where the raw map's round trip competes for HBM); below, the extra tiles of its overlapped tiling cost more than
+    # that round trip saves (convs.10: 0.70 against 0.56 ms; profiles/r05_fused_upconv_blur.md).  A huge value = always the two-launch path.
+    fused_blur_min_width = 256
 
     def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None, src=None, slot=0):
         """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers.

@@ -85,8 +85,11 @@ def test_fused_kernel_spills_stay_outside_the_k_loop(device_asm):
     first, last = _main_loop(body)
     loop = body[first:last + 1]
     assert sum("v_mfma" in line for line in loop) == 100, "two K groups of 50 matrix instructions per step"
-    bad = [line.strip() for line in loop if re.search(r"scratch_|v_readlane|v_writelane|v_readfirstlane|s_and_saveexec", line)]
+    bad = [line.strip() for line in loop if re.search(r"scratch_|v_readlane|v_writelane|v_readfirstlane", line)]
     assert not bad, bad[:5]
+    # one exec-masked region is legitimate: the right-edge tile column zeroes image column W of its operand rows after the DMA (a uniform
+    # branch no other tile takes); a waterfall loop would show as several
+    assert sum("s_and_saveexec" in line for line in loop) <= 1
 
 
 def _kernel_body(asm, mangled_fragment):

@@ -549,7 +549,7 @@ def _styled_up(cin, cout, seed, dev):
     (128, 64, 64, 64, 2, 1),     # two m-tiles, shared noise map (a checkpoint buffer)
     (32, 32, 40, 96, 2, 2),      # tile counts that are not powers of two, wide map: four x tiles
     (256, 64, 24, 64, 1, 0),     # long K loop, no noise map
-    (64, 32, 256, 256, 1, 1),    # generator-sized grid (convs.12's shape class): 10 x 33 tiles
+    (64, 32, 256, 256, 1, 1),    # generator-sized grid (convs.12's shape class): 9 x 33 tiles
 ])
 def test_upconv_blur_fused_equals_two_launches_and_oracle(gpu, cin, cout, h, w, batch, noise_batch):
     """reference models/stylegan2.py:229-238,262-266,338-343 — transposed conv -> blur -> noise -> bias -> leaky ReLU — as ONE kernel against

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--exact", action="store_true", help="the product's exact fused kernel (maua_upconv_blur_f32) against the two-launch pair: whole maps")
+    ap.add_argument("--sweep", default="", help="with --exact: comma-separated segment lengths (MAUA_FUSE_SEG) timed in alternation in this process")
     ap.add_argument("--diag", action="store_true", help="error maps of the experiment for single-tap (shift) kernels: which rows / columns are wrong")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
@@ -66,6 +67,11 @@ def main():
                 bias = torch.randn(cout, device=dev)
                 ws = torch.empty(max(lib.maua_modconv_ws_floats(Bx, cin, cout, h, h, 6), 1), device=dev)
                 nseam = lib.maua_upconv_blur_ws_floats(Bx, cin, cout, h, h)
+                sweep = [int(v) for v in args.sweep.split(",") if v] if h >= 128 else []
+                for sg in sweep:  # (the seam rows' buffer grows with the number of segments)
+                    os.environ["MAUA_FUSE_SEG"] = str(sg)
+                    nseam = max(nseam, lib.maua_upconv_blur_ws_floats(Bx, cin, cout, h, h))
+                os.environ.pop("MAUA_FUSE_SEG", None)
                 seam = torch.full((max(nseam, 1),), float("nan"), device=dev)
                 wq = m.packed_wino(6)
                 assert lib.maua_upconv_blur_ok(cin, cout, h, h)
@@ -88,7 +94,8 @@ def main():
                 pair(), exact()
                 stream.synchronize()
                 diff = torch.nan_to_num((got - ref).abs(), nan=99.0)
-                rec = {"max_abs_err": float(diff.max()), "unwritten": int(torch.isnan(got).sum()), "ref_abs_mean": float(ref.abs().mean()),
+                rec = {"max_abs_err": float(diff.max()), "interior_max_abs_err": float(diff[:, :, :, 64:-128].max()) if h >= 128 else None,
+                       "unwritten": int(torch.isnan(got).sum()), "ref_abs_mean": float(ref.abs().mean()),
                        "by_row_mod16": [round(float(v), 6) for v in diff.amax(dim=(0, 1, 3)).reshape(-1, 16).amax(0)],
                        "by_col_mod56_first8_last8": [round(float(v), 6) for v in torch.cat([diff.amax(dim=(0, 1, 2))[:8], diff.amax(dim=(0, 1, 2))[-8:]])],
                        "worst_rows": [int(v) for v in torch.topk(diff.amax(dim=(0, 1, 3)), 6).indices], "worst_cols": [int(v) for v in torch.topk(diff.amax(dim=(0, 1, 2)), 6).indices]}
@@ -106,6 +113,14 @@ def main():
                 for _ in range(args.rounds):
                     tp.append(timed(pair)), te.append(timed(exact)), tn.append(timed(exact_plain))
                 rec["pair_ms"], rec["exact_ms"], rec["exact_no_noise_no_bias_ms"] = float(np.median(tp)), float(np.median(te)), float(np.median(tn))
+                if sweep:
+                    rows = {sg: [] for sg in sweep}
+                    for _ in range(args.rounds):
+                        for sg in sweep:
+                            os.environ["MAUA_FUSE_SEG"] = str(sg)
+                            rows[sg].append(timed(exact))
+                    os.environ.pop("MAUA_FUSE_SEG", None)
+                    rec["exact_ms_by_seg_tiles"] = {sg: round(float(np.median(v)), 4) for sg, v in rows.items()}
                 out[name] = rec
         print(json.dumps(out))
         return
