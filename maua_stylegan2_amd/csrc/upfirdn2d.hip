@@ -16,6 +16,7 @@
 //    the tile.  Logical tile order is (plane, tile_x, tile_y) with tile_y fastest and an XCD-aware remap so that vertically
 //    adjacent tiles (which share KH-1 halo rows) are served by the same L2; with the tail the channel is fastest (planes that
 //    share a noise tile run back-to-back).
+//  * fir_up2_kernel (up = 2, down = 1, taps <= 4 x 4: the Upsample module as a standalone op): polyphase, store-bound; see the kernel.
 //  * fir_generic_kernel: any up/down/pad/minor, one thread per output, polyphase tap skipping.
 #include "common.h"
 
@@ -45,6 +46,10 @@ struct FirTail {
 #endif
 constexpr int FIR_ROWS_PLAIN = 24, FIR_ROWS_TAIL = 32, FIR_ROWS_TAIL_SMALL = MAUA_FIR_ROWS_TAIL_SMALL;
 constexpr int FIR_TAIL_SMALL_MAX_H = 512;
+#ifndef MAUA_FIR_UP2_ROWS
+#define MAUA_FIR_UP2_ROWS 16
+#endif
+constexpr int FIR_UP2_ROWS = MAUA_FIR_UP2_ROWS;  // output rows per wave strip of fir_up2_kernel ([8,32,512,512] -> 1024^2: 16 rows 0.239 ms, 32 0.267, 64 0.257)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAUA_DEVICE_PASS 1
@@ -233,6 +238,125 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     }
 }
 
+// up = 2, down = 1 (the Upsample module, reference models/stylegan2.py:51-67 -> op/upfirdn2d.py:145-200 with up = 2, pad = (2, 1); the
+// reference's own tiled specialisation is op/upfirdn2d_kernel.cu:313-359, mode 3).  HBM-bound on its STORES: 4 output floats per input
+// float.  Polyphase: output o reads canvas positions o - pad0 + j, of which only the even ones hold data, so with c = o - pad0 and
+// j0 = c & 1 it has two taps per axis, j0 and j0 + 2, on inputs (c + j0) / 2 and the next.  A lane owns the output column PAIR
+// (2 lane, 2 lane + 1) of its wave's 128-column strip: the pair's tap phases are uniform over the wave (weights in SGPRs), its inputs
+// are three consecutive staged columns, and two consecutive output rows share one pair of input rows — per input row 3 LDS reads and
+// two 8-byte stores (512 B per wave instruction), no per-element index arithmetic.  A workgroup is WX x (4 / WX) such strips of TH rows;
+// the input tile (TH / 2 + 2 rows per strip) is staged with scalar-row buffer loads, out-of-range rows / columns read 0.
+// Taps are zero-extended to 4 x 4: KH, KW <= 4.
+template <int WX, int TH>
+__global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ x, const float* __restrict__ k, float* __restrict__ y,
+                                                      int in_h, int in_w, int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0,
+                                                      int tiles_x, int tiles_y) {
+    constexpr int WY = 4 / WX;
+    constexpr int RW = 64 * WX + 2;           // staged columns
+    constexpr int RH = WY * (TH / 2) + 2;     // staged rows
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_per_plane = tiles_x * tiles_y;
+    const int plane = t / tiles_per_plane;
+    t -= plane * tiles_per_plane;
+    const int tile_x = t / tiles_y, tile_y = t - tile_x * tiles_y;
+    const int oy0 = tile_y * (WY * TH), ox0 = tile_x * (128 * WX);
+
+    const int jx = (ox0 - pad_x0) & 1;                  // tap phase of the even column of a pair; the odd column has 1 - jx
+    const int ix0 = (ox0 - pad_x0 + jx) >> 1;           // first staged input column: the even column's first input at lane 0
+    const int dx = 1 - jx;                              // the odd column's inputs start dx columns later
+    const int iy0 = (oy0 - pad_y0) >> 1;                // first staged input row
+    // flipped, zero-extended taps by column phase (uniform loads): ka[i][t] = tap (i, jx + 2 t) of the even column, kb[i][t] = tap
+    // (i, 1 - jx + 2 t) of the odd one
+    auto tap = [&](int i, int j) { return (i < kh && j < kw) ? k[(kh - 1 - i) * kw + (kw - 1 - j)] : 0.f; };
+    float ka[4][2], kb[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) ka[i][tt] = tap(i, jx + 2 * tt), kb[i][tt] = tap(i, 1 - jx + 2 * tt);
+    const unsigned in_row_bytes = (unsigned)in_w * 4u, out_row_bytes = (unsigned)out_w * 4u;
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x) + (size_t)plane * in_h * in_w, 0, (int)((unsigned)in_h * in_row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(y + (size_t)plane * out_h * out_w, 0, (int)((unsigned)out_h * out_row_bytes), 0x00020000);
+#endif
+    // staging: wave w takes rows w, w + 4, ...; a row is WX dense 64-float segments + 2 more columns (lanes 0, 1 of one more load)
+    constexpr int NR = (RH + 3) / 4;
+    unsigned voff[WX + 1];
+#pragma unroll
+    for (int sgm = 0; sgm <= WX; ++sgm) {
+        const int ix = ix0 + sgm * 64 + lane;
+        voff[sgm] = (ix >= 0 && ix < in_w && (sgm < WX || lane < 2)) ? (unsigned)ix * 4u : FIR_OOB;
+    }
+    float v[NR][WX + 1];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int rr = wave + 4 * i;  // (scalar)
+        const int iy = iy0 + rr;
+        (void)iy;
+#pragma unroll
+        for (int sgm = 0; sgm <= WX; ++sgm) {
+            v[i][sgm] = 0.f;
+#ifdef MAUA_DEVICE_PASS
+            if (rr < RH && iy >= 0 && iy < in_h)
+                v[i][sgm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, voff[sgm], (unsigned)iy * in_row_bytes, 0));
+#endif
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int rr = wave + 4 * i;
+        if (rr < RH) {
+#pragma unroll
+            for (int sgm = 0; sgm < WX; ++sgm) lds[rr * RW + sgm * 64 + lane] = v[i][sgm];
+            if (lane < 2) lds[rr * RW + WX * 64 + lane] = v[i][WX];
+        }
+    }
+    __syncthreads();
+
+    const int wx = wave % WX, wy = wave / WX;
+    const int strip_lo = oy0 + wy * TH;
+    const int ox = ox0 + wx * 128 + 2 * lane;
+    // 8-byte stores; a lone last column (odd out_w) goes out as 4 bytes
+    const unsigned out_voff = ox < out_w ? (unsigned)ox * 4u : FIR_OOB;
+    const bool pair_ok = ox + 1 < out_w;
+    typedef __attribute__((address_space(3))) float lds_float;
+    const lds_float* lrow = (const lds_float*)lds + ((wy * (TH / 2)) * RW + wx * 64 + lane);
+    float p0 = lrow[0], p1 = lrow[1], p2 = lrow[2];   // input row ra (three consecutive columns)
+    const int ra_lo = (strip_lo - pad_y0) >> 1;        // == iy0 + wy * TH / 2 (TH, oy0 even)
+#pragma unroll
+    for (int r = 0; r <= TH / 2; ++r) {
+        lrow += RW;
+        const float q0 = lrow[0], q1 = lrow[1], q2 = lrow[2];  // input row ra + 1
+        const float pb0 = dx ? p1 : p0, pb1 = dx ? p2 : p1, qb0 = dx ? q1 : q0, qb1 = dx ? q2 : q1;
+        // the two output rows that read input rows (ra, ra + 1): 2 ra - 1 + pad_y0 with row taps (1, 3), 2 ra + pad_y0 with (0, 2)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int oy = 2 * (ra_lo + r) - 1 + e + pad_y0;  // (scalar)
+            const int i0 = 1 - e;
+            if (oy >= strip_lo && oy < strip_lo + TH && oy < out_h) {
+                const float a = fmaf(ka[i0][0], p0, fmaf(ka[i0][1], p1, fmaf(ka[i0 + 2][0], q0, ka[i0 + 2][1] * q1)));
+                const float b = fmaf(kb[i0][0], pb0, fmaf(kb[i0][1], pb1, fmaf(kb[i0 + 2][0], qb0, kb[i0 + 2][1] * qb1)));
+                (void)a, (void)b;
+#ifdef MAUA_DEVICE_PASS
+                if (pair_ok) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)}, y_rsrc, out_voff,
+                                                          (unsigned)oy * out_row_bytes, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), y_rsrc, out_voff, (unsigned)oy * out_row_bytes, 0);
+                }
+#endif
+            }
+        }
+        p0 = q0, p1 = q1, p2 = q2;
+    }
+}
+
 __global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                           float* __restrict__ y, int major, int in_h, int in_w,
                                                           int minor, int kh, int kw, int up_x, int up_y, int down_x,
@@ -353,6 +477,27 @@ int dispatch_fir_tile(const float* x, const float* k, float* y, int planes, int 
     return MAUA_ENOSYS;
 }
 
+// (up, down) = (2, 1), taps up to 4 x 4: the tiled polyphase kernel
+int launch_fir_up2(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w, int kh, int kw,
+                   int pad_x0, int pad_y0, hipStream_t st) {
+    if ((int64_t)in_h * in_w * 4 >= 0x7fffffffLL || (int64_t)out_h * out_w * 4 >= 0x7fffffffLL) return MAUA_ENOSYS;
+    auto go = [&](auto wx_tag) -> int {
+        constexpr int WX = decltype(wx_tag)::value, TH = FIR_UP2_ROWS, WY = 4 / WX;
+        const int tiles_x = ceil_div(out_w, 128 * WX), tiles_y = ceil_div(out_h, WY * TH);
+        const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
+        if (nblocks <= 0) return 0;
+        if (nblocks > 0x7fffffff) return MAUA_EINVAL;
+        const size_t lds_bytes = sizeof(float) * (size_t)(WY * (TH / 2) + 2) * (64 * WX + 2);
+        hipLaunchKernelGGL((fir_up2_kernel<WX, TH>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y, in_h, in_w, out_h, out_w,
+                           kh, kw, pad_x0, pad_y0, tiles_x, tiles_y);
+        MAUA_LAUNCH_CHECK();
+        return 0;
+    };
+    if (out_w <= 128) return go(std::integral_constant<int, 1>{});
+    if (out_w <= 256) return go(std::integral_constant<int, 2>{});
+    return go(std::integral_constant<int, 4>{});
+}
+
 }  // namespace
 
 extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
@@ -370,6 +515,10 @@ extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int 
         FirTail none{};
         const int rc = dispatch_fir_tile<false>(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, none, st);
         if (rc != MAUA_ENOSYS) return rc;  // (planes of 2 GiB and more take the generic gather below)
+    }
+    if (minor == 1 && up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && kh <= 4 && kw <= 4) {
+        const int rc = launch_fir_up2(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, st);
+        if (rc != MAUA_ENOSYS) return rc;
     }
     const int64_t total = (int64_t)major * out_h * out_w * minor;
     const int64_t blocks = ceil_div64(total, 256);

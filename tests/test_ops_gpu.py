@@ -56,6 +56,72 @@ def test_upfirdn2d_generic_path_vs_oracle(gpu, up, down, k, pad):
     np.testing.assert_allclose(got, want, atol=2e-5)
 
 
+@pytest.mark.parametrize("shape,k,pad", [
+    ((1, 2, 4, 4), 4, (2, 1)), ((2, 3, 64, 64), 4, (2, 1)), ((1, 2, 37, 41), 4, (2, 1)), ((1, 1, 65, 129), 4, (2, 1)),
+    ((1, 2, 128, 128), 4, (2, 1)), ((1, 1, 33, 300), 4, (2, 1)),               # one / two / four strips across, partial tiles
+    ((1, 2, 20, 67), 4, (1, 2)), ((1, 1, 31, 65), 4, (3, 3)), ((2, 1, 19, 23), 4, (0, 0)), ((1, 1, 40, 40), 4, (-1, 1)),
+    ((1, 1, 40, 70), 4, (5, -2)), ((1, 2, 29, 130), 3, (1, 1)), ((1, 2, 17, 66), 2, (1, 0)), ((1, 1, 50, 50), 3, (2, 2)),
+    ((1, 1, 16, 129), 1, (0, 0)),
+])
+def test_upfirdn2d_up2_tiled_path_vs_oracle(gpu, shape, k, pad):
+    """Upsample-style calls (up = 2, down = 1; reference models/stylegan2.py:51-67, op/upfirdn2d_kernel.cu:313-359 mode 3): every pad
+    parity incl. negative pads (crops), odd output widths (a lone last column), 1 .. 4-tap kernels, sizes across the strip / tile edges."""
+    from maua_stylegan2_amd.op import upfirdn2d
+
+    r = np.random.default_rng(sum(shape) + 31 * k + pad[0])
+    x = r.standard_normal(shape).astype(np.float32)
+    kern = r.standard_normal((k, k)).astype(np.float32)
+    want = ops_oracle.upfirdn2d(torch.from_numpy(x), torch.from_numpy(kern), up=2, pad=pad).numpy()
+    got = upfirdn2d(t(x, gpu), t(kern, gpu), up=2, pad=pad).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=2e-5)
+
+
+def test_upfirdn2d_up2_rectangular_taps_and_axis_pads(gpu):
+    """The native-op boundary takes per-axis pads and a kh x kw tap matrix (op/upfirdn2d.cpp:12-22)."""
+    from maua_stylegan2_amd.op import upfirdn2d_native_op
+
+    r = np.random.default_rng(77)
+    x = r.standard_normal((3, 21, 45, 1)).astype(np.float32)
+    kern = r.standard_normal((3, 4)).astype(np.float32)
+    got = upfirdn2d_native_op(t(x, gpu), t(kern, gpu), 2, 2, 1, 1, 2, 1, 0, 3).cpu().numpy()[..., 0]
+    # oracle by hand: zero-stuff, pad (y: 0 / 3, x: 2 / 1), true convolution
+    canvas = np.zeros((3, 42 + 0 + 3, 90 + 2 + 1), dtype=np.float64)
+    canvas[:, 0:42:2, 2:92:2] = x[..., 0]
+    kf = kern[::-1, ::-1].astype(np.float64)
+    want = np.zeros((3, canvas.shape[1] - 2, canvas.shape[2] - 3))
+    for i in range(3):
+        for j in range(4):
+            want += kf[i, j] * canvas[:, i:i + want.shape[1], j:j + want.shape[2]]
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=2e-5)
+
+
+def test_upfirdn2d_up2_full_size_properties(gpu):
+    """Size-independent properties at the generator's largest Upsample, [32, 512, 512] -> [32, 1024, 1024] (pad (2, 1), taps x 4):
+    linearity; an impulse lands as the tap matrix itself (true convolution of the zero-stuffed canvas); a constant map comes back
+    constant away from the border (the four polyphase tap sums are 1 each)."""
+    from maua_stylegan2_amd.op import upfirdn2d
+    from maua_stylegan2_amd.seeding import fir_kernel_2d
+
+    k = torch.from_numpy(fir_kernel_2d((1, 3, 3, 1), 4.0)).to(gpu)  # (gain 4 = up ** 2: reference models/stylegan2.py:56)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn(1, 32, 512, 512, generator=gen).to(gpu)
+    b = torch.randn(1, 32, 512, 512, generator=gen).to(gpu)
+    ya, yb, yab = upfirdn2d(a, k, up=2, pad=(2, 1)), upfirdn2d(b, k, up=2, pad=(2, 1)), upfirdn2d(2 * a - 3 * b, k, up=2, pad=(2, 1))
+    assert ya.shape == (1, 32, 1024, 1024)
+    assert float((yab - (2 * ya - 3 * yb)).abs().max()) < 1e-4
+    imp = torch.zeros(1, 1, 512, 512, device=gpu)
+    imp[0, 0, 300, 411] = 1.0
+    kr = torch.arange(16, dtype=torch.float32, device=gpu).reshape(4, 4)
+    y = upfirdn2d(imp, kr, up=2, pad=(2, 1))
+    # canvas (2 * 300, 2 * 411) reaches out[oy, ox] through flipped tap (i, j) = (600 + 2 - oy, 822 + 2 - ox): y[599 + a, 821 + b] = k[a, b]
+    assert torch.equal(y[0, 0, 599:603, 821:825], kr)
+    assert float(y.sum()) == float(kr.sum())
+    ones = upfirdn2d(torch.ones(1, 2, 512, 512, device=gpu), k, up=2, pad=(2, 1))
+    assert float((ones[:, :, 2:-2, 2:-2] - 1.0).abs().max()) < 1e-6
+
+
 def test_upfirdn2d_native_boundary_minor_axis(gpu):
     """The pybind-level layout [major, h, w, minor] with minor > 1 (op/upfirdn2d.cpp:12-22)."""
     from maua_stylegan2_amd.op import upfirdn2d_native_op

@@ -75,6 +75,18 @@ def main():
             byts = 4 * B * C * ((r + 1) ** 2 + r ** 2)
             out["fir_1024"] = {"ms": ms, "bytes_read": 4 * B * C * (r + 1) ** 2, "bytes_written": 4 * B * C * r * r,
                                "gbs": byts / ms / 1e6}
+            # the Upsample module as a standalone op (up = 2, pad (2, 1), taps x up ** 2): [B, C, 512, 512] -> [B, C, 1024, 1024]
+            xu = torch.randn(B, C, r // 2, r // 2, device=dev)
+            ku = k  # (fir_kernel_2d's gain 4 is the Upsample module's up ** 2)
+            call_up = lambda: lib.maua_upfirdn2d_f32(xu.data_ptr(), ku.data_ptr(), y.data_ptr(), B * C, r // 2, r // 2, 1, 4, 4, 2, 2, 1, 1, 2, 1, 2, 1, sp)  # noqa: E731
+            call_up()
+            e0.record(sp)
+            for _ in range(args.iters):
+                call_up()
+            e1.record(sp)
+            ms = e0.elapsed_ms(e1) / args.iters
+            byts = 4 * B * C * ((r // 2) ** 2 + r ** 2)
+            out["fir_up2_512_to_1024"] = {"ms": ms, "bytes_read": 4 * B * C * (r // 2) ** 2, "bytes_written": 4 * B * C * r * r, "gbs": byts / ms / 1e6}
             nz = torch.randn(1, 1, r, r, device=dev)
             nw = torch.full((1,), 0.1, device=dev)
             bias = torch.randn(C, device=dev)
