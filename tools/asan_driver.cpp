@@ -7,7 +7,7 @@
 // tail on tile-edge shapes, and checks every result against the scalar C restatement (oracle/c/ops_ref.c — test infrastructure).
 //
 //   hipcc --offload-arch=gfx950 -fsanitize=address -shared-libasan [-fno-gpu-sanitize] tools/asan_driver.cpp oracle/c/ops_ref.c \
-//         -Lmaua_stylegan2_amd/csrc/san -lmaua_hip_hostasan -o tools/bin/asan_driver      (tools/asan_run.sh does this)
+//         -Lmaua_stylegan2_amd/csrc/san -lmaua_hip_hostasan -o tools/bin/asan_driver_host      (tools/build_asan_driver.sh)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -175,6 +175,13 @@ int main() {
     fir_case(1, 257, 257, 4, 1, 1, 1, 1);
     fir_case(5, 17, 63, 3, 1, 1, 1, 1);
     fir_case(2, 16, 16, 4, 2, 1, 2, 1);
+    // up = 2 (fir_up2_kernel): strip / tile edges (128-column strips, 16-row strips), odd widths, pad parities, a crop, 3- and 2-tap kernels
+    fir_case(3, 64, 64, 4, 2, 1, 2, 1);
+    fir_case(1, 33, 129, 4, 2, 1, 2, 1);
+    fir_case(2, 17, 67, 4, 2, 1, 1, 2);
+    fir_case(1, 20, 40, 4, 2, 1, -1, 1);
+    fir_case(2, 9, 130, 3, 2, 1, 1, 1);
+    fir_case(1, 8, 65, 2, 2, 1, 1, 0);
     fir_case(2, 31, 45, 4, 1, 2, 1, 1);
     fir_case(1, 9, 7, 2, 3, 1, 0, 1);
     fir_case(1, 1, 1, 4, 1, 1, 2, 2);
