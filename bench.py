@@ -99,6 +99,7 @@ def time_calls(fn, iters, stream_ptr):
 
 INSTANCES = {}  # bench row name -> rocprofv3 kernel instance name (filled by layer_breakdown)
 FUSED_OVERLAP = {}  # breakdown row of a fused up-sampling layer -> tiles launched / tiles of the plain tiling (its executed-flops factor)
+FUSED_GRID = {}     # ... -> threads of its launch (the fused layers share one kernel instance: the PMC table keys their launches by grid)
 
 
 def layer_breakdown(g, batch, noise_batch, stream):
@@ -143,6 +144,10 @@ def layer_breakdown(g, batch, noise_batch, stream):
             rows.append((f"convs.{2*n}.upconv+blur+noise+act (one kernel)", "modconv_up_fused", t_all, 2 * cin * cout * 9 * h * h * batch,
                          4 * batch * (cin * h * h + cout * (2 * h) ** 2)))
             INSTANCES[rows[-1][0]] = "modconv_up2d_kernel<8, 2>"  # (maua_upconv_blur_f32 has one instance; the seam pass is up2d_seam_kernel)
+            # workgroups = images x vertical segments x tile columns x 32-channel tiles; the segment count from the seam workspace the library
+            # asks for ((segments - 1) x 6 rows of 2W floats per image and channel + 4)
+            n_seg = (_lib.load().maua_upconv_blur_ws_floats(batch, cin, cout, h, h) - 4) // (batch * cout * 12 * h) + 1
+            FUSED_GRID[rows[-1][0]] = batch * n_seg * tiles_x * (cout // 32) * 256
         else:
             # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
             raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
@@ -780,6 +785,8 @@ def main():
                     result["roofline"]["what"] = "the single launch with the largest device time (isolated, HIP events on the launch stream)"
                     table, table_path = pmc_traffic_table()
                     rec = (table or {}).get("kernels", {}).get(inst) if inst else None
+                    if rec is not None and rec.get("dispatches_per_step") != 1 and dom[0] in FUSED_GRID:
+                        rec = rec.get("by_grid", {}).get(str(FUSED_GRID[dom[0]]))  # this launch among the launches of its instance
                     if rec is not None and table.get("batch") == B and table.get("size") == size and rec.get("dispatches_per_step") == 1:
                         # HBM bytes of this launch from the PMC passes of the SAME bench command (tools/profile_round.sh ->
                         # tools/make_profiles.py): FETCH_SIZE x2 (guide's gfx950 correction, calibrated on a known-size copy) +

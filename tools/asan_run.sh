@@ -30,20 +30,20 @@ TESTS="tests/test_ops_gpu.py tests/test_property_gpu.py"
 RTDIR=$(dirname "$RT")
 {
   echo "== leg 3: tools/bin/asan_driver_host (host ASAN + UBSan library, no python in the process)"
-  LD_LIBRARY_PATH=$RTDIR:${LD_LIBRARY_PATH:-} timeout 300 tools/bin/asan_driver_host 2>&1 | tail -25
+  LD_LIBRARY_PATH=$RTDIR:${LD_LIBRARY_PATH:-} timeout 300 tools/bin/asan_driver_host 2>&1 | tail -60
   echo "rc=${PIPESTATUS[0]}"
 } > "$O/driver_host.log" 2>&1
 {
   echo "== leg 4: tools/bin/asan_driver_device (device ASAN library, gfx950:xnack+, HSA_XNACK=1)"
-  HSA_XNACK=1 LD_LIBRARY_PATH=$RTDIR:${LD_LIBRARY_PATH:-} timeout 300 tools/bin/asan_driver_device 2>&1 | tail -25
+  HSA_XNACK=1 LD_LIBRARY_PATH=$RTDIR:${LD_LIBRARY_PATH:-} timeout 300 tools/bin/asan_driver_device 2>&1 | tail -60
   echo "rc=${PIPESTATUS[0]}"
 } > "$O/driver_device.log" 2>&1
 {
   echo "sanitizer runs on $(python -c 'import torch;print(torch.cuda.get_device_name(0))' 2>/dev/null), $(date -u +%FT%TZ)"
   echo "--- host ASAN + UBSan"; tail -4 "$O/host.log"
   echo "--- device ASAN"; tail -8 "$O/device.log"
-  echo "--- torch-free driver, host ASAN + UBSan library"; tail -22 "$O/driver_host.log"
-  echo "--- torch-free driver, device ASAN library"; tail -22 "$O/driver_device.log"
+  echo "--- torch-free driver, host ASAN + UBSan library"; tail -50 "$O/driver_host.log"
+  echo "--- torch-free driver, device ASAN library"; tail -50 "$O/driver_device.log"
   echo "--- sanitizer report files:"; ls "$O" | grep -c "_report" ; for f in "$O"/*_report*; do [ -f "$f" ] && { echo "## $f"; head -40 "$f"; }; done
 } > "$O/summary.txt" 2>&1
 cat "$O/summary.txt" | head -120

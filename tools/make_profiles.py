@@ -30,6 +30,20 @@ def table(db, keep=("modconv_mfma", "modconv_w2d", "modconv_up2d", "up2d_edge", 
     return tab
 
 
+def table_by_grid(db, counter):
+    """{instance: {grid_size (threads): {counter: avg, n, us}}} — for instances launched more than once per forward with different grids
+    (the fused up-sampling layers share one instance)."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, grid_size, count(*), avg(value), avg(duration) from counters_collection where counter_name = ? "
+                       "group by kernel_name, grid_size", (counter,)).fetchall()
+    tab = {}
+    for n, grid, k, v, dur in rows:
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"\(.*", "", n).replace("void ", "")
+        tab.setdefault(n, {})[int(grid)] = {counter: v, "n": k, "us": dur / 1e3}
+    return tab
+
+
 def last_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
@@ -144,12 +158,20 @@ duration; "non-MFMA VALU per MFMA" = (SQ_INSTS_VALU - MOPS / 4) / (MOPS / 4).
     # "dispatches_per_step" = dispatches per FORWARD (= per batch)
     steps_in_run = int(next(t["n"] for n, t in fe.items() if n.startswith("style_affine_kernel")))
     kernels = {}
+    fe_grid = table_by_grid(f"{O}/pmc_FETCH_SIZE/bench_results.db", "FETCH_SIZE")
+    wr_grid = table_by_grid(f"{O}/pmc_WRITE_SIZE/bench_results.db", "WRITE_SIZE")
     for n, t in fe.items():
         w = wr.get(n, {})
         if "WRITE_SIZE" not in w:
             continue
         rec = {"read_bytes": 2.0 * t["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0, "dispatches": t["n"],
                "avg_us": t["us"], "dispatches_per_step": t["n"] / steps_in_run if t["n"] % steps_in_run == 0 else None}
+        if rec["dispatches_per_step"] != 1 and len(fe_grid.get(n, {})) > 1:
+            # several launches of one instance per forward: the same averages per launch GRID (threads), so that one launch can be told apart
+            rec["by_grid"] = {str(g): {"read_bytes": 2.0 * a["FETCH_SIZE"] * 1024.0, "write_bytes": wr_grid[n][g]["WRITE_SIZE"] * 1024.0,
+                                       "dispatches": a["n"], "avg_us": a["us"],
+                                       "dispatches_per_step": a["n"] / steps_in_run if a["n"] % steps_in_run == 0 else None}
+                              for g, a in fe_grid[n].items() if g in wr_grid.get(n, {})}
         if n.startswith("fir_strip_kernel") or n in ("fir_tile_kernel<4, 4, 4, false>", "fir_tile_kernel<4, 4, 4, false, 24>"):  # (the plain op: only bench.py's standalone leg launches it)
             rec["planes"] = 256  # bench.py's standalone upfirdn2d leg: [8, 32, 1025, 1025]
         kernels[n] = rec
