@@ -24,6 +24,7 @@ host cores (BASELINE.md §4 legs).  `frame_check` compares the frames of the las
 (un-captured) forward of the same frames, bit for bit.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -386,6 +387,10 @@ def time_region(wl, steps, bps, mode, use_dist, world):
     copy_stream = torch.cuda.Stream(dev) if mode == "pcie" else None
     copied = [None] * n_slots
     wl.sync()
+    # as render() does before its frame loop: no generation-2 collection (45-90 ms on this heap: tools/gather_probe.py) on the thread that
+    # launches the replays; the survivors of one collection are parked in the permanent generation
+    gc.collect()
+    gc.freeze()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)

@@ -16,6 +16,7 @@ with ``input_is_latent=True``), different machinery:
 Sinks: ffmpeg rawvideo pipe (same pixel format / codec arguments as render.py:58-91) when an ``ffmpeg`` binary exists,
 otherwise raw rgb24 bytes to ``output_file`` (+ ".rgb24"), or a null sink for benchmarking (``output_file=None``).
 """
+import gc
 import os
 import queue
 import shutil
@@ -438,6 +439,11 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
 
     worker = SinkWorker(sink) if sink is not None else None
     locked = False
+    # The frame loop runs on the Python thread that launches every graph replay.  A generation-2 collection walks the ~170 k long-lived
+    # objects of a process that has torch imported: 45-90 ms, i.e. 8-15 batches during which no replay is launched (measured: tools/gather_probe.py,
+    # and as a 9 % hole in a 150-batch gathered bench region).  Collect once now, keep the survivors out of the collector's way for the loop.
+    gc.collect()
+    gc.freeze()
     try:
         if not sharding.grouped():
             # pinned staging ring: the D2H of batch k overlaps the replays of the next batches; the sink thread writes a slot and
@@ -555,6 +561,7 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
         if worker is not None:
             worker.close()
     finally:  # the encoder process / output file must not outlive a failed render
+        gc.unfreeze()
         if worker is not None:
             try:
                 worker.close()  # (also: every ring slot has been written before the rings are handed to the next render)
