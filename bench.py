@@ -33,6 +33,8 @@ import time
 # one hardware queue per stream (3 graph lanes + copy stream + default stream; the HIP default is 4): see maua_stylegan2_amd/__init__.py.
 # Must be in the environment before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument otherwise)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 

@@ -8,5 +8,8 @@ import os as _os
 # Read by the runtime when it initialises, i.e. at the first device call: importing this package first is enough.  An explicit setting
 # in the environment wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# One process per GPU over RCCL: the host driver of the target boxes only supports dmabuf IPC; without this RCCL / device-tensor sharing across
+# processes fails with `hipIpcGetMemHandle: invalid argument`.  Same rule: read at runtime initialisation, an explicit setting wins.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 __version__ = "0.1.0"
