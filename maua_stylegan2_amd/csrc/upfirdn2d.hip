@@ -17,6 +17,7 @@
 //    adjacent tiles (which share KH-1 halo rows) are served by the same L2; with the tail the channel is fastest (planes that
 //    share a noise tile run back-to-back).
 //  * fir_up2_kernel (up = 2, down = 1, taps <= 4 x 4: the Upsample module as a standalone op): polyphase, store-bound; see the kernel.
+//  * fir_down2_kernel (up = 1, down = 2, taps <= 4 x 4: the Downsample module / the backward of Upsample; off the inference path): load-bound.
 //  * fir_generic_kernel: any up/down/pad/minor, one thread per output, polyphase tap skipping.
 #include "common.h"
 
@@ -49,6 +50,10 @@ constexpr int FIR_TAIL_SMALL_MAX_H = 512;
 #ifndef MAUA_FIR_UP2_ROWS
 #define MAUA_FIR_UP2_ROWS 16
 #endif
+#ifndef MAUA_FIR_DOWN2_ROWS
+#define MAUA_FIR_DOWN2_ROWS 8
+#endif
+constexpr int FIR_DOWN2_ROWS = MAUA_FIR_DOWN2_ROWS;  // output rows per wave strip of fir_down2_kernel
 constexpr int FIR_UP2_ROWS = MAUA_FIR_UP2_ROWS;  // output rows per wave strip of fir_up2_kernel ([8,32,512,512] -> 1024^2: 16 rows 0.239 ms, 32 0.267, 64 0.257)
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -357,6 +362,120 @@ __global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ 
     }
 }
 
+// up = 1, down = 2 (the Downsample module and the backward of Upsample; the reference tiles it as op/upfirdn2d_kernel.cu:313-359 modes 5 / 6; not
+// on the inference path).  HBM-bound on its LOADS: 4 input floats per output float.  out[oy][ox] = sum kf[i][j] x[2 oy + i - pad_y0][2 ox + j - pad_x0].
+// A lane owns one output column: its four input columns 2 c .. 2 c + 3 are two conflict-free ds_read_b64, two new input rows per output row roll
+// through a 4 x 4 register window; the input tile (2 TH + 2 rows of 128 WX + 2 columns per strip row) is staged with scalar-row dense loads.
+// Taps are zero-extended to 4 x 4: KH, KW <= 4.
+template <int WX, int TH>
+__global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict__ x, const float* __restrict__ k, float* __restrict__ y,
+                                                        int in_h, int in_w, int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0,
+                                                        int tiles_x, int tiles_y) {
+    constexpr int WY = 4 / WX;
+    constexpr int RW = 128 * WX + 2;        // staged columns (even: rows stay 8-byte aligned)
+    constexpr int RH = 2 * WY * TH + 2;     // staged rows
+    constexpr int NSEG = 2 * WX + 1;        // dense 64-float loads per staged row (the last one: 2 columns)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_per_plane = tiles_x * tiles_y;
+    const int plane = t / tiles_per_plane;
+    t -= plane * tiles_per_plane;
+    const int tile_x = t / tiles_y, tile_y = t - tile_x * tiles_y;
+    const int oy0 = tile_y * (WY * TH), ox0 = tile_x * (64 * WX);
+    const int iy0 = 2 * oy0 - pad_y0, ix0 = 2 * ox0 - pad_x0;
+
+    auto tap = [&](int i, int j) { return (i < kh && j < kw) ? k[(kh - 1 - i) * kw + (kw - 1 - j)] : 0.f; };  // flipped, zero-extended (uniform loads)
+    float kf[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kf[i][j] = tap(i, j);
+
+    const unsigned in_row_bytes = (unsigned)in_w * 4u, out_row_bytes = (unsigned)out_w * 4u;
+#ifdef MAUA_DEVICE_PASS
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x) + (size_t)plane * in_h * in_w, 0, (int)((unsigned)in_h * in_row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(y + (size_t)plane * out_h * out_w, 0, (int)((unsigned)out_h * out_row_bytes), 0x00020000);
+#endif
+    unsigned voff[NSEG];
+#pragma unroll
+    for (int sgm = 0; sgm < NSEG; ++sgm) {
+        const int ix = ix0 + sgm * 64 + lane;
+        voff[sgm] = (ix >= 0 && ix < in_w && (sgm < 2 * WX || lane < 2)) ? (unsigned)ix * 4u : FIR_OOB;
+    }
+    // staging in two halves (rows wave, wave + 4, ...): bounds the loads in flight per lane
+    constexpr int NR = (RH + 3) / 4;
+    constexpr int HALF = (NR + 1) / 2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float v[HALF][NSEG];
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const int rr = wave + 4 * (half * HALF + i);  // (scalar)
+            const int iy = iy0 + rr;
+            (void)iy;
+#pragma unroll
+            for (int sgm = 0; sgm < NSEG; ++sgm) {
+                v[i][sgm] = 0.f;
+#ifdef MAUA_DEVICE_PASS
+                if (rr < RH && iy >= 0 && iy < in_h)
+                    v[i][sgm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, voff[sgm], (unsigned)iy * in_row_bytes, 0));
+#endif
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const int rr = wave + 4 * (half * HALF + i);
+            if (rr < RH) {
+#pragma unroll
+                for (int sgm = 0; sgm < 2 * WX; ++sgm) lds[rr * RW + sgm * 64 + lane] = v[i][sgm];
+                if (lane < 2) lds[rr * RW + 2 * WX * 64 + lane] = v[i][2 * WX];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int wx = wave % WX, wy = wave / WX;
+    const int strip_lo = oy0 + wy * TH;
+    const int ox = ox0 + wx * 64 + lane;
+    const unsigned out_voff = ox < out_w ? (unsigned)ox * 4u : FIR_OOB;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+    const lds_f32x2* lrow = (const lds_f32x2*)((const __attribute__((address_space(3))) float*)lds + ((2 * wy * TH) * RW + wx * 128 + 2 * lane));
+    float w[4][4];  // rolling window: input rows 2 o .. 2 o + 3, the lane's four columns
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const f32x2 a = lrow[0], b = lrow[1];
+        w[r + 2][0] = a.x, w[r + 2][1] = a.y, w[r + 2][2] = b.x, w[r + 2][3] = b.y;
+        lrow += RW / 2;
+    }
+#pragma unroll
+    for (int o = 0; o < TH; ++o) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[0][c] = w[2][c], w[1][c] = w[3][c];
+#pragma unroll
+        for (int r = 2; r < 4; ++r) {
+            const f32x2 a = lrow[0], b = lrow[1];
+            w[r][0] = a.x, w[r][1] = a.y, w[r][2] = b.x, w[r][3] = b.y;
+            lrow += RW / 2;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = fmaf(kf[i][j], w[i][j], acc);
+        const int oy = strip_lo + o;  // (scalar)
+        (void)oy, (void)acc;
+#ifdef MAUA_DEVICE_PASS
+        if (oy < out_h) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc), y_rsrc, out_voff, (unsigned)oy * out_row_bytes, 0);
+#endif
+    }
+}
+
 __global__ __launch_bounds__(256) void fir_generic_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                           float* __restrict__ y, int major, int in_h, int in_w,
                                                           int minor, int kh, int kw, int up_x, int up_y, int down_x,
@@ -498,6 +617,28 @@ int launch_fir_up2(const float* x, const float* k, float* y, int planes, int in_
     return go(std::integral_constant<int, 4>{});
 }
 
+// (up, down) = (1, 2), taps up to 4 x 4
+int launch_fir_down2(const float* x, const float* k, float* y, int planes, int in_h, int in_w, int out_h, int out_w, int kh, int kw,
+                     int pad_x0, int pad_y0, hipStream_t st) {
+    if ((int64_t)in_h * in_w * 4 >= 0x7fffffffLL || (int64_t)out_h * out_w * 4 >= 0x7fffffffLL) return MAUA_ENOSYS;
+    auto go = [&](auto wx_tag) -> int {
+        constexpr int WX = decltype(wx_tag)::value, TH = FIR_DOWN2_ROWS, WY = 4 / WX;
+        const int tiles_x = ceil_div(out_w, 64 * WX), tiles_y = ceil_div(out_h, WY * TH);
+        const int64_t nblocks = (int64_t)planes * tiles_x * tiles_y;
+        if (nblocks <= 0) return 0;
+        if (nblocks > 0x7fffffff) return MAUA_EINVAL;
+        const size_t lds_bytes = sizeof(float) * (size_t)(2 * WY * TH + 2) * (128 * WX + 2);
+        static_assert(sizeof(float) * (2 * WY * TH + 2) * (128 * WX + 2) <= 64 * 1024, "dynamic LDS beyond 64 KB needs the launch attribute");
+        hipLaunchKernelGGL((fir_down2_kernel<WX, TH>), dim3((unsigned)nblocks), dim3(256), lds_bytes, st, x, k, y, in_h, in_w, out_h, out_w,
+                           kh, kw, pad_x0, pad_y0, tiles_x, tiles_y);
+        MAUA_LAUNCH_CHECK();
+        return 0;
+    };
+    if (out_w <= 64) return go(std::integral_constant<int, 1>{});
+    if (out_w <= 128) return go(std::integral_constant<int, 2>{});
+    return go(std::integral_constant<int, 4>{});
+}
+
 }  // namespace
 
 extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
@@ -515,6 +656,10 @@ extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int 
         FirTail none{};
         const int rc = dispatch_fir_tile<false>(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, none, st);
         if (rc != MAUA_ENOSYS) return rc;  // (planes of 2 GiB and more take the generic gather below)
+    }
+    if (minor == 1 && up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && kh <= 4 && kw <= 4) {
+        const int rc = launch_fir_down2(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, st);
+        if (rc != MAUA_ENOSYS) return rc;
     }
     if (minor == 1 && up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && kh <= 4 && kw <= 4) {
         const int rc = launch_fir_up2(x, k, y, major, in_h, in_w, out_h, out_w, kh, kw, pad_x0, pad_y0, st);

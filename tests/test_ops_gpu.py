@@ -77,6 +77,53 @@ def test_upfirdn2d_up2_tiled_path_vs_oracle(gpu, shape, k, pad):
     np.testing.assert_allclose(got, want, atol=2e-5)
 
 
+@pytest.mark.parametrize("shape,k,pad", [
+    ((1, 2, 8, 8), 4, (1, 1)), ((2, 3, 128, 128), 4, (1, 1)), ((1, 2, 37, 41), 4, (1, 1)), ((1, 1, 130, 258), 4, (1, 1)),
+    ((1, 2, 129, 131), 4, (1, 1)), ((1, 1, 70, 601), 4, (1, 1)),                # one / two / four strips across, partial tiles, odd sizes
+    ((1, 2, 40, 67), 4, (2, 1)), ((1, 1, 31, 65), 4, (3, 3)), ((2, 1, 19, 23), 4, (0, 0)), ((1, 1, 40, 40), 4, (-1, 1)),
+    ((1, 1, 40, 70), 4, (5, -2)), ((1, 2, 29, 130), 3, (1, 1)), ((1, 2, 17, 66), 2, (0, 0)), ((1, 1, 50, 50), 3, (0, 1)),
+    ((1, 1, 16, 129), 1, (0, 0)),
+])
+def test_upfirdn2d_down2_tiled_path_vs_oracle(gpu, shape, k, pad):
+    """Downsample-style calls (up = 1, down = 2; reference models/stylegan2.py:70-84, op/upfirdn2d_kernel.cu:313-359 modes 5 / 6; also the
+    backward of Upsample, op/upfirdn2d.py:20-60): pads of both parities incl. negative ones, odd sizes, 1 .. 4-tap kernels, strip / tile edges."""
+    from maua_stylegan2_amd.op import upfirdn2d
+
+    r = np.random.default_rng(sum(shape) + 17 * k + pad[0])
+    x = r.standard_normal(shape).astype(np.float32)
+    kern = r.standard_normal((k, k)).astype(np.float32)
+    want = ops_oracle.upfirdn2d(torch.from_numpy(x), torch.from_numpy(kern), down=2, pad=pad).numpy()
+    got = upfirdn2d(t(x, gpu), t(kern, gpu), down=2, pad=pad).cpu().numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=2e-5)
+
+
+def test_upfirdn2d_down2_inverts_the_shape_of_up2_at_full_size(gpu):
+    """Size-independent properties at [32, 1024, 1024] -> [32, 512, 512] (Downsample: pad (1, 1), 4 taps): linearity; a constant map stays
+    constant away from the border (taps sum to 1); an impulse lands as the decimated tap matrix."""
+    from maua_stylegan2_amd.op import upfirdn2d
+    from maua_stylegan2_amd.seeding import fir_kernel_2d
+
+    k = torch.from_numpy(fir_kernel_2d((1, 3, 3, 1), 1.0)).to(gpu)
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    a = torch.randn(1, 32, 1024, 1024, generator=gen).to(gpu)
+    b = torch.randn(1, 32, 1024, 1024, generator=gen).to(gpu)
+    ya, yb, yab = upfirdn2d(a, k, down=2, pad=(1, 1)), upfirdn2d(b, k, down=2, pad=(1, 1)), upfirdn2d(2 * a - 3 * b, k, down=2, pad=(1, 1))
+    assert ya.shape == (1, 32, 512, 512)
+    assert float((yab - (2 * ya - 3 * yb)).abs().max()) < 1e-4
+    ones = upfirdn2d(torch.ones(1, 2, 1024, 1024, device=gpu), k, down=2, pad=(1, 1))
+    assert float((ones[:, :, 1:-1, 1:-1] - 1.0).abs().max()) < 1e-6
+    imp = torch.zeros(1, 1, 1024, 1024, device=gpu)
+    imp[0, 0, 600, 822] = 1.0
+    kr = torch.arange(16, dtype=torch.float32, device=gpu).reshape(4, 4)
+    y = upfirdn2d(imp, kr, down=2, pad=(1, 1))
+    # out[oy, ox] = sum kflip[i, j] x[2 oy + i - 1, 2 ox + j - 1]: x[600, 822] is reached with i = 601 - 2 oy, j = 823 - 2 ox in 0 .. 3:
+    # oy in {299, 300} (i = 3, 1), ox in {410, 411} (j = 3, 1); kflip[i, j] = k[3 - i, 3 - j]
+    want = torch.tensor([[kr[0, 0], kr[0, 2]], [kr[2, 0], kr[2, 2]]], device=gpu)
+    assert torch.equal(y[0, 0, 299:301, 410:412], want)
+    assert float(y.sum()) == float(want.sum())
+
+
 def test_upfirdn2d_up2_rectangular_taps_and_axis_pads(gpu):
     """The native-op boundary takes per-axis pads and a kh x kw tap matrix (op/upfirdn2d.cpp:12-22)."""
     from maua_stylegan2_amd.op import upfirdn2d_native_op

@@ -182,6 +182,11 @@ int main() {
     fir_case(1, 20, 40, 4, 2, 1, -1, 1);
     fir_case(2, 9, 130, 3, 2, 1, 1, 1);
     fir_case(1, 8, 65, 2, 2, 1, 1, 0);
+    // down = 2 (fir_down2_kernel): 64-column strips, 8-row strips, odd sizes, pad parities, a crop, 3-tap kernel
+    fir_case(2, 128, 128, 4, 1, 2, 1, 1);
+    fir_case(1, 37, 259, 4, 1, 2, 2, 1);
+    fir_case(1, 40, 40, 4, 1, 2, -1, 1);
+    fir_case(2, 29, 130, 3, 1, 2, 1, 1);
     fir_case(2, 31, 45, 4, 1, 2, 1, 1);
     fir_case(1, 9, 7, 2, 3, 1, 0, 1);
     fir_case(1, 1, 1, 4, 1, 1, 2, 2);

@@ -87,6 +87,18 @@ def main():
             ms = e0.elapsed_ms(e1) / args.iters
             byts = 4 * B * C * ((r // 2) ** 2 + r ** 2)
             out["fir_up2_512_to_1024"] = {"ms": ms, "bytes_read": 4 * B * C * (r // 2) ** 2, "bytes_written": 4 * B * C * r * r, "gbs": byts / ms / 1e6}
+            # the Downsample module (down = 2, pad (1, 1)): [B, C, 1024, 1024] -> [B, C, 512, 512]
+            xd = torch.randn(B, C, r, r, device=dev)
+            yd = torch.empty(B * C, r // 2, r // 2, 1, device=dev)
+            call_dn = lambda: lib.maua_upfirdn2d_f32(xd.data_ptr(), k.data_ptr(), yd.data_ptr(), B * C, r, r, 1, 4, 4, 1, 1, 2, 2, 1, 1, 1, 1, sp)  # noqa: E731
+            call_dn()
+            e0.record(sp)
+            for _ in range(args.iters):
+                call_dn()
+            e1.record(sp)
+            ms = e0.elapsed_ms(e1) / args.iters
+            byts = 4 * B * C * (r ** 2 + (r // 2) ** 2)
+            out["fir_down2_1024_to_512"] = {"ms": ms, "bytes_read": 4 * B * C * r ** 2, "bytes_written": 4 * B * C * (r // 2) ** 2, "gbs": byts / ms / 1e6}
             nz = torch.randn(1, 1, r, r, device=dev)
             nw = torch.full((1,), 0.1, device=dev)
             bias = torch.randn(C, device=dev)
