@@ -72,6 +72,32 @@ def test_rejects_bad_arguments_without_gpu(built_lib):
     assert lib.maua_resample_f64(fake, 1 << 21, 1, fake, 1 << 20, None) == -22  # phase arithmetic would leave int64
 
 
+def test_fused_upconv_plan_is_a_pure_function_of_the_shape(built_lib):
+    """maua_upconv_blur_ws_floats exposes the fused up-sampling layer's launch plan ((segments - 1) x 6 rows of 2W floats per image and
+    channel + 4): it must depend on nothing but (batch, cout, h, w) — every rank of a sharded job launches the same grid, and the seam
+    workspace a caller sized once stays valid — and stay inside its bounds.  The three shapes of the 1024^2 generator at batch 8 are pinned
+    to the segment counts measured best on the MI355X (profiles/r05_fused_upconv_blur.md 4: 9 / 10 tiles per segment, and 6 for the
+    layer that stays on two launches)."""
+    from maua_stylegan2_amd import _lib
+
+    lib = _lib.load()
+
+    def n_seg(batch, cin, cout, h, w):
+        n = lib.maua_upconv_blur_ws_floats(batch, cin, cout, h, w)
+        assert n >= 4 and (n - 4) % (batch * cout * 12 * w) == 0
+        return (n - 4) // (batch * cout * 12 * w) + 1
+
+    assert lib.maua_upconv_blur_ok(64, 32, 512, 512) == 1 and lib.maua_upconv_blur_ok(512, 256, 64, 64) == 0  # (cin <= 256: LDS)
+    assert lib.maua_upconv_blur_ws_floats(8, 512, 256, 64, 64) == 0
+    assert (n_seg(8, 64, 32, 512, 512), n_seg(8, 128, 64, 256, 256), n_seg(8, 256, 128, 128, 128)) == (8, 4, 3)
+    for shape in [(1, 64, 32, 8, 32), (3, 64, 32, 32, 32), (2, 128, 64, 64, 64), (1, 64, 32, 512, 512), (5, 32, 32, 40, 96), (16, 64, 64, 256, 256)]:
+        first = n_seg(*shape)
+        tiles = shape[3] // 8 + 1
+        assert 1 <= first <= (tiles + 1) // 2, (shape, first)       # segments hold 2 .. 16 tiles
+        assert first >= (tiles + 15) // 16, (shape, first)
+        assert all(n_seg(*shape) == first for _ in range(3))        # cached, and the same on every call
+
+
 def test_product_ops_refuse_cpu_tensors(built_lib):
     import pytest
     import torch
