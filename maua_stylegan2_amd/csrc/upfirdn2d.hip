@@ -576,9 +576,12 @@ int launch_fir_tile(const float* x, const float* k, float* y, int planes, int in
         return 0;
     };
     auto go_wx = [&](auto wx_tag) -> int {
-        if (!TAIL) return go(wx_tag, std::integral_constant<int, FIR_ROWS_PLAIN>{});
-        if (out_h <= FIR_TAIL_SMALL_MAX_H) return go(wx_tag, std::integral_constant<int, FIR_ROWS_TAIL_SMALL>{});
-        return go(wx_tag, std::integral_constant<int, FIR_ROWS_TAIL>{});
+        if constexpr (!TAIL) {  // (constexpr: the strip heights of the other form are never instantiated)
+            return go(wx_tag, std::integral_constant<int, FIR_ROWS_PLAIN>{});
+        } else {
+            if (out_h <= FIR_TAIL_SMALL_MAX_H) return go(wx_tag, std::integral_constant<int, FIR_ROWS_TAIL_SMALL>{});
+            return go(wx_tag, std::integral_constant<int, FIR_ROWS_TAIL>{});
+        }
     };
     // (the kernel addresses a plane through 32-bit buffer offsets)
     if ((int64_t)in_h * in_w * 4 >= 0x7fffffffLL || (int64_t)out_h * out_w * 4 >= 0x7fffffffLL) return MAUA_ENOSYS;
