@@ -127,10 +127,10 @@ def _collect_noise(get_noise, args, out_size, G_res, stylegan1):
         if nz is not None:
             print(list(nz.shape), f"amplitude={nz.std()}")
         maps.append(nz)
-    # (the reference collects + empties the cache after every scale, generate_audiovisual.py:157-158, to fit small GPUs.)  Once, and only the
-    # young generations: the fields of this loop are freed by refcount, a cycle made here is still young, and a full collection walks the
-    # ~170 k long-lived objects of the process for 45 ms (17 of them cost 0.7 s in round 3)
-    gc.collect(1)
+    # once, not per scale (the reference collects + empties the cache after every scale, generate_audiovisual.py:157-158): 17 collections cost
+    # 0.7 s.  A FULL collection on purpose: young-generation collections (tried in round 5) leave the preprocessing's cyclic garbage — device
+    # tensors among it — alive, and render() then pays more in fresh allocations (+60 ms) than the 45 ms the collection costs
+    gc.collect()
     return maps
 
 
@@ -258,7 +258,7 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
         lo, hi = sharding.shard_bounds(n_frames, rank, world)
         shard = (lo, hi, n_frames)
 
-    gc.collect(1)  # (reference :191-192; young generations only, see get_noise_range)
+    gc.collect()  # (reference :191-192; full on purpose, see get_noise_range)
     if generator is None:
         generator = load()
     if grouped and not stylegan1 and not (isinstance(truncation, float) and truncation == 1.0):

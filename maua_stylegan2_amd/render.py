@@ -443,7 +443,7 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
     # objects of a process that has torch imported: 45-90 ms, i.e. 8-15 batches during which no replay is launched (measured: tools/gather_probe.py,
     # and as a 9 % hole in a 150-batch gathered bench region).  Park everything that is alive now in the permanent generation for the
     # duration of the loop: what the loop allocates is then all the collector ever walks.  (No full gc.collect() here: it would cost the same
-    # 45-90 ms up front, as much as it saves on a 900-frame job; generate() has just collected the young generations.)
+    # 45-90 ms up front, as much as it saves on a 900-frame job; generate() has just run one, as the reference does.)
     gc.freeze()
     try:
         if not sharding.grouped():
