@@ -45,6 +45,24 @@ def test_gaussian_filter_noise_sized_vs_oracle(gpu):
     assert float((a - b).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("shape,sigma,causal", [
+    ((37, 5), 0.3, None), ((37, 5), 1, None), ((64, 300), 2.6, None), ((33, 1000), 7, 0.2), ((50, 3, 7), 40, None),   # radius 1 .. 150 > 3 T
+    ((31, 257), 3.9, None), ((32, 256), 4, 0), ((65, 513), 4.1, None), ((900, 18, 8), 20, None), ((7, 4), 5, None),     # 16-row walk residues, T < 32
+    ((1, 9), 2, None), ((129, 1), 11, 0.5),
+])
+def test_gaussian_filter_shapes_vs_oracle(gpu, shape, sigma, causal):
+    """The temporal FIR (maua_temporal_fir_f32; reference audioreactive/signal.py:335-343) across its blocking: 32 output times per thread,
+    source rows walked 16 at a time, 256 features per workgroup — frame counts either side of 32, feature counts either side of 256, radii of
+    every residue, the wrap (radius > T) and zero-beyond-one-wrap (radius = 3 T) branches, causal taps."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    x = torch.from_numpy(seeding.seeded_array(sum(shape), "gfs", shape))
+    want = signal_oracle.gaussian_filter(x, sigma, causal=causal)
+    got = sig.gaussian_filter(x.to(gpu), sigma, causal=causal).cpu()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5)
+
+
 def test_stft_mel_chroma_vs_oracle(gpu):
     from maua_stylegan2_amd.audioreactive import signal as sig
 
