@@ -28,7 +28,10 @@ int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
  * Replaces pybind `upfirdn2d.upfirdn2d(input[major,in_h,in_w,minor], kernel[kh,kw], up_x, up_y, down_x,
  * down_y, pad_x0, pad_x1, pad_y0, pad_y1)` — op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369.
  * y must hold major*out_h*out_w*minor floats, out = (in*up + pad0 + pad1 - k)/down + 1 (floor).
- * `k` is the un-flipped [kh,kw] tap matrix in DEVICE memory (true convolution, as the reference). */
+ * `k` is the un-flipped [kh,kw] tap matrix in DEVICE memory (true convolution, as the reference).
+ * Every argument combination is served; tiled HBM-rate kernels exist for the shapes the reference's own kernel tiles (modes 1-6 of
+ * op/upfirdn2d_kernel.cu:313-359), with minor == 1 and planes below 2 GiB: up = down = 1 with 2..4 square taps (Blur), up = 2 / down = 1
+ * and up = 1 / down = 2 with up to 4 x 4 taps (Upsample, Downsample), any pads incl. negative ones; the rest takes a one-thread-per-output gather. */
 int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int major, int in_h, int in_w, int minor,
                        int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                        int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
