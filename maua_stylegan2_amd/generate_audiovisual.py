@@ -127,10 +127,8 @@ def _collect_noise(get_noise, args, out_size, G_res, stylegan1):
         if nz is not None:
             print(list(nz.shape), f"amplitude={nz.std()}")
         maps.append(nz)
-    # once, not per scale (the reference collects + empties the cache after every scale, generate_audiovisual.py:157-158): 17 collections cost
-    # 0.7 s.  A FULL collection on purpose: young-generation collections (tried in round 5) leave the preprocessing's cyclic garbage — device
-    # tensors among it — alive, and render() then pays more in fresh allocations (+60 ms) than the 45 ms the collection costs
-    gc.collect()
+    # (the reference collects + empties the cache after every scale, generate_audiovisual.py:157-158, to fit small GPUs: 17 full collections cost
+    # 0.7 s here.  The filtered fields are freed by refcount; generate() runs ONE full collection, right before the generator is loaded.)
     return maps
 
 
@@ -258,7 +256,9 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
         lo, hi = sharding.shard_bounds(n_frames, rank, world)
         shard = (lo, hi, n_frames)
 
-    gc.collect()  # (reference :191-192; full on purpose, see get_noise_range)
+    # (reference :191-192.)  The job's one collection — 45 ms on this heap.  Full on purpose: young-generation collections (tried in round 5)
+    # leave the preprocessing's cyclic garbage, device tensors among it, alive, and render() then pays more in fresh allocations (+60 ms)
+    gc.collect()
     if generator is None:
         generator = load()
     if grouped and not stylegan1 and not (isinstance(truncation, float) and truncation == 1.0):
