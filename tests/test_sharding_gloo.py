@@ -752,6 +752,21 @@ def test_played_world_of_eight_ranks_delivers_config4_in_order():
         results = pw.play(job)
         assert results[-1] == n_frames and results[1:-1] == [0] * (world - 1)
         assert seen == list(range(n_frames))
+        import gc
+        assert gc.get_freeze_count() == 0  # render_shard parks the heap for its frame loop (gc.freeze) and hands it back
+
+        def failing_job(rank, final):
+            real = render.synthesize
+            render.synthesize = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("generator failed"))
+            try:
+                return render.render_shard(_FakeGenerator(), latents[:8], [None], 0, 1.0, batch, side, None, None, 1.0, [], {}, False, "slow",
+                                           (0, 8, 8))
+            finally:
+                render.synthesize = real
+
+        with pytest.raises(RuntimeError, match="generator failed"):
+            PlayedWorld(1).play(failing_job)
+        assert gc.get_freeze_count() == 0  # ... also when the loop dies
         assert all(len(pw.rounds[p]) == 29 for p in range(1, world))
 
         def bad_job(rank, final):  # rank 3 skips a broadcast every other rank takes part in
