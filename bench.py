@@ -493,6 +493,50 @@ def rccl_block(dev, rank, world, backend, wl):
             "frames": dict(GATHER_EVIDENCE)}
 
 
+def self_launch(n, backend):
+    """`python bench.py --gpus N` without a rendezvous in the environment: start N ranks of this same command line through
+    torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous on a free port), pass rank 0's JSON line through on stdout and
+    return the launcher's exit code.  The reference's equivalent is DataParallel inside one process (generate_audiovisual.py:54-55).
+    With the `nccl` backend (RCCL) every rank needs its own device: fewer visible devices than ranks is ONE JSON error line, rc 1,
+    before anything is started."""
+    import socket
+    import subprocess
+
+    if backend == "nccl" and not os.environ.get("MAUA_BENCH_RENDEZVOUS_ONLY"):
+        have = torch.cuda.device_count()
+        if have < n:
+            print(json.dumps({"error": f"bench.py --gpus {n}: {have} GPU(s) visible to this process; the nccl (RCCL) backend needs one device per "
+                                       "rank (MAUA_DIST_BACKEND=gloo runs the ranks on a shared device, for debugging the code path only)",
+                              "n_gpus": n, "visible_gpus": have, "value": None}))
+            return 1
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--self-launch"]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))  # (torchrun would pin it to 1: the cpu_baseline leg at N = 1 uses the host cores)
+    print("bench.py: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(args, backend, rank, world):
+    """MAUA_BENCH_RENDEZVOUS_ONLY=1 (tests on a box without a GPU): the ranks the launcher started meet on the process group, rank 0 prints
+    who arrived as one JSON line, nothing touches a device."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo" if backend != "nccl" or not torch.cuda.is_available() else backend)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()})
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "world_size": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup,
+                          "ranks": ranks}))
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -525,17 +569,26 @@ def main():
                          "noise + activation as ONE kernel; a huge value = always the two-launch path)")
     ap.add_argument("--up2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.upwino2d_min_cout (smallest transposed layer on the 2-D F(2,2) kernel)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks through torch.distributed.run from this process also when --gpus is 1 (--gpus N > 1 without a "
+                         "rendezvous in the environment always does)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
     # MAUA_DIST_BACKEND=gloo (debug): run the N > 1 code path with several ranks SHARING one GPU — RCCL wants one GPU per rank, gloo moves
     # device tensors for the collectives this path uses; the rate measured that way is meaningless, the code path is the real one
     backend = os.environ.get("MAUA_DIST_BACKEND", "nccl")
+    if "RANK" not in os.environ and (args.gpus > 1 or args.self_launch):
+        # `python bench.py --gpus N` (the shape the driver uses at N = 1): this process becomes the launcher of N ranks, one per GPU
+        sys.exit(self_launch(args.gpus, backend))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", "n_gpus": args.gpus, "world_size": world}))
+        sys.exit(2)
+    if os.environ.get("MAUA_BENCH_RENDEZVOUS_ONLY"):
+        sys.exit(rendezvous_only(args, backend, rank, world))
     device_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)

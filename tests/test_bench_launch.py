@@ -1,0 +1,105 @@
+"""bench.py as the driver starts it: `python bench.py --gpus N [--steps K --warmup W]` with NO rendezvous in the environment must
+start its own N ranks (it used to exit rc 2 unless started under torch.distributed.run).  The reference's
+counterpart is DataParallel inside one process (/root/reference/generate_audiovisual.py:54-55).
+
+CPU box: the exact driver-shaped command with the gloo backend and MAUA_BENCH_RENDEZVOUS_ONLY=1 (the ranks meet, rank 0 prints
+who arrived, nothing touches a device), the torch.distributed.run shape the driver uses for N > 1, and the nccl refusal when fewer
+devices than ranks are visible.  GPU box: `--gpus 2` for real on the shared device over gloo, and `--gpus 1 --self-launch` against
+the plain run.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def _json_line(stdout):
+    """The ONE JSON line of the run: the last stdout line that parses (gloo's own connection chatter goes to stdout as well)."""
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_driver_shaped_command_launches_its_own_ranks(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300,
+                       env=_env(MAUA_DIST_BACKEND="gloo", MAUA_BENCH_RENDEZVOUS_ONLY="1"), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == line["world_size"] == n and line["steps"] == 3 and line["warmup"] == 1
+    assert sorted(x["rank"] for x in line["ranks"]) == list(range(n)) == sorted(x["local_rank"] for x in line["ranks"])
+    assert len({x["pid"] for x in line["ranks"]}) == n  # one process per rank
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=%d" % n in r.stderr
+
+
+def test_torchrun_shape_is_not_relaunched():
+    """The driver's N > 1 form: already under torch.distributed.run -> bench.py must NOT start a second generation of ranks."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=_env(MAUA_DIST_BACKEND="gloo", MAUA_BENCH_RENDEZVOUS_ONLY="1"), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == line["world_size"] == 2
+    assert "bench.py: launching" not in r.stderr
+
+
+def test_gpus_flag_must_match_the_started_world():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29732", BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=_env(MAUA_DIST_BACKEND="gloo", MAUA_BENCH_RENDEZVOUS_ONLY="1"), cwd=REPO)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in _json_line(r.stdout)["error"]
+
+
+def test_nccl_refuses_more_ranks_than_devices_with_one_json_line():
+    import torch
+
+    n = torch.cuda.device_count() + 1 if torch.cuda.is_available() else 8
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n)], capture_output=True, text=True, timeout=300, env=_env(MAUA_DIST_BACKEND="nccl"),
+                       cwd=REPO)
+    assert r.returncode == 1
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == n and line["value"] is None and "one device per rank" in line["error"]
+
+
+FAST = ["--steps", "2", "--warmup", "1", "--batches-per-step", "6", "--no-cpu-baseline", "--no-breakdown", "--no-side-configs", "--no-pcie-side"]
+
+
+@pytest.mark.gpu
+def test_gpus_2_self_launched_on_the_shared_device(gpu):
+    """`python bench.py --gpus 2` end to end: two ranks (gloo moves the device tensors; both on the one GPU of the box), weights
+    broadcast, inputs scattered, every batch gathered to rank 0 inside the timed region, rc 0, one parsed line with n_gpus == 2."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + FAST, capture_output=True, text=True, timeout=900,
+                       env=_env(MAUA_DIST_BACKEND="gloo"), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["rccl"]["world_size"] == 2 and line["steps"] == 2
+    assert line["rccl"]["weights"]["param_checksums_equal_after_broadcast"] and line["rccl"]["frames"]["payload_check"] == "ok"
+    assert line["frame_check"]["max_abs_grey_level_diff_graph_vs_eager"] == 0 and line["value"] > 0
+    assert len({x["pid"] for x in line["rccl"]["ranks"]}) == 2
+
+
+@pytest.mark.gpu
+def test_gpus_1_self_launched_agrees_with_the_plain_run(gpu):
+    """N = 1 through the launcher (one rank on the nccl = RCCL backend: every collective issued) against the plain N = 1 run."""
+    args = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-breakdown", "--no-side-configs", "--no-pcie-side"]
+    plain = subprocess.run([sys.executable, BENCH, "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, env=_env(), cwd=REPO)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    launched = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--self-launch"] + args, capture_output=True, text=True, timeout=900,
+                              env=_env(), cwd=REPO)
+    assert launched.returncode == 0, launched.stderr[-3000:]
+    a, b = _json_line(plain.stdout), _json_line(launched.stdout)
+    assert b["n_gpus"] == 1 and b["rccl"]["world_size"] == 1 and b["rccl"]["backend"] == "nccl"
+    print(f"plain {a['value']:.1f} frames/s, self-launched (one nccl rank, synth region) {b['value']:.1f}")
+    assert abs(b["value"] / a["value"] - 1.0) < 0.03  # (the runs of one box scatter by ~1 % themselves)
