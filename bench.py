@@ -130,6 +130,10 @@ def layer_breakdown(g, batch, noise_batch, stream):
                  2 * 512 * 3 * 16 * batch, 4 * batch * (512 + 3) * 16))
     li = 2
     image = g._buf(batch, "rgb1", (batch, 3, 4, 4))
+    # the style fold as Generator._forward_device plans it (no bends here): a producer stores its map multiplied by the consumer's styles
+    # (post_off), the consumer then runs the kernel instance without the style multiplies (prescaled) — the launches timed below are the
+    # instances the captured forward replays (the operand VALUES do not matter for the time)
+    posted = False
     for n in range(g.log_size - 2):
         up, plain, rgb = g.convs[2 * n], g.convs[2 * n + 1], g.to_rgbs[n]
         cin, cout = up.conv.in_channel, up.conv.out_channel
@@ -137,7 +141,10 @@ def layer_breakdown(g, batch, noise_batch, stream):
         e_up, e_pl, e_rgb = ent[li], ent[li + 1], ent[li + 2]
         nz1, nz2 = noise_batch[2 * n + 1], noise_batch[2 * n + 2]
         xin = out
-        t_all = time_calls(lambda: up.run(xin, s, e_up["s_off"], demod_of(e_up), nz1, bufs, f"u{n}"), 10, sp)
+        pre_up = posted
+        post_up = e_pl["s_off"] if g.style_fold and plain.accepts_prescaled(2 * h, 2 * h) else None
+        t_all = time_calls(lambda: up.run(xin, s, e_up["s_off"], demod_of(e_up), nz1, bufs, f"u{n}", prescaled=pre_up, post_off=post_up), 10, sp)
+        posted = up.posted
         blur_bytes = 4 * batch * cout * ((2 * h + 1) ** 2 + (2 * h) ** 2)
         if getattr(up, "last_path", "pair") == "fused":
             # transposed conv + blur + noise + bias + activation as ONE kernel (maua_upconv_blur_f32) + its seam pass: a single row.  Its
@@ -146,7 +153,8 @@ def layer_breakdown(g, batch, noise_batch, stream):
             FUSED_OVERLAP[f"convs.{2*n}.upconv+blur+noise+act (one kernel)"] = (tiles_x * 64.0 / (2 * h)) * ((h // 8 + 1) / (h // 8))
             rows.append((f"convs.{2*n}.upconv+blur+noise+act (one kernel)", "modconv_up_fused", t_all, 2 * cin * cout * 9 * h * h * batch,
                          4 * batch * (cin * h * h + cout * (2 * h) ** 2)))
-            INSTANCES[rows[-1][0]] = "modconv_up2d_kernel<8, 2>"  # (maua_upconv_blur_f32 has one instance; the seam pass is up2d_seam_kernel)
+            # (maua_upconv_blur_f32's kernel instance; the seam pass is up2d_seam_kernel)
+            INSTANCES[rows[-1][0]] = f"modconv_up2d_kernel<8, 2, {'true' if pre_up else 'false'}>"
             # workgroups = images x vertical segments x tile columns x 32-channel tiles; the segment count from the seam workspace the library
             # asks for ((segments - 1) x 6 rows of 2W floats per image and channel + 4)
             n_seg = (_lib.load().maua_upconv_blur_ws_floats(batch, cin, cout, h, h) - 4) // (batch * cout * 12 * h) + 1
@@ -156,7 +164,7 @@ def layer_breakdown(g, batch, noise_batch, stream):
             raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
             n_ws = _lib.load().maua_modconv_ws_floats(batch, cin, cout, h, h, up.conv.conv_mode(h, h))
             ws = g._buf(batch, "bench.ws", (max(n_ws, 1),)) if n_ws else None
-            t_up = time_calls(lambda: up.conv.run(xin, s, e_up["s_off"], demod_of(e_up), raw, ws), 10, sp)
+            t_up = time_calls(lambda: up.conv.run(xin, s, e_up["s_off"], demod_of(e_up), raw, ws, prescaled=pre_up), 10, sp)
             rows.append((f"convs.{2*n}.upconv", "modconv_up", t_up, 2 * cin * cout * 9 * h * h * batch, 0))
             INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
             rows.append((f"convs.{2*n}.blur+noise+act", "upfirdn2d_tail", max(t_all - t_up, 1e-6), 16 * 2 * batch * cout * (2 * h) ** 2, blur_bytes))
@@ -165,17 +173,22 @@ def layer_breakdown(g, batch, noise_batch, stream):
         rgb_buf = bufs(f"rgb{n}", (batch, 3, 2 * h, 2 * h))
         is_last = n == g.log_size - 3
         fuse = dict(module=rgb, s_off=e_rgb["s_off"], skip=img_in, out=rgb_buf, store=not is_last)
-        plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=fuse)
+        pre_pl = posted
+        nxt = None if is_last else g.convs[2 * n + 2]
+        post_pl = ent[li + 3]["s_off"] if (nxt is not None and g.style_fold and nxt.accepts_prescaled(2 * h, 2 * h)) else None
+        plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=fuse, prescaled=pre_pl, post_off=post_pl)
+        posted = plain.posted
         fused = bool(fuse.get("done"))  # the generator folds ToRGB into the conv epilogue for <= 64-channel layers
         conv_flops = 2 * cout * cout * 9 * (2 * h) ** 2 * batch
         rgb_flops = 2 * cout * 3 * (2 * h) ** 2 * batch
         if fused:
-            t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=dict(fuse)), 10, sp)
+            t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=dict(fuse), prescaled=pre_pl,
+                                                post_off=post_pl), 10, sp)
             # <= 64 channels: one launch; wider layers: the conv leaves per-tile partial ToRGB sums and a 3*m_tiles-plane pass adds them
             label = "(fused)" if cout <= 64 else "(fused: partial sums + plane sum)"
             rows.append((f"convs.{2*n+1}+to_rgbs.{n} {label}", "modconv", t_pl, conv_flops + rgb_flops, 0))
         else:
-            t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}"), 10, sp)
+            t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", prescaled=pre_pl), 10, sp)
             rows.append((f"convs.{2*n+1}", "modconv", t_pl, conv_flops, 0))
         INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
         out = g._buf(batch, f"convs.{2*n+1}", (batch, cout, 2 * h, 2 * h))
@@ -561,6 +574,8 @@ def main():
                     help="A/B switch of an EXPERIMENTS build (tools/build_exp.sh, pass it with --lib): maua_tuning_set(KEY, VALUE) before "
                          "the graphs are captured; the product library has no such entry")
     ap.add_argument("--lib", default=None, help="A/B / ablation switch: load this build of libmaua_hip.so instead of the in-tree one")
+    ap.add_argument("--no-style-fold", action="store_true",
+                    help="A/B switch: every convolution multiplies its input by its styles itself (round 5's form) instead of reading a map its producer pre-multiplied")
     ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
@@ -608,6 +623,10 @@ def main():
 
     if args.no_partial_rgb:
         StyledConv.partial_rgb_fusion = False
+    if args.no_style_fold:
+        from maua_stylegan2_amd.models.stylegan2 import Generator
+
+        Generator.style_fold = False
     if args.wino2d_min_cout is not None:
         ModulatedConv2d.winograd2d_min_cout = args.wino2d_min_cout
     if args.up2d_min_cout is not None:

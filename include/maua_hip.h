@@ -20,7 +20,7 @@ extern "C" {
 #define MAUA_ENOSYS (-38)
 
 /* ABI version of this header; bumped on any signature change. */
-int maua_abi_version(void);  /* 3: + maua_upconv_blur_f32 (round 5); 2: frame source (maua_frame_source_t) arguments; no tuning entry */
+int maua_abi_version(void);  /* 4: the style fold (post_s arguments, s == NULL; round 6); 3: + maua_upconv_blur_f32 (round 5); 2: frame source (maua_frame_source_t) arguments; no tuning entry */
 /* Number of compute units / name of device 0 (diagnostics for bench.py). */
 int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
 
@@ -78,6 +78,20 @@ typedef struct {
 int maua_frame_source_seek(maua_frame_source_t* src, int frame0, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ generator layers
+ * THE STYLE FOLD (ABI 4).  ModulatedConv2d multiplies its input by the per-sample styles before the shared-weight contraction
+ * (models/stylegan2.py:220-221, w = scale * W * s  <=>  conv(scale * W, x * s)).  Every feature map of the generator has exactly one
+ * modulated 3x3 convolution as consumer (its ToRGB is computed in the producer's epilogue from the un-scaled value), so the multiply can
+ * move into the PRODUCER's epilogue — once per element instead of once per element AND output-channel tile of the consumer's K loop:
+ *   producers (maua_blur_noise_act_f32, maua_upconv_blur_f32, maua_styledconv_torgb_f32 and _partial_f32 in mode 5) take `post_s`
+ *     = the CONSUMER's styles [B, stride] indexed by the producer's output channel, NULL = store the map as it is:
+ *       y_stored[b,o] = y[b,o] * post_s[b * stride + o];
+ *   consumers (maua_modconv3x3_f32 with up == 5 or 6, maua_upconv_blur_f32, the two ToRGB-fused entries in mode 5) accept s == NULL
+ *     = "x arrives multiplied by my styles": kernel instances without the style multiplies in their K loop (4 of 16 transform
+ *     instructions per window of the 2-D Winograd kernel, 9 of 23 per K step of the F(2,2)^2 transposed kernel).  d (demodulation)
+ *     is unaffected: it is computed from the styles by maua_demod_f32 either way.
+ * MAUA_ENOSYS for s == NULL / post_s != NULL in the other modes.  The caller keeps the un-folded form wherever something else reads
+ * the feature map (a network bend on that layer id, return_activation_maps).
+ *
  * Fused Blur -> NoiseInjection -> FusedLeakyReLU tail of an up-sampling StyledConv
  * (models/stylegan2.py:238,262-266,338-343; op/fused_act.py:74-83):
  *   y[b,c] = lrelu_0.2( upfirdn2d(x[b,c], k, pad=(pad0,pad1)) * gain[b,c] + noise_w * noise[b,0] + bias[c] ) * sqrt(2)
@@ -90,7 +104,7 @@ int maua_frame_source_seek(maua_frame_source_t* src, int frame0, void* stream);
 int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch, int channels, int in_h, int in_w,
                             int kh, int kw, int pad0, int pad1, const float* gain, const float* noise,
                             int64_t noise_batch_stride, const float* noise_w, const float* bias,
-                            const maua_frame_source_t* src, int noise_slot, void* stream);
+                            const maua_frame_source_t* src, int noise_slot, const float* post_s, int post_stride, void* stream);
 
 /* The WHOLE up-sampling StyledConv in one pass (round 5): transposed 3x3 modulated convolution (stride 2) -> Blur (4x4 SEPARABLE taps, pad
  * (1, 1)) -> NoiseInjection -> FusedLeakyReLU — models/stylegan2.py:229-238,262-266,338-343 — without the raw (2H+1) x (2W+1) map that
@@ -107,7 +121,7 @@ int64_t maua_upconv_blur_ws_floats(int batch, int cin, int cout, int h, int w);
 int maua_upconv_blur_f32(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws,
                          const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                          const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w, float wscale,
-                         void* stream);
+                         const float* post_s /* [B, s_stride] or NULL */, void* stream);
 
 /* All style affines and demodulation factors of one forward, two launches in total, table-driven.
  *  affine (EqualLinear, models/stylegan2.py:140-146,207,220), with the truncation lerp of Generator.forward
@@ -195,7 +209,8 @@ int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w);
  *             maua_pack_weight_sbf16_f32.  Not used unless the caller asks for it; the default path computes in fp32.
  *   up == 8 : SIDE MEASUREMENT — the transposed convolution of up == 1 with split-bf16 products (four polyphase phase launches of the
  *             up == 7 kernel + fp32 edge lines), same packed weight as up == 7, fuse_act == 0, ws as for up == 6.
- * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride];
+ * wp = tap-major packed weight from maua_pack_weight_f32; s = per-sample input scales [B, s_stride] (NULL with up == 5 / 6: x arrives
+ * pre-scaled, see THE STYLE FOLD above);
  * d = demod [B,cout] (NULL = 1).  `ws` is a caller-owned fp32 workspace of at least maua_modconv_ws_floats()
  * floats used for split-K partial sums on small feature maps and, for up == 6, for the exported last input column [B, cin, H]
  * (may be NULL when that returns 0). */
@@ -221,7 +236,8 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
                               const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                               const float* rgb_w, const float* rgb_s, float rgb_wscale, const float* rgb_bias,
                               const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,
-                              uint8_t* frames_u8, const maua_frame_source_t* src, int noise_slot, void* stream);
+                              uint8_t* frames_u8, const maua_frame_source_t* src, int noise_slot,
+                              const float* post_s /* [B, s_stride] or NULL; mode 5 only */, void* stream);
 
 /* The same fusion for layers wider than one weight tile (128..512 output channels, mode 5 only): every output-channel tile leaves
  * its share of the ToRGB sum  sum_{i in tile} (rgb_wscale * rgb_w[c,i] * rgb_s[b,i]) * y[b,i,Y,X]  in
@@ -232,7 +248,8 @@ int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const flo
                                       int batch, int cin, int cout, int h, int w, int mode, float wscale, const float* noise,
                                       int64_t noise_batch_stride, const float* noise_w, const float* bias, const float* rgb_w,
                                       const float* rgb_s, float rgb_wscale, float* rgb_partial,
-                                      const maua_frame_source_t* src, int noise_slot, void* stream);
+                                      const maua_frame_source_t* src, int noise_slot, const float* post_s /* [B, s_stride] or NULL */,
+                                      void* stream);
 
 /* StyleGAN1 (`--stylegan1`, models/stylegan1.py:258-318 LayerEpilogue) — conv bias, per-channel-weighted noise, LeakyReLU(0.2),
  * instance norm (biased variance, eps 1e-5) and the style modulation in one launch:

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmaua_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MauaHipError(RuntimeError):
@@ -62,10 +62,10 @@ _SIGNATURES = {
     "maua_upfirdn2d_f16": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
     "maua_upfirdn2d_f64": (c_int, [_P, _P, _P] + [c_int] * 14 + [_P]),
     "maua_frame_source_seek": (c_int, [_P, c_int, _P]),
-    "maua_blur_noise_act_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, c_int64, _P, _P, _P, c_int, _P]),
+    "maua_blur_noise_act_f32": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P, c_int64, _P, _P, _P, c_int, _P, c_int, _P]),
     "maua_upconv_blur_ok": (c_int, [c_int] * 4),
     "maua_upconv_blur_ws_floats": (c_int64, [c_int] * 5),
-    "maua_upconv_blur_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 5 + [c_float, _P]),
+    "maua_upconv_blur_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 5 + [c_float, _P, _P]),
     "maua_style_affine_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "maua_demod_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, _P]),
     "maua_pack_weight_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
@@ -86,9 +86,9 @@ _SIGNATURES = {
     "maua_modconv_last_instance": (c_int, [c_char_p, c_int]),
     "maua_modconv3x3_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, c_int, _P, c_int64, _P, _P, _P, _P, c_int, _P]),
     "maua_styledconv_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
-                                          _P, _P, _P, _P, c_int, _P, _P, c_int, _P]),
+                                          _P, _P, _P, _P, c_int, _P, _P, c_int, _P, _P]),
     "maua_styledconv_torgb_partial_f32": (c_int, [_P, _P, _P, c_int, _P, _P] + [c_int] * 6 + [c_float, _P, c_int64, _P, _P, _P, _P, c_float,
-                                                  _P, _P, c_int, _P]),
+                                                  _P, _P, c_int, _P, _P]),
     "maua_torgb_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "maua_frames_to_u8": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "maua_crop_resize_u8": (c_int, [_P, _P] + [c_int] * 9 + [_P]),

@@ -50,7 +50,7 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
                     const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                     const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, uint8_t* rgb_u8,
-                    int rgb_mode, const maua_frame_source_t* src, int noise_slot, void* stream);
+                    int rgb_mode, const maua_frame_source_t* src, int noise_slot, const float* post_s, void* stream);
 
 // modconv_up2d.hip (mode 6 of maua_modconv3x3_f32): transposed convolution with F(2,2) on both axes of its polyphase form
 const char* maua_up2d_last_instance();

@@ -1341,8 +1341,12 @@ struct RgbArgs {
 int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, int batch,
                  int cin, int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise,
                  int64_t noise_batch_stride, const float* noise_w, const float* bias, float* ws, const RgbArgs* rgb,
-                 const maua_frame_source_t* src, int noise_slot, void* stream) {
-    if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
+                 const maua_frame_source_t* src, int noise_slot, const float* post_s, void* stream) {
+    if (!x || !wp || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
+    // the style fold (include/maua_hip.h): s == NULL = x arrives multiplied by this layer's styles — the 2-D Winograd and the F(2,2)^2
+    // transposed kernels have instances without the multiply; post_s = the consumer's styles, applied to the stored map by the
+    // 2-D Winograd kernels' epilogue
+    if ((!s && up != 5 && up != 6) || (post_s && up != 5)) return MAUA_ENOSYS;
     if ((noise || (src && fuse_act)) && !noise_w) return MAUA_EINVAL;
     if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     if (up == 5) {  // 2-D Winograd F(2x4, 3x3), modconv_w2d.hip
@@ -1350,7 +1354,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
                                        noise_w, bias, rgb ? rgb->w : nullptr, rgb ? rgb->s : nullptr, rgb ? rgb->wscale : 0.f,
                                        rgb ? rgb->bias : nullptr, rgb ? rgb->skip : nullptr, rgb ? rgb->k4 : nullptr,
                                        rgb ? rgb->out : nullptr, rgb ? rgb->u8 : nullptr, rgb ? (rgb->store_features ? 1 : 2) : 0,
-                                       src, noise_slot, stream);
+                                       src, noise_slot, post_s, stream);
         if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
         return rc;
     }
@@ -1436,7 +1440,7 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
                                    int fuse_act, const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                    const float* bias, float* ws, const maua_frame_source_t* src, int noise_slot, void* stream) {
     return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, up, wscale, fuse_act, noise, noise_batch_stride,
-                        noise_w, bias, ws, nullptr, src, noise_slot, stream);
+                        noise_w, bias, ws, nullptr, src, noise_slot, nullptr, stream);
 }
 
 extern "C" int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,
@@ -1444,12 +1448,12 @@ extern "C" int maua_styledconv_torgb_partial_f32(const float* x, const float* wp
                                                  const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                                  const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                                                  float* rgb_partial, const maua_frame_source_t* src, int noise_slot,
-                                                 void* stream) {
+                                                 const float* post_s, void* stream) {
     if (mode != 5) return MAUA_ENOSYS;  // only the 2-D Winograd kernel leaves partial ToRGB sums
-    if (!x || !wp || !s || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || ((noise || src) && !noise_w)) return MAUA_EINVAL;
+    if (!x || !wp || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || ((noise || src) && !noise_w)) return MAUA_EINVAL;
     if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     const int rc = maua_w2d_launch(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, wscale, 1, noise, noise_batch_stride, noise_w, bias,
-                                   rgb_w, rgb_s, rgb_wscale, nullptr, nullptr, nullptr, rgb_partial, nullptr, 3, src, noise_slot, stream);
+                                   rgb_w, rgb_s, rgb_wscale, nullptr, nullptr, nullptr, rgb_partial, nullptr, 3, src, noise_slot, post_s, stream);
     if (rc == 0) snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_w2d_last_instance());
     return rc;
 }
@@ -1460,9 +1464,9 @@ extern "C" int maua_styledconv_torgb_f32(const float* x, const float* wp, const 
                                          const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                                          const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out,
                                          int store_features, uint8_t* frames_u8, const maua_frame_source_t* src, int noise_slot,
-                                         void* stream) {
+                                         const float* post_s, void* stream) {
     RgbArgs rgb{rgb_w, rgb_s, rgb_bias, rgb_skip, rgb_k4, rgb_out, rgb_wscale, store_features, frames_u8};
     if (mode == 1) return MAUA_ENOSYS;
     return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, mode, wscale, 1, noise, noise_batch_stride, noise_w,
-                        bias, nullptr, &rgb, src, noise_slot, stream);
+                        bias, nullptr, &rgb, src, noise_slot, post_s, stream);
 }

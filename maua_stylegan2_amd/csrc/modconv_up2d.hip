@@ -124,6 +124,9 @@ struct Up2dArgs {
     // receives the h-rows either side of a segment boundary for up2d_seam_kernel
     float* hbuf;
     int seg_tiles, tiles_total_y;
+    // the style fold (round 6; include/maua_hip.h).  Producer side (FUSE == 2): post_s [B, s_stride] = the styles of the layer that consumes yb,
+    // multiplied into the stored map.  Consumer side: s == NULL (instances with PRE = true) = x arrives multiplied by this layer's styles.
+    const float* post_s;
 #ifdef MAUA_EXPERIMENTS
     int real_blocks;       // FUSE == 1 (tools/fuse_probe.py): blocks beyond this number repeat earlier tiles (the price of an overlapped tiling)
 #endif
@@ -156,7 +159,7 @@ __device__ __forceinline__ void u2_blur_taps(const float* k4, float (&kx)[4], fl
 
 // FUSE: 0 = the raw (2H+1) x (2W+1) map (mode 6 of maua_modconv3x3_f32); 2 = the whole up-sampling StyledConv, exact (maua_upconv_blur_f32);
 // 1 = experiments builds only: the fused epilogue with the tile halos taken as zero (the measurement that preceded the exact form)
-template <int CC, int FUSE = 0>
+template <int CC, int FUSE = 0, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     constexpr int U2_A_FLOATS = u2_a_floats(CC), U2_PBUF = u2_pbuf(CC), U2_P_INSTR = u2_p_instr(CC);
     constexpr int A_PER_WAVE = 2 * CC / 4;                 // weight DMA instructions per wave and K step
@@ -192,7 +195,9 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     const int m0 = mt_id * U2_BM;
     const size_t plane = (size_t)p.H * p.W;
 
-    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    if constexpr (!PRE)
+        for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    (void)Ss;
 
     const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
     const size_t plane_bytes = plane * sizeof(float);
@@ -246,8 +251,9 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         float gain = p.wscale;
         if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
         Eg[i] = gain;
+        if constexpr (FUSE == 2) Eg[U2_BM + i] = p.post_s ? p.post_s[(size_t)b0 * p.s_stride + m0 + i] : 1.f;  // scale of the stored map
     }
-    float* SV = Eg + U2_BM;
+    float* SV = Eg + 2 * U2_BM;
     if constexpr (FUSE == 2) {
         // h-rows above the segment's first tile: zero — exact at the top of the image (raw rows -3 .. -1 are padding); below a segment
         // boundary the three output rows that would need them are left to up2d_seam_kernel
@@ -336,21 +342,26 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         constexpr int ks = decltype(ks_c)::value;
         const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u) + ks * KG_A_BYTES, pb = b_addr + (cur ? P_BUF_BYTES : 0u) + ks * KG_P_BYTES;
         // ---- operand reads: style, the 3 x 3 window (six 8-byte reads), the first weight row behind them (LDS returns in order)
-        float sc = lds_read32(s_addr);
-        s_addr += 4 * 4u;
+        float sc = 1.f;
+        if constexpr (!PRE) {
+            sc = lds_read32(s_addr);
+            s_addr += 4 * 4u;
+        }
         f32x2 w0l = lds_read64<0>(pb), w0h = lds_read64<8>(pb);
         f32x2 w1l = lds_read64<ROW_BYTES>(pb), w1h = lds_read64<ROW_BYTES + 8>(pb);
         f32x2 w2l = lds_read64<2 * ROW_BYTES>(pb), w2h = lds_read64<2 * ROW_BYTES + 8>(pb);
         f32x2 a2[2];
         a2[0] = lds_read64<0>(ap);
+        if constexpr (PRE) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w0l), "+v"(w0h), "+v"(w1l), "+v"(w1h), "+v"(w2l), "+v"(w2h));
+        else
         asm volatile("s_waitcnt lgkmcnt(1)"
                      : "+v"(sc), "+v"(w0l), "+v"(w0h), "+v"(w1l), "+v"(w1h), "+v"(w2l), "+v"(w2h));
-        // ---- window forms: rows (r0 - r1, r1, r2 - r1, r2), then columns likewise: B[a][b], 9 multiplies + 14 subtractions
+        // ---- window forms: rows (r0 - r1, r1, r2 - r1, r2), then columns likewise: B[a][b], 9 multiplies (none when the map arrives
+        // pre-scaled: PRE) + 14 subtractions
         float bv[4][4];
         {
-            const float d00 = w0l.y * sc, d01 = w0h.x * sc, d02 = w0h.y * sc;
-            const float d10 = w1l.y * sc, d11 = w1h.x * sc, d12 = w1h.y * sc;
-            const float d20 = w2l.y * sc, d21 = w2h.x * sc, d22 = w2h.y * sc;
+            float d00 = w0l.y, d01 = w0h.x, d02 = w0h.y, d10 = w1l.y, d11 = w1h.x, d12 = w1h.y, d20 = w2l.y, d21 = w2h.x, d22 = w2h.y;
+            if constexpr (!PRE) d00 *= sc, d01 *= sc, d02 *= sc, d10 *= sc, d11 *= sc, d12 *= sc, d20 *= sc, d21 *= sc, d22 *= sc;
             const float r[4][3] = {{d00 - d10, d01 - d11, d02 - d12}, {d10, d11, d12}, {d20 - d10, d21 - d11, d22 - d12}, {d20, d21, d22}};
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -545,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
             // vertical pass + tail + stores
             const f32x2 gain2 = f32x2{Eg[ol] * act_gain, Eg[ol + 1] * act_gain};
             const f32x2 bias2 = pk->bias ? f32x2{pk->bias[m0 + ol] * act_gain, pk->bias[m0 + ol + 1] * act_gain} : f32x2{0.f, 0.f};
+            const f32x2 post2 = FUSE == 2 ? f32x2{Eg[U2_BM + ol], Eg[U2_BM + ol + 1]} : f32x2{1.f, 1.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x2 val[4];
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 for (int c = 0; c < 4; ++c) {
                     const f32x2 bl = ((S[q][c] * ky[0] + S[q + 1][c] * ky[1]) + S[q + 2][c] * ky[2]) + S[q + 3][c] * ky[3];
                     const f32x2 tt = bl * gain2 + (f32x2{nzq[c], nzq[c]} + bias2);
-                    val[c] = __builtin_elementwise_max(tt, tt * 0.2f);
+                    val[c] = __builtin_elementwise_max(tt, tt * 0.2f) * post2;
                 }
                 const int Y = Y0 + q;
                 const bool row_keep = Y >= 0 && Y < OHb && !(seam_above && wv == 0 && q < 3);  // (uniform)
@@ -639,6 +651,7 @@ __global__ __launch_bounds__(256) void up2d_seam_kernel(Up2dArgs p, int n_bnd) {
     float gain = p.wscale * act_gain;
     if (p.d) gain *= p.d[(size_t)b * p.Cout + c];
     const float bias = p.bias ? p.bias[c] * act_gain : 0.f;
+    const float post = p.post_s ? p.post_s[(size_t)b * p.s_stride + c] : 1.f;
     const float* hb = p.hbuf + (((size_t)b * p.Cout + c) * n_bnd + g) * 6 * (size_t)OWb + 4 * x4;
     f32x4 h[6];
 #pragma unroll
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(256) void up2d_seam_kernel(Up2dArgs p, int n_bnd) {
         for (int e = 0; e < 4; ++e) {
             const float bl = ((h[k][e] * ky[0] + h[k + 1][e] * ky[1]) + h[k + 2][e] * ky[2]) + h[k + 3][e] * ky[3];
             const float tt = bl * gain + (nz[e] + bias);
-            out[e] = fmaxf(tt, tt * 0.2f);
+            out[e] = fmaxf(tt, tt * 0.2f) * post;
         }
         *reinterpret_cast<f32x4*>(p.yb + (((size_t)b * p.Cout + c) * OHb + Y) * (size_t)OWb + 4 * x4) = out;
     }
@@ -699,7 +712,7 @@ __global__ __launch_bounds__(256) void up2d_edge_kernel(Up2dArgs p, const float*
     const float* t0 = taps + (line ? 3 : 0) * tsz + o0 + i16;
     const float* t1 = taps + (line ? 4 : 1) * tsz + o0 + i16;
     const float* t2 = taps + 2 * tsz + o0 + i16;
-    const float* sp = p.s + (size_t)b0 * p.s_stride;
+    const float* sp = p.s ? p.s + (size_t)b0 * p.s_stride : nullptr;  // (NULL: the map arrives pre-scaled)
     f32x4 even = f32x4{0.f, 0.f, 0.f, 0.f}, odd = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int UNR = 8;
     const int c_per_wave = (p.Cin / 4 + 3) / 4 * 4;  // channels per wave, a multiple of the MFMA K
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(256) void up2d_edge_kernel(Up2dArgs p, const float*
             const int c = c0 + 4 * q + kq;
             const bool okc = c < c_end;
             const int cc = okc ? c : c_begin;
-            sc[q] = okc ? sp[cc] : 0.f;
+            sc[q] = okc ? (sp ? sp[cc] : 1.f) : 0.f;
             a0[q] = t0[(size_t)cc * p.Cout];
             a1[q] = t1[(size_t)cc * p.Cout];
             a2v[q] = t2[(size_t)cc * p.Cout];
@@ -815,7 +828,7 @@ const char* maua_up2d_last_instance() { return g_up2d_instance; }
 // exported last input column xcol [B, cin, H]: used by the split-bf16 side path (modconv_sbf16.hip), whose phase kernels cover p < H, q < W.
 int maua_up2d_edge_launch(const float* x, const float* edge_taps, const float* s, int s_stride, const float* d, float* y, const float* xcol,
                           int batch, int cin, int cout, int h, int w, float wscale, void* stream) {
-    if (!x || !edge_taps || !s || !y || !xcol || cout % 16) return MAUA_EINVAL;
+    if (!x || !edge_taps || !y || !xcol || cout % 16) return MAUA_EINVAL;
     Up2dArgs a{};
     a.x = x, a.wq = nullptr, a.s = s, a.d = d, a.y = y, a.xcol = const_cast<float*>(xcol);
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
@@ -928,8 +941,8 @@ extern "C" int64_t maua_upconv_blur_ws_floats(int batch, int cin, int cout, int 
 extern "C" int maua_upconv_blur_f32(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws,
                                     const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                     const float* bias, const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h,
-                                    int w, float wscale, void* stream) {
-    if (!x || !wq || !s || !y || !k4 || batch <= 0) return MAUA_EINVAL;
+                                    int w, float wscale, const float* post_s, void* stream) {
+    if (!x || !wq || !y || !k4 || batch <= 0) return MAUA_EINVAL;
     if (!maua_upconv_blur_ok(cin, cout, h, w)) return MAUA_ENOSYS;
     if ((noise || src) && !noise_w) return MAUA_EINVAL;
     if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
@@ -943,14 +956,15 @@ extern "C" int maua_upconv_blur_f32(const float* x, const float* wq, const float
     a.tiles_x = f.tiles_x, a.tiles_y = f.n_seg, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
     a.seg_tiles = f.seg_tiles, a.tiles_total_y = f.tiles_total_y;
     a.yb = y, a.hbuf = ws, a.k4 = k4, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.noise_batch_stride = noise_batch_stride;
-    a.src = src, a.noise_slot = noise_slot;
-    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM + 4 * 3 * 64 * 8);
+    a.src = src, a.noise_slot = noise_slot, a.post_s = post_s;
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 2 * U2_BM + 4 * 3 * 64 * 8);
     static_assert((size_t)2 * u2_a_floats(8) + (size_t)2 * u2_pbuf(8) >= 2 * 4 * 3 * 64 * 8, "the exchange region lives in the operand buffers");
     if (lds_bytes > 80 * 1024) return MAUA_ENOSYS;  // two workgroups per CU
     const int64_t blocks = (int64_t)batch * f.n_seg * f.tiles_x * a.m_tiles;
-    static unsigned long long lds_ok = 0;
-    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 2>), &lds_ok, 160 * 1024)) return rc;
-    snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<8, 2>");
+    static unsigned long long lds_ok = 0, lds_ok_pre = 0;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 2, false>), &lds_ok, 160 * 1024)) return rc;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 2, true>), &lds_ok_pre, 160 * 1024)) return rc;
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), s ? "modconv_up2d_kernel<8, 2, false>" : "modconv_up2d_kernel<8, 2, true>");
     hipStream_t st = (hipStream_t)stream;
 #ifdef MAUA_EXPERIMENTS
     if (getenv("MAUA_FUSE_DEBUG")) {
@@ -960,7 +974,8 @@ extern "C" int maua_upconv_blur_f32(const float* x, const float* wq, const float
                 cin, cout, h, w, batch, f.tiles_x, f.tiles_total_y, f.n_seg, f.seg_tiles, (long long)blocks, lds_bytes, occ);
     }
 #endif
-    hipLaunchKernelGGL((modconv_up2d_kernel<8, 2>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    if (s) hipLaunchKernelGGL((modconv_up2d_kernel<8, 2, false>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL((modconv_up2d_kernel<8, 2, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     MAUA_LAUNCH_CHECK();
     if (f.n_seg > 1) {
         const int64_t threads = (int64_t)batch * cout * (f.n_seg - 1) * (2 * w / 4);
@@ -985,7 +1000,7 @@ extern "C" int maua_exp_upconv_blur_fused_f32(const float* x, const float* wq, c
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
     a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
     a.yb = yb, a.k4 = k4, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.noise_batch_stride = noise_batch_stride;
-    const size_t k_loop = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM);
+    const size_t k_loop = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 2 * U2_BM);
     const size_t lds_bytes = k_loop > 49152 + 4096 ? k_loop : 49152 + 4096;
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
     a.real_blocks = (int)blocks;
@@ -1011,15 +1026,18 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     const int cc = u2_cc(cin);
     a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + U2_BM);
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 2 * U2_BM);
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
-    static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
-    static unsigned long long lds_ok1 = 0;
-    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<4>), &lds_ok, 160 * 1024)) return rc;
-    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8>), &lds_ok1, 160 * 1024)) return rc;
-    snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<%d>", cc);
-    if (cc == 8) hipLaunchKernelGGL(modconv_up2d_kernel<8>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
-    else hipLaunchKernelGGL(modconv_up2d_kernel<4>, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    static unsigned long long lds_ok[4] = {0, 0, 0, 0};  // per instance: devices on which the attribute has been set (common.h)
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<4, 0, false>), &lds_ok[0], 160 * 1024)) return rc;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 0, false>), &lds_ok[1], 160 * 1024)) return rc;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<4, 0, true>), &lds_ok[2], 160 * 1024)) return rc;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 0, true>), &lds_ok[3], 160 * 1024)) return rc;
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), s ? "modconv_up2d_kernel<%d, 0, false>" : "modconv_up2d_kernel<%d, 0, true>", cc);
+    if (cc == 8 && s) hipLaunchKernelGGL((modconv_up2d_kernel<8, 0, false>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    else if (cc == 8) hipLaunchKernelGGL((modconv_up2d_kernel<8, 0, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    else if (s) hipLaunchKernelGGL((modconv_up2d_kernel<4, 0, false>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    else hipLaunchKernelGGL((modconv_up2d_kernel<4, 0, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     MAUA_LAUNCH_CHECK();
     // edge lines: W + 1 positions along the bottom row (incl. the corner), H along the right column
     const int nt0 = ceil_div(w + 1, 16), nt1 = ceil_div(h, 16);

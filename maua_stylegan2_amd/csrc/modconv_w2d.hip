@@ -90,6 +90,26 @@ template <int N>
 __device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
+// 16-byte MUBUF store whose channel offset is a SCALAR (soffset SGPR), followed by its own wait states.  Round 6 finding, measured on the
+// MI355X (tools/dbg/w2dw_val.py: every thread's value correct in its register, the fourth dword of the stored row not): the compiler
+// treats a buffer store of more than 64 bits as hazard-free when its soffset is a register (LLVM GCNHazardRecognizer::createsVALUHazard:
+// "this hazard only exists if the instruction is not using a register in the soffset field") and lets the very next instructions
+// overwrite the data registers — it had emitted `buffer_store_dwordx4 v[190:193], .., s67 offen` followed at once by four v_mov into
+// v190..v193 for the next row, and on gfx950 the row-0 store then carried the NEXT row's last dword in a quarter of its lanes.  With an
+// immediate soffset it keeps 2 wait states (and those builds were right).  The store therefore goes out as one inline-assembly blob
+// with `s_nop` behind it: no instruction the compiler schedules can reach the data registers earlier than 4 wait states after the issue.
+__device__ __forceinline__ void buffer_store_b128_sgpr_offset(u32x4 data, const float* base, unsigned voffset_bytes, unsigned soffset_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    // raw buffer descriptor (stride 0, 2^31 - 1 records, DATA_FORMAT = 32 as __builtin_amdgcn_make_buffer_rsrc(.., 0, 0x7fffffff, 0x00020000))
+    i32x4 rsrc = i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff), 0x7fffffff, 0x00020000};
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 3" ::"v"(data), "v"(voffset_bytes), "s"(rsrc), "s"(soffset_bytes) : "memory");
+#else
+    (void)data, (void)base, (void)voffset_bytes, (void)soffset_bytes;
+#endif
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -114,6 +134,11 @@ struct W2dArgs {
     const float* rgb_k4;
     float* rgb_out;
     uint8_t* rgb_u8;  // when set: uint8 NHWC frames [B, H, W, 3] (render.py:40-43); rgb_out may then be NULL
+    // the style fold (round 6).  Producer side: post_s [B, s_stride] = the styles of the layer that CONSUMES y — the stored feature map is
+    // act(..) * post_s[b, o] (the fused ToRGB reads the un-scaled value), so that the consumer's K loop drops its per-window style multiplies
+    // (models/stylegan2.py:220-221 reassociated: conv(W, x * s) with the multiply moved into the producer's epilogue, once per element
+    // instead of once per output-channel tile).  Consumer side: s == NULL (kernel instances with PRE = true) = x arrives pre-scaled.
+    const float* post_s;
     int B, Cin, Cout, H, W;
     int s_stride;
     float wscale;
@@ -186,7 +211,7 @@ __host__ __device__ inline int w2d_col(int tm, int mt, int i16, int kq) {
 #define MAUA_W2D_MINB64 2
 #endif
 
-template <int TM, int TN, int MINB = 2>
+template <int TM, int TN, int MINB = 2, bool PRE = false>
 __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     constexpr int BM = 16 * TM;
     constexpr int NPOS = 16 * TN;
@@ -244,10 +269,11 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         const bool ok = sg < W2D_SEGS && pr < PH && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
         rel_bytes[g] = ok ? (unsigned)(yy * p.W + xx) * 4u : 0x80000000u;
     }
-    for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    if constexpr (!PRE)
+        for (int e = tid; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
     const char* ximg = reinterpret_cast<const char*>(p.x + (size_t)b0 * p.Cin * plane);
     const size_t plane_bytes = plane * sizeof(float);
-    (void)ximg, (void)plane_bytes;
+    (void)ximg, (void)plane_bytes, (void)Ss;
 #ifdef MAUA_DEVICE_PASS
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ximg), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wq), 0, 0x7fffffff, 0x00020000);
@@ -305,6 +331,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
         }
         *reinterpret_cast<f32x4*>(E + 8 * i) = e;
         E[8 * i + 4] = r2;
+        E[8 * i + 5] = p.post_s ? p.post_s[(size_t)b0 * p.s_stride + o] : 1.f;  // scale of the STORED feature value (the consumer's style)
     }
 
     // ---- accumulators: [x-frequency][m-tile][n-tile]
@@ -351,8 +378,11 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
 #endif
         // ---- operand reads of this chunk: style, raw window rows, first weight row
         const unsigned a_off = cur ? A_BUF_BYTES : 0u, p_off = cur ? P_BUF_BYTES : 0u;
-        float sc = lds_read32(s_addr);
-        s_addr += W2D_CC * 4u;
+        float sc = 1.f;
+        if constexpr (!PRE) {
+            sc = lds_read32(s_addr);
+            s_addr += W2D_CC * 4u;
+        }
         unsigned ap[TM / 2];
 #pragma unroll
         for (int h = 0; h < TM / 2; ++h) ap[h] = a_addr[h] + a_off;
@@ -409,9 +439,12 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t5) : "v"(m5), "v"(D34.x), "v"(d5));
             asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u0) : "v"(d0), "v"(t0));
             asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u5) : "v"(D12.x), "v"(t5));
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b12) : "v"(b12), "v"(sc2));
-            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b34) : "v"(b34), "v"(sc2));
-            bv[n][0] = u0 * sc, bv[n][5] = u5 * sc;
+            if constexpr (!PRE) {  // (PRE: the producer's epilogue multiplied the map by this layer's styles: 12 instead of 16 per window)
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b12) : "v"(b12), "v"(sc2));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b34) : "v"(b34), "v"(sc2));
+                u0 *= sc, u5 *= sc;
+            }
+            bv[n][0] = u0, bv[n][5] = u5;
             bv[n][1] = b12.x, bv[n][2] = b12.y, bv[n][3] = b34.x, bv[n][4] = b34.y;
 #else
             const float d0 = fmaf(sgn, wb0[slot].y, wa0[slot].y), d1 = fmaf(sgn, wb[slot][0].x, wa[slot][0].x);
@@ -420,6 +453,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             // B_x^T for F(4,3) (interpolation points 0, +-1, +-2, inf), as in modconv.hip's mode 3
             const float a_ = fmaf(-4.f, d2, d4), b_ = fmaf(-4.f, d1, d3);
             const float c_ = d4 - d2, e_ = d3 - d1;
+            static_assert(!PRE, "the pre-scaled instances use the packed transform");
             bv[n][0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4)) * sc;
             bv[n][1] = (a_ + b_) * sc;
             bv[n][2] = (a_ - b_) * sc;
@@ -447,6 +481,12 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
                 constexpr int n = decltype(n_c)::value;
                 constexpr int slot = n % WSLOTS;
                 constexpr int behind = (n + 1 < TN && WSLOTS > 1) ? 8 : 0;
+                if constexpr (PRE)
+                    asm volatile("s_waitcnt lgkmcnt(%8)"
+                                 : "+v"(wa[slot][0]), "+v"(wa[slot][1]), "+v"(wb[slot][0]), "+v"(wb[slot][1]), "+v"(wa0[slot]),
+                                   "+v"(wa5[slot]), "+v"(wb0[slot]), "+v"(wb5[slot])
+                                 : "n"(behind));
+                else
                 asm volatile("s_waitcnt lgkmcnt(%9)"
                              : "+v"(sc), "+v"(wa[slot][0]), "+v"(wa[slot][1]), "+v"(wb[slot][0]), "+v"(wb[slot][1]), "+v"(wa0[slot]),
                                "+v"(wa5[slot]), "+v"(wb0[slot]), "+v"(wb5[slot])
@@ -486,6 +526,12 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             }
             // outstanding behind window n: window n+1 (8 reads) unless n is the last, plus the weight reads when they are out
             constexpr int behind = ((n + 1 < TN && WSLOTS > 1) ? 8 : 0) + (n == TN - 1 ? TM / 2 : 0);
+            if constexpr (PRE)
+                asm volatile("s_waitcnt lgkmcnt(%8)"
+                             : "+v"(wa[slot][0]), "+v"(wa[slot][1]), "+v"(wb[slot][0]), "+v"(wb[slot][1]), "+v"(wa0[slot]),
+                               "+v"(wa5[slot]), "+v"(wb0[slot]), "+v"(wb5[slot])
+                             : "n"(behind));
+            else
             asm volatile("s_waitcnt lgkmcnt(%9)"
                          : "+v"(sc), "+v"(wa[slot][0]), "+v"(wa[slot][1]), "+v"(wb[slot][0]), "+v"(wb[slot][1]), "+v"(wa0[slot]),
                            "+v"(wa5[slot]), "+v"(wb0[slot]), "+v"(wb5[slot])
@@ -565,10 +611,8 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
     const float row_sign = cr ? -1.f : 1.f;      // A_y^T of F(2,3): row 0 = Z1 + (Z2 + Z0), row 1 = Z1 - (Z2 + Z3)
     const float slope = act ? 0.2f : 1.f;        // leaky ReLU as max(t, slope t); slope 1 = no activation
     const unsigned plane_b = (unsigned)plane * 4u;
-#ifdef MAUA_DEVICE_PASS
-    const __amdgpu_buffer_rsrc_t y_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(p.y + ((size_t)b0 * p.Cout + m0) * plane, 0, 0x7fffffff, 0x00020000);
-#endif
+    const float* y_base = p.y + ((size_t)b0 * p.Cout + m0) * plane;  // (uniform: the store builds its buffer descriptor from it)
+    (void)y_base;
     const float* zbase = Z + cp * 4;
     const int zo_off = (cr ? 3 : 0) * 16 * NPOS * 4;
 
@@ -633,7 +677,8 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             const f32x4 z2 = *reinterpret_cast<const f32x4*>(zp + 2 * 16 * NPOS * 4);
             const f32x4 zo = *reinterpret_cast<const f32x4*>(zp + zo_off);
             const f32x4 e = *reinterpret_cast<const f32x4*>(E + 8 * ol);  // gain, bias, ToRGB weights 0, 1
-            const float r2 = E[8 * ol + 4];
+            const f32x2 r2ps = *reinterpret_cast<const f32x2*>(E + 8 * ol + 4);  // third ToRGB weight, post scale
+            const float r2 = r2ps.x;
             const f32x4 raw = (z2 + zo) * row_sign + z1;
             const f32x4 tt = raw * e[0] + (nz * nw + e[1]);
             const f32x4 v4 = __builtin_elementwise_max(tt, tt * slope);
@@ -644,7 +689,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
             }
 #ifdef MAUA_DEVICE_PASS
             if (store_feat)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), y_rsrc, pix_off * 4u, (unsigned)ol * plane_b, 0);
+                buffer_store_b128_sgpr_offset(__builtin_bit_cast(u32x4, v4 * r2ps.y), y_base, pix_off * 4u, (unsigned)ol * plane_b);
 #endif
         }
     }
@@ -730,7 +775,7 @@ __global__ __launch_bounds__(256, MINB) void modconv_w2d_kernel(W2dArgs p) {
 constexpr int WW_TN = 4, WW_BM = 32;
 constexpr int WW_A_FLOATS = 24 * W2D_CC * WW_BM;
 
-template <bool PLUS>
+template <bool PLUS, bool PRE = false>
 __device__ __forceinline__ void ww_transform(const f32x2 (&a)[4], const f32x2 (&b)[4], float sc, float m5, float (&bv)[6]) {
     // D = a +- b (the F(2,3) row combination), then B_x^T of F(4,3) on register pairs exactly as in modconv_w2d_kernel
     f32x2 D12, D34, ba, ec, b12, b34;
@@ -753,12 +798,16 @@ __device__ __forceinline__ void ww_transform(const f32x2 (&a)[4], const f32x2 (&
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t5) : "v"(m5), "v"(D34.x), "v"(d5));
     asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u0) : "v"(d0), "v"(t0));
     asm("v_fma_f32 %0, 4.0, %1, %2" : "=v"(u5) : "v"(D12.x), "v"(t5));
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b12) : "v"(b12), "v"(sc2));
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b34) : "v"(b34), "v"(sc2));
-    bv[0] = u0 * sc, bv[5] = u5 * sc;
+    if constexpr (!PRE) {  // (PRE: x arrives multiplied by this layer's styles)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b12) : "v"(b12), "v"(sc2));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b34) : "v"(b34), "v"(sc2));
+        u0 *= sc, u5 *= sc;
+    }
+    bv[0] = u0, bv[5] = u5;
     bv[1] = b12.x, bv[2] = b12.y, bv[3] = b34.x, bv[4] = b34.y;
 }
 
+template <bool PRE = false>
 __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     constexpr int TN = WW_TN, BM = WW_BM;
     constexpr int TH = 4 * TN, PH = TH + 2;
@@ -830,7 +879,8 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     // bias, ToRGB weights) then runs under the DMA's instead of in front of it
     issue(0, 0);
     // (styles: the first 256 channels' load goes out here and is written below, next to the table — one round trip for both)
-    const float s_first = *(tid < p.Cin ? p.s + (size_t)b0 * p.s_stride + tid : p.s);
+    const float* dummy = p.wq;  // (always valid)
+    const float s_first = *((!PRE && tid < p.Cin) ? p.s + (size_t)b0 * p.s_stride + tid : dummy);
     const bool act = p.fuse_act != 0;
     const float act_gain = act ? 1.41421356237309515f : 1.f;
     const float* noise_base = p.noise;
@@ -846,20 +896,24 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
         // address and are masked by a wave-uniform select.  Written as `if (p.d) gain *= p.d[..]` etc. the compiler emitted a branch and
         // a full wait per operand: four dependent global round trips (~3 us) in front of every workgroup's K loop.
         const int i = tid, o = m0 + i;
-        const float* dummy = p.s;
         const float dv = *(p.d ? p.d + (size_t)b0 * p.Cout + o : dummy);
         const float bv_ = *((act && p.bias) ? p.bias + o : dummy);
         const float sv_ = *(p.rgb ? p.rgb_s + (size_t)b0 * p.s_stride + o : dummy);
         const float w0 = *(p.rgb ? p.rgb_w + 0 * p.Cout + o : dummy), w1 = *(p.rgb ? p.rgb_w + 1 * p.Cout + o : dummy);
         const float w2 = *(p.rgb ? p.rgb_w + 2 * p.Cout + o : dummy);
+        const float pv_ = *(p.post_s ? p.post_s + (size_t)b0 * p.s_stride + o : dummy);
         const float gain = p.wscale * act_gain * (p.d ? dv : 1.f);
         const float ms = p.rgb ? p.rgb_wscale * sv_ : 0.f;
-        // channel PAIRS side by side (the epilogue works on register pairs): [pair][gain x2 | bias x2 | rgb0 x2 | rgb1 x2 | rgb2 x2 | pad x2]
+        // channel PAIRS side by side (the epilogue works on register pairs): [pair][gain x2 | bias x2 | rgb0 x2 | rgb1 x2 | rgb2 x2 | post scale x2]
         float* ep = E + 12 * (i >> 1) + (i & 1);
         ep[0] = gain, ep[2] = (act && p.bias) ? bv_ * act_gain : 0.f, ep[4] = ms * w0, ep[6] = ms * w1, ep[8] = ms * w2;
+        ep[10] = p.post_s ? pv_ : 1.f;
     }
-    if (tid < p.Cin) Ss[tid] = s_first;
-    for (int e = tid + 256; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    if constexpr (!PRE) {
+        if (tid < p.Cin) Ss[tid] = s_first;
+        for (int e = tid + 256; e < p.Cin; e += 256) Ss[e] = p.s[(size_t)b0 * p.s_stride + e];
+    }
+    (void)s_first;
 
     f32x4 acc[4][6][2];  // [y-frequency][x-frequency][m-tile]; the first K step runs with C = 0
     float m5 = -5.f;
@@ -882,8 +936,11 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
         const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (chunk + 1 < p.n_chunks && !W2D_ABL(2)) issue(chunk + 1, cur ^ 1);
         const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u), pw = w_addr + (cur ? P_BUF_BYTES : 0u);
-        float sc = lds_read32(s_addr);
-        s_addr += W2D_CC * 4u;
+        float sc = 1.f;
+        if constexpr (!PRE) {
+            sc = lds_read32(s_addr);
+            s_addr += W2D_CC * 4u;
+        }
         f32x2 SA[4], SB[4], a2[2];
         float bv[6];
         auto read_row = [&](f32x2(&dst)[4], auto r_c) {
@@ -917,22 +974,25 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
         read_row(SA, I0{});
         read_row(SB, I2{});
         a2[0] = lds_read64<0>(ap);
+        if constexpr (PRE)
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(SA[0]), "+v"(SA[1]), "+v"(SA[2]), "+v"(SA[3]), "+v"(SB[0]), "+v"(SB[1]), "+v"(SB[2]), "+v"(SB[3]));
+        else
         asm volatile("s_waitcnt lgkmcnt(1)"
                      : "+v"(sc), "+v"(SA[0]), "+v"(SA[1]), "+v"(SA[2]), "+v"(SA[3]), "+v"(SB[0]), "+v"(SB[1]), "+v"(SB[2]), "+v"(SB[3]));
-        ww_transform<false>(SA, SB, sc, m5, bv);  // f0: d0 - d2
+        ww_transform<false, PRE>(SA, SB, sc, m5, bv);  // f0: d0 - d2
         __builtin_amdgcn_sched_barrier(0);
         read_row(SA, I1{});                        // (row 0 is dead)
         block(I0{}, I4{});
         asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(SA[0]), "+v"(SA[1]), "+v"(SA[2]), "+v"(SA[3]));
-        ww_transform<true>(SA, SB, sc, m5, bv);   // f1: d1 + d2
+        ww_transform<true, PRE>(SA, SB, sc, m5, bv);   // f1: d1 + d2
         __builtin_amdgcn_sched_barrier(0);
         block(I1{}, I0{});
-        ww_transform<false>(SB, SA, sc, m5, bv);  // f2: d2 - d1
+        ww_transform<false, PRE>(SB, SA, sc, m5, bv);  // f2: d2 - d1
         __builtin_amdgcn_sched_barrier(0);
         read_row(SB, I3{});                        // (row 2 is dead)
         block(I2{}, I4{});
         asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(SB[0]), "+v"(SB[1]), "+v"(SB[2]), "+v"(SB[3]));
-        ww_transform<false>(SA, SB, sc, m5, bv);  // f3: d1 - d3
+        ww_transform<false, PRE>(SA, SB, sc, m5, bv);  // f3: d1 - d3
         __builtin_amdgcn_sched_barrier(0);
         block(I3{}, I0{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -964,10 +1024,8 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
     const float slope = act ? 0.2f : 1.f;
     const bool store_feat = p.rgb != 2;
     const unsigned plane_b = (unsigned)plane * 4u;
-#ifdef MAUA_DEVICE_PASS
-    const __amdgpu_buffer_rsrc_t y_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(p.y + ((size_t)b0 * p.Cout + m0) * plane, 0, 0x7fffffff, 0x00020000);
-#endif
+    const float* y_base = p.y + ((size_t)b0 * p.Cout + m0) * plane;  // (uniform: the store builds its buffer descriptor from it)
+    (void)y_base;
     const unsigned y_voff = pix0 * 4u + (unsigned)(4 * kq) * plane_b;
     (void)y_voff;
     const float* Elane = E + 12 * (2 * kq);
@@ -1038,7 +1096,8 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
             }
             const float* ep = Elane + 12 * (8 * m + vp);
             const f32x4 gb = *reinterpret_cast<const f32x4*>(ep), r01 = *reinterpret_cast<const f32x4*>(ep + 4);
-            const f32x2 r2p = *reinterpret_cast<const f32x2*>(ep + 8);
+            const f32x4 r2ps = *reinterpret_cast<const f32x4*>(ep + 8);
+            const f32x2 r2p = f32x2{r2ps[0], r2ps[1]}, post2 = f32x2{r2ps[2], r2ps[3]};
             const f32x2 gain2 = f32x2{gb[0], gb[1]}, bias2 = f32x2{gb[2], gb[3]};
             const f32x2 w0 = f32x2{r01[0], r01[1]}, w1 = f32x2{r01[2], r01[3]};
             f32x2 val[2][4];
@@ -1069,9 +1128,8 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
                     const int ol = 16 * m + 2 * vp + h;  // + 4 kq through y_voff
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
-                        const f32x4 row = f32x4{val[r][0][h], val[r][1][h], val[r][2][h], val[r][3][h]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, row), y_rsrc, y_voff + (unsigned)(r * p.W) * 4u,
-                                                               (unsigned)ol * plane_b, 0);
+                        const f32x4 row = f32x4{val[r][0][h], val[r][1][h], val[r][2][h], val[r][3][h]} * post2[h];
+                        buffer_store_b128_sgpr_offset(__builtin_bit_cast(u32x4, row), y_base, y_voff + (unsigned)(r * p.W) * 4u, (unsigned)ol * plane_b);
                     }
                 }
             }
@@ -1185,12 +1243,12 @@ size_t w2d_lds_bytes(int tm, int tn, int cin) {
 
 char g_w2d_instance[64] = "";
 
-template <int TM, int TN, int MINB = 2>
+template <int TM, int TN, int MINB = 2, bool PRE = false>
 int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
-    auto kern = modconv_w2d_kernel<TM, TN, MINB>;
+    auto kern = modconv_w2d_kernel<TM, TN, MINB, PRE>;
     static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
     if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(kern), &lds_ok, 160 * 1024)) return rc;
-    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2d_kernel<%d, %d, %d>", TM, TN, MINB);
+    snprintf(g_w2d_instance, sizeof(g_w2d_instance), PRE ? "modconv_w2d_kernel<%d, %d, %d, true>" : "modconv_w2d_kernel<%d, %d, %d, false>", TM, TN, MINB);
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
 #ifdef MAUA_EXPERIMENTS  // occupancy probe (MAUA_W2D_LDS_PAD with an experiments build): extra dynamic LDS so that a CU holds one workgroup instead of two
     static const size_t lds_pad = getenv("MAUA_W2D_LDS_PAD") ? (size_t)atoi(getenv("MAUA_W2D_LDS_PAD")) : 0;
@@ -1202,12 +1260,13 @@ int w2d_launch_t(const W2dArgs& a, hipStream_t st) {
     return 0;
 }
 
+template <bool PRE>
 int w2dw_launch(const W2dArgs& a, hipStream_t st) {
     static unsigned long long lds_ok = 0;  // per launcher: devices on which the attribute has been set (common.h)
-    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_w2dw_kernel), &lds_ok, 160 * 1024)) return rc;
-    snprintf(g_w2d_instance, sizeof(g_w2d_instance), "modconv_w2dw_kernel");
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_w2dw_kernel<PRE>), &lds_ok, 160 * 1024)) return rc;
+    snprintf(g_w2d_instance, sizeof(g_w2d_instance), PRE ? "modconv_w2dw_kernel<true>" : "modconv_w2dw_kernel<false>");
     const int64_t blocks = (int64_t)a.B * a.tiles_y * a.tiles_x * a.m_tiles;
-    hipLaunchKernelGGL(modconv_w2dw_kernel, dim3((unsigned)blocks), dim3(256), w2dw_lds_bytes(a.Cin), st, a);
+    hipLaunchKernelGGL(modconv_w2dw_kernel<PRE>, dim3((unsigned)blocks), dim3(256), w2dw_lds_bytes(a.Cin), st, a);
     MAUA_LAUNCH_CHECK();
     return 0;
 }
@@ -1238,14 +1297,14 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
                     int cout, int h, int w, float wscale, int fuse_act, const float* noise, int64_t noise_batch_stride,
                     const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                     const float* rgb_bias, const float* rgb_skip, const float* rgb_k4, float* rgb_out, uint8_t* rgb_u8,
-                    int rgb_mode, const maua_frame_source_t* src, int noise_slot, void* stream) {
+                    int rgb_mode, const maua_frame_source_t* src, int noise_slot, const float* post_s, void* stream) {
     int tm = 0, tn = 0;
     if (!maua_w2d_tiles(cin, cout, h, w, &tm, &tn)) return MAUA_EINVAL;
     if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)24 * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
     W2dArgs a{};
     a.x = x, a.wq = wq, a.s = s, a.d = d, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.y = y;
     a.rgb_w = rgb_w, a.rgb_s = rgb_s, a.rgb_bias = rgb_bias, a.rgb_skip = rgb_skip, a.rgb_k4 = rgb_k4, a.rgb_out = rgb_out;
-    a.rgb_u8 = rgb_u8;
+    a.rgb_u8 = rgb_u8, a.post_s = post_s;
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale, a.fuse_act = fuse_act;
     a.noise_batch_stride = noise_batch_stride;
     a.src = src, a.noise_slot = noise_slot;
@@ -1259,9 +1318,11 @@ int maua_w2d_launch(const float* x, const float* wq, const float* s, int s_strid
 #ifndef MAUA_W2D_NO_WW
     if (tm == 2 && h % (4 * WW_TN) == 0 && rgb_mode != 3) {  // 32 output channels: the wave-complete kernel (16-row tiles)
         a.tiles_y = h / (4 * WW_TN);
-        return w2dw_launch(a, st);
+        return s ? w2dw_launch<false>(a, st) : w2dw_launch<true>(a, st);
     }
 #endif
+    if (!s)  // x arrives multiplied by this layer's styles (the producer's post_s)
+        return tm == 4 ? w2d_launch_t<4, MAUA_W2D_TN64, MAUA_W2D_MINB64, true>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32, true>(a, st);
     return tm == 4 ? w2d_launch_t<4, MAUA_W2D_TN64, MAUA_W2D_MINB64>(a, st) : w2d_launch_t<2, MAUA_W2D_TN32, MAUA_W2D_MINB32>(a, st);
 }
 
@@ -1283,3 +1344,4 @@ extern "C" int maua_modconv_w2d_mtiles(int cin, int cout, int h, int w) {
     int tm = 0, tn = 0;
     return maua_w2d_tiles(cin, cout, h, w, &tm, &tn) ? cout / (16 * tm) : 0;
 }
+

@@ -35,6 +35,10 @@ struct FirTail {
     const maua_frame_source_t* src;  // when set: noise / noise_batch_stride come from src->noise[noise_slot] at frame src->frame0
     int noise_slot;
     int plane_major;  // block order: 1 = plane by plane (sequential HBM rows), 0 = channel fastest (planes sharing a noise tile back to back)
+    // the style fold (round 6): the stored map is multiplied by post_s[b * post_stride + c] — the styles of the modulated convolution that
+    // consumes it (models/stylegan2.py:220-221: conv(W, x * s) with the multiply moved here, once per element)
+    const float* post_s;
+    int post_stride;
 };
 
 // Output rows per wave strip (TH).  Plain: 24 (27 KB of LDS: five workgroups per CU instead of four — 5.51 vs 5.33 TB/s on [8,32,1025,1025]
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
     const unsigned out_voff = ox < out_w ? (unsigned)ox * 4u : FIR_OOB;
 
     // tail operands: this lane's 32 noise values are fetched now, in flight together with the input tile
-    float g = 1.f, nw = 0.f, bs = 0.f;
+    float g = 1.f, nw = 0.f, bs = 0.f, post = 1.f;
     float nzv[TAIL ? TH : 1];
     if (TAIL) {
         const int b = plane / tail.channels;
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
         // leaky ReLU * sqrt2 as max(t, 0.2 t) on pre-scaled operands: t = sqrt2 (g v + nw noise + bias)
         g = 1.41421356237309515f * (tail.gain ? tail.gain[plane] : 1.f);
         bs = tail.bias ? tail.bias[c] * 1.41421356237309515f : 0.f;
+        if (tail.post_s) post = tail.post_s[(size_t)b * tail.post_stride + c];
 #pragma unroll
         for (int o = 0; o < TH; ++o) nzv[o] = 0.f;
         const float* noise = tail.noise;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(const float* __restrict__
             float val = acc[o_done % KH];
             if (TAIL) {
                 const float tt = fmaf(val, g, fmaf(nw, nzv[TAIL ? o_done : 0], bs));
-                val = fmaxf(tt, 0.2f * tt);
+                val = fmaxf(tt, 0.2f * tt) * post;
             }
 #ifdef MAUA_DEVICE_PASS
             if (oy < out_h)
@@ -680,7 +685,8 @@ extern "C" int maua_upfirdn2d_f32(const float* x, const float* k, float* y, int 
 extern "C" int maua_blur_noise_act_f32(const float* x, const float* k, float* y, int batch, int channels, int in_h,
                                        int in_w, int kh, int kw, int pad0, int pad1, const float* gain,
                                        const float* noise, int64_t noise_batch_stride, const float* noise_w,
-                                       const float* bias, const maua_frame_source_t* src, int noise_slot, void* stream) {
+                                       const float* bias, const maua_frame_source_t* src, int noise_slot, const float* post_s,
+                                       int post_stride, void* stream) {
     if (!x || !k || !y || batch <= 0 || channels <= 0 || in_h <= 0 || in_w <= 0) return MAUA_EINVAL;
     if ((noise || src) && !noise_w) return MAUA_EINVAL;
     if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
@@ -693,7 +699,8 @@ extern "C" int maua_blur_noise_act_f32(const float* x, const float* k, float* y,
 #ifndef MAUA_FIR_PLANE_MAJOR_MAX_H
 #define MAUA_FIR_PLANE_MAJOR_MAX_H 512
 #endif
-    FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels, src, noise_slot, out_h <= MAUA_FIR_PLANE_MAJOR_MAX_H ? 1 : 0};
+    FirTail tail{gain, noise, noise_w, bias, noise_batch_stride, channels, src, noise_slot, out_h <= MAUA_FIR_PLANE_MAJOR_MAX_H ? 1 : 0,
+                 post_s, post_stride};
     return dispatch_fir_tile<true>(x, k, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, pad0, pad0, tail,
                                    (hipStream_t)stream);
 }

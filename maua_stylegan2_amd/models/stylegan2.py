@@ -294,17 +294,18 @@ class ModulatedConv2d(nn.Module):
                     cin=self.in_channel, cout=self.out_channel, lat_idx=lat_idx, s_off=s_off, d_off=d_off,
                     wscale=self.scale)
 
-    def run(self, x, s, s_off, d, out, ws, fuse_act=False, noise=None, noise_w=None, bias=None, src=None, slot=0):
+    def run(self, x, s, s_off, d, out, ws, fuse_act=False, noise=None, noise_w=None, bias=None, src=None, slot=0, prescaled=False):
         """3x3 only. x [B,Cin,H,W]; s [B,S] (this layer's slice at s_off); d [B,Cout] or None.
         Writes ``out`` ([B,Cout,H,W] or [B,Cout,2H+1,2W+1] when upsample).  ``src`` (device pointer of a frame source,
-        include/maua_hip.h): the noise map comes from its slot ``slot`` instead of ``noise``."""
+        include/maua_hip.h): the noise map comes from its slot ``slot`` instead of ``noise``.  ``prescaled``: x arrives multiplied by
+        this layer's styles (the style fold, include/maua_hip.h; modes 5 and 6 only)."""
         lib = _lib.load()
         b, cin, h, w = x.shape
         mode = self.conv_mode(h, w)
         wp = self.packed_wino(mode) if mode >= 2 else self.packed()[0]
         nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
         rc = lib.maua_modconv3x3_f32(
-            x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b, cin,
+            x.data_ptr(), wp.data_ptr(), None if prescaled else s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b, cin,
             self.out_channel, h, w, mode, float(self.scale), int(fuse_act), _lib.ptr(noise), nstride,
             _lib.ptr(noise_w), _lib.ptr(bias), _lib.ptr(ws), src if fuse_act else None, slot, _lib.stream_ptr(x.device),
         )
@@ -475,14 +476,25 @@ class StyledConv(nn.Module):
     # that round trip saves (convs.10: 0.70 against 0.56 ms; profiles/r05_fused_upconv_blur.md).  A huge value = always the two-launch path.
     fused_blur_min_width = 256
 
-    def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None, src=None, slot=0):
+    def accepts_prescaled(self, h, w):
+        """True when this layer's convolution has a kernel instance without the style multiplies for an [*, Cin, h, w] input (the style
+        fold, include/maua_hip.h: the 2-D Winograd kernels, mode 5, and the F(2,2)^2 transposed kernel, mode 6, fused with its blur or not)."""
+        return self.conv.conv_mode(h, w) in (5, 6)
+
+    def run(self, x, s, s_off, d, noise, bufs, tag, rgb=None, src=None, slot=0, prescaled=False, post_off=None):
         """Fused forward on precomputed styles. ``bufs(name, shape)`` hands out static device buffers.
+        The style fold (include/maua_hip.h): ``prescaled`` = x arrives multiplied by this layer's styles (the producer applied them);
+        ``post_off`` = offset inside ``s`` of the styles of the layer that consumes this layer's output: where this layer's path can, it
+        stores its map multiplied by them and sets ``self.posted`` (the consumer is then run with ``prescaled``).
         ``rgb`` (plain layers only): dict(module=ToRGB, s_off, skip, out, store) — fold the following ToRGB into the conv
         epilogue when the layer qualifies; on success ``rgb["done"]`` is set and ``rgb["out"]`` holds the image.
         ``src`` / ``slot``: the noise map is read through the frame source (``noise`` is then ignored and may be None)."""
         lib = _lib.load()
         conv = self.conv
         b, cin, h, w = x.shape
+        self.posted = False
+        s_ptr = None if prescaled else s.data_ptr() + 4 * s_off
+        post_ptr = None if post_off is None else s.data_ptr() + 4 * post_off
         n_ws = lib.maua_modconv_ws_floats(b, cin, conv.out_channel, h, w, conv.conv_mode(h, w))
         # one split-K workspace PER LAYER: a shared name would be re-allocated whenever the size changes, and a captured
         # hipGraph keeps writing through the pointer of the buffer that was freed
@@ -509,16 +521,18 @@ class StyledConv(nn.Module):
                     mode = conv.conv_mode(h, w)
                     wp = conv.packed_wino(mode) if mode >= 2 else conv.packed()[0]
                     nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
+                    post = post_ptr if mode == 5 else None
                     rc = lib.maua_styledconv_torgb_f32(
-                        x.data_ptr(), wp.data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), b,
+                        x.data_ptr(), wp.data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(), b,
                         cin, conv.out_channel, h, w, mode, float(conv.scale), _lib.ptr(noise), nstride,
                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
                         s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), t.bias.data_ptr(), _lib.ptr(skip),
                         _lib.ptr(t.upsample.kernel) if skip is not None else None,
                         rgb["out"].data_ptr() if (rgb.get("u8") is None or rgb.get("tap")) else None,
-                        int(rgb.get("store", True)), _lib.ptr(rgb.get("u8")), src, slot, _lib.stream_ptr(x.device))
+                        int(rgb.get("store", True)), _lib.ptr(rgb.get("u8")), src, slot, post, _lib.stream_ptr(x.device))
                     if rc == 0:
                         rgb["done"] = True
+                        self.posted = post is not None
                         return out
                     if rc != -38:  # MAUA_ENOSYS = layer shape not fusable -> two launches below
                         _lib.check(rc, "maua_styledconv_torgb_f32")
@@ -534,11 +548,12 @@ class StyledConv(nn.Module):
                     part = bufs(tag + ".rgb_partial", (b, 3 * m_tiles, h, w))
                     nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
                     _lib.check(lib.maua_styledconv_torgb_partial_f32(
-                        x.data_ptr(), conv.packed_wino(5).data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d),
+                        x.data_ptr(), conv.packed_wino(5).data_ptr(), s_ptr, s.shape[1], _lib.ptr(d),
                         out.data_ptr(), b, cin, conv.out_channel, h, w, 5, float(conv.scale), _lib.ptr(noise), nstride,
                         self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
-                        s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), src, slot,
+                        s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), src, slot, post_ptr,
                         _lib.stream_ptr(x.device)), "maua_styledconv_torgb_partial_f32")
+                    self.posted = post_ptr is not None
                     sel, ones = _partial_rgb_operands(m_tiles, b, x.device)
                     _lib.check(lib.maua_torgb_f32(part.data_ptr(), sel.data_ptr(), ones.data_ptr(), 3 * m_tiles, t.bias.data_ptr(),
                                                   _lib.ptr(skip), _lib.ptr(t.upsample.kernel) if skip is not None else None,
@@ -548,7 +563,7 @@ class StyledConv(nn.Module):
                     rgb["u8_done"] = False  # the image is in rgb["out"] as fp32 planes: a last layer still needs the frame epilogue
                     return out
             return conv.run(x, s, s_off, d, out, ws, fuse_act=True, noise=noise, noise_w=self.noise.weight,
-                            bias=self.activate.bias, src=src, slot=slot)
+                            bias=self.activate.bias, src=src, slot=slot, prescaled=prescaled)
         k = conv.blur.kernel
         pad0, pad1 = conv.blur.pad
         if (self.fused_blur_min_width <= w and conv.conv_mode(h, w) == 6 and (pad0, pad1) == (1, 1) and conv.blur_is_separable()
@@ -560,21 +575,23 @@ class StyledConv(nn.Module):
             seam = bufs(tag + ".seam", (n_seam,)) if n_seam else None
             nstride = 0 if noise is None or noise.shape[0] == 1 else 4 * h * w
             _lib.check(lib.maua_upconv_blur_f32(
-                x.data_ptr(), conv.packed_wino(6).data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(),
+                x.data_ptr(), conv.packed_wino(6).data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(),
                 _lib.ptr(seam), k.data_ptr(), _lib.ptr(noise), nstride, self.noise.weight.data_ptr(), self.activate.bias.data_ptr(),
-                src, slot, b, cin, conv.out_channel, h, w, float(conv.scale), _lib.stream_ptr(x.device)), "maua_upconv_blur_f32")
+                src, slot, b, cin, conv.out_channel, h, w, float(conv.scale), post_ptr, _lib.stream_ptr(x.device)), "maua_upconv_blur_f32")
+            self.posted = post_ptr is not None
             return out
         self.last_path = "pair"
         raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
-        conv.run(x, s, s_off, d, raw, ws)
+        conv.run(x, s, s_off, d, raw, ws, prescaled=prescaled)
         oh, ow = raw.shape[2] + pad0 + pad1 - k.shape[0] + 1, raw.shape[3] + pad0 + pad1 - k.shape[1] + 1
         out = bufs(tag, (b, conv.out_channel, oh, ow))
         nstride = 0 if noise is None or noise.shape[0] == 1 else oh * ow
         rc = lib.maua_blur_noise_act_f32(raw.data_ptr(), k.data_ptr(), out.data_ptr(), b, conv.out_channel, raw.shape[2],
                                          raw.shape[3], k.shape[0], k.shape[1], pad0, pad1, None, _lib.ptr(noise), nstride,
                                          self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), src, slot,
-                                         _lib.stream_ptr(x.device))
+                                         post_ptr, s.shape[1], _lib.stream_ptr(x.device))
         _lib.check(rc, "maua_blur_noise_act_f32")
+        self.posted = post_ptr is not None
         return out
 
     def forward(self, inputs, style, noise=None, transform_dict_list=[]):
@@ -686,6 +703,8 @@ class Generator(nn.Module):
     # parity-test tap: a forward that writes uint8 frames from the last layer's epilogue ALSO leaves the fp32 image of the last
     # resolution (``GraphLane.image``) — the same kernel instance writes both, so the float comparison sees exactly what became the frame
     tap_float_image = False
+    # the style fold (include/maua_hip.h THE STYLE FOLD; A/B switch): producers store their map multiplied by the consumer's styles
+    style_fold = True
 
     def _build(self, size, style_dim, n_mlp, channel_multiplier, blur_kernel, lr_mlp, constant_input, min_rgb_size):
         self.size = size
@@ -908,6 +927,17 @@ class Generator(nn.Module):
                 nz = bufs(f"rand_noise_{i}", (batch, 1, h, w)).normal_()
             return nz.to(dev)
 
+        # the style fold (include/maua_hip.h): a layer's epilogue multiplies the map it stores by the NEXT convolution's styles, which then
+        # runs without the multiplies in its K loop.  Only where nothing else reads the map: no bend on the producer's layer id, no
+        # activation maps handed out (the ToRGB of a plain layer is computed in its own epilogue from the un-scaled value).
+        fold = self.style_fold and not want_acts
+
+        def post_for(layer_id, consumer, h, w, consumer_entry):
+            """s offset of ``consumer``'s styles if the producer with ``layer_id`` may store its map pre-multiplied by them, else None."""
+            if not fold or any(bd["layer"] == layer_id for bd in bends) or not consumer.accepts_prescaled(h, w):
+                return None
+            return consumer_entry["s_off"]
+
         acts = []
         if isinstance(self.input, LatentInput):
             x = self.input.run(latent, trunc, tl, bufs("const", (batch, self.input.channel, self.input.size, self.input.size)),
@@ -918,7 +948,8 @@ class Generator(nn.Module):
         x = self.const_manipulation.run(x, bends, bufs, "const", src)
         li = 0
         out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1",
-                             src=src, slot=0)
+                             src=src, slot=0)  # (conv1 never posts: to_rgb1 reads its map in a pass of its own)
+        posted = False  # whether `out` carries the next convolution's styles already
         out = self.conv1.manipulation.run(out, bends, bufs, "conv1", src)
         acts.append(out)
         li += 1
@@ -931,7 +962,9 @@ class Generator(nn.Module):
         for n in range(self.log_size - 2):
             up, plain, rgb = self.convs[2 * n], self.convs[2 * n + 1], self.to_rgbs[n]
             out = up.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 1, out.shape[2] * 2, out.shape[3] * 2),
-                         bufs, f"convs.{2 * n}", src=src, slot=2 * n + 1)
+                         bufs, f"convs.{2 * n}", src=src, slot=2 * n + 1, prescaled=posted,
+                         post_off=post_for(2 * n + 2, plain, out.shape[2] * 2, out.shape[3] * 2, ent[li + 1]))
+            posted = up.posted
             out = up.manipulation.run(out, bends, bufs, f"convs.{2 * n}", src)
             acts.append(out)
             li += 1
@@ -947,8 +980,11 @@ class Generator(nn.Module):
             if wants_rgb and not bent and not getattr(self, "disable_rgb_fusion", False):
                 fuse = dict(module=rgb, s_off=ent[li + 1]["s_off"], skip=image, out=rgb_buf,
                             store=(not is_last) or want_acts, u8=frames_u8 if is_last else None, tap=self.tap_float_image)
+            nxt = self.convs[2 * n + 2] if not is_last else None
             out = plain.run(out, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(2 * n + 2, out.shape[2], out.shape[3]),
-                            bufs, f"convs.{2 * n + 1}", rgb=fuse, src=src, slot=2 * n + 2)
+                            bufs, f"convs.{2 * n + 1}", rgb=fuse, src=src, slot=2 * n + 2, prescaled=posted,
+                            post_off=None if nxt is None else post_for(layer_id, nxt, out.shape[2], out.shape[3], ent[li + 2]))
+            posted = plain.posted
             out = plain.manipulation.run(out, bends, bufs, f"convs.{2 * n + 1}", src)
             acts.append(out)
             li += 1
@@ -957,6 +993,7 @@ class Generator(nn.Module):
                 if is_last and frames_u8 is not None and fuse.get("u8_done", True) and not self.tap_float_image:
                     image = None  # left the device path as uint8 frames
             elif wants_rgb:
+                assert not posted  # (a separate ToRGB pass reads the un-scaled map: plain.run only posts from the ToRGB-fused paths)
                 image = rgb.run(out, s, ent[li]["s_off"], image, rgb_buf)
             li += 1
         if frames_u8 is not None and image is not None:  # last layer not fusable (bend on it, > 64 channels, ...)

@@ -344,3 +344,59 @@ def test_generator_with_split_bf16_conv_layers_matches_reference_golden(gpu, gol
     print(f"[split-bf16 generator {size}] {switched} conv layers on the bf16 cores: max |image - reference| = {err:.2e} "
           f"(fp32 path: {err32:.2e}; image std {float(fp32.std()):.2f}), max |split - fp32| = {float((img - fp32).abs().max()):.2e}")
     assert err < TOL, f"{size}: max abs err {err}"
+
+
+@pytest.mark.parametrize("size", [256, 1024])
+def test_style_fold_on_equals_off_and_the_reference_image(gpu, golden, size):
+    """Round 6, the style fold (include/maua_hip.h): every producer from the first 2-D Winograd / F(2,2)^2 consumer on stores its map
+    multiplied by the next convolution's styles (reference models/stylegan2.py:220-221 reassociated).  Whole generator, fold on (the
+    default) against fold off — same kernels otherwise — and against the reference's own image; the number of folded layers is checked
+    so that the switch cannot silently do nothing."""
+    gold = golden(f"gen_{size}.npz")
+    batch, stride = int(gold["batch"]), int(gold["stride"])
+    s_sd, s_lat, s_noise, _ = (int(v) for v in gold["seeds"])
+    g = build(size, gpu, s_sd)
+    lat = seeding.seeded_latents(batch, g.n_latent, seed=s_lat).to(gpu)
+    assert g.style_fold
+    on, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    folded = [i for i, c in enumerate(g.convs) if c.posted]
+    g.style_fold = False
+    off, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    assert not any(c.posted for c in g.convs)
+    g.style_fold = True
+    # 1024^2: convs.4's tail (16^2 -> 32^2) is the first producer whose consumer (convs.5, 2-D Winograd) takes a pre-scaled map; every
+    # layer up to convs.14 follows.  256^2: convs.4 .. convs.10.
+    assert folded == list(range(4, len(g.convs) - 1)), folded
+    err = float((on - off).abs().max())
+    print(f"[style fold, {size}^2] {len(folded)} folded layers; fold on vs off {err:.2e} at image std {float(off.std()):.2f}")
+    assert err < 1e-4
+    assert np.abs(on.cpu().numpy()[:, :, ::stride, ::stride] - gold["image_buffer_noise"]).max() < TOL
+
+
+def test_style_fold_steps_aside_for_bends_and_activation_maps(gpu):
+    """A bend on a layer id, or return_activation_maps, reads the un-scaled map: the producer of that map must not fold (the layers
+    either side still do)."""
+    import torch.nn as nn
+
+    g = build(256, gpu, 1)
+    lat = seeding.seeded_latents(2, g.n_latent, seed=2).to(gpu)
+
+    class Gain(nn.Module):
+        def forward(self, x):
+            return x * 1.25
+
+    plain, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    assert g.convs[6].posted and g.convs[7].posted
+    bends = [{"layer": 8, "transform": Gain()}, {"layer": 9, "transform": Gain()}]  # layer ids 8 / 9 = convs.6 / convs.7
+    bent, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True, transform_dict_list=bends)
+    assert not g.convs[6].posted and not g.convs[7].posted and g.convs[5].posted and g.convs[8].posted
+    g.style_fold = False
+    bent_off, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True, transform_dict_list=bends)
+    g.style_fold = True
+    assert float((bent - bent_off).abs().max()) < 1e-4 and float((bent - plain).abs().max()) > 1e-2
+    _, acts = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True, return_activation_maps=True)
+    assert not any(c.posted for c in g.convs)
+    g.style_fold = False
+    _, acts_off = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True, return_activation_maps=True)
+    for a, b in zip(acts, acts_off):
+        assert torch.equal(a, b)

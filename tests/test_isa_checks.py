@@ -130,3 +130,41 @@ def test_wave_complete_kernel_k_step_composition(device_asm):
     drains = [i for i, line in enumerate(body[lo:hi + 1]) if "s_waitcnt" in line and "vmcnt(0)" in line]
     barrier = next(i for i, line in enumerate(body[lo:hi + 1]) if "s_barrier" in line)
     assert drains and all(0 < barrier - d < 12 for d in drains), (drains, barrier)
+
+
+@pytest.mark.parametrize("name", SOURCES + STREAMING)
+def test_wide_buffer_stores_carry_their_own_wait_states(device_asm, name):
+    """Round 6 finding (csrc/modconv_w2d.hip buffer_store_b128_sgpr_offset; profiles/r06_store_hazard.md): a MUBUF store of more than 64
+    bits whose soffset is an SGPR is hazard-free in the compiler's model, which then lets the next instructions overwrite the data
+    registers — on the MI355X the stored row carried the NEXT row's last dword in a quarter of the lanes.  Every buffer store of 3 or 4
+    dwords in the hot kernels therefore sits in an inline-assembly blob with `s_nop` right behind it (global_store_* has no soffset and
+    is covered by the compiler's own rule)."""
+    lines = [line.strip() for line in device_asm[name].split("\n")]
+    wide = [i for i, line in enumerate(lines) if re.match(r"buffer_store_(dwordx[34]|format_xyzw?)\b", line)]
+    for i in wide:
+        assert lines[i + 1].startswith("s_nop"), f"{name}.hip: `{lines[i]}` (asm line {i}) is not followed by its wait states"
+    if name == "modconv_w2d":
+        assert wide, "the 2-D Winograd kernels store their feature rows with buffer_store_dwordx4"
+
+
+def test_prescaled_instances_drop_the_style_multiplies(device_asm):
+    """The style fold (include/maua_hip.h): kernel instances for a map that arrives multiplied by the layer's styles run the K step
+    without the style multiplies — 4 of 16 transform instructions per window of the 2-D Winograd kernels (16 of 64 per K step of the
+    wave-complete kernel), 9 of 23 VALU per K group of the F(2,2)^2 transposed kernel — and without the style's LDS read."""
+    def k_step(source, fragment):
+        body = _kernel_body(device_asm[source], fragment)
+        lo, hi = _main_loop(body)
+        ops = [line.split()[0] for line in body[lo:hi + 1] if line.strip() and not line.strip().startswith((".", ";")) and not line.strip().endswith(":")]
+        return (sum(op.startswith("v_mfma") for op in ops), sum(op.startswith("v_") and not op.startswith("v_mfma") for op in ops),
+                sum(op.startswith("ds_read") for op in ops))
+
+    mf0, valu0, lds0 = k_step("modconv_w2d", "modconv_w2dw_kernelILb0")
+    mf1, valu1, lds1 = k_step("modconv_w2d", "modconv_w2dw_kernelILb1")
+    assert mf0 == mf1 == 48 and valu0 - valu1 >= 16 and lds0 - lds1 == 1, (valu0, valu1, lds0, lds1)
+    mf0, valu0, lds0 = k_step("modconv_w2d", "modconv_w2d_kernelILi4ELi2ELi2ELb0")
+    mf1, valu1, lds1 = k_step("modconv_w2d", "modconv_w2d_kernelILi4ELi2ELi2ELb1")
+    assert mf0 == mf1 and valu0 - valu1 >= 8 and lds0 - lds1 == 1, (valu0, valu1, lds0, lds1)  # two windows per wave and K step
+    mf0, valu0, lds0 = k_step("modconv_up2d", "modconv_up2d_kernelILi8ELi0ELb0")
+    mf1, valu1, lds1 = k_step("modconv_up2d", "modconv_up2d_kernelILi8ELi0ELb1")
+    # two K groups per step; the 18 scalar multiplies were packed by the compiler (v_pk_mul_f32): 39 -> 30 VALU per 100 matrix instructions
+    assert mf0 == mf1 == 100 and valu0 - valu1 >= 8 and valu1 <= 32 and lds0 - lds1 == 2, (valu0, valu1, lds0, lds1)

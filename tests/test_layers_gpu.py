@@ -611,7 +611,7 @@ def test_upconv_blur_fused_c_abi_contract(gpu):
     def call(out, noise, nstride, src=None, slot=0, cin_=cin, ws_=ws, k_=k):
         return lib.maua_upconv_blur_f32(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), out.data_ptr(), _lib.ptr(ws_), k_.data_ptr(),
                                         _lib.ptr(noise), nstride, m.noise.weight.data_ptr(), m.activate.bias.data_ptr(), src, slot, b, cin_, cout,
-                                        h, w, float(conv.scale), st)
+                                        h, w, float(conv.scale), None, st)
 
     frame0 = 2
     direct = torch.full((b, cout, 2 * h, 2 * w), float("nan"), device=gpu)
@@ -645,3 +645,170 @@ def test_upconv_blur_fused_c_abi_contract(gpu):
         assert launches, "a non-separable blur must not reach the fused kernel"
     finally:
         StyledConv.fused_blur_min_width = keep
+
+
+# ---- round 6: the style fold (include/maua_hip.h THE STYLE FOLD) — producers store their map multiplied by the consumer's styles -----------
+
+
+def _fold_chain(gpu, c0, c1, c2, h, w, batch, fused_min_width, seed):
+    """up(c0 -> c1) -> plain(c1 -> c1) + ToRGB -> up(c1 -> c2) as three StyledConv modules + one ToRGB with seeded weights; returns
+    (modules, oracle state dict, inputs)."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv, ToRGB
+
+    r = np.random.default_rng(seed)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))  # noqa: E731
+    mods, sd = {}, {}
+    for name, (ci, co, up) in {"A": (c0, c1, True), "B": (c1, c1, False), "C": (c1, c2, True)}.items():
+        m = StyledConv(ci, co, 3, 512, upsample=up)
+        part = {"conv.weight": f32(r.standard_normal((1, co, ci, 3, 3))), "conv.modulation.weight": f32(r.standard_normal((ci, 512))),
+                "conv.modulation.bias": f32(1 + 0.1 * r.standard_normal(ci)), "noise.weight": f32([0.37]),
+                "activate.bias": f32(0.3 * r.standard_normal(co))}
+        if up:
+            part["conv.blur.kernel"] = m.conv.blur.kernel.clone()
+        m.load_state_dict(part, strict=True)
+        m.fused_blur_min_width = fused_min_width
+        mods[name] = m.to(gpu)
+        sd.update({f"{name}.{k}": v for k, v in part.items()})
+    t_rgb = ToRGB(c1, 512)
+    part = {"bias": f32(0.3 * r.standard_normal((1, 3, 1, 1))), "upsample.kernel": f32(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)),
+            "conv.weight": f32(r.standard_normal((1, 3, c1, 1, 1))), "conv.modulation.weight": f32(r.standard_normal((c1, 512))),
+            "conv.modulation.bias": f32(1 + 0.1 * r.standard_normal(c1))}
+    t_rgb.load_state_dict(part, strict=True)
+    mods["T"] = t_rgb.to(gpu)
+    sd.update({f"T.{k}": v for k, v in part.items()})
+    inputs = dict(x=f32(r.standard_normal((batch, c0, h, w))), lat=f32(r.standard_normal((batch, 4, 512))),
+                  nzA=f32(r.standard_normal((batch, 1, 2 * h, 2 * w))), nzB=f32(r.standard_normal((batch, 1, 2 * h, 2 * w))),
+                  nzC=f32(r.standard_normal((batch, 1, 4 * h, 4 * w))), skip=f32(r.standard_normal((batch, 3, h, w))))
+    return mods, sd, inputs
+
+
+@pytest.mark.parametrize("c0,c1,c2,h,w,batch,fused_min_width", [
+    (64, 128, 64, 16, 32, 2, 1 << 30),   # tail -> modconv_w2d_kernel<4,2,2,PRE> (two m-tiles: partial ToRGB sums) -> modconv_up2d_kernel<8,0,PRE> + tail
+    (64, 32, 32, 32, 32, 2, 32),         # fused up-sampling layer -> modconv_w2dw_kernel<PRE> (ToRGB fused) -> fused up-sampling layer <8,2,PRE>
+    (128, 64, 32, 16, 32, 1, 1 << 30),   # tail -> modconv_w2d_kernel<4,2,2,PRE> (one m-tile, ToRGB fused) -> mode 6 PRE + tail
+    (64, 64, 32, 24, 32, 3, 32),         # fused -> <4,2,2,PRE> -> fused (h not a power of two, three images)
+    (36, 32, 32, 8, 32, 1, 1 << 30),     # modconv_up2d_kernel<4,...> (cin % 8 != 0) producer side: tail -> w2dw -> <8,0,PRE>
+])
+def test_style_fold_chain_equals_unfolded_chain_and_oracle(gpu, c0, c1, c2, h, w, batch, fused_min_width):
+    """reference models/stylegan2.py:220-221 reassociated: every producer stores act(..) * s_next (post_s), the consumer runs the kernel
+    instance without its style multiplies (s == NULL).  Three layers + ToRGB through StyledConv.run, folded against un-folded (same
+    kernels otherwise: 2e-5 of the output scale — one rounding per element moves) and against the oracle's chain (the layer tests'
+    tolerance); the ToRGB image must not see the fold at all (it is computed from the un-scaled value)."""
+    from maua_stylegan2_amd.models.stylegan2 import _style_table
+    from oracle import stylegan2_oracle as so
+
+    mods, sd, inp = _fold_chain(gpu, c0, c1, c2, h, w, batch, fused_min_width, seed=c0 + c1 + c2 + h + w)
+    A, B, C, T = mods["A"], mods["B"], mods["C"], mods["T"]
+    lib = _lib.load()
+    assert B.accepts_prescaled(2 * h, 2 * w) and C.accepts_prescaled(2 * h, 2 * w)
+    entries, s_off, d_off = [], 0, 0
+    for m, li in ((A.conv, 0), (B.conv, 1), (T.conv, 2), (C.conv, 3)):
+        entries.append(m.table_entry(li, s_off, d_off))
+        s_off += m.in_channel
+        d_off += batch * m.out_channel if m.demodulate else 0
+    table = _style_table(entries, gpu)
+    styles = torch.empty(batch, s_off, device=gpu)
+    demod = torch.empty(max(d_off, 1), device=gpu)
+    st = _lib.stream_ptr(gpu)
+    lat = inp["lat"].to(gpu).contiguous()
+    _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), batch, 4, 512, None, None, table.data_ptr(), 4, max(e["cin"] for e in entries),
+                                         styles.data_ptr(), s_off, None, st), "affine")
+    _lib.check(lib.maua_demod_f32(table.data_ptr(), 4, max(e["cout"] for e in entries), styles.data_ptr(), s_off, demod.data_ptr(), batch, st),
+               "demod")
+    dm = lambda e: demod[e["d_off"]: e["d_off"] + batch * e["cout"]].view(batch, e["cout"])  # noqa: E731
+    g = {k: v.to(gpu) for k, v in inp.items()}
+
+    def chain(fold):
+        keep = {}
+
+        def bufs(name, shape):
+            keep[name] = torch.full(shape, float("nan"), device=gpu)
+            return keep[name]
+
+        a = A.run(g["x"], styles, entries[0]["s_off"], dm(entries[0]), g["nzA"], bufs, "A", post_off=entries[1]["s_off"] if fold else None)
+        assert A.posted == fold and A.last_path == ("fused" if fused_min_width <= w and lib.maua_upconv_blur_ok(c0, c1, h, w) else "pair")
+        img = torch.full((batch, 3, 2 * h, 2 * w), float("nan"), device=gpu)
+        fuse = dict(module=T, s_off=entries[2]["s_off"], skip=g["skip"], out=img, store=True)
+        bb = B.run(a, styles, entries[1]["s_off"], dm(entries[1]), g["nzB"], bufs, "B", rgb=fuse, prescaled=fold,
+                   post_off=entries[3]["s_off"] if fold else None)
+        assert fuse.get("done") and B.posted == fold
+        c = C.run(bb, styles, entries[3]["s_off"], dm(entries[3]), g["nzC"], bufs, "C", prescaled=fold)
+        assert not C.posted
+        torch.cuda.synchronize()
+        return a.clone(), bb.clone(), img.clone(), c.clone()
+
+    a0, b0, img0, out0 = chain(False)
+    a1, b1, img1, out1 = chain(True)
+    for tns in (a0, b0, img0, out0, a1, b1, img1, out1):
+        assert torch.isfinite(tns).all()  # (NaN-prefilled buffers: every element written)
+    sB = styles[:, entries[1]["s_off"]: entries[1]["s_off"] + c1][:, :, None, None]
+    sC = styles[:, entries[3]["s_off"]: entries[3]["s_off"] + c1][:, :, None, None]
+    # the stored maps of the folded chain are the un-folded ones times the consumer's styles
+    np.testing.assert_allclose(a1.cpu().numpy(), (a0 * sB).cpu().numpy(), atol=2e-6 * float((a0 * sB).abs().max()), rtol=1e-6)
+    scale = float(out0.abs().max())
+    assert float((b1 - b0 * sC).abs().max()) <= 2e-5 * float((b0 * sC).abs().max())
+    assert float((img1 - img0).abs().max()) <= 2e-5 * float(img0.abs().max())
+    assert float((out1 - out0).abs().max()) <= 2e-5 * scale, float((out1 - out0).abs().max()) / scale
+    # ... and the whole chain against the oracle
+    wa = so.styled_conv(sd, "A", inp["x"], inp["lat"][:, 0], inp["nzA"], True)
+    wb = so.styled_conv(sd, "B", wa, inp["lat"][:, 1], inp["nzB"], False)
+    wimg = so.to_rgb(sd, "T", wb, inp["lat"][:, 2], inp["skip"])
+    wc = so.styled_conv(sd, "C", wb, inp["lat"][:, 3], inp["nzC"], True)
+    np.testing.assert_allclose(img1.cpu().numpy(), wimg.numpy(), atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(out1.cpu().numpy(), wc.numpy(), atol=1e-3, rtol=1e-4)
+    print(f"[style fold {c0}->{c1}->{c2} @{h}x{w}] folded vs un-folded {float((out1 - out0).abs().max()) / scale:.2e} of the output scale; "
+          f"vs oracle {float((out1.cpu() - wc).abs().max()):.2e} abs at scale {scale:.1f}")
+
+
+def test_style_fold_abi_contract(gpu):
+    """s == NULL / post_s outside the kernels that implement them is MAUA_ENOSYS (include/maua_hip.h), never a silently un-scaled result."""
+    lib = _lib.load()
+    st = _lib.stream_ptr(gpu)
+    b, cin, cout, h, w = 1, 32, 32, 16, 32
+    x = torch.randn(b, cin, h, w, device=gpu)
+    y = torch.empty(b, cout, 2 * h + 1, 2 * w + 1, device=gpu)
+    wp = torch.randn(24 * cin * cout + 64, device=gpu)
+    ws = torch.empty(1 << 16, device=gpu)
+    for mode in (0, 1, 2, 3, 4, 7, 8):
+        rc = lib.maua_modconv3x3_f32(x.data_ptr(), wp.data_ptr(), None, cin, None, y.data_ptr(), b, cin, cout, h, w, mode, 1.0, 0, None, 0,
+                                     None, None, ws.data_ptr(), None, 0, st)
+        assert rc == -38, (mode, rc)
+    s = torch.randn(b, cin, device=gpu)
+    rgb_w, rgb_b, img = torch.randn(3, cout, device=gpu), torch.zeros(3, device=gpu), torch.empty(b, 3, h, w, device=gpu)
+    nw, bias = torch.zeros(1, device=gpu), torch.zeros(cout, device=gpu)
+    for mode in (0, 2, 3):  # post_s: the 2-D Winograd kernels only
+        rc = lib.maua_styledconv_torgb_f32(x.data_ptr(), wp.data_ptr(), s.data_ptr(), cin, None, y.data_ptr(), b, cin, cout, h, w, mode, 1.0,
+                                           None, 0, nw.data_ptr(), bias.data_ptr(), rgb_w.data_ptr(), s.data_ptr(), 1.0, rgb_b.data_ptr(), None,
+                                           None, img.data_ptr(), 1, None, None, 0, s.data_ptr(), st)
+        assert rc == -38, (mode, rc)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cin,cout,h,w,up", [(36, 32, 8, 32, True), (64, 64, 16, 32, True), (36, 64, 16, 32, False), (32, 32, 32, 64, False),
+                                             (28, 32, 8, 32, False)])
+def test_prescaled_instances_equal_the_style_multiplying_ones(gpu, cin, cout, h, w, up):
+    """maua_modconv3x3_f32 with s == NULL on x * s against the same call with (x, s): modconv_up2d_kernel<4 | 8, 0, true> (+ its edge
+    lines and exported column), modconv_w2d_kernel<4,2,2,true>, <2,2,3,true> and modconv_w2dw_kernel<true>."""
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+
+    r = np.random.default_rng(cin + cout + h + w)
+    m = ModulatedConv2d(cin, cout, 3, 512, upsample=up).to(gpu)
+    mode = m.conv_mode(h, w)
+    assert mode == (6 if up else 5)
+    lib = _lib.load()
+    b = 2
+    x = torch.from_numpy(r.standard_normal((b, cin, h, w)).astype(np.float32)).to(gpu)
+    s = torch.from_numpy((1 + 0.5 * r.standard_normal((b, cin))).astype(np.float32)).to(gpu)
+    d = torch.from_numpy((0.5 + r.random((b, cout))).astype(np.float32)).to(gpu)
+    shape = (b, cout, 2 * h + 1, 2 * w + 1) if up else (b, cout, h, w)
+    n_ws = lib.maua_modconv_ws_floats(b, cin, cout, h, w, mode)
+    ws = torch.empty(max(n_ws, 1), device=gpu)
+    a, p = torch.full(shape, float("nan"), device=gpu), torch.full(shape, float("nan"), device=gpu)
+    m.run(x, s, 0, d, a, ws)
+    name_a = _lib.last_modconv_instance()
+    m.run((x * s[:, :, None, None]).contiguous(), s, 0, d, p, ws, prescaled=True)
+    name_p = _lib.last_modconv_instance()
+    torch.cuda.synchronize()
+    assert name_a.endswith("false>") and name_p.endswith("true>") and name_a[:-6] == name_p[:-5], (name_a, name_p)
+    assert torch.isfinite(a).all() and torch.isfinite(p).all()
+    assert float((a - p).abs().max()) <= 2e-5 * float(a.abs().max())

@@ -142,7 +142,7 @@ static void blur_tail_case(int batch, int channels, int in_h, int in_w) {
     DevBuf<float> dx(x.size()), dk(16), dn(noise.size()), db(channels), dw(1), dy(want.size());
     dx.upload(x), dk.upload(taps), dn.upload(noise), db.upload(bias), dw.upload(std::vector<float>{noise_w});
     const int rc = maua_blur_noise_act_f32(dx.p, dk.p, dy.p, batch, channels, in_h, in_w, 4, 4, 1, 1, nullptr, dn.p, (int64_t)out_h * out_w, dw.p, db.p,
-                                           nullptr, 0, nullptr);
+                                           nullptr, 0, nullptr, 0, nullptr);
     HIP_OK(hipDeviceSynchronize());
     char name[128];
     snprintf(name, sizeof(name), "blur + noise + bias + act [%d,%d,%d,%d] rc=%d", batch, channels, in_h, in_w, rc);
@@ -177,9 +177,9 @@ static void upconv_blur_case(int batch, int cin, int cout, int h, int w) {
     const int rc_pack = maua_pack_weight_up2d_f32(dwt.p, dwq.p, cout, cin, nullptr);
     const int rc_conv = maua_modconv3x3_f32(dx.p, dwq.p, ds.p, cin, dd.p, draw.p, batch, cin, cout, h, w, 6, wscale, 0, nullptr, 0, nullptr, nullptr, dws.p, nullptr, 0, nullptr);
     const int rc_tail = maua_blur_noise_act_f32(draw.p, dk.p, dref.p, batch, cout, 2 * h + 1, 2 * w + 1, 4, 4, 1, 1, nullptr, dn.p, (int64_t)plane_out, dnw.p, db.p, nullptr, 0,
-                                  nullptr);
+                                  nullptr, 0, nullptr);
     const int rc_fused = maua_upconv_blur_f32(dx.p, dwq.p, ds.p, cin, dd.p, dgot.p, dseam.p, dk.p, dn.p, (int64_t)plane_out, dnw.p, db.p, nullptr, 0, batch, cin, cout, h, w,
-                               wscale, nullptr);
+                               wscale, nullptr, nullptr);
     HIP_OK(hipDeviceSynchronize());
     char name[128];
     const int rc = rc_pack | rc_conv | rc_tail | rc_fused;

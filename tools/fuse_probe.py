@@ -79,17 +79,17 @@ def main():
                 def pair():
                     m.run(x, s, 0, d, raw_map, ws)
                     _lib.check(lib.maua_blur_noise_act_f32(raw_map.data_ptr(), k4.data_ptr(), ref.data_ptr(), Bx, cout, 2 * h + 1, 2 * h + 1, 4, 4,
-                                                           1, 1, None, nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, sp), "tail")
+                                                           1, 1, None, nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, None, 0, sp), "tail")
 
                 def exact():
                     _lib.check(lib.maua_upconv_blur_f32(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), got.data_ptr(), seam.data_ptr(),
                                                         k4.data_ptr(), nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, Bx, cin, cout, h,
-                                                        h, float(m.scale), sp), "maua_upconv_blur_f32")
+                                                        h, float(m.scale), None, sp), "maua_upconv_blur_f32")
 
                 def exact_plain():  # (no noise map, no bias: what the tail's global loads cost)
                     _lib.check(lib.maua_upconv_blur_f32(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), got.data_ptr(), seam.data_ptr(),
                                                         k4.data_ptr(), None, 0, nw.data_ptr(), None, None, 0, Bx, cin, cout, h,
-                                                        h, float(m.scale), sp), "maua_upconv_blur_f32")
+                                                        h, float(m.scale), None, sp), "maua_upconv_blur_f32")
 
                 pair(), exact()
                 stream.synchronize()
@@ -150,7 +150,7 @@ def main():
                 got = torch.full((Bd, cout, 2 * h, 2 * h), float("nan"), device=dev)
                 _lib.check(lib.maua_blur_noise_act_f32(raw_map.data_ptr(), k.data_ptr(), ref.data_ptr(), Bd, cout, 2 * h + 1, 2 * h + 1, 4, 4, 1, 1,
                                                        None, nz.data_ptr() if tail else None, 4 * h * h, nw.data_ptr(), bias.data_ptr() if tail else None,
-                                                       None, 0, sp), "tail")
+                                                       None, 0, None, 0, sp), "tail")
                 _lib.check(fused(x.data_ptr(), wq.data_ptr(), s.data_ptr(), cin, d.data_ptr(), got.data_ptr(), k.data_ptr(),
                                  nz.data_ptr() if tail else None, 4 * h * h, nw.data_ptr(), bias.data_ptr() if tail else None, Bd, cin, cout, h, h,
                                  float(m.scale), 0, sp), "fused")
@@ -188,7 +188,7 @@ def main():
 
             def pair_tail():
                 _lib.check(lib.maua_blur_noise_act_f32(raw_map.data_ptr(), k4.data_ptr(), ref.data_ptr(), B, cout, 2 * h + 1, 2 * h + 1, 4, 4,
-                                                       1, 1, None, nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, sp),
+                                                       1, 1, None, nz.data_ptr(), 4 * h * h, nw.data_ptr(), bias.data_ptr(), None, 0, None, 0, sp),
                            "maua_blur_noise_act_f32")
 
             def run_fused(extra):

@@ -103,7 +103,7 @@ def main():
             nw = torch.full((1,), 0.1, device=dev)
             bias = torch.randn(C, device=dev)
             y2 = torch.empty(B, C, r, r, device=dev)
-            call2 = lambda: lib.maua_blur_noise_act_f32(x.data_ptr(), k.data_ptr(), y2.data_ptr(), B, C, r + 1, r + 1, 4, 4, 1, 1, None, nz.data_ptr(), 0, nw.data_ptr(), bias.data_ptr(), None, 0, sp)  # noqa: E731
+            call2 = lambda: lib.maua_blur_noise_act_f32(x.data_ptr(), k.data_ptr(), y2.data_ptr(), B, C, r + 1, r + 1, 4, 4, 1, 1, None, nz.data_ptr(), 0, nw.data_ptr(), bias.data_ptr(), None, 0, None, 0, sp)  # noqa: E731
             call2()
             e0.record(sp)
             for _ in range(args.iters):

@@ -112,7 +112,7 @@ int main() {
     for (int path : {1, 7, 9, 0}) {
         maua_tuning_set(0, path);
         char nm[64]; snprintf(nm, 64, "fir+noise+act tail path %d", path);
-        rep(nm, time_ms([&] { maua_blur_noise_act_f32(fx, fk, fy, 8, 32, r + 1, r + 1, 4, 4, 1, 1, nullptr, nzb, 0, nwb, bsb, st); }, st), fb);
+        rep(nm, time_ms([&] { maua_blur_noise_act_f32(fx, fk, fy, 8, 32, r + 1, r + 1, 4, 4, 1, 1, nullptr, nzb, 0, nwb, bsb, nullptr, 0, nullptr, 0, st); }, st), fb);
     }
     maua_tuning_set(0, 0);
     rep("fir vec4 (aligned ptrs)", time_ms([&] { maua_upfirdn2d_f32(fx, fk, fy, planes, r + 1, r + 1, 1, 4, 4, 1, 1, 1, 1, 1, 1, 1, 1, st); }, st), fb);
