@@ -1,12 +1,14 @@
+"""Round 6 (profiles/r06_store_hazard.md): the two wave-complete 2-D Winograd shapes whose 16-byte row stores lost their last dword when the
+compiler re-used the data registers right behind a buffer store with an SGPR soffset.  python tools/store_hazard_check.py [libmaua_hip.so [abi]]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from maua_stylegan2_amd import _lib
 from maua_stylegan2_amd.models.stylegan2 import StyledConv
 from oracle import stylegan2_oracle as so
 torch.set_grad_enabled(False)
 gpu = torch.device("cuda:0")
-if len(sys.argv) > 1:
+if len(sys.argv) > 1:  # (an alternative build of the library)
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 if len(sys.argv) > 2:
     _lib.ABI_VERSION = int(sys.argv[2])
