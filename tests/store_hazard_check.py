@@ -1,5 +1,5 @@
 """Round 6 (profiles/r06_store_hazard.md): the two wave-complete 2-D Winograd shapes whose 16-byte row stores lost their last dword when the
-compiler re-used the data registers right behind a buffer store with an SGPR soffset.  python tools/store_hazard_check.py [libmaua_hip.so [abi]]"""
+compiler re-used the data registers right behind a buffer store with an SGPR soffset.  python tests/store_hazard_check.py [libmaua_hip.so [abi]]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
