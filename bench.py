@@ -404,8 +404,10 @@ def time_region(wl, steps, bps, mode, use_dist, world):
     wl.sync()
     # as render() does before its frame loop: no generation-2 collection (45-90 ms on this heap: tools/gather_probe.py) on the thread that
     # launches the replays; the survivors of one collection are parked in the permanent generation
-    gc.collect()
-    gc.freeze()
+    from maua_stylegan2_amd.render import parked_heap
+
+    gc.collect()  # (generate() runs one right before render(), as the reference does: generate_audiovisual.py:194-205)
+    parked = parked_heap().__enter__()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -442,6 +444,7 @@ def time_region(wl, steps, bps, mode, use_dist, world):
     wl.sync()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    parked.__exit__(None, None, None)  # (the region parked the heap for itself: hand it back)
     if use_dist:
         dist.barrier()
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -839,19 +842,18 @@ def main():
                     ach = algo_flops * ratio / ms / 1e9
                     return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "launch_ms": ms,
-                            "achieved_definition": "flops the matrix cores executed (algorithmic direct-conv flops x executed_ratio) / launch duration",
+                            "achieved_definition": ("USEFUL flops the matrix cores executed (algorithmic direct-conv flops x executed_ratio of the "
+                                                    "layer's algorithm; redundant tiles of an overlapped tiling NOT counted) / launch duration"),
                             "executed_ratio": ratio, "algorithm": algo_text,
                             "algorithmic": {"flops": algo_flops, "achieved": algo_flops / ms / 1e9,
                                             "frac": algo_flops / ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
                                             "note": "direct-conv flops as SURVEY 8d / BASELINE.md 3.1 count them; can exceed the peak"}}
 
                 def executed(row_name):
-                    """(executed / algorithmic matrix flops, description) of a breakdown row."""
-                    ratio, text = EXECUTED.get(mode_of(row_name), (1.0, "direct form"))
-                    if row_name in FUSED_OVERLAP:
-                        ratio *= FUSED_OVERLAP[row_name]
-                        text += f"; x {FUSED_OVERLAP[row_name]:.3f} for the overlapped tiling of the fused blur (60 of 64 columns kept per tile, one extra tile row)"
-                    return ratio, text
+                    """(USEFUL executed / algorithmic matrix flops, description) of a breakdown row: the multiplies the layer's algorithm needs.  The
+                    fused up-sampling layers launch FUSED_OVERLAP x as many tiles (overlapped tiling: 60 of 64 columns kept, one extra tile row);
+                    those redundant products keep the matrix cores busy but are not throughput — they are reported beside, never inside, `frac`."""
+                    return EXECUTED.get(mode_of(row_name), (1.0, "direct form"))
 
                 conv_rows = [r for r in rows if r[1].startswith("modconv")]
                 # (a) the single launch with the largest device time
@@ -873,10 +875,11 @@ def main():
                         result["roofline"]["traffic"] = rec["read_bytes"] + rec["write_bytes"]
                         result["roofline"]["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {table_path}"
                     if dom[0] in FUSED_OVERLAP:
-                        # the fused up-sampling layer: `frac` counts what the matrix cores executed INCLUDING the redundant tiles of its
-                        # overlapped tiling (PMC-verifiable: SQ_INSTS_VALU_MFMA_MOPS_F32); the same launch without them:
+                        # the fused up-sampling layer: `frac` = USEFUL products only; what the matrix cores executed INCLUDING the redundant
+                        # tiles of its overlapped tiling (PMC-verifiable: SQ_INSTS_VALU_MFMA_MOPS_F32) is a utilisation, reported beside it
                         result["roofline"]["redundant_tile_factor"] = FUSED_OVERLAP[dom[0]]
-                        result["roofline"]["frac_without_redundant_tiles"] = result["roofline"]["frac"] / FUSED_OVERLAP[dom[0]]
+                        result["roofline"]["matrix_core_utilisation_including_redundant_tiles"] = result["roofline"]["frac"] * FUSED_OVERLAP[dom[0]]
+                        result["roofline"]["frac_without_redundant_tiles"] = result["roofline"]["frac"]  # (the name rounds 4-5 used for this figure)
                         # input map + activated output map + noise map + packed weight read / written once
                         result["roofline"]["algorithmic_bytes"] = dom[4] + B * size * size * 4 + 21 * 64 * 32 * 4
                         result["roofline"]["hbm_frac_of_launch"] = result["roofline"]["algorithmic_bytes"] / (dom[2] * 1e-3) / (HBM_PEAK_GBS * 1e9)
@@ -915,8 +918,12 @@ def main():
                     exec_per_batch = sum(v["exec"] for v in by_inst.values())
                     result["whole_forward_executed_tflops"] = exec_per_batch / (result["ms_per_batch"] * 1e-3) / 1e12
                     result["whole_forward_executed_frac"] = result["whole_forward_executed_tflops"] / MFMA_F32_PEAK_TFLOPS
-                    result["whole_forward_executed_note"] = ("sum over the conv launches of (direct-conv flops x executed ratio of their algorithm) per batch / "
-                                                             "ms_per_batch of the timed region / 157.3 TFLOP/s")
+                    result["whole_forward_executed_note"] = ("sum over the conv launches of (direct-conv flops x executed ratio of their algorithm; the "
+                                                             "redundant tiles of the fused up-sampling layers not counted) per batch / ms_per_batch of the "
+                                                             "timed region / 157.3 TFLOP/s")
+                    redundant = sum(r[3] * executed(r[0])[0] * (FUSED_OVERLAP[r[0]] - 1.0) for r in conv_rows if r[0] in FUSED_OVERLAP)
+                    result["whole_forward_matrix_core_utilisation"] = ((exec_per_batch + redundant) / (result["ms_per_batch"] * 1e-3) / 1e12
+                                                                       / MFMA_F32_PEAK_TFLOPS)
                     result["conv_kernel_instances"] = {
                         k: {"ms_per_batch": v["ms"], "share_of_serial_forward": v["ms"] / total_ms, "executed_tflops": v["exec"] / v["ms"] / 1e9,
                             "executed_frac": v["exec"] / v["ms"] / 1e9 / MFMA_F32_PEAK_TFLOPS, "algorithmic_tflops": v["algo"] / v["ms"] / 1e9,

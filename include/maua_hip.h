@@ -277,7 +277,10 @@ int maua_crop_resize_u8(const uint8_t* in, uint8_t* out, int batch, int in_h, in
 /* ------------------------------------------------------------------------------------------------ audio / temporal
  * Circular Gaussian FIR along time (audioreactive/signal.py:319-368): x [T, F] -> y [T, F], taps[2*radius+1]
  * already normalised / causal-weighted by the host; circular index when radius <= T, else the reference's
- * single-wrap-then-zero padding (:350-355). */
+ * single-wrap-then-zero padding (:350-355).  The taps are staged in LDS with 96 floats of zero padding: radius <=
+ * MAUA_TEMPORAL_FIR_MAX_RADIUS (a Gaussian of sigma ~2000 frames), MAUA_EINVAL above.  A non-finite sample stays inside the filter's
+ * support, as with the reference's conv1d. */
+#define MAUA_TEMPORAL_FIR_MAX_RADIUS 8143
 int maua_temporal_fir_f32(const float* x, const float* taps, float* y, int n_frames, int64_t features, int radius,
                           void* stream);
 

@@ -98,7 +98,10 @@ def generate_latents(n_latents, ckpt, G_res, noconst=False, latent_dim=512, n_ml
     mapping = th.nn.Sequential(PixelNorm(), *[EqualLinear(latent_dim, latent_dim, lr_mul=0.01, activation="fused_lrelu")
                                               for _ in range(n_mlp)])
     if ckpt is not None:
-        weights = th.load(ckpt, map_location="cpu")["g_ema"]
+        try:  # zip-format checkpoints are mapped: only the pages of the eight style.* matrices are ever read
+            weights = th.load(ckpt, map_location="cpu", mmap=True)["g_ema"]
+        except (RuntimeError, ValueError, TypeError):
+            weights = th.load(ckpt, map_location="cpu")["g_ema"]
         mapping.load_state_dict({k[len("style."):]: v for k, v in weights.items() if k.startswith("style.")})
         del weights
     mapping = mapping.cuda()

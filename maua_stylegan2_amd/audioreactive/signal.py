@@ -185,6 +185,9 @@ def resample(x, num):
     return out
 
 
+TEMPORAL_FIR_MAX_RADIUS = 8143  # MAUA_TEMPORAL_FIR_MAX_RADIUS (include/maua_hip.h)
+
+
 def gaussian_filter(x, sigma, causal=None):
     """Circular Gaussian smoothing along time (dim 0), HIP FIR kernel; same tap construction as reference :335-343."""
     lib = _lib.load()
@@ -206,6 +209,9 @@ def gaussian_filter(x, sigma, causal=None):
               f"\t Filter size has been lowered to ({radius}). You might want to consider lowering sigma ({sigma}).")
     feats = xd.numel() // max(n_frames, 1)
     y = th.empty_like(xd)
+    if radius > TEMPORAL_FIR_MAX_RADIUS:  # (include/maua_hip.h: the taps live in LDS)
+        raise RuntimeError(f"gaussian_filter: radius {radius} frames (sigma {sigma}) exceeds the device filter's {TEMPORAL_FIR_MAX_RADIUS} taps "
+                           "each side — a Gaussian that wide is a mean over the clip; lower sigma")
     with th.cuda.device(xd.device):
         _lib.check(lib.maua_temporal_fir_f32(xd.data_ptr(), taps.data_ptr(), y.data_ptr(), n_frames, feats, radius,
                                              _lib.stream_ptr(xd.device)), "maua_temporal_fir_f32")

@@ -891,9 +891,14 @@ double fuse_end_time(const std::vector<float>& cost, int cus_per_xcd) {
 }
 FusePlan fuse_plan(int batch, int cout, int h, int w) {
     static std::mutex lock;
-    static std::map<std::array<int, 4>, FusePlan> cache;
-    const std::array<int, 4> key{batch, cout, h, w};
+    static std::map<std::array<int, 5>, FusePlan> cache;
+    static int cus_of[64] = {};  // per device: the plan models THIS device's CUs (a second, different GPU must not inherit the first one's plan)
     std::lock_guard<std::mutex> guard(lock);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cus_of[dev] && (hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_of[dev] < 8)) cus_of[dev] = 256;
+    cus = cus_of[dev];
+    const std::array<int, 5> key{batch, cout, h, w, cus};
     FusePlan f{};
     f.tiles_x = (2 * w + 59) / 60;  // a tile keeps 60 of its 64 raw columns
     if (FUSE_ABL(16)) f.tiles_x = w / 32;
@@ -906,11 +911,6 @@ FusePlan fuse_plan(int batch, int cout, int h, int w) {
     }
 #endif
     if (auto it = cache.find(key); it != cache.end()) return it->second;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-    }
     const int per_seg = f.tiles_x * (cout / U2_BM);   // workgroups of one (image, segment): consecutive in the list
     double best = 1e30;
     std::vector<float> cost;

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void temporal_fir_kernel(const float* __restri
     float w0[16], w1[16], w2[16];  // taps j0 - 32 .. j0 - 17, j0 - 16 .. j0 - 1, j0 .. j0 + 15
 #pragma unroll
     for (int i = 0; i < 16; ++i) w0[i] = 0.f, w1[i] = 0.f;
+    bool dirty = false;
     // y[t] = sum_k taps[k] * xpad[t + k], xpad[i] = x[(i - radius) mod T] inside one wrap, 0 beyond (radius > T branch)
     const int n_rows = ntaps + FIR_TT - 1;
     for (int j0 = 0; j0 < n_rows; j0 += 16) {
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void temporal_fir_kernel(const float* __restri
             w = inside ? w : 0;
             const float got = x[(int64_t)w * F + f];
             v[jj] = inside ? got : 0.f;
+            dirty |= (__float_as_uint(v[jj]) & 0x7f800000u) == 0x7f800000u;  // inf / NaN: see the exact pass below
         }
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj)
@@ -72,6 +74,22 @@ __global__ __launch_bounds__(256) void temporal_fir_kernel(const float* __restri
             }
 #pragma unroll
         for (int i = 0; i < 16; ++i) w0[i] = w1[i], w1[i] = w2[i];
+    }
+    if (dirty) {
+        // A non-finite sample met zero-PADDED taps above (every row of the walk multiplies all 32 outputs, the taps outside the filter's
+        // support being zeros: 0 * inf = NaN up to 45 frames outside the support).  The reference's conv1d (audioreactive/signal.py:359)
+        // confines it to the support: such a thread — there are none in a sane render — recomputes its outputs tap by tap.
+        for (int u = 0; u < FIR_TT; ++u) {
+            float sum = 0.f;
+            for (int k = 0; k < ntaps; ++k) {
+                const int i = t0 + u + k - radius;
+                const bool inside = i >= -T && i < 2 * T;
+                const int w = i < 0 ? i + T : (i >= T ? i - T : i);
+                sum = fmaf(tp[FIR_PAD_LO + k], inside ? x[(int64_t)w * F + f] : 0.f, sum);
+            }
+            if (t0 + u < T) y[(int64_t)(t0 + u) * F + f] = sum;
+        }
+        return;
     }
 #pragma unroll
     for (int u = 0; u < FIR_TT; ++u)
@@ -618,7 +636,7 @@ extern "C" int maua_temporal_fir_f32(const float* x, const float* taps, float* y
                                      int radius, void* stream) {
     if (!x || !taps || !y || n_frames <= 0 || features <= 0 || radius < 0) return MAUA_EINVAL;
     const size_t lds = (size_t)(FIR_PAD_LO + 2 * radius + 1 + FIR_PAD_HI) * sizeof(float);
-    if (lds > 64 * 1024) return MAUA_EINVAL;
+    if (lds > 64 * 1024) return MAUA_EINVAL;  // radius > MAUA_TEMPORAL_FIR_MAX_RADIUS (include/maua_hip.h)
     const int64_t bx = ceil_div64(features, 256);
     if (bx > 0x7fffffff) return MAUA_EINVAL;
     hipLaunchKernelGGL(temporal_fir_kernel, dim3((unsigned)bx, ceil_div(n_frames, FIR_TT)), dim3(256), lds,

@@ -687,7 +687,8 @@ class Generator(nn.Module):
                 raise RuntimeError(f"checkpoint {checkpoint!r} lacks {sorted(missing)[:5]} ... ({len(missing)} tensors): the generator "
                                    "was built without initial values and cannot be completed from it")
             self.load_state_dict(state["g_ema"], strict=True)
-        if size != output_size or base_res_factor != 1:  # reference :461-470 (resizes only the noise buffers)
+        self._random_noise_buffers = size != output_size or base_res_factor != 1
+        if self._random_noise_buffers:  # reference :461-470 (resizes only the noise buffers)
             for layer_idx in range(self.num_layers):
                 res = (layer_idx + 5) // 2
                 shape = [1, 1, int(base_res_factor * 2 ** res * (2 if output_size == 1080 else 1)),

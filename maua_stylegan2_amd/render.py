@@ -209,6 +209,37 @@ def crop_resize_for_delivery(u8, out_size, scratch):
 
 
 _LANE_STREAMS = {}
+class parked_heap:
+    """``with parked_heap():`` — no generation-2 collection on the thread that launches the graph replays: everything alive at entry moves
+    to the collector's permanent generation (gc.freeze) and comes back at exit.  Re-entrant and shared between threads: the freeze is
+    process-global, so the FIRST frame loop in parks the heap and the LAST one out thaws it (an unconditional unfreeze at the end of one
+    render thawed the heap under a second render's loop), and a heap the embedding application froze itself (a pre-fork server:
+    gc.get_freeze_count() > 0 at entry of the first loop) is left frozen."""
+
+    _lock = threading.Lock()
+    _users = 0
+    _ours = False
+
+    def __enter__(self):
+        cls = parked_heap
+        with cls._lock:
+            if cls._users == 0:
+                cls._ours = gc.get_freeze_count() == 0
+                if cls._ours:
+                    gc.freeze()
+            cls._users += 1
+        return self
+
+    def __exit__(self, *exc):
+        cls = parked_heap
+        with cls._lock:
+            cls._users -= 1
+            if cls._users == 0 and cls._ours:
+                gc.unfreeze()
+                cls._ours = False
+        return False
+
+
 _RING_LOCKS = {}  # device index -> lock held by the single-GPU render loop while it uses that device's rings (two renders in two threads)
 _PINNED_RING = {}  # device index -> pinned staging slots of the single-GPU render loop (reallocated when the frame shape changes)
 _DEVICE_RING = {}  # device index -> their device-side twins (a batch leaves its lane's frame buffer before it crosses PCIe)
@@ -444,7 +475,8 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
     # and as a 9 % hole in a 150-batch gathered bench region).  Park everything that is alive now in the permanent generation for the
     # duration of the loop: what the loop allocates is then all the collector ever walks.  (No full gc.collect() here: it would cost the same
     # 45-90 ms up front, as much as it saves on a 900-frame job; generate() has just run one, as the reference does.)
-    gc.freeze()
+    parked = parked_heap()
+    parked.__enter__()
     try:
         if not sharding.grouped():
             # pinned staging ring: the D2H of batch k overlaps the replays of the next batches; the sink thread writes a slot and
@@ -562,7 +594,7 @@ def render_shard(generator, latents, noise, offset, duration, batch_size, out_si
         if worker is not None:
             worker.close()
     finally:  # the encoder process / output file must not outlive a failed render
-        gc.unfreeze()
+        parked.__exit__(None, None, None)
         if worker is not None:
             try:
                 worker.close()  # (also: every ring slot has been written before the rings are handed to the next render)

@@ -335,6 +335,17 @@ class FrameStream:
                 release()
 
 
+def _tracker_pid():
+    """pid of the multiprocessing resource tracker this process reports to (0 if it cannot be told)."""
+    try:
+        from multiprocessing import resource_tracker
+
+        resource_tracker.ensure_running()
+        return int(getattr(resource_tracker._resource_tracker, "_pid", 0) or 0)
+    except Exception:  # noqa: BLE001
+        return 0
+
+
 class HostFrameStore:
     """Alternative frame transport for a multi-GPU job on ONE host (``MAUA_FRAME_TRANSPORT=host`` / ``render(..., transport="host")``):
     every rank copies its batch-rounds to the host over ITS OWN PCIe link, into a POSIX shared-memory segment it owns (pinned in
@@ -366,22 +377,46 @@ class HostFrameStore:
         self.token = str(token)
         self.round_bytes = self.batch * int(np.prod(self.shape))
         size = self.HEADER + max(self.rounds, 1) * self.round_bytes
-        # tmpfs reserves nothing at ftruncate: a segment larger than what /dev/shm can still hold dies with SIGBUS on first touch,
-        # not with a Python error (64 MB is the container default) — check first
-        try:
-            import os
+        # tmpfs reserves nothing at ftruncate: segments larger than what /dev/shm can still hold die with SIGBUS on first touch, not
+        # with a Python error (64 MB is the container default).  Every rank of the node sees the same free space, so the check is on
+        # the node's SUM (all ranks of a job have segments of one size), the pages are then really reserved (posix_fallocate), and the
+        # outcome is collective: one rank that cannot have its segment makes EVERY rank raise — none is left waiting in the barrier below.
+        import os
 
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", self.world)) if grouped() else 1
+        problem = None
+        try:
             vfs = os.statvfs("/dev/shm")
             free_bytes = vfs.f_bavail * vfs.f_frsize
         except OSError:
             free_bytes = None
-        if free_bytes is not None and size > free_bytes:
-            raise RuntimeError(f"MAUA_FRAME_TRANSPORT=host: rank {self.rank} needs a {size / 2**20:.0f} MiB shared-memory segment for its "
-                               f"{max(self.rounds, 1) * self.batch} frames but /dev/shm has {free_bytes / 2**20:.0f} MiB free — enlarge "
-                               f"/dev/shm (docker --shm-size) or use the default gather transport")
-        self._mine = shared_memory.SharedMemory(name=self._name(self.rank), create=True, size=size)
+        if free_bytes is not None and local * size > free_bytes:
+            problem = (f"MAUA_FRAME_TRANSPORT=host: the {local} rank(s) of this node need {local} x {size / 2**20:.0f} MiB of shared memory for "
+                       f"their frames ({max(self.rounds, 1) * self.batch} per rank) but /dev/shm has {free_bytes / 2**20:.0f} MiB free — enlarge "
+                       f"/dev/shm (docker --shm-size) or use the default gather transport")
+        self._mine = None
+        if problem is None:
+            try:
+                self._mine = shared_memory.SharedMemory(name=self._name(self.rank), create=True, size=size)
+                fd = getattr(self._mine, "_fd", -1)
+                if fd is not None and fd >= 0:
+                    os.posix_fallocate(fd, 0, size)  # reserve the pages now: ENOSPC here instead of SIGBUS in the frame loop
+            except OSError as exc:
+                problem = f"MAUA_FRAME_TRANSPORT=host: rank {self.rank} could not reserve its {size / 2**20:.0f} MiB shared-memory segment: {exc}"
+        if grouped():
+            flag = th.tensor([0 if problem is None else 1], dtype=th.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and problem is None:
+                problem = "MAUA_FRAME_TRANSPORT=host: another rank could not reserve its shared-memory segment (see its error)"
+        if problem is not None:
+            if self._mine is not None:
+                self._mine.close()
+                self._mine.unlink()
+                self._mine = None
+            raise RuntimeError(problem)
         self._header = np.ndarray((2,), dtype=np.int64, buffer=self._mine.buf)
         self._header[:] = 0
+        self._header[1] = _tracker_pid()  # (the owner's resource tracker: see _peer)
         self._frames = th.from_numpy(np.ndarray((max(self.rounds, 1), self.batch) + self.shape, dtype=np.uint8, buffer=self._mine.buf,
                                                 offset=self.HEADER))
         self._on_gpu = th.device(device).type == "cuda"
@@ -462,13 +497,18 @@ class HostFrameStore:
         if p not in self._peers:
             np = self._np
             shm = self._shm_mod.SharedMemory(name=self._name(p))
-            try:  # Python < 3.13 registers ATTACHED segments with this process's resource tracker as well: the owner unlinks them,
-                from multiprocessing import resource_tracker  # a second unlink at exit only prints warnings
-
-                resource_tracker.unregister(shm._name, "shared_memory")
-            except Exception:  # noqa: BLE001 - bookkeeping only
-                pass
             header = np.ndarray((2,), dtype=np.int64, buffer=shm.buf)
+            # Python < 3.13 registers ATTACHED segments with this process's resource tracker as well; the owner unlinks them, so this
+            # process's tracker must forget the name — but only if it is a tracker of its OWN (torchrun: one per rank).  Ranks started with
+            # multiprocessing share ONE tracker with the owner: un-registering there removes the owner's registration (a KeyError
+            # traceback at its unlink, and no clean-up if the owner crashes).  The owner left its tracker's pid in the header.
+            if int(header[1]) != _tracker_pid():
+                try:
+                    from multiprocessing import resource_tracker
+
+                    resource_tracker.unregister(shm._name, "shared_memory")
+                except Exception:  # noqa: BLE001 - bookkeeping only
+                    pass
             frames = th.from_numpy(np.ndarray((max(self.rounds, 1), self.batch) + self.shape, dtype=np.uint8, buffer=shm.buf,
                                               offset=self.HEADER))
             self._peers[p] = (shm, header, frames)

@@ -451,3 +451,33 @@ def test_device_resize_formula_is_pils_bilinear(shape, box):
     frame = np.random.default_rng(sum(shape)).integers(0, 256, shape, dtype=np.uint8)
     want = np.array(PIL.Image.fromarray(np.ascontiguousarray(frame[y0:y0 + ch, x0:x0 + cw])).resize((ow, oh), PIL.Image.BILINEAR))
     assert np.array_equal(pil_bilinear_upscale_restated(frame, x0, y0, cw, ch, ow, oh), want)
+
+
+def test_parked_heap_is_refcounted_and_respects_a_foreign_freeze():
+    """render_shard / bench.time_region park the heap (gc.freeze) for their frame loop.  The freeze is process-global: the last loop out
+    thaws it, not the first (two renders in two threads), and a heap the embedding application froze itself stays frozen."""
+    import gc
+
+    from maua_stylegan2_amd.render import parked_heap
+
+    assert gc.get_freeze_count() == 0
+    with parked_heap():
+        assert gc.get_freeze_count() > 0
+        with parked_heap():
+            pass
+        assert gc.get_freeze_count() > 0  # the inner loop's exit must not thaw the heap under the outer one
+    assert gc.get_freeze_count() == 0
+    gc.freeze()  # the application's own freeze (e.g. a pre-fork server)
+    try:
+        n = gc.get_freeze_count()
+        with parked_heap():
+            assert gc.get_freeze_count() >= n
+        assert gc.get_freeze_count() > 0  # left as it was found
+    finally:
+        gc.unfreeze()
+    try:
+        with parked_heap():
+            raise RuntimeError("loop died")
+    except RuntimeError:
+        pass
+    assert gc.get_freeze_count() == 0

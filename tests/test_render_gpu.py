@@ -1146,3 +1146,50 @@ def test_generate_1920_wide_output_is_delivered_as_1080p(gpu, tmp_path, monkeypa
     want = np.array(PIL.Image.fromarray(np.ascontiguousarray(wide[:, 112:-112, :])).resize((1920, 1080), PIL.Image.BILINEAR))
     diff = np.abs(frames[i].astype(np.int16) - want.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (int(diff.max()), float((diff > 0).mean()))
+
+
+def test_generator_is_kept_across_generate_calls_and_follows_the_checkpoint_file(gpu, tmp_path, monkeypatch):
+    """Round 6: a process that renders job after job from one checkpoint (reference generate_audiovisual.py:37-56 reloads per call) keeps
+    the generator — packed weights, captured lanes — as long as the FILE is the same (path, mtime, size) and the architecture flags are;
+    the frames of the second job equal the first's bit for bit; a rewritten checkpoint is loaded again; MAUA_GENERATOR_CACHE=0 and a
+    process group always load.  The module is built on the device (no CPU copy first)."""
+    import scipy.io.wavfile
+
+    from maua_stylegan2_amd import generate_audiovisual as gav
+    from maua_stylegan2_amd import render
+    from maua_stylegan2_amd.audioreactive.examples import default as plugin
+
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(render.shutil, "which", lambda name: None)
+    monkeypatch.delenv("MAUA_GENERATOR_CACHE", raising=False)
+    gav._GENERATOR_CACHE.clear()
+    sr = 22050
+    scipy.io.wavfile.write("track.wav", sr, (seeding.synthetic_audio(1.0, sr) * 32767).astype(np.int16))
+    np.save("lat.npy", seeding.seeded_latents(12, 16, seed=3).numpy())
+    torch.save({"g_ema": seeding.seeded_state_dict(512, seed=1)}, "a.pt")
+    loads = []
+    real_load = gav.load_generator
+    monkeypatch.setattr(gav, "load_generator", lambda **kw: loads.append(kw["ckpt"]) or real_load(**kw))
+
+    def job(name, ckpt="a.pt"):
+        torch.manual_seed(11), np.random.seed(11)  # (the plugin's noise draws)
+        out = gav.generate(ckpt=ckpt, audio_file="track.wav", initialize=plugin.initialize, get_latents=plugin.get_latents,
+                           get_noise=plugin.get_noise, latent_file="lat.npy", G_res=512, out_size=512, fps=12, batch=4,
+                           output_file=str(tmp_path / name))
+        return np.fromfile(out + ".rgb24", dtype=np.uint8)
+
+    first = job("1.mp4")
+    g1 = gav._GENERATOR_CACHE["entry"][1]
+    assert all(p.is_cuda for p in g1.parameters()) and len(loads) == 1
+    lanes1 = dict(g1._graph_lanes)
+    second = job("2.mp4")
+    assert len(loads) == 1 and gav._GENERATOR_CACHE["entry"][1] is g1
+    assert all(g1._graph_lanes[k] is v for k, v in lanes1.items())  # the captured lanes served the second job as they were
+    assert np.array_equal(first, second)
+    torch.save({"g_ema": seeding.seeded_state_dict(512, seed=2)}, "a.pt")  # the same path, another checkpoint
+    third = job("3.mp4")
+    assert len(loads) == 2 and gav._GENERATOR_CACHE["entry"][1] is not g1 and not np.array_equal(first, third)
+    monkeypatch.setenv("MAUA_GENERATOR_CACHE", "0")
+    fourth = job("4.mp4")
+    assert len(loads) == 3 and np.array_equal(third, fourth)
+    gav._GENERATOR_CACHE.clear()

@@ -63,6 +63,29 @@ def test_gaussian_filter_shapes_vs_oracle(gpu, shape, sigma, causal):
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5)
 
 
+def test_gaussian_filter_confines_a_non_finite_sample_to_its_support(gpu):
+    """reference audioreactive/signal.py:357-359 (circular pad + conv1d): an inf / NaN sample reaches the outputs within `radius` frames of
+    it and no other.  The device kernel walks source rows against zero-PADDED taps (0 * inf = NaN up to 45 frames outside the support):
+    threads that meet a non-finite sample recompute tap by tap.  Also: the documented radius limit raises instead of a bare error code."""
+    from maua_stylegan2_amd.audioreactive import signal as sig
+
+    T, F, sigma = 400, 300, 3.0
+    radius = int(sigma * 4)
+    x = torch.from_numpy(seeding.seeded_array(5, "gfinf", (T, F)))
+    x[200, 7] = float("inf")
+    x[57, 280] = float("nan")
+    got = sig.gaussian_filter(x.to(gpu), sigma).cpu()
+    want = signal_oracle.gaussian_filter(x, sigma)
+    bad = ~torch.isfinite(got)
+    assert torch.equal(bad, ~torch.isfinite(want))
+    rows7 = torch.nonzero(bad[:, 7]).flatten()
+    assert rows7.min() == 200 - radius and rows7.max() == 200 + radius and bad[:, 7].sum() == 2 * radius + 1
+    assert bad[:, 280].sum() == 2 * radius + 1 and bad.sum() == 2 * (2 * radius + 1)
+    np.testing.assert_allclose(got[~bad].numpy(), want[~bad].numpy(), atol=2e-5)
+    with pytest.raises(RuntimeError, match="exceeds the device filter"):
+        sig.gaussian_filter(torch.zeros(4000, 2, device=gpu), 2500.0)
+
+
 def test_stft_mel_chroma_vs_oracle(gpu):
     from maua_stylegan2_amd.audioreactive import signal as sig
 
