@@ -12,7 +12,7 @@ O=$R/gpurun_out/asan
 mkdir -p "$O"
 cd "$R"
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
-export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:detect_odr_violation=0:log_path=$O/asan_report
+export ASAN_OPTIONS=detect_leaks=0:allocator_may_return_null=1:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0:detect_odr_violation=0:log_path=$O/asan_report
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$O/ubsan_report
 TESTS="tests/test_ops_gpu.py tests/test_property_gpu.py"
 {
