@@ -251,9 +251,12 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         float gain = p.wscale;
         if (p.d) gain *= p.d[(size_t)b0 * p.Cout + m0 + i];
         Eg[i] = gain;
-        if constexpr (FUSE == 2) Eg[U2_BM + i] = p.post_s ? p.post_s[(size_t)b0 * p.s_stride + m0 + i] : 1.f;  // scale of the stored map
+        if constexpr (FUSE == 2) {
+            Eg[U2_BM + i] = p.post_s ? p.post_s[(size_t)b0 * p.s_stride + m0 + i] : 1.f;  // scale of the stored map
+            Eg[2 * U2_BM + i] = p.bias ? p.bias[m0 + i] * 1.41421356237309515f : 0.f;       // bias * sqrt2, once per workgroup (round 6: it was
+        }                                                                                   // two global loads per channel pair and TILE)
     }
-    float* SV = Eg + 2 * U2_BM;
+    float* SV = Eg + 3 * U2_BM;
     if constexpr (FUSE == 2) {
         // h-rows above the segment's first tile: zero — exact at the top of the image (raw rows -3 .. -1 are padding); below a segment
         // boundary the three output rows that would need them are left to up2d_seam_kernel
@@ -555,7 +558,8 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 for (int c = 0; c < 4; ++c) S[3 + r][c] = Hh[r][c];
             // vertical pass + tail + stores
             const f32x2 gain2 = f32x2{Eg[ol] * act_gain, Eg[ol + 1] * act_gain};
-            const f32x2 bias2 = pk->bias ? f32x2{pk->bias[m0 + ol] * act_gain, pk->bias[m0 + ol + 1] * act_gain} : f32x2{0.f, 0.f};
+            const f32x2 bias2 = FUSE == 2 ? f32x2{Eg[2 * U2_BM + ol], Eg[2 * U2_BM + ol + 1]}
+                                          : (pk->bias ? f32x2{pk->bias[m0 + ol] * act_gain, pk->bias[m0 + ol + 1] * act_gain} : f32x2{0.f, 0.f});
             const f32x2 post2 = FUSE == 2 ? f32x2{Eg[U2_BM + ol], Eg[U2_BM + ol + 1]} : f32x2{1.f, 1.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -957,7 +961,7 @@ extern "C" int maua_upconv_blur_f32(const float* x, const float* wq, const float
     a.seg_tiles = f.seg_tiles, a.tiles_total_y = f.tiles_total_y;
     a.yb = y, a.hbuf = ws, a.k4 = k4, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.noise_batch_stride = noise_batch_stride;
     a.src = src, a.noise_slot = noise_slot, a.post_s = post_s;
-    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 2 * U2_BM + 4 * 3 * 64 * 8);
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 3 * U2_BM + 4 * 3 * 64 * 8);
     static_assert((size_t)2 * u2_a_floats(8) + (size_t)2 * u2_pbuf(8) >= 2 * 4 * 3 * 64 * 8, "the exchange region lives in the operand buffers");
     if (lds_bytes > 80 * 1024) return MAUA_ENOSYS;  // two workgroups per CU
     const int64_t blocks = (int64_t)batch * f.n_seg * f.tiles_x * a.m_tiles;
@@ -1000,7 +1004,7 @@ extern "C" int maua_exp_upconv_blur_fused_f32(const float* x, const float* wq, c
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
     a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
     a.yb = yb, a.k4 = k4, a.noise = noise, a.noise_w = noise_w, a.bias = bias, a.noise_batch_stride = noise_batch_stride;
-    const size_t k_loop = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 2 * U2_BM);
+    const size_t k_loop = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 3 * U2_BM);
     const size_t lds_bytes = k_loop > 49152 + 4096 ? k_loop : 49152 + 4096;
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
     a.real_blocks = (int)blocks;
@@ -1026,7 +1030,7 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     const int cc = u2_cc(cin);
     a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 2 * U2_BM);
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 3 * U2_BM);
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;
     static unsigned long long lds_ok[4] = {0, 0, 0, 0};  // per instance: devices on which the attribute has been set (common.h)
     if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<4, 0, false>), &lds_ok[0], 160 * 1024)) return rc;

@@ -54,5 +54,27 @@ for cin, cout, h, w, up, b in cases:
     mode = m.conv.conv_mode(h, w)
     print(f"cin {cin:4d} cout {cout:4d} {h}x{w} up={int(up)} batch {b} mode {mode}: {'ok' if ok else 'MISMATCH'}")
     bad += not ok
+# round 6: the whole generator with the style fold (every producer stores its map pre-multiplied, the consumers run the PRE instances; the
+# 16-byte stores with SGPR channel offsets carry their own wait states, profiles/r06_store_hazard.md): 20 forwards of 4 frames, bit-identical
+from maua_stylegan2_amd import seeding  # noqa: E402
+from maua_stylegan2_amd.models.stylegan2 import Generator  # noqa: E402
+
+for size in (1024, 256):
+    g = Generator(size, 512, 8, channel_multiplier=2, constant_input=True)
+    g.load_state_dict(seeding.seeded_state_dict(size, seed=0))
+    g = g.to(dev).eval()
+    lat = seeding.seeded_latents(4, g.n_latent, seed=1).to(dev)
+    torch.empty = poisoned_empty
+    ref, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+    ok = bool(torch.isfinite(ref).all()) and any(c.posted for c in g.convs)
+    for _ in range(20):
+        y, _ = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True)
+        if not torch.equal(y, ref):
+            ok = False
+            break
+    torch.empty = _empty
+    print(f"generator {size}^2 batch 4, style fold on ({sum(c.posted for c in g.convs)} folded maps): {'ok' if ok else 'MISMATCH'}")
+    bad += not ok
+    del g
 print("soak:", "all deterministic" if not bad else f"{bad} cases nondeterministic")
 sys.exit(1 if bad else 0)
