@@ -40,7 +40,9 @@
 // the timing is an upper bound of what optimising that part could return): 1 no MFMA, 2 no DMA after the first chunk, 4 no feature
 // stores, 8 no epilogue, 16 no K-step barrier, 32 no input transform (raw window values feed the MFMAs), 64 no window reads, 128 half the weight DMA pieces, 1024 no patch DMA,
 // 256 no ToRGB tail after the passes, 512 no combine phase (barriers and the A_x^T / exchange writes stay, so the accumulators
-// remain live).  0 in the product, which carries no run-time switch of any kind.
+// remain live); wave-complete kernel's epilogue split (round 6, profiles/r06_w2dw_epilogue_split.md): 2048 no inverse transform (one accumulator per
+// output instead of A_x^T / A_y^T), 4096 no ToRGB products / butterfly / skip / frames, 8192 no tail (gain, noise, bias, leaky ReLU).
+// 0 in the product, which carries no run-time switch of any kind.
 #if !defined(MAUA_EXPERIMENTS)
 #undef MAUA_W2D_ABL  // the product ignores the mask even when somebody passes it
 #endif
@@ -1080,6 +1082,16 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
             // A_x^T per y-frequency (y0 = m0+m1+m2+m3+m4, y1 = (m1-m2) + 2(m3-m4), y2 = (m1+m2) + 4(m3+m4), y3 = (m1-m2) + 8(m3-m4) + m5)
             // accumulated straight into A_y^T of F(2,3): row 0 = Z0 + Z1 + Z2, row 1 = Z1 - Z2 - Z3
             f32x2 raw0[4], raw1[4];
+            if constexpr (W2D_ABL(2048)) {  // (ablation: no inverse transform — every accumulator is still read once (a dead accumulator would take its
+                // matrix instructions out of the K loop): 16 plain adds instead of the 56 operations of A_x^T and A_y^T)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    raw0[px] = (pair_of(acc[0][px][m]) + pair_of(acc[2][px][m])) + pair_of(acc[0][4 + (px & 1)][m]);
+                    raw1[px] = (pair_of(acc[1][px][m]) + pair_of(acc[3][px][m])) + pair_of(acc[1][4 + (px & 1)][m]);
+                }
+#pragma unroll
+                for (int px = 0; px < 2; ++px) raw0[px] += pair_of(acc[2][4 + px][m]), raw1[px] += pair_of(acc[3][4 + px][m]);
+            } else
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const f32x2 M0 = pair_of(acc[f][0][m]), M1 = pair_of(acc[f][1][m]), M2 = pair_of(acc[f][2][m]);
@@ -1103,11 +1115,21 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
             f32x2 val[2][4];
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
+                if constexpr (W2D_ABL(8192)) {  // (ablation: no tail)
+                    val[0][px] = raw0[px], val[1][px] = raw1[px];
+                    continue;
+                }
                 const f32x2 t0 = raw0[px] * gain2 + (nzp[0][px] + bias2), t1 = raw1[px] * gain2 + (nzp[1][px] + bias2);
                 val[0][px] = __builtin_elementwise_max(t0, t0 * slope2);
                 val[1][px] = __builtin_elementwise_max(t1, t1 * slope2);
             }
-            if (p.rgb) {
+            if constexpr (W2D_ABL(4096)) {  // (ablation: the values stay live through one add each instead of three products)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) rgb2[0][r][px] = (m == 0 && vp == 0) ? val[r][px] : rgb2[0][r][px] + val[r][px];
+            }
+            if (p.rgb && !W2D_ABL(4096)) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1135,6 +1157,17 @@ __global__ __launch_bounds__(256, 2) void modconv_w2dw_kernel(W2dArgs p) {
             }
 #endif
         }
+    }
+    if constexpr (W2D_ABL(4096)) {
+        if (p.B < 0) {  // never true
+            f32x2 sum = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) sum += rgb2[0][r][px];
+            *reinterpret_cast<f32x2*>(p.y + tid * 2) = sum;
+        }
+        return;
     }
     if (!p.rgb) return;
     // ---- fused ToRGB: lanes j, j + 16, j + 32, j + 48 hold disjoint channels of one position.  Step 1 (xor 32) sums both rows of the
