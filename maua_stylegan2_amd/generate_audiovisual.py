@@ -117,12 +117,15 @@ def load_generator(ckpt, is_stylegan1, G_res, out_size, noconst, latent_dim, n_m
 _GENERATOR_CACHE = {}
 
 
-def _cached_generator(load, ckpt, flags):
+def _cached_generator(load, ckpt, flags, before_load=lambda: None):
+    """(generator, came from the cache).  ``before_load`` runs in front of every real load (generate() passes its one full collection)."""
     if sharding.grouped() or os.environ.get("MAUA_GENERATOR_CACHE", "1") in ("0", "") or ckpt is None:
+        before_load()
         return load(), False
     try:
         st = os.stat(ckpt)
     except OSError:
+        before_load()
         return load(), False
     key = (os.path.realpath(ckpt), st.st_mtime_ns, st.st_size, th.cuda.current_device()) + tuple(flags)
     hit = _GENERATOR_CACHE.get("entry")
@@ -135,6 +138,7 @@ def _cached_generator(load, ckpt, flags):
                     getattr(generator.noises, f"noise_{i}").normal_()
         return generator, True
     _GENERATOR_CACHE.pop("entry", None)  # (one entry: a generator owns GBs of static buffers)
+    before_load()
     generator = load()
     _GENERATOR_CACHE["entry"] = (key, generator)
     return generator, False
@@ -296,12 +300,17 @@ def generate(ckpt, audio_file, initialize=None, get_latents=None, get_noise=None
         lo, hi = sharding.shard_bounds(n_frames, rank, world)
         shard = (lo, hi, n_frames)
 
-    # (reference :191-192.)  The job's one collection — 45 ms on this heap.  Full on purpose: young-generation collections (tried in round 5)
-    # leave the preprocessing's cyclic garbage, device tensors among it, alive, and render() then pays more in fresh allocations (+60 ms)
-    gc.collect()
+    # (reference :191-192.)  The job's one collection — 45-70 ms on this heap.  Full on purpose where it runs: young-generation collections
+    # (tried in round 5) leave the preprocessing's cyclic garbage, device tensors among it, alive, and a render that has to LOAD its generator
+    # then pays more in fresh allocations (+60 ms).  A job whose generator is already there (kept from the previous job: the allocator's
+    # pools are warm, nothing large is about to be allocated) skips it — measured 0.87-0.99 s against 0.90-1.01 s per warm 900-frame job
+    # (tools/e2e_config3.py --gc none / full, alternating); the interpreter's own thresholds collect the garbage of a run of jobs.
+    hit = False
     if generator is None:
-        generator, _ = _cached_generator(load, ckpt, (bool(stylegan1), G_res, out_size, bool(noconst), latent_dim, n_mlp, channel_multiplier,
-                                                      base_res_factor))
+        generator, hit = _cached_generator(load, ckpt, (bool(stylegan1), G_res, out_size, bool(noconst), latent_dim, n_mlp, channel_multiplier,
+                                                        base_res_factor), before_load=gc.collect)
+    if not hit and grouped:
+        gc.collect()
     if grouped and not stylegan1 and not (isinstance(truncation, float) and truncation == 1.0):
         # the truncation centre is a random draw (mean_latent(2**14), reference models/stylegan2.py:539-540): one draw, on rank
         # 0, for every shard — otherwise neighbouring shards are truncated toward slightly different centres

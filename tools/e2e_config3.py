@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--stage-times", action="store_true", help="print device-synchronised wall time per preprocessing stage")
     ap.add_argument("--repeat", type=int, default=1, help="run generate() this many times in one process (the later runs are warm)")
+    ap.add_argument("--gc", choices=["full", "young", "none"], default="full",
+                    help="A/B of the collection generate() runs before a LOAD of the generator (the product skips it when the generator is kept from the previous job): "
+                         "as the product, generation 0 only, or never")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="maua_e2e_")
     os.chdir(work)
@@ -84,6 +87,17 @@ def main():
             if hasattr(ar, name):
                 setattr(ar, name, getattr(sig, name))
         timed(gav.gc, "collect", "  gc.collect")
+    if args.gc != "full":
+        import gc as _gc
+
+        class _Gc:  # (stands in for the module inside generate_audiovisual only)
+            def __getattr__(self, name):
+                return getattr(_gc, name)
+
+            def collect(self, *a):
+                return _gc.collect(0) if args.gc == "young" else 0
+
+        gav.gc = _Gc()
     for run in range(args.repeat):
         counted.update(frames=0, bytes=0, checksum=0)
         if args.stage_times:
