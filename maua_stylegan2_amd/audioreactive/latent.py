@@ -88,23 +88,54 @@ def wrapping_slice(tensor, start, length, return_indices=False):
     return indices if return_indices else tensor[indices]
 
 
-def generate_latents(n_latents, ckpt, G_res, noconst=False, latent_dim=512, n_mlp=8, channel_multiplier=2):
-    """``n_latents`` random w vectors, each repeated over the generator's layers: [n_latents, n_latent, latent_dim] on the
-    CPU (reference :136-159).  Only the mapping network is needed for that, so only its ``style.*`` tensors are read from
-    the checkpoint and put on the device (the reference builds and uploads a second full generator).  z is mapped on
-    [N, latent_dim] — the evident intent; the reference's map_latents branch normalises over a singleton axis."""
-    from ..models.stylegan2 import EqualLinear, PixelNorm
+_MAPPING_CACHE = {}  # (checkpoint path, mtime, size, latent_dim, n_mlp, device) -> mapping network on the device (8 MB; one entry)
 
-    mapping = th.nn.Sequential(PixelNorm(), *[EqualLinear(latent_dim, latent_dim, lr_mul=0.01, activation="fused_lrelu")
-                                              for _ in range(n_mlp)])
+
+def _mapping_network(ckpt, latent_dim, n_mlp):
+    """The checkpoint's mapping network (``style.*``) on the current device.  Built ON the device without initial values when a checkpoint
+    will overwrite every tensor (eight 512 x 512 normal draws + scalings on the CPU were 0.05 s of a 0.9 s job), and kept for the next job on
+    the same checkpoint FILE (path, mtime, size) — the generator itself is kept the same way (generate_audiovisual._cached_generator)."""
+    import os
+
+    from ..models import stylegan2 as sg2
+
+    dev = th.device("cuda", th.cuda.current_device())
+    key = None
+    if ckpt is not None:
+        try:
+            st = os.stat(ckpt)
+            key = (os.path.realpath(ckpt), st.st_mtime_ns, st.st_size, latent_dim, n_mlp, dev.index)
+        except OSError:
+            key = None
+        if key is not None and _MAPPING_CACHE.get("key") == key:
+            return _MAPPING_CACHE["net"]
+    sg2._SKIP_INIT.on = ckpt is not None
+    try:
+        with th.device(dev):
+            mapping = th.nn.Sequential(sg2.PixelNorm(), *[sg2.EqualLinear(latent_dim, latent_dim, lr_mul=0.01, activation="fused_lrelu")
+                                                          for _ in range(n_mlp)])
+    finally:
+        sg2._SKIP_INIT.on = False
     if ckpt is not None:
         try:  # zip-format checkpoints are mapped: only the pages of the eight style.* matrices are ever read
             weights = th.load(ckpt, map_location="cpu", mmap=True)["g_ema"]
         except (RuntimeError, ValueError, TypeError):
             weights = th.load(ckpt, map_location="cpu")["g_ema"]
-        mapping.load_state_dict({k[len("style."):]: v for k, v in weights.items() if k.startswith("style.")})
+        mapping.load_state_dict({k[len("style."):]: v for k, v in weights.items() if k.startswith("style.")}, strict=True)
         del weights
-    mapping = mapping.cuda()
+    mapping = mapping.to(dev)
+    if key is not None:
+        _MAPPING_CACHE.clear()
+        _MAPPING_CACHE.update(key=key, net=mapping)
+    return mapping
+
+
+def generate_latents(n_latents, ckpt, G_res, noconst=False, latent_dim=512, n_mlp=8, channel_multiplier=2):
+    """``n_latents`` random w vectors, each repeated over the generator's layers: [n_latents, n_latent, latent_dim] on the
+    CPU (reference :136-159).  Only the mapping network is needed for that, so only its ``style.*`` tensors are read from
+    the checkpoint and put on the device (the reference builds and uploads a second full generator).  z is mapped on
+    [N, latent_dim] — the evident intent; the reference's map_latents branch normalises over a singleton axis."""
+    mapping = _mapping_network(ckpt, latent_dim, n_mlp)
     w = mapping(th.randn((n_latents, latent_dim), device="cuda"))
     n_layers = 2 * int(np.log2(G_res)) - 2
     return w[:, None, :].repeat(1, n_layers, 1).cpu()

@@ -48,6 +48,28 @@ def _to_dev(x, dtype=th.float32):
     return x.to(device=_dev(), dtype=dtype).contiguous()
 
 
+_DEVICE_CONSTANTS = {}  # (device, dtype, shape, content hash) -> device tensor, insertion-ordered (oldest dropped beyond 48 entries)
+
+
+def _const_dev(arr, dtype=None, device=None):
+    """A host-built CONSTANT table (window, filterbank, CQT frequencies ...) on the device, uploaded once per content: an upload from pageable
+    memory blocks the host until everything queued on the stream before it has run, so re-uploading the same half-megabyte filterbank in every
+    call made the front end wait for its own kernels three times per job (0.075 s of a 0.9 s warm generate(), round 6 profile).  The result is
+    shared: callers must not write to it."""
+    arr = np.ascontiguousarray(arr if dtype is None else np.asarray(arr).astype(dtype, copy=False))
+    if device is not None and th.device(device).type != "cuda":  # (host-side callers, e.g. the CPU tests of complex_flux)
+        return th.from_numpy(arr.copy())
+    dev = _dev()
+    key = (dev.index, arr.dtype.str, arr.shape, hash(arr.tobytes()))
+    hit = _DEVICE_CONSTANTS.get(key)
+    if hit is None:
+        hit = th.from_numpy(arr.copy()).to(dev)
+        _DEVICE_CONSTANTS[key] = hit
+        while len(_DEVICE_CONSTANTS) > 48:
+            _DEVICE_CONSTANTS.pop(next(iter(_DEVICE_CONSTANTS)))
+    return hit
+
+
 # ------------------------------------------------------------------------------------------------ filterbanks (host, once)
 def _hz_to_mel(f):
     f = np.asarray(f, dtype=np.float64)
@@ -99,7 +121,7 @@ def stft_power(audio, n_fft=2048, hop=512):
     y = _to_dev(audio)
     n = y.numel()
     n_frames = 1 + n // hop
-    win = th.from_numpy((0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32)).to(y.device)
+    win = _hann(n_fft, y.device)
     p = th.empty((n_fft // 2 + 1, n_frames), dtype=th.float32, device=y.device)
     with th.cuda.device(y.device):
         _lib.check(lib.maua_stft_power_f32(y.data_ptr(), n, win.data_ptr(), n_fft, hop, p.data_ptr(), n_frames,
@@ -110,7 +132,7 @@ def stft_power(audio, n_fft=2048, hop=512):
 def project(fb, p, to_db=False, amin=1e-10):
     """fb [M,K] (numpy or tensor) @ p [K,N] on device, optional 10*log10(max(amin, .))."""
     lib = _lib.load()
-    fbt = _to_dev(fb)
+    fbt = _const_dev(fb, np.float32) if isinstance(fb, np.ndarray) else _to_dev(fb)
     m, k = fbt.shape
     n = p.shape[1]
     out = th.empty((m, n), dtype=th.float32, device=p.device)
@@ -121,7 +143,7 @@ def project(fb, p, to_db=False, amin=1e-10):
 
 
 def _hann(n_fft, device):
-    return th.from_numpy((0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32)).to(device)
+    return _const_dev((0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32))
 
 
 def hpss(audio, margin=1.0, kernel_size=31, power=2.0, n_fft=2048, hop=512):
@@ -347,9 +369,9 @@ def complex_flux(re, im, fb, filt):
     width = int((last - first).max()) + 3
     rows = np.clip(first[:, None] - 1 + np.arange(width)[None, :], 0, n_bins - 1)  # [bands, width] bin indices
     keep = (np.arange(width)[None, :] <= (last - first + 2)[:, None])              # beyond a band's span: ignored (inf)
-    idx = th.from_numpy(rows).to(lgd.device)
+    idx = _const_dev(rows, device=lgd.device)
     gathered = lgd[idx.reshape(-1)].reshape(rows.shape[0], width, -1)
-    gathered = th.where(th.from_numpy(keep).to(lgd.device)[:, :, None], gathered, th.full_like(gathered, float("inf")))
+    gathered = th.where(_const_dev(keep, device=lgd.device)[:, :, None], gathered, th.full_like(gathered, float("inf")))
     mask = gathered.min(dim=1).values                                              # [bands, frames]
     prev = th.cat([filt[:, :1], filt[:, :-1]], dim=1)
     widened = th.nn.functional.max_pool1d(th.nn.functional.pad(prev.t()[None], (1, 1), mode="replicate"), 3, 1)[0].t()
@@ -492,8 +514,8 @@ def cqt_magnitude(audio, sr, hop=512, n_bins=252, fmin=CQT_FMIN, bins_per_octave
     lengths = np.ceil(q * sr / freqs).astype(np.int32)
     n_frames = 1 + y.numel() // hop
     out = th.empty((n_bins, n_frames), dtype=th.float32, device=y.device)
-    f_dev = th.from_numpy(freqs.astype(np.float32)).to(y.device)
-    l_dev = th.from_numpy(lengths).to(y.device)
+    f_dev = _const_dev(freqs.astype(np.float32))
+    l_dev = _const_dev(lengths)
     with th.cuda.device(y.device):
         _lib.check(_lib.load().maua_cqt_mag_f32(y.data_ptr(), y.numel(), f_dev.data_ptr(), l_dev.data_ptr(), n_bins, hop,
                                                 float(sr), out.data_ptr(), n_frames, _lib.stream_ptr(y.device)),
