@@ -1197,10 +1197,12 @@ Plan make_plan(int batch, int cin, int cout, int h, int w, int mode) {
         g.PSTRIDE = ni * g.PH * g.PWS;
     };
     shape(pl.bn);
-    if (up && g.GH * g.GW >= 2 * pl.bn && !MAUA_CFG(4)) {
+    if (up && g.GH * g.GW > pl.bn && !MAUA_CFG(4)) {
         // The (H+1)x(W+1) position grid never fits power-of-two 2-D tiles (29 % idle MFMA columns at 65x65); tiles are
         // instead runs of BN consecutive positions of the flattened grid, one image each.  A position reads inputs
         // p, p-1, p-GW, p-GW-1 of the pitch-GW flattened (zero-padded) input: two runs of BN+1 floats per channel.
+        // (From two runs per image on — round 6: the 9 x 9 grid of the 8^2 -> 16^2 layer took 16 x 16 = 256 slots as a 2-D tile, 32 % of its
+        // MFMA columns useful; as two runs of 64 it is 63 %.)
         g.flat = 1;
         g.lsw = 5, g.lsh = 0, g.lnsx = ilog2(pl.bn / 32), g.lnsy = 0, g.lni = 0;
         g.tiles_x = ceil_div(g.GH * g.GW, pl.bn), g.tiles_y = 1, g.img_groups = batch;

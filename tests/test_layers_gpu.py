@@ -81,6 +81,7 @@ def test_to_rgb_golden(gpu, golden, name):
     (512, 512, 4, False, 3), (512, 512, 8, True, 2), (512, 512, 16, False, 1), (512, 256, 32, True, 1),
     (128, 128, 64, False, 2), (128, 64, 64, True, 1), (64, 64, 128, False, 1), (64, 32, 96, True, 1),
     (32, 32, 160, False, 2), (40, 24, 20, False, 1), (24, 72, 12, True, 2), (16, 8, 128, True, 2), (8, 40, 130, True, 1),
+    (72, 40, 9, True, 3), (512, 512, 8, True, 8), (40, 96, 7, True, 2),  # position grids of 100 / 81 (two flat runs per image) / 64 (one 2-D tile)
 ])
 def test_modconv_shapes_vs_oracle(gpu, cin, cout, hw, up, batch):
     """Every tile configuration (BM 32/64/128, split-K, polyphase) against the oracle's reference formulation."""
