@@ -242,7 +242,7 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
 /* The same fusion for layers wider than one weight tile (128..512 output channels, mode 5 only): every output-channel tile leaves
  * its share of the ToRGB sum  sum_{i in tile} (rgb_wscale * rgb_w[c,i] * rgb_s[b,i]) * y[b,i,Y,X]  in
  * rgb_partial [B, 3 * maua_modconv_w2d_mtiles(), H, W] (plane 3 m + c), the feature map y is stored as usual.  The caller finishes with
- * maua_torgb_f32 over the 3 m_tiles planes (selection weights, unit styles), which adds bias and the up-sampled skip: the ToRGB of
+ * maua_torgb_f32 over the 3 m_tiles planes (w = s = NULL: its plane-sum form), which adds bias and the up-sampled skip: the ToRGB of
  * models/stylegan2.py:356-365 then reads 3 m_tiles planes instead of all `cout` feature planes.  MAUA_ENOSYS for mode != 5. */
 int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y,
                                       int batch, int cin, int cout, int h, int w, int mode, float wscale, const float* noise,
@@ -261,7 +261,9 @@ int maua_sg1_epilogue_f32(const float* x, const float* bias, const float* noise,
 
 /* ToRGB (models/stylegan2.py:356-365): 1x1 modulated conv without demod + bias + 2x FIR-upsampled skip
  * (Upsample :34-52, kernel k4 = 4x4 taps in device memory, pad (2,1)).  skip == NULL: no skip.
- *   y[b,c,Y,X] = sum_i (wscale * w[c,i] * s[b,i]) * x[b,i,Y,X] + bias[c] + up2(skip)[b,c,Y,X] */
+ *   y[b,c,Y,X] = sum_i (wscale * w[c,i] * s[b,i]) * x[b,i,Y,X] + bias[c] + up2(skip)[b,c,Y,X]
+ * w == NULL and s == NULL: x holds per-tile partial ToRGB sums [B, cin = 3 M, H, W] (maua_styledconv_torgb_partial_f32), plane 3 m + c
+ * feeding colour c:  y[b,c] = sum_m x[b, 3 m + c] + bias[c] + up2(skip)[b,c]  (wdt % 4 == 0; one round trip of independent loads). */
 int maua_torgb_f32(const float* x, const float* w, const float* s, int s_stride, const float* bias,
                    const float* skip, const float* k4, float* y, int batch, int cin, int h, int wdt,
                    float wscale, void* stream);

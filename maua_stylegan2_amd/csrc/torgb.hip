@@ -133,12 +133,80 @@ __global__ __launch_bounds__(256) void torgb_kernel(const float* __restrict__ x,
     }
 }
 
+// w == NULL (and s == NULL): x holds per-tile partial ToRGB sums [B, 3 M, H, W], plane 3 m + c feeding colour c (what the 2-D Winograd layers
+// of more than one weight tile leave, maua_styledconv_torgb_partial_f32): y[b, c] = sum_m x[b, 3 m + c] + bias[c] + up2(skip)[b, c].
+// Until round 6 this went through torgb_kernel with a 0 / 1 selection matrix: ~20 us per launch whatever the map size (five launches per
+// 1024^2 forward, tools/rocpd_timeline.py), because that kernel is four DEPENDENT round trips — weights x styles into LDS, the channel loop,
+// the slice combine, the skip gather with its tap loads.  Here a thread owns four pixels of one colour and every load it needs — M plane
+// quads, the 2 x 4 window of the skip image, the taps (uniform) — is independent of every other: one round trip.
+__global__ __launch_bounds__(256) void rgb_planes_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                         const float* __restrict__ skip, const float* __restrict__ k4,
+                                                         float* __restrict__ y, int m_tiles, int h, int wdt) {
+    const int plane = h * wdt;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y % 3, b = blockIdx.y / 3;
+    if (q * 4 >= plane) return;
+    const int pix = q * 4;
+    const int Y = pix / wdt, X0 = pix - Y * wdt;
+    const float* xp = x + ((size_t)b * 3 * m_tiles + c) * plane + pix;
+    float4 acc = *reinterpret_cast<const float4*>(xp);
+    // skip window: canvas row Y + i - 2 holds data for even values only: tap rows i0 = Y & 1 and i0 + 2 on skip rows iy0, iy0 + 1;
+    // columns X0 / 2 - 1 .. X0 / 2 + 2 serve the four pixels (even X: taps 0, 2; odd X: taps 1, 3)
+    float v[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float kf[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float bc = bias ? bias[c] : 0.f;
+    if (skip) {
+        const int sh = h >> 1, sw = wdt >> 1;
+        const float* sp = skip + ((size_t)b * 3 + c) * sh * sw;
+        const int i0 = Y & 1;
+        const int iy0 = (Y + i0 - 2) >> 1;  // (-1 for Y = 0, 1: the canvas padding)
+        const int ix0 = (X0 >> 1) - 1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int iy = iy0 + r;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int ix = ix0 + cc;
+                if (iy >= 0 && iy < sh && ix >= 0 && ix < sw) v[r][cc] = sp[iy * sw + ix];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kf[r][j] = k4[(3 - (i0 + 2 * r)) * 4 + (3 - j)];  // (uniform per row parity: scalar loads)
+        }
+    }
+    for (int m = 1; m < m_tiles; ++m) {
+        const float4 t = *reinterpret_cast<const float4*>(xp + (size_t)3 * m * plane);
+        acc.x += t.x, acc.y += t.y, acc.z += t.z, acc.w += t.w;
+    }
+    float out[4] = {acc.x + bc, acc.y + bc, acc.z + bc, acc.w + bc};
+    if (skip) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j0 = e & 1, ca = (e + 1) >> 1;  // columns ca (tap j0), ca + 1 (tap j0 + 2) of the window
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                a = fmaf(kf[r][j0], v[r][ca], a);
+                a = fmaf(kf[r][j0 + 2], v[r][ca + 1], a);
+            }
+            out[e] += a;
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((size_t)b * 3 + c) * plane + pix) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 }  // namespace
 
 extern "C" int maua_torgb_f32(const float* x, const float* w, const float* s, int s_stride, const float* bias,
                               const float* skip, const float* k4, float* y, int batch, int cin, int h, int wdt,
                               float wscale, void* stream) {
-    if (!x || !w || !s || !y || batch <= 0 || cin <= 0 || h <= 0 || wdt <= 0) return MAUA_EINVAL;
+    if (!x || !y || batch <= 0 || cin <= 0 || h <= 0 || wdt <= 0 || (!w != !s)) return MAUA_EINVAL;
+    if (!w) {  // plane sum of per-tile partial ToRGB sums (see rgb_planes_kernel)
+        if (cin % 3 || wdt % 4 || (skip && (!k4 || (h & 1) || (wdt & 1)))) return MAUA_EINVAL;
+        hipLaunchKernelGGL(rgb_planes_kernel, dim3(ceil_div(h * wdt / 4, 256), 3 * batch), dim3(256), 0, (hipStream_t)stream, x, bias, skip,
+                           k4, y, cin / 3, h, wdt);
+        MAUA_LAUNCH_CHECK();
+        return 0;
+    }
     const int vec = (wdt % 4 == 0) ? 4 : 1;      // a 4-pixel group must stay inside one row
     if (skip && (!k4 || (h & 1) || (wdt & 1))) return MAUA_EINVAL;
     const int quads = h * wdt / vec;

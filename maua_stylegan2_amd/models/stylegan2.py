@@ -440,22 +440,6 @@ class ManipulationLayer(nn.Module):
         return x
 
 
-_PARTIAL_RGB = {}
-
-
-def _partial_rgb_operands(m_tiles, batch, device):
-    """Operands that make maua_torgb_f32 add up the per-tile partial ToRGB sums [B, 3 m_tiles, H, W]: a [3, 3 m_tiles] selection
-    matrix (plane 3 m + c feeds colour c) and unit styles; cached per (m_tiles, batch, device) — static, so graph-capture safe."""
-    key = (m_tiles, batch, str(device))
-    if key not in _PARTIAL_RGB:
-        sel = th.zeros(3, 3 * m_tiles, dtype=th.float32)
-        for m in range(m_tiles):
-            for c in range(3):
-                sel[c, 3 * m + c] = 1.0
-        _PARTIAL_RGB[key] = (sel.to(device), th.ones(batch, 3 * m_tiles, dtype=th.float32, device=device))
-    return _PARTIAL_RGB[key]
-
-
 class StyledConv(nn.Module):
     """reference :310-343: ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU -> ManipulationLayer."""
 
@@ -554,11 +538,10 @@ class StyledConv(nn.Module):
                         s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), src, slot, post_ptr,
                         _lib.stream_ptr(x.device)), "maua_styledconv_torgb_partial_f32")
                     self.posted = post_ptr is not None
-                    sel, ones = _partial_rgb_operands(m_tiles, b, x.device)
-                    _lib.check(lib.maua_torgb_f32(part.data_ptr(), sel.data_ptr(), ones.data_ptr(), 3 * m_tiles, t.bias.data_ptr(),
+                    _lib.check(lib.maua_torgb_f32(part.data_ptr(), None, None, 0, t.bias.data_ptr(),
                                                   _lib.ptr(skip), _lib.ptr(t.upsample.kernel) if skip is not None else None,
                                                   rgb["out"].data_ptr(), b, 3 * m_tiles, h, w, 1.0, _lib.stream_ptr(x.device)),
-                               "maua_torgb_f32")
+                               "maua_torgb_f32")  # (w = s = NULL: the plane sum + bias + up-sampled skip)
                     rgb["done"] = True
                     rgb["u8_done"] = False  # the image is in rgb["out"] as fp32 planes: a last layer still needs the frame epilogue
                     return out

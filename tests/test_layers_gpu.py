@@ -77,6 +77,46 @@ def test_to_rgb_golden(gpu, golden, name):
     np.testing.assert_allclose(y.cpu().numpy(), g[f"{name}.y"], atol=TOL)
 
 
+@pytest.mark.parametrize("m_tiles,h,w,batch,with_skip", [(8, 64, 64, 2, True), (2, 256, 256, 1, True), (4, 32, 96, 3, False), (1, 8, 4, 1, True),
+                                                         (3, 6, 20, 2, True)])
+def test_torgb_plane_sum_form(gpu, m_tiles, h, w, batch, with_skip):
+    """maua_torgb_f32 with w = s = NULL (the sum of per-tile partial ToRGB planes + bias + up-sampled skip) against the same call with a
+    0 / 1 selection matrix and unit styles (the general kernel, which the golden vectors pin) and against the oracle's upfirdn2d."""
+    from maua_stylegan2_amd.models.stylegan2 import Upsample
+    from oracle import ops_oracle as oo
+
+    r = np.random.default_rng(m_tiles * 1000 + h + w)
+    part = r.standard_normal((batch, 3 * m_tiles, h, w)).astype(np.float32)
+    bias = r.standard_normal(3).astype(np.float32)
+    skip = r.standard_normal((batch, 3, h // 2, w // 2)).astype(np.float32) if with_skip else None
+    up = Upsample([1, 3, 3, 1]).to(gpu)
+    k4 = up.kernel
+    lib = _lib.load()
+    d_part, d_bias = t(part, gpu), t(bias, gpu)
+    d_skip = t(skip, gpu) if with_skip else None
+    got = torch.full((batch, 3, h, w), float("nan"), device=gpu)
+    _lib.check(lib.maua_torgb_f32(d_part.data_ptr(), None, None, 0, d_bias.data_ptr(), _lib.ptr(d_skip), k4.data_ptr() if with_skip else None,
+                                  got.data_ptr(), batch, 3 * m_tiles, h, w, 1.0, _lib.stream_ptr(gpu)), "maua_torgb_f32")
+    sel = np.zeros((3, 3 * m_tiles), np.float32)
+    for m in range(m_tiles):
+        for c in range(3):
+            sel[c, 3 * m + c] = 1.0
+    ones = torch.ones(batch, 3 * m_tiles, device=gpu)
+    ref = torch.full((batch, 3, h, w), float("nan"), device=gpu)
+    _lib.check(lib.maua_torgb_f32(d_part.data_ptr(), t(sel, gpu).data_ptr(), ones.data_ptr(), 3 * m_tiles, d_bias.data_ptr(), _lib.ptr(d_skip),
+                                  k4.data_ptr() if with_skip else None, ref.data_ptr(), batch, 3 * m_tiles, h, w, 1.0, _lib.stream_ptr(gpu)),
+               "maua_torgb_f32")
+    want = part.reshape(batch, m_tiles, 3, h, w).sum(1) + bias[None, :, None, None]
+    if with_skip:
+        want = want + oo.upfirdn2d(torch.from_numpy(skip), k4.cpu(), up=2, down=1, pad=up.pad).numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), atol=2e-6 * m_tiles, rtol=0)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-5, rtol=1e-5)
+    # rejected: a plane count that is not 3 M, a width that is not a multiple of 4, one of w / s alone
+    assert lib.maua_torgb_f32(d_part.data_ptr(), None, None, 0, None, None, None, got.data_ptr(), batch, 3 * m_tiles + 1, h, w, 1.0, None) == -22
+    assert lib.maua_torgb_f32(d_part.data_ptr(), None, None, 0, None, None, None, got.data_ptr(), batch, 3 * m_tiles, h, w + 2, 1.0, None) == -22
+    assert lib.maua_torgb_f32(d_part.data_ptr(), d_bias.data_ptr(), None, 0, None, None, None, got.data_ptr(), batch, 3 * m_tiles, h, w, 1.0, None) == -22
+
+
 @pytest.mark.parametrize("cin,cout,hw,up,batch", [
     (512, 512, 4, False, 3), (512, 512, 8, True, 2), (512, 512, 16, False, 1), (512, 256, 32, True, 1),
     (128, 128, 64, False, 2), (128, 64, 64, True, 1), (64, 64, 128, False, 1), (64, 32, 96, True, 1),
