@@ -123,11 +123,18 @@ def layer_breakdown(g, batch, noise_batch, stream):
 
     li = 0
     x = g._buf(batch, "const", (batch, 512, 4, 4))
-    rows.append(("conv1", "modconv", time_calls(lambda: g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1"), 20, sp),
-                 2 * 512 * 512 * 9 * 16 * batch, 0))
+    fuse1 = dict(module=g.to_rgb1, s_off=ent[1]["s_off"], skip=None, out=bufs("rgb1", (batch, 3, 4, 4)), store=True)
+    g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1", rgb=fuse1)
     out = g._buf(batch, "conv1", (batch, 512, 4, 4))
-    rows.append(("to_rgb1", "torgb", time_calls(lambda: g.to_rgb1.run(out, s, ent[1]["s_off"], None, bufs("rgb1", (batch, 3, 4, 4))), 20, sp),
-                 2 * 512 * 3 * 16 * batch, 4 * batch * (512 + 3) * 16))
+    if fuse1.get("done"):  # the low-resolution entry: convolution slabs, slab sum + tail + per-group ToRGB sums, plane sum (three launches)
+        rows.append(("conv1+to_rgb1 (slabs, reduce + tail + partial ToRGB sums, plane sum)", "modconv",
+                     time_calls(lambda: g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1", rgb=dict(fuse1)), 20, sp),
+                     2 * 512 * 512 * 9 * 16 * batch + 2 * 512 * 3 * 16 * batch, 0))
+    else:
+        rows.append(("conv1", "modconv", time_calls(lambda: g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1"), 20, sp),
+                     2 * 512 * 512 * 9 * 16 * batch, 0))
+        rows.append(("to_rgb1", "torgb", time_calls(lambda: g.to_rgb1.run(out, s, ent[1]["s_off"], None, bufs("rgb1", (batch, 3, 4, 4))), 20, sp),
+                     2 * 512 * 3 * 16 * batch, 4 * batch * (512 + 3) * 16))
     li = 2
     image = g._buf(batch, "rgb1", (batch, 3, 4, 4))
     # the style fold as Generator._forward_device plans it (no bends here): a producer stores its map multiplied by the consumer's styles
@@ -159,6 +166,10 @@ def layer_breakdown(g, batch, noise_batch, stream):
             # asks for ((segments - 1) x 6 rows of 2W floats per image and channel + 4)
             n_seg = (_lib.load().maua_upconv_blur_ws_floats(batch, cin, cout, h, h) - 4) // (batch * cout * 12 * h) + 1
             FUSED_GRID[rows[-1][0]] = batch * n_seg * tiles_x * (cout // 32) * 256
+        elif getattr(up, "last_path", "pair") == "lowres":
+            # the low-resolution entry (maua_upconv_blur_lowres_f32): polyphase convolution -> split-K slabs, then slab sum + blur + noise + act
+            rows.append((f"convs.{2*n}.upconv+blur+noise+act (slabs, reduce + blur + tail)", "modconv_up", t_all, 2 * cin * cout * 9 * h * h * batch, 0))
+            INSTANCES[rows[-1][0]] = _lib.last_modconv_instance()
         else:
             # transposed conv alone and blur tail alone (they are separate launches inside StyledConv.run)
             raw = bufs(f"raw{n}", (batch, cout, 2 * h + 1, 2 * h + 1))
@@ -185,7 +196,8 @@ def layer_breakdown(g, batch, noise_batch, stream):
             t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", rgb=dict(fuse), prescaled=pre_pl,
                                                 post_off=post_pl), 10, sp)
             # <= 64 channels: one launch; wider layers: the conv leaves per-tile partial ToRGB sums and a 3*m_tiles-plane pass adds them
-            label = "(fused)" if cout <= 64 else "(fused: partial sums + plane sum)"
+            label = ("(fused)" if cout <= 64 else "(slabs, reduce + tail + partial ToRGB sums, plane sum)" if getattr(plain, "last_path", "") == "lowres"
+                     else "(fused: partial sums + plane sum)")
             rows.append((f"convs.{2*n+1}+to_rgbs.{n} {label}", "modconv", t_pl, conv_flops + rgb_flops, 0))
         else:
             t_pl = time_calls(lambda: plain.run(mid, s, e_pl["s_off"], demod_of(e_pl), nz2, bufs, f"p{n}", prescaled=pre_pl), 10, sp)
@@ -579,6 +591,8 @@ def main():
     ap.add_argument("--lib", default=None, help="A/B / ablation switch: load this build of libmaua_hip.so instead of the in-tree one")
     ap.add_argument("--no-style-fold", action="store_true",
                     help="A/B switch: every convolution multiplies its input by its styles itself (round 5's form) instead of reading a map its producer pre-multiplied")
+    ap.add_argument("--no-lowres-fusion", action="store_true",
+                    help="A/B switch: the 4^2 .. 32^2 layers as convolution, reduce + tail, blur / ToRGB (separate launches) instead of the low-resolution entries")
     ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
@@ -626,6 +640,8 @@ def main():
 
     if args.no_partial_rgb:
         StyledConv.partial_rgb_fusion = False
+    if args.no_lowres_fusion:
+        StyledConv.lowres_fusion = False
     if args.no_style_fold:
         from maua_stylegan2_amd.models.stylegan2 import Generator
 

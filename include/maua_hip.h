@@ -20,7 +20,7 @@ extern "C" {
 #define MAUA_ENOSYS (-38)
 
 /* ABI version of this header; bumped on any signature change. */
-int maua_abi_version(void);  /* 4: the style fold (post_s arguments, s == NULL; round 6); 3: + maua_upconv_blur_f32 (round 5); 2: frame source (maua_frame_source_t) arguments; no tuning entry */
+int maua_abi_version(void);  /* 5: + the low-resolution entries (maua_*_lowres_*), maua_torgb_f32's plane-sum form; 4: the style fold (post_s arguments, s == NULL; round 6); 3: + maua_upconv_blur_f32 (round 5); 2: frame source (maua_frame_source_t) arguments; no tuning entry */
 /* Number of compute units / name of device 0 (diagnostics for bench.py). */
 int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
 
@@ -238,6 +238,30 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
                               const float* rgb_skip, const float* rgb_k4, float* rgb_out, int store_features,
                               uint8_t* frames_u8, const maua_frame_source_t* src, int noise_slot,
                               const float* post_s /* [B, s_stride] or NULL; mode 5 only */, void* stream);
+
+/* LOW-RESOLUTION LAYERS (ABI 5; the 4^2 .. 32^2 outputs of a generator).  Their convolutions are the split-K direct / polyphase kernels of
+ * maua_modconv3x3_f32 (up = 0 / 1), and on maps of a few KB every launch is a fixed 5 .. 20 us whatever it computes.  These entries run the
+ * convolution with its split-K slabs left in `ws` (maua_lowres_ws_floats floats: one slab when K is not split) and reduce them in the SAME
+ * launch that applies what follows:
+ *   maua_upconv_blur_lowres_f32   = maua_modconv3x3_f32(up = 1) + maua_blur_noise_act_f32 (4 x 4 taps, pad (1, 1)) of an up-sampling
+ *       StyledConv (models/stylegan2.py:229-238, :338-343): y [B, Cout, 2H, 2W], bit-identical to that pair wherever K is split (without a
+ *       split the pair applies wscale * d as one factor, this entry as two);  post_s as THE STYLE FOLD;
+ *   maua_styledconv_rgbpart_lowres_f32 = maua_modconv3x3_f32(up = 0, fuse_act = 1) of a plain StyledConv — y bit-identical — that also
+ *       leaves per-32-channel-group partial ToRGB sums (models/stylegan2.py:356-365) in rgb_partial [B, 3 * Cout / 32, H, W] (plane 3 g + c),
+ *       which maua_torgb_f32's plane-sum form (w = s = NULL) turns into the image.
+ * maua_lowres_ok: up != 0: 2H * 2W <= 1024;  up == 0: Cout % 32 == 0, H * W % 16 == 0, H * W <= 1024.  MAUA_ENOSYS otherwise.
+ * `wp` = maua_pack_weight_f32 (the direct tap-major form); s must not be NULL (these kernels have no pre-scaled instance). */
+int maua_lowres_ok(int cin, int cout, int h, int w, int up);
+int64_t maua_lowres_ws_floats(int batch, int cin, int cout, int h, int w, int up);
+int maua_upconv_blur_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, float* ws,
+                                const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
+                                const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w, float wscale,
+                                const float* post_s, void* stream);
+int maua_styledconv_rgbpart_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, float* ws,
+                                       const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
+                                       const float* rgb_w, const float* rgb_s, float rgb_wscale, float* rgb_partial,
+                                       const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w,
+                                       float wscale, void* stream);
 
 /* The same fusion for layers wider than one weight tile (128..512 output channels, mode 5 only): every output-channel tile leaves
  * its share of the ToRGB sum  sum_{i in tile} (rgb_wscale * rgb_w[c,i] * rgb_s[b,i]) * y[b,i,Y,X]  in

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmaua_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MauaHipError(RuntimeError):
@@ -66,6 +66,11 @@ _SIGNATURES = {
     "maua_upconv_blur_ok": (c_int, [c_int] * 4),
     "maua_upconv_blur_ws_floats": (c_int64, [c_int] * 5),
     "maua_upconv_blur_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 5 + [c_float, _P, _P]),
+    "maua_lowres_ok": (c_int, [c_int] * 5),
+    "maua_lowres_ws_floats": (c_int64, [c_int] * 6),
+    "maua_upconv_blur_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 5 + [c_float, _P, _P]),
+    "maua_styledconv_rgbpart_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, _P, c_int]
+                                           + [c_int] * 5 + [c_float, _P]),
     "maua_style_affine_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "maua_demod_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, _P]),
     "maua_pack_weight_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

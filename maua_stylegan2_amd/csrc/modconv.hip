@@ -85,6 +85,7 @@ struct ConvGeom {
     int flat;         // transposed mode: tiles are runs of BN consecutive positions of the row-major (H+1)x(W+1) grid
     int rgb;          // fused ToRGB epilogue: 0 off, 1 on, 2 on and the feature map itself is not stored
     float rgb_wscale;
+    int force_ws;     // the partial sums go to the workspace slabs also when K is not split (the low-resolution entries reduce them themselves)
 #ifdef MAUA_EXPERIMENTS
     int debug;        // (maua_tuning_set key 1) 1 skip stores, 2 skip MFMA, 4 skip loads, 32 skip weight DMA, 64 skip patch loads,
                       // 128 fold the patch loads onto 4 KB per channel (always cache hits; wrong results).  Not a member of the product's struct.
@@ -710,7 +711,7 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     // Per-channel epilogue operands (wscale * demod, bias) go through LDS: fetched once per workgroup with all loads in
     // flight together.  (Loading them per accumulator element from global memory serialises ~64 dependent L2 round
     // trips behind the stores — that was ~45 % of the lifetime of a 32-channel 1024^2 workgroup.)
-    const bool to_ws = g.splits > 1;
+    const bool to_ws = g.splits > 1 || g.force_ws;
     float* outp = to_ws ? (p.ws + (size_t)split * g.ws_slab) : p.y;
     const float* noise_base = p.noise;
     int64_t noise_bstride = g.noise_batch_stride;
@@ -991,6 +992,17 @@ void modconv_mfma_kernel(ConvGeom g, ConvPtrs p) {
     }
 }
 
+// The tail behind a slab sum, with every rounding spelled out (no fp contraction): reduce_tail_kernel and reduce_tail_rgbpart_kernel must
+// store the same bits for the same slabs, whatever the compiler would fuse in either context.
+__device__ __forceinline__ float slab_tail(float v, float dv, float nw, float nzv, float bv, bool act) {
+#pragma clang fp contract(off)  // (HIP's __fmul_rn / __fadd_rn are plain operators: they do not stop the contraction)
+    v = v * dv;
+    if (!act) return v;
+    const float nz = nw * nzv;
+    const float t = v + nz;
+    return lrelu_gain(t + bv);
+}
+
 // Sum split-K slabs and apply the same tail as the fused epilogue.
 __global__ __launch_bounds__(256) void reduce_tail_kernel(const float* __restrict__ ws, int splits, int64_t slab,
                                                           float* __restrict__ y, const float* __restrict__ d,
@@ -1006,24 +1018,237 @@ __global__ __launch_bounds__(256) void reduce_tail_kernel(const float* __restric
     }
     const float nw = (fuse_act && noise) ? noise_w[0] : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // every operand of this element is fetched before the first use: the slab values (up to 32, all in flight: with four at a time a
+        // 32-way split was eight dependent round trips, 8 us per launch on maps of a few KB), the demodulation factor, the noise value, the bias
+        const int64_t bc = i / plane;
+        const int64_t pix = i - bc * plane;
+        const int b = (int)(bc / cout), o = (int)(bc - (int64_t)b * cout);
+        const float dv = d ? d[bc] : 1.f;
+        const float nzv = nw != 0.f ? noise[(size_t)b * noise_batch_stride + pix] : 0.f;
+        const float bv = (fuse_act && bias) ? bias[o] : 0.f;
         float v = 0.f;
         int s = 0;
-        for (; s + 4 <= splits; s += 4) {  // 4 independent loads in flight
+        for (; s + 32 <= splits; s += 32) {
+            float a[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a[k] = ws[(size_t)(s + k) * slab + i];
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) v += (a[k] + a[k + 1]) + (a[k + 2] + a[k + 3]);  // (the association of the 4-wide form)
+        }
+        if (s + 16 <= splits) {
+            float a[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = ws[(size_t)(s + k) * slab + i];
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) v += (a[k] + a[k + 1]) + (a[k + 2] + a[k + 3]);
+            s += 16;
+        }
+        for (; s + 4 <= splits; s += 4) {
             const float a0 = ws[(size_t)s * slab + i], a1 = ws[(size_t)(s + 1) * slab + i];
             const float a2 = ws[(size_t)(s + 2) * slab + i], a3 = ws[(size_t)(s + 3) * slab + i];
             v += (a0 + a1) + (a2 + a3);
         }
         for (; s < splits; ++s) v += ws[(size_t)s * slab + i];
-        const int64_t bc = i / plane;
-        const int64_t pix = i - bc * plane;
-        const int b = (int)(bc / cout), o = (int)(bc - (int64_t)b * cout);
-        if (d) v *= d[bc];
-        if (fuse_act) {
-            float nz = 0.f;
-            if (nw != 0.f) nz = nw * noise[(size_t)b * noise_batch_stride + pix];
-            v = lrelu_gain(v + nz + (bias ? bias[o] : 0.f));
+        y[i] = slab_tail(v, dv, nw, nzv, bv, fuse_act != 0);
+    }
+}
+
+// ---- low-resolution layers (4^2 .. 32^2 outputs): the split-K reduction fused with what follows it -----------------------------------------
+// On these maps every launch is a fixed cost of 5 .. 20 us whatever it computes (tools/rocpd_timeline.py): the transposed layers ran
+// convolution -> reduce_tail -> blur + noise + act (three launches, 22 .. 33 us for the last two), the plain ones convolution -> reduce_tail ->
+// ToRGB (16 .. 29 us).  The two kernels below take the workspace slabs of the convolution directly.
+//
+// Up-sampling layer: one workgroup per (image, channel) plane.  The raw (2H+1) x (2W+1) plane — the sum of the split-K slabs times the
+// demodulation factor, exactly reduce_tail_kernel's value — is formed in LDS, then the 4 x 4 blur (pad (1, 1)), noise, bias, leaky ReLU and the
+// style fold's scale are applied in the arithmetic order of fir_tile_kernel: the result is bit-identical to the three-launch path.
+__global__ __launch_bounds__(256) void reduce_blur_tail_kernel(const float* __restrict__ ws, int splits, int64_t slab, float* __restrict__ y,
+                                                               const float* __restrict__ d, const float* __restrict__ k4,
+                                                               const float* __restrict__ noise, int64_t noise_batch_stride,
+                                                               const float* __restrict__ noise_w, const float* __restrict__ bias,
+                                                               const float* __restrict__ post_s, int post_stride, int cout, int h, int w,
+                                                               const maua_frame_source_t* __restrict__ src, int noise_slot) {
+    extern __shared__ __attribute__((aligned(16))) float raw[];  // [(2h + 3)][(2w + 3)]: the raw plane inside a border of zeros (the blur's padding)
+    const int RH = 2 * h + 1, RW = 2 * w + 1, OH = 2 * h, OW = 2 * w, PW = RW + 2;
+    const int bc = blockIdx.x, b = bc / cout, c = bc - b * cout;
+    const int tid = threadIdx.x;
+    if (src) {
+        noise_batch_stride = src->noise_stride[noise_slot];
+        noise = src->noise[noise_slot];
+        if (noise) noise += (int64_t)src->frame0 * noise_batch_stride;
+    }
+    float kf[4][4];  // flipped taps (uniform loads)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kf[i][j] = k4[(3 - i) * 4 + (3 - j)];
+    const float dv = d ? d[bc] : 1.f;
+    const float g = 1.41421356237309515f;
+    const float nw = noise ? noise_w[0] * 1.41421356237309515f : 0.f;
+    const float bs = bias ? bias[c] * 1.41421356237309515f : 0.f;
+    const float post = post_s ? post_s[(size_t)b * post_stride + c] : 1.f;
+    const float* wp = ws + (size_t)bc * RH * RW;
+    const int n_raw = RH * RW, n_out = OH * OW;
+    // the lane's noise values (at most four outputs per thread: 2h x 2w <= 1024, checked by the launcher) travel with the slab loads
+    float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (noise)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid + 256 * k < n_out) nzv[k] = noise[(size_t)b * noise_batch_stride + tid + 256 * k];
+    {
+        // a thread owns raw elements tid, tid + 256, ... (at most five: (2h + 1)(2w + 1) <= 33 x 33): the slab loads of ALL of them are issued
+        // before the first add, eight slabs at a time (element by element the plane took five dependent round trips)
+        constexpr int NE = 5;
+        float v[NE];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) v[q] = 0.f;
+        int sp = 0;
+        for (; sp + 8 <= splits; sp += 8) {
+            float a[NE][8];
+#pragma unroll
+            for (int q = 0; q < NE; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[q][k] = (tid + 256 * q < n_raw) ? wp[(size_t)(sp + k) * slab + tid + 256 * q] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                v[q] += (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);  // (reduce_tail_kernel's association)
+                v[q] += (a[q][4] + a[q][5]) + (a[q][6] + a[q][7]);
+            }
         }
-        y[i] = v;
+        for (; sp + 4 <= splits; sp += 4) {
+            float a[NE][4];
+#pragma unroll
+            for (int q = 0; q < NE; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[q][k] = (tid + 256 * q < n_raw) ? wp[(size_t)(sp + k) * slab + tid + 256 * q] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) v[q] += (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
+        }
+        for (; sp < splits; ++sp) {
+            float a[NE];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) a[q] = (tid + 256 * q < n_raw) ? wp[(size_t)sp * slab + tid + 256 * q] : 0.f;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) v[q] += a[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = tid + 256 * q;
+            if (e < n_raw) {
+                const int r = e / RW;
+                raw[(r + 1) * PW + (e - r * RW) + 1] = v[q] * dv;
+            }
+        }
+        // the border: rows 0 and RH + 1, columns 0 and RW + 1 of the rows between
+        for (int e = tid; e < 2 * PW + 2 * RH; e += 256) {
+            const int cell = e < PW ? e : e < 2 * PW ? (RH + 1) * PW + (e - PW) : (1 + ((e - 2 * PW) >> 1)) * PW + ((e & 1) ? RW + 1 : 0);
+            raw[cell] = 0.f;
+        }
+    }
+    __syncthreads();
+    float* yp = y + (size_t)bc * n_out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = tid + 256 * k;
+        if (o >= n_out) break;
+        const int Y = o / OW, X = o - Y * OW;
+        float acc = 0.f;
+        const float* win = raw + Y * PW + X;  // raw[Y - 1 + i][X - 1 + j] of the un-bordered plane
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = (i == 0 && j == 0) ? kf[0][0] * win[0] : fmaf(kf[i][j], win[i * PW + j], acc);
+        const float tt = fmaf(acc, g, fmaf(nw, nzv[k], bs));
+        yp[o] = fmaxf(tt, 0.2f * tt) * post;
+    }
+}
+
+// Plain layer followed by a ToRGB: one workgroup per (image, group of 32 output channels, PT pixels; PT = 32, or 16 on 4 x 4 maps).  A thread
+// sums the slabs of 32 PT / 256 elements (channels cl, cl + 256 / PT, ... of the group at one pixel: a wave instruction reads whole 128-byte
+// rows of PT pixels), applies reduce_tail_kernel's tail (the stored feature map is bit-identical to that kernel's) and multiplies the activated
+// values by their channels' three modulated ToRGB weights; the 32 channels of the group meet in LDS and leave as three partial planes
+// rgb_part [B][3 * (cout / 32)][H][W] (plane 3 g + colour), which maua_torgb_f32's plane-sum form (5 us) turns into the image — instead of
+// a ToRGB pass that re-reads the feature map (10 .. 22 us on these maps).
+template <int PT>
+__global__ __launch_bounds__(256) void reduce_tail_rgbpart_kernel(const float* __restrict__ ws, int splits, int64_t slab, float* __restrict__ y,
+                                                                  const float* __restrict__ d, const float* __restrict__ noise,
+                                                                  int64_t noise_batch_stride, const float* __restrict__ noise_w,
+                                                                  const float* __restrict__ bias, const float* __restrict__ rgb_w,
+                                                                  const float* __restrict__ rgb_s, int s_stride, float rgb_wscale,
+                                                                  float* __restrict__ rgb_part, int cout, int plane,
+                                                                  const maua_frame_source_t* __restrict__ src, int noise_slot) {
+    constexpr int CL = 256 / PT;   // channel lanes
+    constexpr int NC = 32 / CL;    // channels per thread
+    __shared__ float part[3][CL][PT];
+    const int tid = threadIdx.x, px = tid % PT, cl = tid / PT;
+    const int ptiles = plane / PT, groups = cout / 32;
+    int t = blockIdx.x;
+    const int pt = t % ptiles;
+    t /= ptiles;
+    const int gidx = t % groups, b = t / groups;
+    const int pix = pt * PT + px;
+    if (src) {
+        noise_batch_stride = src->noise_stride[noise_slot];
+        noise = src->noise[noise_slot];
+        if (noise) noise += (int64_t)src->frame0 * noise_batch_stride;
+    }
+    const float nw = noise ? noise_w[0] : 0.f;
+    const float nzv = nw != 0.f ? noise[(size_t)b * noise_batch_stride + pix] : 0.f;
+    float dv[NC], bv[NC], ms[NC], w0[NC], w1[NC], w2[NC], v[NC];
+    int64_t idx[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = gidx * 32 + cl + CL * q;
+        const int64_t bc = (int64_t)b * cout + c;
+        idx[q] = bc * plane + pix;
+        dv[q] = d ? d[bc] : 1.f;
+        bv[q] = bias ? bias[c] : 0.f;
+        ms[q] = rgb_s[(size_t)b * s_stride + c];
+        w0[q] = rgb_w[c], w1[q] = rgb_w[cout + c], w2[q] = rgb_w[2 * cout + c];
+        v[q] = 0.f;
+    }
+    int sp = 0;
+    for (; sp + 8 <= splits; sp += 8) {  // eight slabs of every element in flight
+        float a[NC][8];
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[q][k] = ws[(size_t)(sp + k) * slab + idx[q]];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            v[q] += (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);  // (reduce_tail_kernel's association)
+            v[q] += (a[q][4] + a[q][5]) + (a[q][6] + a[q][7]);
+        }
+    }
+    for (; sp + 4 <= splits; sp += 4) {
+        float a[NC][4];
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[q][k] = ws[(size_t)(sp + k) * slab + idx[q]];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) v[q] += (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
+    }
+    for (; sp < splits; ++sp)
+#pragma unroll
+        for (int q = 0; q < NC; ++q) v[q] += ws[(size_t)sp * slab + idx[q]];
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const float t2 = slab_tail(v[q], dv[q], nw, nzv, bv[q], true);
+        y[idx[q]] = t2;
+        // modulated ToRGB weights as torgb_kernel forms them: (wscale * w) * s
+        r0 = fmaf((rgb_wscale * w0[q]) * ms[q], t2, r0);
+        r1 = fmaf((rgb_wscale * w1[q]) * ms[q], t2, r1);
+        r2 = fmaf((rgb_wscale * w2[q]) * ms[q], t2, r2);
+    }
+    part[0][cl][px] = r0, part[1][cl][px] = r1, part[2][cl][px] = r2;
+    __syncthreads();
+    if (tid < 3 * PT) {
+        const int col = tid / PT, q = tid % PT;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < CL; ++k) a += part[col][k][q];
+        rgb_part[((size_t)b * 3 * groups + 3 * gidx + col) * plane + pt * PT + q] = a;
     }
 }
 
@@ -1343,8 +1568,11 @@ struct RgbArgs {
 int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, int batch,
                  int cin, int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise,
                  int64_t noise_batch_stride, const float* noise_w, const float* bias, float* ws, const RgbArgs* rgb,
-                 const maua_frame_source_t* src, int noise_slot, const float* post_s, void* stream) {
+                 const maua_frame_source_t* src, int noise_slot, const float* post_s, void* stream, int* partial_splits = nullptr) {
+    // partial_splits != NULL (modes 0 and 1, the low-resolution entries): the convolution leaves its split-K slabs (one slab when K is not
+    // split) in ws and the caller reduces them; *partial_splits receives the slab count
     if (!x || !wp || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
+    if (partial_splits && (up > 1 || rgb || !ws)) return MAUA_EINVAL;
     // the style fold (include/maua_hip.h): s == NULL = x arrives multiplied by this layer's styles — the 2-D Winograd and the F(2,2)^2
     // transposed kernels have instances without the multiply; post_s = the consumer's styles, applied to the stored map by the
     // 2-D Winograd kernels' epilogue
@@ -1378,6 +1606,7 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
     if (up == 4 && (fuse_act || rgb)) return MAUA_EINVAL;  // raw output only: the blur kernel applies the tail
     Plan pl = make_plan(batch, cin, cout, h, w, up);
     if (pl.g.splits > 1 && !ws) return MAUA_EINVAL;
+    pl.g.force_ws = partial_splits ? 1 : 0;
     pl.g.s_stride = s_stride;
     pl.g.wscale = wscale;
     pl.g.fuse_act = fuse_act;
@@ -1425,6 +1654,10 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
         else rc = launch_conv<128, 128, 2, 0>(pl, ptrs, st);
     }
     if (rc) return rc;
+    if (partial_splits) {
+        *partial_splits = pl.g.splits;
+        return 0;
+    }
     if (pl.g.splits > 1) {
         const int64_t total = pl.g.ws_slab;
         const int64_t blocks = ceil_div64(total, 256);
@@ -1443,6 +1676,66 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
                                    const float* bias, float* ws, const maua_frame_source_t* src, int noise_slot, void* stream) {
     return modconv_impl(x, wp, s, s_stride, d, y, batch, cin, cout, h, w, up, wscale, fuse_act, noise, noise_batch_stride,
                         noise_w, bias, ws, nullptr, src, noise_slot, nullptr, stream);
+}
+
+// ---- low-resolution entries: convolution (modes 0 / 1) + the fused reducers above
+extern "C" int maua_lowres_ok(int cin, int cout, int h, int w, int up) {
+    if (cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    if (up) return 4 * h * w <= 1024;                                   // reduce_blur_tail_kernel: at most four outputs per thread
+    return cout % 32 == 0 && (h * w) % 16 == 0 && h * w <= 1024;        // reduce_tail_rgbpart_kernel: 32-channel groups, 16 / 32-pixel tiles
+}
+
+extern "C" int64_t maua_lowres_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
+    if (batch <= 0 || !maua_lowres_ok(cin, cout, h, w, up)) return 0;
+    Plan pl = make_plan(batch, cin, cout, h, w, up ? 1 : 0);
+    return pl.g.ws_slab * pl.g.splits;
+}
+
+extern "C" int maua_upconv_blur_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, float* ws,
+                                           const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                           const float* bias, const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout,
+                                           int h, int w, float wscale, const float* post_s, void* stream) {
+    if (!x || !wp || !s || !y || !ws || !k4 || batch <= 0) return MAUA_EINVAL;
+    if (!maua_lowres_ok(cin, cout, h, w, 1)) return MAUA_ENOSYS;
+    if ((noise || src) && !noise_w) return MAUA_EINVAL;
+    if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
+    int splits = 0;
+    // (the convolution writes slabs only: y is passed as a non-null placeholder)
+    if (int rc = modconv_impl(x, wp, s, s_stride, nullptr, y, batch, cin, cout, h, w, 1, wscale, 0, nullptr, 0, nullptr, nullptr, ws, nullptr,
+                              nullptr, 0, nullptr, stream, &splits))
+        return rc;
+    const int64_t slab = (int64_t)batch * cout * (2 * h + 1) * (2 * w + 1);
+    const size_t lds = (size_t)(2 * h + 3) * (2 * w + 3) * sizeof(float);
+    hipLaunchKernelGGL(reduce_blur_tail_kernel, dim3((unsigned)(batch * cout)), dim3(256), lds, (hipStream_t)stream, ws, splits, slab, y, d, k4,
+                       noise, noise_batch_stride, noise_w, bias, post_s, s_stride, cout, h, w, src, noise_slot);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int maua_styledconv_rgbpart_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y,
+                                                  float* ws, const float* noise, int64_t noise_batch_stride, const float* noise_w,
+                                                  const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
+                                                  float* rgb_partial, const maua_frame_source_t* src, int noise_slot, int batch, int cin,
+                                                  int cout, int h, int w, float wscale, void* stream) {
+    if (!x || !wp || !s || !y || !ws || !rgb_w || !rgb_s || !rgb_partial || batch <= 0) return MAUA_EINVAL;
+    if (!maua_lowres_ok(cin, cout, h, w, 0)) return MAUA_ENOSYS;
+    if ((noise || src) && !noise_w) return MAUA_EINVAL;
+    if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
+    int splits = 0;
+    if (int rc = modconv_impl(x, wp, s, s_stride, nullptr, y, batch, cin, cout, h, w, 0, wscale, 0, nullptr, 0, nullptr, nullptr, ws, nullptr,
+                              nullptr, 0, nullptr, stream, &splits))
+        return rc;
+    const int64_t slab = (int64_t)batch * cout * h * w;
+    const int pt = (h * w) % 32 == 0 ? 32 : 16;
+    const int64_t blocks = (int64_t)batch * (cout / 32) * (h * w / pt);
+    if (pt == 32)
+        hipLaunchKernelGGL(reduce_tail_rgbpart_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, splits, slab, y, d, noise,
+                           noise_batch_stride, noise_w, bias, rgb_w, rgb_s, s_stride, rgb_wscale, rgb_partial, cout, h * w, src, noise_slot);
+    else
+        hipLaunchKernelGGL(reduce_tail_rgbpart_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, splits, slab, y, d, noise,
+                           noise_batch_stride, noise_w, bias, rgb_w, rgb_s, s_stride, rgb_wscale, rgb_partial, cout, h * w, src, noise_slot);
+    MAUA_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int maua_styledconv_torgb_partial_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d,

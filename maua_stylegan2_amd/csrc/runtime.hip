@@ -5,7 +5,7 @@
 #include <stddef.h>
 #include <string.h>
 
-extern "C" int maua_abi_version(void) { return 4; }
+extern "C" int maua_abi_version(void) { return 5; }
 
 // src->frame0 = frame0 on `stream`: the only per-replay input traffic of a captured forward (include/maua_hip.h, frame source)
 extern "C" int maua_frame_source_seek(maua_frame_source_t* src, int frame0, void* stream) {

@@ -41,6 +41,17 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
     const float inv = 1.0f / sqrtf((float)style_dim);
     const int per_lane = style_dim / 64;
 
+    // this wave's weight rows: fetched BEFORE the latents are staged (they depend on the table entry only; behind the staging barrier their
+    // round trip was a fourth dependent one on a launch the whole forward waits for)
+    float w[RPW][MAX_PER_LANE], bias[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int i = min(row0 + wave * RPW + r, L.cin - 1);
+#pragma unroll
+        for (int q = 0; q < MAX_PER_LANE; ++q)
+            w[r][q] = (q < per_lane) ? L.mod_w[(size_t)i * style_dim + q * 64 + lane] : 0.f;
+        bias[r] = L.mod_b[i];
+    }
     for (int bc = 0; bc < batch; bc += BCHUNK) {
         const int nb = min(BCHUNK, batch - bc);
         __syncthreads();
@@ -54,15 +65,6 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
             lat[e] = v;
         }
         __syncthreads();
-        float w[RPW][MAX_PER_LANE], bias[RPW];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int i = min(row0 + wave * RPW + r, L.cin - 1);
-#pragma unroll
-            for (int q = 0; q < MAX_PER_LANE; ++q)
-                w[r][q] = (q < per_lane) ? L.mod_w[(size_t)i * style_dim + q * 64 + lane] : 0.f;
-            bias[r] = L.mod_b[i];
-        }
         for (int b = 0; b < nb; ++b) {
             float acc[RPW];
 #pragma unroll
@@ -96,6 +98,16 @@ __global__ __launch_bounds__(256) void demod_kernel(const maua_style_layer_t* __
     const int per_lane = (L.cin + 63) / 64;
     const float ws2 = L.wscale * L.wscale;
 
+    float w[RPW][MAX_PER_LANE];  // (fetched before the styles are staged: see style_affine_kernel)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int o = min(row0 + wave * RPW + r, L.cout - 1);
+#pragma unroll
+        for (int q = 0; q < MAX_PER_LANE; ++q) {
+            const int i = q * 64 + lane;
+            w[r][q] = (q < per_lane && i < L.cin) ? L.wsq[(size_t)o * L.cin + i] : 0.f;
+        }
+    }
     for (int bc = 0; bc < batch; bc += BCHUNK) {
         const int nb = min(BCHUNK, batch - bc);
         __syncthreads();
@@ -105,16 +117,6 @@ __global__ __launch_bounds__(256) void demod_kernel(const maua_style_layer_t* __
             s2[e] = v * v;
         }
         __syncthreads();
-        float w[RPW][MAX_PER_LANE];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int o = min(row0 + wave * RPW + r, L.cout - 1);
-#pragma unroll
-            for (int q = 0; q < MAX_PER_LANE; ++q) {
-                const int i = q * 64 + lane;
-                w[r][q] = (q < per_lane && i < L.cin) ? L.wsq[(size_t)o * L.cin + i] : 0.f;
-            }
-        }
         for (int b = 0; b < nb; ++b) {
             float acc[RPW];
 #pragma unroll

@@ -459,6 +459,10 @@ class StyledConv(nn.Module):
     # overlapped pipeline, where the raw map's round trip competes for HBM); below, the extra tiles of its overlapped tiling cost more than
     # that round trip saves (convs.10: 0.70 against 0.56 ms; profiles/r05_fused_upconv_blur.md).  A huge value = always the two-launch path.
     fused_blur_min_width = 256
+    # the 4^2 .. 32^2 layers (split-K direct / polyphase kernels): the convolution leaves its split-K slabs and ONE more launch reduces them
+    # together with what follows — blur + noise + bias + activation of an up-sampling layer (maua_upconv_blur_lowres_f32), tail + per-group
+    # partial ToRGB sums of a plain one (maua_styledconv_rgbpart_lowres_f32) — instead of reduce, then blur / ToRGB (A/B switch)
+    lowres_fusion = True
 
     def accepts_prescaled(self, h, w):
         """True when this layer's convolution has a kernel instance without the style multiplies for an [*, Cin, h, w] input (the style
@@ -482,7 +486,9 @@ class StyledConv(nn.Module):
         n_ws = lib.maua_modconv_ws_floats(b, cin, conv.out_channel, h, w, conv.conv_mode(h, w))
         # one split-K workspace PER LAYER: a shared name would be re-allocated whenever the size changes, and a captured
         # hipGraph keeps writing through the pointer of the buffer that was freed
-        ws = bufs(tag + ".ws", (n_ws,)) if n_ws else None
+        low = (self.lowres_fusion and not prescaled and conv.conv_mode(h, w) == (1 if conv.upsample else 0)
+               and lib.maua_lowres_ok(cin, conv.out_channel, h, w, int(conv.upsample)))
+        ws = bufs(tag + ".ws", (n_ws,)) if (n_ws and not low) else None
         if src is not None:
             noise = None
         if noise is not None:
@@ -545,6 +551,30 @@ class StyledConv(nn.Module):
                     rgb["done"] = True
                     rgb["u8_done"] = False  # the image is in rgb["out"] as fp32 planes: a last layer still needs the frame epilogue
                     return out
+            if low and rgb is not None and self.partial_rgb_fusion and (w % 4 == 0) and post_ptr is None:
+                t = rgb["module"]
+                skip = rgb["skip"]
+                if skip is None or (tuple(t.upsample.kernel.shape) == (4, 4) and t.upsample.factor == 2
+                                    and skip.shape[2] * 2 == h and skip.shape[3] * 2 == w):
+                    groups = conv.out_channel // 32
+                    lws = bufs(tag + ".lws", (lib.maua_lowres_ws_floats(b, cin, conv.out_channel, h, w, 0),))
+                    part = bufs(tag + ".rgb_partial", (b, 3 * groups, h, w))
+                    nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
+                    _lib.check(lib.maua_styledconv_rgbpart_lowres_f32(
+                        x.data_ptr(), conv.packed()[0].data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(), lws.data_ptr(),
+                        _lib.ptr(noise), nstride, self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
+                        s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), src, slot, b, cin, conv.out_channel, h, w,
+                        float(conv.scale), _lib.stream_ptr(x.device)), "maua_styledconv_rgbpart_lowres_f32")
+                    _lib.check(lib.maua_torgb_f32(part.data_ptr(), None, None, 0, t.bias.data_ptr(), _lib.ptr(skip),
+                                                  _lib.ptr(t.upsample.kernel) if skip is not None else None, rgb["out"].data_ptr(), b,
+                                                  3 * groups, h, w, 1.0, _lib.stream_ptr(x.device)), "maua_torgb_f32")
+                    rgb["done"] = True
+                    rgb["u8_done"] = False
+                    self.last_path = "lowres"
+                    return out
+            if ws is None and n_ws:
+                ws = bufs(tag + ".ws", (n_ws,))
+            self.last_path = "plain"
             return conv.run(x, s, s_off, d, out, ws, fuse_act=True, noise=noise, noise_w=self.noise.weight,
                             bias=self.activate.bias, src=src, slot=slot, prescaled=prescaled)
         k = conv.blur.kernel
@@ -563,6 +593,20 @@ class StyledConv(nn.Module):
                 src, slot, b, cin, conv.out_channel, h, w, float(conv.scale), post_ptr, _lib.stream_ptr(x.device)), "maua_upconv_blur_f32")
             self.posted = post_ptr is not None
             return out
+        if low and tuple(k.shape) == (4, 4) and (pad0, pad1) == (1, 1):
+            # transposed convolution -> split-K slabs, then ONE launch: slab sum, demodulation, blur, noise, bias, leaky ReLU (+ the style fold's scale)
+            self.last_path = "lowres"
+            out = bufs(tag, (b, conv.out_channel, 2 * h, 2 * w))
+            lws = bufs(tag + ".lws", (lib.maua_lowres_ws_floats(b, cin, conv.out_channel, h, w, 1),))
+            nstride = 0 if noise is None or noise.shape[0] == 1 else 4 * h * w
+            _lib.check(lib.maua_upconv_blur_lowres_f32(
+                x.data_ptr(), conv.packed()[0].data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(), lws.data_ptr(), k.data_ptr(),
+                _lib.ptr(noise), nstride, self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), src, slot, b, cin, conv.out_channel,
+                h, w, float(conv.scale), post_ptr, _lib.stream_ptr(x.device)), "maua_upconv_blur_lowres_f32")
+            self.posted = post_ptr is not None
+            return out
+        if ws is None and n_ws:
+            ws = bufs(tag + ".ws", (n_ws,))
         self.last_path = "pair"
         raw = bufs(tag + ".raw", (b, conv.out_channel, 2 * h + 1, 2 * w + 1))
         conv.run(x, s, s_off, d, raw, ws, prescaled=prescaled)
@@ -931,16 +975,23 @@ class Generator(nn.Module):
             x.copy_(self.input.input.expand(batch, -1, -1, -1))
         x = self.const_manipulation.run(x, bends, bufs, "const", src)
         li = 0
+        # min_rgb_size (reference :553,567): resolutions below it contribute no ToRGB, the skip chain starts later
+        current_size = 4
+        image = None
+        fuse1 = None
+        if (self.min_rgb_size <= current_size and not any(bd["layer"] == 1 for bd in bends)
+                and not getattr(self, "disable_rgb_fusion", False)):
+            fuse1 = dict(module=self.to_rgb1, s_off=ent[li + 1]["s_off"], skip=None, out=bufs("rgb1", (batch, 3) + tuple(x.shape[2:])),
+                         store=True)
         out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1",
-                             src=src, slot=0)  # (conv1 never posts: to_rgb1 reads its map in a pass of its own)
+                             rgb=fuse1, src=src, slot=0)  # (conv1 never posts: its consumer is a polyphase layer without a pre-scaled instance)
         posted = False  # whether `out` carries the next convolution's styles already
         out = self.conv1.manipulation.run(out, bends, bufs, "conv1", src)
         acts.append(out)
         li += 1
-        # min_rgb_size (reference :553,567): resolutions below it contribute no ToRGB, the skip chain starts later
-        current_size = 4
-        image = None
-        if self.min_rgb_size <= current_size:
+        if fuse1 is not None and fuse1.get("done"):
+            image = fuse1["out"]
+        elif self.min_rgb_size <= current_size:
             image = self.to_rgb1.run(out, s, ent[li]["s_off"], None, bufs("rgb1", (batch, 3) + tuple(out.shape[2:])))
         li += 1
         for n in range(self.log_size - 2):

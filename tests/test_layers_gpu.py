@@ -370,6 +370,118 @@ def test_fused_torgb_epilogue_equals_separate_launches(gpu, cin, cout, h, w, wit
             assert torch.isnan(feat_buf["f"]).all()  # never written
 
 
+def _lowres_setup(gpu, cin, cout, h, w, b, up, seed):
+    """A StyledConv (+ ToRGB for the plain case) with random weights, styles / demodulation factors from the table kernels, inputs."""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv, ToRGB, _style_table
+
+    r = np.random.default_rng(seed)
+    conv, rgb = StyledConv(cin, cout, 3, 512, upsample=up), ToRGB(cout, 512)
+    sd = {
+        "C.conv.weight": r.standard_normal((1, cout, cin, 3, 3)), "C.conv.modulation.weight": r.standard_normal((cin, 512)),
+        "C.conv.modulation.bias": 1 + 0.1 * r.standard_normal(cin), "C.noise.weight": np.array([0.23]),
+        "C.activate.bias": 0.3 * r.standard_normal(cout),
+        "T.bias": 0.3 * r.standard_normal((1, 3, 1, 1)), "T.upsample.kernel": seeding.fir_kernel_2d((1, 3, 3, 1), 4.0),
+        "T.conv.weight": r.standard_normal((1, 3, cout, 1, 1)), "T.conv.modulation.weight": r.standard_normal((cout, 512)),
+        "T.conv.modulation.bias": 1 + 0.1 * r.standard_normal(cout),
+    }
+    if up:
+        sd["C.conv.blur.kernel"] = seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)
+    sd = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in sd.items()}
+    conv.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("C.")}, strict=True)
+    rgb.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("T.")}, strict=True)
+    conv, rgb = conv.to(gpu), rgb.to(gpu)
+    lib = _lib.load()
+    s1 = torch.from_numpy(r.standard_normal((b, 512)).astype(np.float32))
+    s2 = torch.from_numpy(r.standard_normal((b, 512)).astype(np.float32))
+    entries = [conv.conv.table_entry(0, 0, 0), rgb.conv.table_entry(1, cin, b * cout)]
+    table = _style_table(entries, gpu)
+    lat = torch.stack([s1, s2], 1).to(gpu).contiguous()
+    styles = torch.empty(b, cin + cout, device=gpu)
+    demod = torch.empty(b * cout, device=gpu)
+    st = _lib.stream_ptr(gpu)
+    _lib.check(lib.maua_style_affine_f32(lat.data_ptr(), b, 2, 512, None, None, table.data_ptr(), 2, max(cin, cout), styles.data_ptr(),
+                                         cin + cout, None, st), "affine")
+    _lib.check(lib.maua_demod_f32(table.data_ptr(), 2, cout, styles.data_ptr(), cin + cout, demod.data_ptr(), b, st), "demod")
+    x = torch.from_numpy(r.standard_normal((b, cin, h, w)).astype(np.float32))
+    return conv, rgb, sd, styles, demod, x, s1, s2, r
+
+
+@pytest.mark.parametrize("cin,cout,h,w,b,noise_b,post", [(512, 512, 4, 4, 8, 8, False), (512, 512, 8, 8, 8, 1, False), (512, 512, 16, 16, 3, 3, True),
+                                                           (24, 40, 5, 7, 2, 2, True), (64, 32, 16, 8, 1, 1, False), (32, 64, 1, 1, 2, 2, False)])
+def test_upconv_blur_lowres_equals_three_launches_and_oracle(gpu, cin, cout, h, w, b, noise_b, post):
+    """The low-resolution entry of an up-sampling StyledConv (polyphase convolution -> split-K slabs, then slab sum + demodulation + blur +
+    noise + bias + leaky ReLU in one launch) against the three-launch path it replaces — BIT-identical: the slab sum keeps reduce_tail_kernel's
+    association, the blur fir_tile_kernel's order — and against the oracle; with the style fold's scale on the stored map."""
+    from oracle import stylegan2_oracle as so
+
+    conv, _, sd, styles, demod, x, s1, _, r = _lowres_setup(gpu, cin, cout, h, w, b, True, cin + cout + h + w)
+    assert conv.conv.conv_mode(h, w) == 1 and _lib.load().maua_lowres_ok(cin, cout, h, w, 1) == 1
+    nz = torch.from_numpy(r.standard_normal((noise_b, 1, 2 * h, 2 * w)).astype(np.float32))
+    post_s = torch.from_numpy(r.standard_normal((b, cin + cout)).astype(np.float32)).to(gpu) if post else None
+    full = styles if not post else torch.cat([styles, post_s], 1).contiguous()  # (post_off indexes the same table: a second block of styles)
+    outs = {}
+    for fused in (True, False):
+        conv.lowres_fusion = fused
+        held = {}
+
+        def bufs(name, shape):
+            held[name] = torch.full(tuple(int(v) for v in shape), float("nan"), device=gpu)
+            return held[name]
+
+        y = conv.run(x.to(gpu), full, 0, demod.view(b, cout), nz.to(gpu), bufs, "u", post_off=(cin + cout) if post else None)
+        assert conv.last_path == ("lowres" if fused else "pair") and conv.posted == post
+        outs[fused] = y.cpu().numpy()
+    if _lib.load().maua_modconv_ws_floats(b, cin, cout, h, w, 1) > 0:  # K is split: the same slabs, the same association
+        assert np.array_equal(outs[True], outs[False])
+    else:                                                              # (wscale * d as one factor in the pair, as two here)
+        np.testing.assert_allclose(outs[True], outs[False], atol=1e-5, rtol=1e-5)
+    want = so.styled_conv(sd, "C", x, s1, nz.expand(b, -1, -1, -1) if noise_b == 1 else nz, True).numpy()
+    if post:
+        want = want * post_s[:, :cout].cpu().numpy()[:, :, None, None]
+    np.testing.assert_allclose(outs[True], want, atol=5e-4 * max(1.0, float(np.abs(want).max()) / 8), rtol=2e-4)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,b,with_skip", [(512, 512, 4, 4, 8, False), (512, 512, 8, 8, 8, True), (512, 512, 16, 16, 2, True),
+                                                        (40, 96, 4, 8, 3, True), (64, 32, 16, 16, 1, False), (32, 64, 4, 4, 2, False)])
+def test_styledconv_rgbpart_lowres_equals_separate_launches_and_oracle(gpu, cin, cout, h, w, b, with_skip):
+    """The low-resolution entry of a plain StyledConv + ToRGB (direct convolution -> split-K slabs; slab sum + tail + per-group partial ToRGB sums;
+    plane sum) against convolution, reduce + tail, ToRGB as separate launches: the feature map BIT-identical, the image within rounding of the
+    re-associated channel sum; and against the oracle."""
+    from oracle import stylegan2_oracle as so
+
+    conv, rgb, sd, styles, demod, x, s1, s2, r = _lowres_setup(gpu, cin, cout, h, w, b, False, 3 * cin + cout + h + w)
+    conv.conv.winograd_min_cout = conv.conv.winograd43_min_cout = conv.conv.winograd2d_min_cout = 1 << 30
+    assert conv.conv.conv_mode(h, w) == 0 and _lib.load().maua_lowres_ok(cin, cout, h, w, 0) == 1
+    nz = torch.from_numpy(r.standard_normal((b, 1, h, w)).astype(np.float32))
+    skip = torch.from_numpy(r.standard_normal((b, 3, h // 2, w // 2)).astype(np.float32)) if with_skip else None
+    feat_want = so.styled_conv(sd, "C", x, s1, nz, False)
+    img_want = so.to_rgb(sd, "T", feat_want, s2, skip).numpy()
+    got = {}
+    for fused in (True, False):
+        conv.lowres_fusion = fused
+        held = {}
+
+        def bufs(name, shape):
+            held[name] = torch.full(tuple(int(v) for v in shape), float("nan"), device=gpu)
+            return held[name]
+
+        img = torch.full((b, 3, h, w), float("nan"), device=gpu)
+        fuse = dict(module=rgb, s_off=cin, skip=skip.to(gpu) if with_skip else None, out=img, store=True)
+        y = conv.run(x.to(gpu), styles, 0, demod.view(b, cout), nz.to(gpu), bufs, "p", rgb=fuse)
+        assert bool(fuse.get("done")) == fused and conv.last_path == ("lowres" if fused else "plain")
+        if not fused:
+            rgb.run(y, styles, cin, skip.to(gpu) if with_skip else None, img)
+        got[fused] = (y.cpu().numpy(), img.cpu().numpy())
+    if _lib.load().maua_modconv_ws_floats(b, cin, cout, h, w, 0) > 0:
+        assert np.array_equal(got[True][0], got[False][0])
+    else:
+        np.testing.assert_allclose(got[True][0], got[False][0], atol=1e-5, rtol=1e-5)
+    scale = max(1.0, float(np.abs(img_want).max()))
+    np.testing.assert_allclose(got[True][1], got[False][1], atol=2e-5 * scale, rtol=1e-5)
+    np.testing.assert_allclose(got[True][0], feat_want.numpy(), atol=5e-4, rtol=2e-4)
+    np.testing.assert_allclose(got[True][1], img_want, atol=2e-3, rtol=1e-4)
+
+
 @pytest.mark.parametrize("cin,cout,h,w,batch", [
     (128, 64, 64, 64, 2),     # 64-row tile, flat pair runs, FAST path
     (64, 32, 48, 96, 1),      # 32-row tile (three patch slots per thread)
