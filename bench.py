@@ -124,9 +124,18 @@ def layer_breakdown(g, batch, noise_batch, stream):
     li = 0
     x = g._buf(batch, "const", (batch, 512, 4, 4))
     fuse1 = dict(module=g.to_rgb1, s_off=ent[1]["s_off"], skip=None, out=bufs("rgb1", (batch, 3, 4, 4)), store=True)
-    g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1", rgb=fuse1)
     out = g._buf(batch, "conv1", (batch, 512, 4, 4))
-    if fuse1.get("done"):  # the low-resolution entry: convolution slabs, slab sum + tail + per-group ToRGB sums, plane sum (three launches)
+    if getattr(g.conv1, "last_path", "") == "const":  # (what the captured forward ran: conv1 as T s on the constant input, csrc/constconv.hip)
+        rows.append(("conv1+to_rgb1 (constant input: y = T s, tail + partial ToRGB sums in the same launch; plane sum)", "modconv",
+                     time_calls(lambda: g._run_const_conv(s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, dict(fuse1), None, batch), 20, sp),
+                     2 * 512 * 512 * 9 * 16 * batch + 2 * 512 * 3 * 16 * batch, 0))
+        INSTANCES[rows[-1][0]] = "const_conv_kernel"
+        fuse1 = None
+    else:
+        g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1", rgb=fuse1)
+    if fuse1 is None:
+        pass
+    elif fuse1.get("done"):  # the low-resolution entry: convolution slabs, slab sum + tail + per-group ToRGB sums, plane sum (three launches)
         rows.append(("conv1+to_rgb1 (slabs, reduce + tail + partial ToRGB sums, plane sum)", "modconv",
                      time_calls(lambda: g.conv1.run(x, s, ent[0]["s_off"], demod_of(ent[0]), noise_batch[0], bufs, "c1", rgb=dict(fuse1)), 20, sp),
                      2 * 512 * 512 * 9 * 16 * batch + 2 * 512 * 3 * 16 * batch, 0))
@@ -869,6 +878,8 @@ def main():
                     """(USEFUL executed / algorithmic matrix flops, description) of a breakdown row: the multiplies the layer's algorithm needs.  The
                     fused up-sampling layers launch FUSED_OVERLAP x as many tiles (overlapped tiling: 60 of 64 columns kept, one extra tile row);
                     those redundant products keep the matrix cores busy but are not throughput — they are reported beside, never inside, `frac`."""
+                    if "constant input" in row_name:  # conv1 as y = T s (csrc/constconv.hip): fp32 VALU, 1/9 of the direct form's multiplies
+                        return (0.0, "y = T s on the vector units: no matrix-core products")
                     return EXECUTED.get(mode_of(row_name), (1.0, "direct form"))
 
                 conv_rows = [r for r in rows if r[1].startswith("modconv")]

@@ -20,7 +20,7 @@ extern "C" {
 #define MAUA_ENOSYS (-38)
 
 /* ABI version of this header; bumped on any signature change. */
-int maua_abi_version(void);  /* 5: + the low-resolution entries (maua_*_lowres_*), maua_torgb_f32's plane-sum form; 4: the style fold (post_s arguments, s == NULL; round 6); 3: + maua_upconv_blur_f32 (round 5); 2: frame source (maua_frame_source_t) arguments; no tuning entry */
+int maua_abi_version(void);  /* 5: + the low-resolution entries (maua_*_lowres_*), maua_const_styledconv_f32, maua_torgb_f32's plane-sum form; 4: the style fold (post_s arguments, s == NULL; round 6); 3: + maua_upconv_blur_f32 (round 5); 2: frame source (maua_frame_source_t) arguments; no tuning entry */
 /* Number of compute units / name of device 0 (diagnostics for bench.py). */
 int maua_device_info(int* cu_count, int* lds_bytes, char* name, int name_len);
 
@@ -262,6 +262,20 @@ int maua_styledconv_rgbpart_lowres_f32(const float* x, const float* wp, const fl
                                        const float* rgb_w, const float* rgb_s, float rgb_wscale, float* rgb_partial,
                                        const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w,
                                        float wscale, void* stream);
+
+/* conv1 on a ConstantInput (models/stylegan2.py:269-278, :547-549; csrc/constconv.hip).  The input of a generator's first StyledConv is
+ * the learned 4 x 4 constant, the same for every frame and scaled per (frame, channel) by the styles, so
+ *   y[b,o,p] = act( (wscale * sum_i T[o,p,i] s[b,i]) * d[b,o] + noise_w * noise[b,p] + bias[o] ),  T[o,p,i] = sum_taps W[o,i,ky,kx] c[i, p + (ky,kx) - 1]
+ * with T a function of the checkpoint alone: maua_pack_const_conv_f32 (w [Cout,Cin,3,3], c [Cin,4,4] -> T, Cout * 16 * Cin floats, once per
+ * weight version), then maua_const_styledconv_f32 per batch — 1/9 of the convolution's multiply-adds, one read of T, no split-K.
+ * rgb_partial != NULL: per-32-channel-group partial ToRGB sums [B, 3 * Cout / 32, 4, 4] as maua_styledconv_rgbpart_lowres_f32 leaves them.
+ * maua_const_conv_ok: h == w == 4, Cin % 8 == 0, Cout % 32 == 0 (Cin <= 1536: the styles of eight frames in LDS); MAUA_ENOSYS otherwise. */
+int maua_const_conv_ok(int cin, int cout, int h, int w);
+int maua_pack_const_conv_f32(const float* w, const float* c, float* T, int cout, int cin, int h, int wd, void* stream);
+int maua_const_styledconv_f32(const float* T, const float* s, int s_stride, const float* d, float* y, const float* noise,
+                              int64_t noise_batch_stride, const float* noise_w, const float* bias, const float* rgb_w, const float* rgb_s,
+                              float rgb_wscale, float* rgb_partial, const maua_frame_source_t* src, int noise_slot, int batch, int cin,
+                              int cout, int h, int w, float wscale, void* stream);
 
 /* The same fusion for layers wider than one weight tile (128..512 output channels, mode 5 only): every output-channel tile leaves
  * its share of the ToRGB sum  sum_{i in tile} (rgb_wscale * rgb_w[c,i] * rgb_s[b,i]) * y[b,i,Y,X]  in

@@ -71,6 +71,9 @@ _SIGNATURES = {
     "maua_upconv_blur_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 5 + [c_float, _P, _P]),
     "maua_styledconv_rgbpart_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, _P, c_int]
                                            + [c_int] * 5 + [c_float, _P]),
+    "maua_const_conv_ok": (c_int, [c_int] * 4),
+    "maua_pack_const_conv_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "maua_const_styledconv_f32": (c_int, [_P, _P, c_int, _P, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, _P, c_int] + [c_int] * 5 + [c_float, _P]),
     "maua_style_affine_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, c_int, _P, _P]),
     "maua_demod_f32": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, _P]),
     "maua_pack_weight_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

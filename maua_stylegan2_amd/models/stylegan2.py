@@ -825,6 +825,22 @@ class Generator(nn.Module):
             self._arena[key] = (chunk, used + aligned)
         return raw[:nbytes].view(dtype).view(shape)
 
+    def _const_conv_operand(self):
+        """T [Cout / 32, 16, Cin / 8, 32, 8] = conv1's weight applied to the learned constant (csrc/constconv.hip): a function of the checkpoint,
+        rebuilt when either parameter changes."""
+        w, c = self.conv1.conv.weight, self.input.input
+        key = (w.data_ptr(), w._version, c.data_ptr(), c._version, str(w.device))
+        cached = self.__dict__.get("_const_T")
+        if cached is None or cached[0] != key:
+            cout, cin = self.conv1.conv.out_channel, self.conv1.conv.in_channel
+            T = th.empty(cout * 16 * cin, dtype=th.float32, device=w.device)
+            with th.cuda.device(w.device):
+                _lib.check(_lib.load().maua_pack_const_conv_f32(_lib.require_cuda(w.detach(), "weight").data_ptr(),
+                                                                _lib.require_cuda(c.detach(), "input").data_ptr(), T.data_ptr(), cout, cin, 4, 4,
+                                                                _lib.stream_ptr(w.device)), "maua_pack_const_conv_f32")
+            self.__dict__["_const_T"] = cached = (key, T)
+        return cached[1]
+
     def _style_layers(self):
         """(module ModulatedConv2d, latent index) in forward order: conv1, to_rgb1, then per resolution
         conv_up, conv, to_rgb with latent indices i, i+1, i+2 (reference :549-569)."""
@@ -967,24 +983,35 @@ class Generator(nn.Module):
             return consumer_entry["s_off"]
 
         acts = []
+        # conv1 on a ConstantInput nobody bends: y = T s with T = W * const precomputed (csrc/constconv.hip) — no [B, C, 4, 4] copy of the
+        # constant, no convolution
+        c1 = self.conv1.conv
+        const_conv = (isinstance(self.input, ConstantInput) and self.conv1.lowres_fusion and not any(bd["layer"] == 0 for bd in bends)
+                      and tuple(self.input.input.shape[2:]) == (4, 4) and c1.kernel_size == 3 and not c1.upsample
+                      and lib.maua_const_conv_ok(c1.in_channel, c1.out_channel, 4, 4))
+        x = None
         if isinstance(self.input, LatentInput):
             x = self.input.run(latent, trunc, tl, bufs("const", (batch, self.input.channel, self.input.size, self.input.size)),
                                src=src, n_latent=self.n_latent, style_dim=self.style_dim)
-        else:
+        elif not const_conv:
             x = bufs("const", (batch,) + tuple(self.input.input.shape[1:]))
             x.copy_(self.input.input.expand(batch, -1, -1, -1))
-        x = self.const_manipulation.run(x, bends, bufs, "const", src)
+        if x is not None:
+            x = self.const_manipulation.run(x, bends, bufs, "const", src)
         li = 0
         # min_rgb_size (reference :553,567): resolutions below it contribute no ToRGB, the skip chain starts later
         current_size = 4
         image = None
         fuse1 = None
+        hw0 = tuple(self.input.input.shape[2:]) if x is None else tuple(x.shape[2:])
         if (self.min_rgb_size <= current_size and not any(bd["layer"] == 1 for bd in bends)
                 and not getattr(self, "disable_rgb_fusion", False)):
-            fuse1 = dict(module=self.to_rgb1, s_off=ent[li + 1]["s_off"], skip=None, out=bufs("rgb1", (batch, 3) + tuple(x.shape[2:])),
-                         store=True)
-        out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1",
-                             rgb=fuse1, src=src, slot=0)  # (conv1 never posts: its consumer is a polyphase layer without a pre-scaled instance)
+            fuse1 = dict(module=self.to_rgb1, s_off=ent[li + 1]["s_off"], skip=None, out=bufs("rgb1", (batch, 3) + hw0), store=True)
+        if const_conv:
+            out = self._run_const_conv(s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, 4, 4), bufs, fuse1, src, batch)
+        else:
+            out = self.conv1.run(x, s, ent[li]["s_off"], demod_of(ent[li]), noise_for(0, x.shape[2], x.shape[3]), bufs, "conv1",
+                                 rgb=fuse1, src=src, slot=0)  # (conv1 never posts: its consumer is a polyphase layer without a pre-scaled instance)
         posted = False  # whether `out` carries the next convolution's styles already
         out = self.conv1.manipulation.run(out, bends, bufs, "conv1", src)
         acts.append(out)
@@ -1038,6 +1065,40 @@ class Generator(nn.Module):
         if want_latents:
             lat_out = latent if trunc is None else tl[None, None, :] + trunc[:, None, None] * (latent - tl[None, None, :])
         return image, acts, lat_out
+
+    def _run_const_conv(self, s, s_off, d, noise, bufs, rgb, src, batch):
+        """conv1 + noise + bias + activation (+ the partial ToRGB sums of to_rgb1 and their plane sum) on the constant input: one launch of
+        maua_const_styledconv_f32 (+ one of maua_torgb_f32's plane-sum form)."""
+        lib = _lib.load()
+        m, c1 = self.conv1, self.conv1.conv
+        dev = self.input.input.device
+        cin, cout = c1.in_channel, c1.out_channel
+        out = bufs("conv1", (batch, cout, 4, 4))
+        if src is not None:
+            noise = None
+        if noise is not None:
+            noise = _lib.require_cuda(noise, "noise")
+            if noise.dim() != 4 or noise.shape[1] != 1 or tuple(noise.shape[-2:]) != (4, 4) or noise.shape[0] not in (1, batch):
+                raise RuntimeError(f"noise {tuple(noise.shape)} does not match feature map [{batch}, 1, 4, 4] (batch must be 1 or {batch})")
+            noise = noise.contiguous()
+        nstride = 0 if noise is None or noise.shape[0] == 1 else 16
+        part, t = None, None
+        if rgb is not None:
+            t = rgb["module"]
+            part = bufs("conv1.rgb_partial", (batch, 3 * (cout // 32), 4, 4))
+        st = _lib.stream_ptr(dev)
+        _lib.check(lib.maua_const_styledconv_f32(
+            self._const_conv_operand().data_ptr(), s.data_ptr() + 4 * s_off, s.shape[1], _lib.ptr(d), out.data_ptr(), _lib.ptr(noise), nstride,
+            m.noise.weight.data_ptr(), m.activate.bias.data_ptr(), None if t is None else t.conv.weight.data_ptr(),
+            None if t is None else s.data_ptr() + 4 * rgb["s_off"], 0.0 if t is None else float(t.conv.scale), _lib.ptr(part), src, 0, batch,
+            cin, cout, 4, 4, float(c1.scale), st), "maua_const_styledconv_f32")
+        if rgb is not None:
+            _lib.check(lib.maua_torgb_f32(part.data_ptr(), None, None, 0, t.bias.data_ptr(), None, None, rgb["out"].data_ptr(), batch,
+                                          3 * (cout // 32), 4, 4, 1.0, st), "maua_torgb_f32")
+            rgb["done"] = True
+        m.posted = False
+        m.last_path = "const"
+        return out
 
     # ------------------------------------------------------------------ hipGraph
     def weights_key(self):

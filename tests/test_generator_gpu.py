@@ -400,3 +400,38 @@ def test_style_fold_steps_aside_for_bends_and_activation_maps(gpu):
     _, acts_off = g(styles=lat, noise=None, truncation=1.0, randomize_noise=False, input_is_latent=True, return_activation_maps=True)
     for a, b in zip(acts, acts_off):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("batch,noise_mode", [(1, "per_frame"), (8, "per_frame"), (11, "shared"), (3, "buffer")])
+def test_const_conv_equals_the_convolution_on_the_repeated_constant(gpu, batch, noise_mode):
+    """conv1 on the ConstantInput as y = T s (maua_const_styledconv_f32, T = conv1's weight applied to the constant once per checkpoint)
+    against the layer run as a convolution over const.repeat(batch) (lowres_fusion off: reference models/stylegan2.py:547-549 literally):
+    conv1's activation map, to_rgb1's contribution to the image and the whole image; and a changed constant / weight rebuilds T.  (The
+    golden-image tests of this file run with the switch on: they pin the same path against the reference's images.)"""
+    from maua_stylegan2_amd.models.stylegan2 import StyledConv
+
+    g = build(16, gpu, seed=3)
+    lat = seeding.seeded_latents(batch, g.n_latent, seed=5).to(gpu)
+    per = [n.to(gpu) for n in seeding.seeded_noise(batch, 16, seed=7)]
+    noise = per if noise_mode == "per_frame" else [n[:1] for n in per] if noise_mode == "shared" else None
+    outs = {}
+    try:
+        for on in (True, False):
+            StyledConv.lowres_fusion = on
+            img, acts = g(styles=lat, noise=noise, randomize_noise=False, input_is_latent=True, return_activation_maps=True)
+            assert g.conv1.last_path == ("const" if on else "plain")
+            outs[on] = (img.cpu().numpy(), acts[0].cpu().numpy())
+        scale = float(np.abs(outs[False][1]).max())
+        np.testing.assert_allclose(outs[True][1], outs[False][1], atol=2e-6 * scale, rtol=2e-5)
+        np.testing.assert_allclose(outs[True][0], outs[False][0], atol=2e-5, rtol=1e-4)
+        # a new constant (in place) and a new weight (swapped Parameter, as model rewriting does) both invalidate T
+        StyledConv.lowres_fusion = True
+        g.input.input.mul_(1.5)
+        g.conv1.conv.weight = torch.nn.Parameter(g.conv1.conv.weight.detach().flip(1).contiguous())
+        img_on = g(styles=lat, noise=noise, randomize_noise=False, input_is_latent=True)[0].cpu().numpy()
+        StyledConv.lowres_fusion = False
+        img_off = g(styles=lat, noise=noise, randomize_noise=False, input_is_latent=True)[0].cpu().numpy()
+        assert np.abs(img_off - outs[False][0]).max() > 1e-3
+        np.testing.assert_allclose(img_on, img_off, atol=2e-5, rtol=1e-4)
+    finally:
+        StyledConv.lowres_fusion = True
