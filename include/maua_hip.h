@@ -249,14 +249,18 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
  *   maua_styledconv_rgbpart_lowres_f32 = maua_modconv3x3_f32(up = 0, fuse_act = 1) of a plain StyledConv — y bit-identical — that also
  *       leaves per-32-channel-group partial ToRGB sums (models/stylegan2.py:356-365) in rgb_partial [B, 3 * Cout / 32, H, W] (plane 3 g + c),
  *       which maua_torgb_f32's plane-sum form (w = s = NULL) turns into the image.
- * maua_lowres_ok: up != 0: 2H * 2W <= 1024;  up == 0: Cout % 32 == 0, H * W % 16 == 0, H * W <= 1024.  MAUA_ENOSYS otherwise.
- * `wp` = maua_pack_weight_f32 (the direct tap-major form); s must not be NULL (these kernels have no pre-scaled instance). */
+ * `up` of the up-sampling entry picks the convolution: 1 = the polyphase kernel (wp = maua_pack_weight_f32), 6 = F(2,2) on both axes of the
+ * polyphase form (csrc/modconv_up2d.hip on 16 x 16-position tiles, K split over workgroups; wp = maua_pack_weight_up2d_f32): 16-wide
+ * inputs, 25 instead of 36 products per 2 x 2 positions and that kernel's operand pipeline (the 16^2 -> 32^2 layer: 129 -> ?? us).
+ * maua_lowres_ok: up == 1: 2H * 2W <= 1024;  up == 6: W == 16, H % 16 == 0, Cin % 8 == 0, Cout % 32 == 0, 2H * 2W <= 1024;
+ * up == 0: Cout % 32 == 0, H * W % 16 == 0, H * W <= 1024.  MAUA_ENOSYS otherwise.
+ * `wp` of the plain entry = maua_pack_weight_f32 (the direct tap-major form); s must not be NULL (no pre-scaled instances here). */
 int maua_lowres_ok(int cin, int cout, int h, int w, int up);
 int64_t maua_lowres_ws_floats(int batch, int cin, int cout, int h, int w, int up);
 int maua_upconv_blur_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, float* ws,
                                 const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
-                                const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w, float wscale,
-                                const float* post_s, void* stream);
+                                const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w, int up,
+                                float wscale, const float* post_s, void* stream);
 int maua_styledconv_rgbpart_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, float* ws,
                                        const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                                        const float* rgb_w, const float* rgb_s, float rgb_wscale, float* rgb_partial,

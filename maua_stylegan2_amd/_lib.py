@@ -68,7 +68,7 @@ _SIGNATURES = {
     "maua_upconv_blur_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 5 + [c_float, _P, _P]),
     "maua_lowres_ok": (c_int, [c_int] * 5),
     "maua_lowres_ws_floats": (c_int64, [c_int] * 6),
-    "maua_upconv_blur_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 5 + [c_float, _P, _P]),
+    "maua_upconv_blur_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 6 + [c_float, _P, _P]),
     "maua_styledconv_rgbpart_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, _P, c_int]
                                            + [c_int] * 5 + [c_float, _P]),
     "maua_const_conv_ok": (c_int, [c_int] * 4),

@@ -58,6 +58,12 @@ int64_t maua_up2d_ws_floats(int batch, int cin, int h);
 int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
                      int cout, int h, int w, float wscale, void* stream);
 
+// ... its form for 16-wide inputs with K split over several workgroups per tile (partial raw maps in slabs; maua_upconv_blur_lowres_f32, up = 6)
+int maua_up2d16_ok(int cin, int cout, int h, int w);
+int maua_up2d16_splits(int batch, int cin, int cout, int h, int w);
+int maua_up2d16_launch(const float* x, const float* wq, const float* s, int s_stride, float* y, float* xcol, int batch, int cin, int cout, int h,
+                       int w, float wscale, int* splits_out, void* stream);
+
 // modconv_sbf16.hip (mode 7 of maua_modconv3x3_f32; side measurement, off by default): plain 3x3 convolution with split-bf16 products
 int maua_sbf16_ok(int cin, int cout, int h, int w);
 const char* maua_sbf16_last_instance();

@@ -1066,7 +1066,8 @@ __global__ __launch_bounds__(256) void reduce_blur_tail_kernel(const float* __re
                                                                const float* __restrict__ noise, int64_t noise_batch_stride,
                                                                const float* __restrict__ noise_w, const float* __restrict__ bias,
                                                                const float* __restrict__ post_s, int post_stride, int cout, int h, int w,
-                                                               const maua_frame_source_t* __restrict__ src, int noise_slot) {
+                                                               const maua_frame_source_t* __restrict__ src, int noise_slot, int edge_slab0) {
+    // edge_slab0 (the F(2,2)^2 form, modconv_up2d.hip): raw row 2h and column 2w are written by the edge kernel, into slab 0 only
     extern __shared__ __attribute__((aligned(16))) float raw[];  // [(2h + 3)][(2w + 3)]: the raw plane inside a border of zeros (the blur's padding)
     const int RH = 2 * h + 1, RW = 2 * w + 1, OH = 2 * h, OW = 2 * w, PW = RW + 2;
     const int bc = blockIdx.x, b = bc / cout, c = bc - b * cout;
@@ -1099,15 +1100,20 @@ __global__ __launch_bounds__(256) void reduce_blur_tail_kernel(const float* __re
         // before the first add, eight slabs at a time (element by element the plane took five dependent round trips)
         constexpr int NE = 5;
         float v[NE];
+        int nsl[NE];  // slabs that hold this element
 #pragma unroll
-        for (int q = 0; q < NE; ++q) v[q] = 0.f;
+        for (int q = 0; q < NE; ++q) {
+            v[q] = 0.f;
+            const int e = tid + 256 * q, r = e / RW;
+            nsl[q] = e >= n_raw ? 0 : (edge_slab0 && (r == RH - 1 || e - r * RW == RW - 1)) ? 1 : splits;
+        }
         int sp = 0;
         for (; sp + 8 <= splits; sp += 8) {
             float a[NE][8];
 #pragma unroll
             for (int q = 0; q < NE; ++q)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a[q][k] = (tid + 256 * q < n_raw) ? wp[(size_t)(sp + k) * slab + tid + 256 * q] : 0.f;
+                for (int k = 0; k < 8; ++k) a[q][k] = (sp + k < nsl[q]) ? wp[(size_t)(sp + k) * slab + tid + 256 * q] : 0.f;
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 v[q] += (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);  // (reduce_tail_kernel's association)
@@ -1119,14 +1125,14 @@ __global__ __launch_bounds__(256) void reduce_blur_tail_kernel(const float* __re
 #pragma unroll
             for (int q = 0; q < NE; ++q)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[q][k] = (tid + 256 * q < n_raw) ? wp[(size_t)(sp + k) * slab + tid + 256 * q] : 0.f;
+                for (int k = 0; k < 4; ++k) a[q][k] = (sp + k < nsl[q]) ? wp[(size_t)(sp + k) * slab + tid + 256 * q] : 0.f;
 #pragma unroll
             for (int q = 0; q < NE; ++q) v[q] += (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
         }
         for (; sp < splits; ++sp) {
             float a[NE];
 #pragma unroll
-            for (int q = 0; q < NE; ++q) a[q] = (tid + 256 * q < n_raw) ? wp[(size_t)sp * slab + tid + 256 * q] : 0.f;
+            for (int q = 0; q < NE; ++q) a[q] = (sp < nsl[q]) ? wp[(size_t)sp * slab + tid + 256 * q] : 0.f;
 #pragma unroll
             for (int q = 0; q < NE; ++q) v[q] += a[q];
         }
@@ -1680,13 +1686,16 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
 
 // ---- low-resolution entries: convolution (modes 0 / 1) + the fused reducers above
 extern "C" int maua_lowres_ok(int cin, int cout, int h, int w, int up) {
-    if (cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    if (cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (up != 0 && up != 1 && up != 6)) return 0;
+    if (up == 6) return 4 * h * w <= 1024 && maua_up2d16_ok(cin, cout, h, w);  // the F(2,2)^2 kernel's 16-column tiles (modconv_up2d.hip)
     if (up) return 4 * h * w <= 1024;                                   // reduce_blur_tail_kernel: at most four outputs per thread
     return cout % 32 == 0 && (h * w) % 16 == 0 && h * w <= 1024;        // reduce_tail_rgbpart_kernel: 32-channel groups, 16 / 32-pixel tiles
 }
 
 extern "C" int64_t maua_lowres_ws_floats(int batch, int cin, int cout, int h, int w, int up) {
     if (batch <= 0 || !maua_lowres_ok(cin, cout, h, w, up)) return 0;
+    if (up == 6)  // slabs + the exported last input column
+        return (int64_t)maua_up2d16_splits(batch, cin, cout, h, w) * batch * cout * (2 * h + 1) * (2 * w + 1) + maua_up2d_ws_floats(batch, cin, h);
     Plan pl = make_plan(batch, cin, cout, h, w, up ? 1 : 0);
     return pl.g.ws_slab * pl.g.splits;
 }
@@ -1694,20 +1703,23 @@ extern "C" int64_t maua_lowres_ws_floats(int batch, int cin, int cout, int h, in
 extern "C" int maua_upconv_blur_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, float* ws,
                                            const float* k4, const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                            const float* bias, const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout,
-                                           int h, int w, float wscale, const float* post_s, void* stream) {
-    if (!x || !wp || !s || !y || !ws || !k4 || batch <= 0) return MAUA_EINVAL;
-    if (!maua_lowres_ok(cin, cout, h, w, 1)) return MAUA_ENOSYS;
+                                           int h, int w, int up, float wscale, const float* post_s, void* stream) {
+    if (!x || !wp || !s || !y || !ws || !k4 || batch <= 0 || (up != 1 && up != 6)) return MAUA_EINVAL;
+    if (!maua_lowres_ok(cin, cout, h, w, up)) return MAUA_ENOSYS;
     if ((noise || src) && !noise_w) return MAUA_EINVAL;
     if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     int splits = 0;
-    // (the convolution writes slabs only: y is passed as a non-null placeholder)
-    if (int rc = modconv_impl(x, wp, s, s_stride, nullptr, y, batch, cin, cout, h, w, 1, wscale, 0, nullptr, 0, nullptr, nullptr, ws, nullptr,
-                              nullptr, 0, nullptr, stream, &splits))
-        return rc;
     const int64_t slab = (int64_t)batch * cout * (2 * h + 1) * (2 * w + 1);
+    if (up == 6) {  // F(2,2) on both axes (wp = maua_pack_weight_up2d_f32), K split over workgroups; the exported column behind the slabs
+        float* xcol = ws + (int64_t)maua_up2d16_splits(batch, cin, cout, h, w) * slab;
+        if (int rc = maua_up2d16_launch(x, wp, s, s_stride, ws, xcol, batch, cin, cout, h, w, wscale, &splits, stream)) return rc;
+        snprintf(g_last_instance, sizeof(g_last_instance), "%s", maua_up2d_last_instance());
+    } else if (int rc = modconv_impl(x, wp, s, s_stride, nullptr, y, batch, cin, cout, h, w, 1, wscale, 0, nullptr, 0, nullptr, nullptr, ws,
+                                     nullptr, nullptr, 0, nullptr, stream, &splits))  // (the convolution writes slabs only: y is a placeholder)
+        return rc;
     const size_t lds = (size_t)(2 * h + 3) * (2 * w + 3) * sizeof(float);
     hipLaunchKernelGGL(reduce_blur_tail_kernel, dim3((unsigned)(batch * cout)), dim3(256), lds, (hipStream_t)stream, ws, splits, slab, y, d, k4,
-                       noise, noise_batch_stride, noise_w, bias, post_s, s_stride, cout, h, w, src, noise_slot);
+                       noise, noise_batch_stride, noise_w, bias, post_s, s_stride, cout, h, w, src, noise_slot, up == 6 ? 1 : 0);
     MAUA_LAUNCH_CHECK();
     return 0;
 }

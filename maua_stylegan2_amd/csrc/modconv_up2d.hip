@@ -127,6 +127,10 @@ struct Up2dArgs {
     // the style fold (round 6; include/maua_hip.h).  Producer side (FUSE == 2): post_s [B, s_stride] = the styles of the layer that consumes yb,
     // multiplied into the stored map.  Consumer side: s == NULL (instances with PRE = true) = x arrives multiplied by this layer's styles.
     const float* post_s;
+    // FUSE == 0, the low-resolution entry (maua_upconv_blur_lowres_f32 with up = 6): K is split over `splits` workgroups per tile, split k
+    // takes chunks [k * chunks_per_split, ...) and writes its partial raw map (gain = wscale, no demodulation) to y + k * slab
+    int splits, chunks_per_split;
+    int64_t slab;
 #ifdef MAUA_EXPERIMENTS
     int real_blocks;       // FUSE == 1 (tools/fuse_probe.py): blocks beyond this number repeat earlier tiles (the price of an overlapped tiling)
 #endif
@@ -159,8 +163,18 @@ __device__ __forceinline__ void u2_blur_taps(const float* k4, float (&kx)[4], fl
 
 // FUSE: 0 = the raw (2H+1) x (2W+1) map (mode 6 of maua_modconv3x3_f32); 2 = the whole up-sampling StyledConv, exact (maua_upconv_blur_f32);
 // 1 = experiments builds only: the fused epilogue with the tile halos taken as zero (the measurement that preceded the exact form)
-template <int CC, int FUSE = 0, bool PRE = false>
+// TW: position columns of a tile.  32 = 8 x 32 positions, wave w takes block row w (every layer from 32-wide inputs on); 16 = 16 x 16 positions
+// for 16-wide inputs (round 6: the 16^2 -> 32^2 layer of a generator, which ran the polyphase kernel of modconv.hip at 0.46 of the matrix
+// peak): wave w takes block rows 2 w, 2 w + 1 (lanes 0 .. 7 / 8 .. 15 of a K lane group), the staged patch is 17 rows of five 16-byte
+// segments (340 of the 352 floats per channel plane), everything else — K loop, operand layout of the packed weight — is unchanged.
+template <int CC, int FUSE = 0, bool PRE = false, int TW = 32>
 __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
+    static_assert(TW == 32 || (TW == 16 && FUSE == 0), "16-column tiles exist for the raw-output form only");
+    constexpr int T_ROWS = 256 / TW;              // position rows of a tile
+    constexpr int U2_PROWS = T_ROWS + 1;          // staged input rows: the tile's rows + the row above   (shadow the 32-column constants)
+    constexpr int U2_PSEGS = TW / 4 + 1;          // 16-byte segments per staged row: image columns tx0 - 4 .. tx0 + TW - 1
+    constexpr int U2_PWS = 4 * U2_PSEGS;          // LDS row stride (floats)
+    static_assert(U2_PROWS * U2_PWS <= U2_PLANE, "the staged plane must fit the channel pitch");
     constexpr int U2_A_FLOATS = u2_a_floats(CC), U2_PBUF = u2_pbuf(CC), U2_P_INSTR = u2_p_instr(CC);
     constexpr int A_PER_WAVE = 2 * CC / 4;                 // weight DMA instructions per wave and K step
     constexpr int P_PER_WAVE = (U2_P_INSTR + 3) / 4;       // patch DMA instructions per wave and K step (the last ones may be idle)
@@ -183,13 +197,15 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
     const int tile_x = t % p.tiles_x;
     t /= p.tiles_x;
     const int tile_y = t % p.tiles_y;                  // FUSE == 2: the vertical segment
-    const int b0 = t / p.tiles_y;
+    t /= p.tiles_y;
+    const int b0 = FUSE == 0 ? t % p.B : t;
+    const int split = FUSE == 0 ? t / p.B : 0;         // (FUSE == 0 with splits > 1: this workgroup's share of K)
     // first position column of the tile.  FUSE == 2: a tile keeps 60 of its 64 raw columns, [60 u, 60 u + 60): tile column 0 starts at position 0 and keeps its
     // lanes 0 .. 14 (the image's left padding is a true zero); the others start at the ODD position 30 u - 1 (raw column 60 u - 2) and shift
     // every lane's outputs right by two columns (its own columns 2, 3 + columns 0, 1 of lane j + 1), which keeps the stores 16-byte aligned;
     // their operand DMA segments are then only 4-byte aligned in HBM (the LDS-DMA accepts that: tools/dma_align_probe.hip)
     const bool shifted = FUSE == 2 && !FUSE_ABL(16) && tile_x > 0;
-    const int tx0 = (FUSE == 2 && !FUSE_ABL(16)) ? (tile_x ? 30 * tile_x - 1 : 0) : tile_x * 32;
+    const int tx0 = (FUSE == 2 && !FUSE_ABL(16)) ? (tile_x ? 30 * tile_x - 1 : 0) : tile_x * TW;
     const int first_tile = FUSE == 2 ? tile_y * p.seg_tiles : tile_y;
     const int n_tiles = (FUSE == 2 && !FUSE_ABL(32)) ? min(p.seg_tiles, p.tiles_total_y - first_tile) : 1;  // (ablation 32: one tile per workgroup, known at compile time; run with MAUA_FUSE_SEG=1)
     const int m0 = mt_id * U2_BM;
@@ -271,13 +287,15 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         for (int i = 0; i < MAUA_FUSE_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     for (int tile = 0; tile < n_tiles; ++tile) {
-    const int ty0 = (first_tile + tile) * 8;   // first position row of the tile
+    const int ty0 = (first_tile + tile) * T_ROWS;   // first position row of the tile
     // (FUSE == 2: everything derived from the lane id is re-derived per tile behind an opaque copy — hoisted out of the tile loop these
     // values would have to survive a K loop that uses 238 registers, i.e. live in scratch)
     int lane_t = lane;
     if constexpr (FUSE == 2) asm volatile("" : "+v"(lane_t));
     const int j_t = lane_t & 15, kq_t = lane_t >> 4;
-    const unsigned b_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + kq_t * U2_PLANE + (2 * wv) * U2_PWS + 2 * j_t + 2) * 4u;
+    // this lane's block: (row, column) = (w, j) on 32-column tiles, (2 w + j / 8, j % 8) on 16-column ones
+    const int brow_t = TW == 32 ? wv : 2 * wv + (j_t >> 3), bcol_t = TW == 32 ? j_t : (j_t & 7);
+    const unsigned b_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + kq_t * U2_PLANE + (2 * brow_t) * U2_PWS + 2 * bcol_t + 2) * 4u;
     const unsigned a_addr = lds0 + (unsigned)(kq_t * U2_BM + 2 * j_t) * 4u;
     // ---- patch DMA of this lane.  Slot s = 64 i + lane of instruction i is 16-byte slot s of the buffer:
     // channel s / 88, then row (s % 88) / 9 and segment (s % 88) % 9 (slots 81..87 of a channel are padding).  Rows above / below
@@ -313,7 +331,9 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
                 for (int b = 0; b < 2; ++b) acc_oo[a][b][m] = z4;
         }
     }
-    unsigned s_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + 2 * U2_PBUF + kq_t) * 4u;
+    const int chunk_begin = FUSE == 0 ? split * p.chunks_per_split : 0;
+    const int chunk_end = FUSE == 0 ? min(p.n_chunks, chunk_begin + p.chunks_per_split) : p.n_chunks;
+    unsigned s_addr = lds0 + (unsigned)(2 * U2_A_FLOATS + 2 * U2_PBUF + chunk_begin * CC + kq_t) * 4u;
 
     // FUSE == 2, tiles with an odd origin that reach the image's right edge: the 16-byte segment that holds column W - 1 also holds the first
     // floats of the NEXT image row where column W belongs; x[., W] feeds raw columns 2W and 2W + 1 and must be zero (columns beyond feed nothing
@@ -326,21 +346,24 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
             __syncthreads();
         }
     };
-    issue(0, 0);
+    issue(chunk_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     zero_edge(0);
     // The right-edge tiles of the first m-tile export the last input column from their staged patch (row float 35 = image column
     // tx0 + 31 = W - 1) into xcol[b][c][row]: the edge kernel then reads that column with unit stride (gathering it from x costs
     // one 128-byte line per element: 32 of the edge launch's 45 us)
-    const bool export_col = FUSE == 0 && mt_id == 0 && tx0 + 32 == p.W && wv == 3 && lane < CC * 8;
-    const int ex_c = lane >> 3, ex_r = lane & 7;
+    // (CC * T_ROWS values per chunk: the lanes of the last EXW waves)
+    constexpr int EXW = (CC * T_ROWS + 63) / 64;
+    const int ex_l = (wv - (4 - EXW)) * 64 + lane;
+    const bool export_col = FUSE == 0 && mt_id == 0 && tx0 + TW == p.W && wv >= 4 - EXW && ex_l < CC * T_ROWS;
+    const int ex_c = ex_l / T_ROWS, ex_r = ex_l % T_ROWS;
     int cur = 0;
-    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-        if (chunk + 1 < p.n_chunks) issue(chunk + 1, cur ^ 1);
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+        if (chunk + 1 < chunk_end) issue(chunk + 1, cur ^ 1);
         if (export_col)
             p.xcol[((size_t)b0 * p.Cin + (size_t)chunk * CC + ex_c) * p.H + ty0 + ex_r] =
-                Ps[cur * U2_PBUF + ex_c * U2_PLANE + (ex_r + 1) * U2_PWS + 35];
+                Ps[cur * U2_PBUF + ex_c * U2_PLANE + (ex_r + 1) * U2_PWS + TW + 3];
         static_for<0, CC / 4>([&](auto ks_c) {  // the MFMA K groups of this step: 4 channels each
         constexpr int ks = decltype(ks_c)::value;
         const unsigned ap = a_addr + (cur ? A_BUF_BYTES : 0u) + ks * KG_A_BYTES, pb = b_addr + (cur ? P_BUF_BYTES : 0u) + ks * KG_P_BYTES;
@@ -598,8 +621,9 @@ __global__ __launch_bounds__(256, 2) void modconv_up2d_kernel(Up2dArgs p) {
         // ---- epilogue: phase sums, per-channel gain, 16-byte stores of the 4 x 4 output patch
         const int OW = 2 * p.W + 1;
         const size_t plane_out = (size_t)(2 * p.H + 1) * OW;
-        float* yimg = p.y + ((size_t)b0 * p.Cout + m0) * plane_out;
-        const unsigned pix_off = (unsigned)(2 * (ty0 + 2 * wv)) * (unsigned)OW + (unsigned)(2 * (tx0 + 2 * j));
+        float* yimg = p.y + (size_t)split * p.slab + ((size_t)b0 * p.Cout + m0) * plane_out;
+        const int brow = TW == 32 ? wv : 2 * wv + (j >> 3), bcol = TW == 32 ? j : (j & 7);
+        const unsigned pix_off = (unsigned)(2 * (ty0 + 2 * brow)) * (unsigned)OW + (unsigned)(2 * (tx0 + 2 * bcol));
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -1019,6 +1043,50 @@ extern "C" int maua_exp_upconv_blur_fused_f32(const float* x, const float* wq, c
 
 int64_t maua_up2d_ws_floats(int batch, int cin, int h) { return (int64_t)batch * cin * h; }
 
+// ---- 16-wide inputs, K split over several workgroups per tile, partial raw maps in slabs (the low-resolution entry, modconv.hip)
+int maua_up2d16_ok(int cin, int cout, int h, int w) { return cin > 0 && cout > 0 && cin % 8 == 0 && cout % U2_BM == 0 && w == 16 && h >= 16 && h % 16 == 0; }
+
+// splits: until the launch covers the chip twice (two workgroups per CU), never below four K steps per workgroup
+int maua_up2d16_splits(int batch, int cin, int cout, int h, int w) {
+    const int n_chunks = cin / 8;
+    const int64_t base = (int64_t)batch * (h / 16) * (w / 16) * (cout / U2_BM);
+    int splits = 1;
+    while (base * splits < 512 && n_chunks / (splits * 2) >= 4) splits *= 2;
+    return splits;
+}
+
+// y: `splits` slabs of [B][Cout][2H+1][2W+1] (split k's partial map, gain = wscale; the edge lines — row 2H, column 2W — in slab 0 only);
+// xcol: [B][Cin][H] (the exported last input column for the edge kernel)
+int maua_up2d16_launch(const float* x, const float* wq, const float* s, int s_stride, float* y, float* xcol, int batch, int cin, int cout, int h,
+                       int w, float wscale, int* splits_out, void* stream) {
+    if (!maua_up2d16_ok(cin, cout, h, w) || !x || !wq || !s || !y || !xcol || !splits_out) return MAUA_EINVAL;
+    if ((int64_t)cin * h * w * 4 > 0x7fffffffLL || (int64_t)U2_NU * cin * cout * 4 > 0x7fffffffLL) return MAUA_EINVAL;  // descriptor ranges
+    if ((int64_t)U2_BM * (2 * h + 1) * (2 * w + 1) * 4 > 0xffffffffLL) return MAUA_EINVAL;                              // 32-bit store offsets
+    constexpr int cc = 8;
+    Up2dArgs a{};
+    a.x = x, a.wq = wq, a.s = s, a.d = nullptr, a.y = y, a.xcol = xcol;
+    a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
+    a.tiles_x = w / 16, a.tiles_y = h / 16, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
+    a.splits = maua_up2d16_splits(batch, cin, cout, h, w);
+    a.chunks_per_split = (a.n_chunks + a.splits - 1) / a.splits;
+    a.splits = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    a.slab = (int64_t)batch * cout * (2 * h + 1) * (2 * w + 1);
+    *splits_out = a.splits;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 3 * U2_BM);
+    const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles * a.splits;
+    static unsigned long long lds_ok = 0;
+    if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 0, false, 16>), &lds_ok, 160 * 1024)) return rc;
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), "modconv_up2d_kernel<8, 0, false, 16>");
+    hipLaunchKernelGGL((modconv_up2d_kernel<8, 0, false, 16>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    MAUA_LAUNCH_CHECK();
+    const int nt0 = ceil_div(w + 1, 16), nt1 = ceil_div(h, 16);
+    const int64_t eblocks = (int64_t)batch * (cout / 16) * (nt0 + nt1);
+    hipLaunchKernelGGL(up2d_edge_kernel, dim3((unsigned)eblocks), dim3(256), 0, st, a, wq + (size_t)U2_NU * cin * cout, nt0, nt1);
+    MAUA_LAUNCH_CHECK();
+    return 0;
+}
+
 int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stride, const float* d, float* y, float* ws, int batch, int cin,
                      int cout, int h, int w, float wscale, void* stream) {
     if (!maua_modconv_up2d_ok(cin, cout, h, w) || !ws) return MAUA_EINVAL;
@@ -1029,6 +1097,7 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     a.B = batch, a.Cin = cin, a.Cout = cout, a.H = h, a.W = w, a.s_stride = s_stride, a.wscale = wscale;
     const int cc = u2_cc(cin);
     a.tiles_x = w / 32, a.tiles_y = h / 8, a.m_tiles = cout / U2_BM, a.n_chunks = cin / cc;
+    a.splits = 1, a.chunks_per_split = a.n_chunks, a.slab = 0;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = sizeof(float) * ((size_t)2 * u2_a_floats(cc) + (size_t)2 * u2_pbuf(cc) + (size_t)((cin + 3) & ~3) + 3 * U2_BM);
     const int64_t blocks = (int64_t)batch * a.tiles_y * a.tiles_x * a.m_tiles;

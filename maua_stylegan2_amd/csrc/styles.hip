@@ -55,14 +55,22 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
     for (int bc = 0; bc < batch; bc += BCHUNK) {
         const int nb = min(BCHUNK, batch - bc);
         __syncthreads();
-        for (int e = tid; e < nb * style_dim; e += 256) {
-            const int b = e / style_dim, j = e - b * style_dim;
-            float v = latents[((size_t)(bc + b) * n_latent + L.lat_idx) * style_dim + j];
-            if (trunc) {
-                const float tl = trunc_latent ? trunc_latent[j] : 0.f;
-                v = tl + trunc[bc + b] * (v - tl);
+        for (int e0 = 0; e0 < nb * style_dim; e0 += 16 * 256) {  // 16 loads per thread in flight (a plain loop staged them as 16 dependent round trips)
+            float v[16], tlv[16], tr[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + tid + 256 * q;
+                const bool ok = e < nb * style_dim;
+                const int b = ok ? e / style_dim : 0, j = ok ? e - b * style_dim : 0;
+                v[q] = ok ? latents[((size_t)(bc + b) * n_latent + L.lat_idx) * style_dim + j] : 0.f;
+                tlv[q] = (ok && trunc && trunc_latent) ? trunc_latent[j] : 0.f;
+                tr[q] = (ok && trunc) ? trunc[bc + b] : 1.f;
             }
-            lat[e] = v;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + tid + 256 * q;
+                if (e < nb * style_dim) lat[e] = trunc ? tlv[q] + tr[q] * (v[q] - tlv[q]) : v[q];
+            }
         }
         __syncthreads();
         for (int b = 0; b < nb; ++b) {
@@ -111,10 +119,20 @@ __global__ __launch_bounds__(256) void demod_kernel(const maua_style_layer_t* __
     for (int bc = 0; bc < batch; bc += BCHUNK) {
         const int nb = min(BCHUNK, batch - bc);
         __syncthreads();
-        for (int e = tid; e < nb * L.cin; e += 256) {
-            const int b = e / L.cin, i = e - b * L.cin;
-            const float v = s[(size_t)(bc + b) * s_stride + L.s_off + i];
-            s2[e] = v * v;
+        for (int e0 = 0; e0 < nb * L.cin; e0 += 16 * 256) {  // (16 loads per thread in flight: see style_affine_kernel)
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + tid + 256 * q;
+                const bool ok = e < nb * L.cin;
+                const int b = ok ? e / L.cin : 0, i = ok ? e - b * L.cin : 0;
+                v[q] = ok ? s[(size_t)(bc + b) * s_stride + L.s_off + i] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + tid + 256 * q;
+                if (e < nb * L.cin) s2[e] = v[q] * v[q];
+            }
         }
         __syncthreads();
         for (int b = 0; b < nb; ++b) {

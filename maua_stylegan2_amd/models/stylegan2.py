@@ -463,6 +463,8 @@ class StyledConv(nn.Module):
     # together with what follows — blur + noise + bias + activation of an up-sampling layer (maua_upconv_blur_lowres_f32), tail + per-group
     # partial ToRGB sums of a plain one (maua_styledconv_rgbpart_lowres_f32) — instead of reduce, then blur / ToRGB (A/B switch)
     lowres_fusion = True
+    # ... and the 16-wide up-sampling layer among them on the F(2,2)^2 kernel (16 x 16-position tiles, K split) instead of the polyphase one (A/B switch)
+    lowres_up2d = True
 
     def accepts_prescaled(self, h, w):
         """True when this layer's convolution has a kernel instance without the style multiplies for an [*, Cin, h, w] input (the style
@@ -488,6 +490,8 @@ class StyledConv(nn.Module):
         # hipGraph keeps writing through the pointer of the buffer that was freed
         low = (self.lowres_fusion and not prescaled and conv.conv_mode(h, w) == (1 if conv.upsample else 0)
                and lib.maua_lowres_ok(cin, conv.out_channel, h, w, int(conv.upsample)))
+        # (up-sampling layers: 6 = the F(2,2)^2 kernel on 16-wide inputs where the shape allows it, else 1 = the polyphase kernel)
+        low_up = 6 if (low and conv.upsample and self.lowres_up2d and lib.maua_lowres_ok(cin, conv.out_channel, h, w, 6)) else 1
         ws = bufs(tag + ".ws", (n_ws,)) if (n_ws and not low) else None
         if src is not None:
             noise = None
@@ -597,12 +601,13 @@ class StyledConv(nn.Module):
             # transposed convolution -> split-K slabs, then ONE launch: slab sum, demodulation, blur, noise, bias, leaky ReLU (+ the style fold's scale)
             self.last_path = "lowres"
             out = bufs(tag, (b, conv.out_channel, 2 * h, 2 * w))
-            lws = bufs(tag + ".lws", (lib.maua_lowres_ws_floats(b, cin, conv.out_channel, h, w, 1),))
+            lws = bufs(tag + ".lws", (lib.maua_lowres_ws_floats(b, cin, conv.out_channel, h, w, low_up),))
             nstride = 0 if noise is None or noise.shape[0] == 1 else 4 * h * w
+            wpk = conv.packed_wino(6) if low_up == 6 else conv.packed()[0]
             _lib.check(lib.maua_upconv_blur_lowres_f32(
-                x.data_ptr(), conv.packed()[0].data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(), lws.data_ptr(), k.data_ptr(),
+                x.data_ptr(), wpk.data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(), lws.data_ptr(), k.data_ptr(),
                 _lib.ptr(noise), nstride, self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), src, slot, b, cin, conv.out_channel,
-                h, w, float(conv.scale), post_ptr, _lib.stream_ptr(x.device)), "maua_upconv_blur_lowres_f32")
+                h, w, low_up, float(conv.scale), post_ptr, _lib.stream_ptr(x.device)), "maua_upconv_blur_lowres_f32")
             self.posted = post_ptr is not None
             return out
         if ws is None and n_ws:

@@ -325,3 +325,133 @@ def test_partial_rgb_planes_stay_inside_their_buffers(gpu):
                                                0.1, part.data_ptr(), None, 0, post.data_ptr(), _lib.stream_ptr(gpu))
     assert rc == 0, rc
     g.check(written=("y", "rgb_partial"))
+
+
+LOWRES_UP = [  # (up, cin, cout, h, w, batch, noise_batch)
+    (1, 512, 512, 4, 4, 8, 8),     # polyphase kernel, K split 32-fold: slabs, then reduce + blur + tail
+    (1, 24, 40, 5, 7, 3, 1),       # generic loads, ragged, K not split (one slab), shared noise
+    (1, 512, 512, 8, 8, 2, 2),     # two flat runs per image
+    (6, 8, 32, 16, 16, 1, 1),      # F(2,2)^2 on 16 x 16-position tiles, minimum: one K step, one slab; exported column + edge lines
+    (6, 72, 96, 16, 16, 3, 0),     # nine K steps, three output-channel tiles, no noise
+    (6, 512, 512, 16, 16, 8, 8),   # the generator's 16^2 -> 32^2 layer at the bench batch: K split four-fold
+]
+
+
+@pytest.mark.parametrize("up,cin,cout,h,w,batch,noise_batch", LOWRES_UP)
+def test_lowres_upsampling_entry_stays_inside_its_buffers(gpu, up, cin, cout, h, w, batch, noise_batch):
+    """maua_upconv_blur_lowres_f32 (transposed convolution -> split-K slabs [+ exported column], slab sum + demodulation + blur + noise + bias +
+    act + post scale in one launch): every operand, the slab workspace at exactly maua_lowres_ws_floats and the output guarded."""
+    from oracle import ops_oracle
+
+    lib = _lib.load()
+    m, r = _layer(cin, cout, True, cin + cout + h + w + up, gpu)
+    assert lib.maua_lowres_ok(cin, cout, h, w, up) == 1
+    g = Guard(gpu)
+    stride = max(cin, cout)
+    x_ = torch.from_numpy(r.standard_normal((batch, cin, h, w)).astype(np.float32))
+    s_row = torch.from_numpy((1 + 0.3 * r.standard_normal((batch, stride))).astype(np.float32))
+    d_ = torch.from_numpy((0.5 + r.random((batch, cout))).astype(np.float32))
+    post_row = torch.from_numpy((1 + 0.3 * r.standard_normal((batch, stride))).astype(np.float32))
+    bias_ = torch.from_numpy((0.3 * r.standard_normal(cout)).astype(np.float32))
+    nz_ = torch.from_numpy(r.standard_normal((max(noise_batch, 1), 1, 2 * h, 2 * w)).astype(np.float32))
+    x, s, d, post, bias = g.inp(x_, "x"), g.inp(s_row, "s"), g.inp(d_, "d"), g.inp(post_row, "post_s"), g.inp(bias_, "bias")
+    k4, nw = g.inp(m.blur.kernel, "k4"), g.inp(torch.tensor([0.37]), "noise_w")
+    nz = g.inp(nz_, "noise") if noise_batch else None
+    wp = _packed(m, 6 if up == 6 else 0, g)
+    y = g.out((batch, cout, 2 * h, 2 * w), "y")
+    n_ws = lib.maua_lowres_ws_floats(batch, cin, cout, h, w, up)
+    assert n_ws >= batch * cout * (2 * h + 1) * (2 * w + 1)
+    ws = g.out((n_ws,), "ws")
+    rc = lib.maua_upconv_blur_lowres_f32(x.data_ptr(), wp.data_ptr(), s.data_ptr(), stride, d.data_ptr(), y.data_ptr(), ws.data_ptr(), k4.data_ptr(),
+                                         _lib.ptr(nz), 0 if noise_batch <= 1 else 4 * h * w, nw.data_ptr(), bias.data_ptr(), None, 0, batch, cin,
+                                         cout, h, w, up, float(m.scale), post.data_ptr(), _lib.stream_ptr(gpu))
+    assert rc == 0, rc
+    g.check(written=("y",))
+    raw = _direct_conv(x_, s_row[:, :cin], d_, m.weight.cpu(), True)
+    blurred = ops_oracle.upfirdn2d(raw, m.blur.kernel.cpu(), up=1, down=1, pad=(1, 1))
+    t = blurred + (0.37 * nz_ if noise_batch else 0.0) + bias_[None, :, None, None]
+    want = torch.where(t > 0, t, 0.2 * t) * 2 ** 0.5 * post_row[:, :cout, None, None]
+    assert float((y.cpu() - want).abs().max()) <= 3e-4 * float(want.abs().max())
+    # rejected: the pre-scaled form (no such instances here), a shape outside the entry's range
+    assert lib.maua_upconv_blur_lowres_f32(x.data_ptr(), wp.data_ptr(), None, stride, d.data_ptr(), y.data_ptr(), ws.data_ptr(), k4.data_ptr(), None, 0,
+                                           None, None, None, 0, batch, cin, cout, h, w, up, float(m.scale), None, None) == -22
+    assert lib.maua_lowres_ok(cin, cout, 32, 32, up) == 0 and lib.maua_lowres_ok(cin, cout, 16, 32, 6) == 0
+
+
+LOWRES_PLAIN = [(512, 512, 4, 4, 8, True), (40, 96, 4, 8, 3, True), (512, 512, 16, 16, 2, False), (64, 32, 8, 8, 1, True)]  # (cin, cout, h, w, batch, noise)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,batch,with_noise", LOWRES_PLAIN)
+def test_lowres_plain_entry_and_plane_sum_stay_inside_their_buffers(gpu, cin, cout, h, w, batch, with_noise):
+    """maua_styledconv_rgbpart_lowres_f32 (direct convolution -> slabs; slab sum + tail + per-group partial ToRGB sums) and maua_torgb_f32's
+    plane-sum form over its planes (+ bias + up-sampled skip)."""
+    lib = _lib.load()
+    m, r = _layer(cin, cout, False, cin + cout + h + w, gpu)
+    assert lib.maua_lowres_ok(cin, cout, h, w, 0) == 1
+    g = Guard(gpu)
+    f = lambda *shape: torch.from_numpy(r.standard_normal(shape).astype(np.float32))  # noqa: E731
+    stride = max(cin, cout)
+    x_, s_, d_ = f(batch, cin, h, w), 1 + 0.3 * f(batch, stride), 0.5 + torch.rand(batch, cout)
+    bias_, nz_ = 0.3 * f(cout), f(batch, 1, h, w)
+    x, s, d = g.inp(x_, "x"), g.inp(s_, "s"), g.inp(d_, "d")
+    nz, nw, bias = (g.inp(nz_, "noise") if with_noise else None), g.inp(torch.tensor([0.2]), "noise_w"), g.inp(bias_, "bias")
+    rgb_w_, rgb_s_, rgb_b_ = f(3, cout), 1 + 0.3 * f(batch, stride), 0.3 * f(3)
+    rgb_w, rgb_s, rgb_b = g.inp(rgb_w_, "rgb_w"), g.inp(rgb_s_, "rgb_s"), g.inp(rgb_b_, "rgb_bias")
+    skip_ = f(batch, 3, h // 2, w // 2)
+    skip, k4 = g.inp(skip_, "skip"), g.inp(torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)), "k4")
+    wp = _packed(m, 0, g)
+    groups = cout // 32
+    y, part, img = g.out((batch, cout, h, w), "y"), g.out((batch, 3 * groups, h, w), "rgb_partial"), g.out((batch, 3, h, w), "rgb")
+    ws = g.out((lib.maua_lowres_ws_floats(batch, cin, cout, h, w, 0),), "ws")
+    rc = lib.maua_styledconv_rgbpart_lowres_f32(x.data_ptr(), wp.data_ptr(), s.data_ptr(), stride, d.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                                _lib.ptr(nz), h * w, nw.data_ptr(), bias.data_ptr(), rgb_w.data_ptr(), rgb_s.data_ptr(), 0.1,
+                                                part.data_ptr(), None, 0, batch, cin, cout, h, w, float(m.scale), _lib.stream_ptr(gpu))
+    assert rc == 0, rc
+    rc = lib.maua_torgb_f32(part.data_ptr(), None, None, 0, rgb_b.data_ptr(), skip.data_ptr(), k4.data_ptr(), img.data_ptr(), batch, 3 * groups, h, w,
+                            1.0, _lib.stream_ptr(gpu))
+    assert rc == 0, rc
+    g.check(written=("y", "rgb_partial", "rgb"))
+    t = _direct_conv(x_, s_[:, :cin], d_, m.weight.cpu(), False) + (0.2 * nz_ if with_noise else 0.0) + bias_[None, :, None, None]
+    feat = torch.where(t > 0, t, 0.2 * t) * 2 ** 0.5
+    assert float((y.cpu() - feat).abs().max()) <= 3e-4 * float(feat.abs().max())
+    from oracle import ops_oracle
+    from maua_stylegan2_amd.models.stylegan2 import Upsample
+
+    up = Upsample([1, 3, 3, 1])
+    want = torch.einsum("co,bo,bohw->bchw", 0.1 * rgb_w_, rgb_s_[:, :cout], feat) + rgb_b_[None, :, None, None] \
+        + ops_oracle.upfirdn2d(skip_, up.kernel, up=2, down=1, pad=up.pad)
+    assert float((img.cpu() - want).abs().max()) <= 3e-4 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("batch,with_rgb", [(1, True), (8, True), (11, False)])
+def test_const_conv_stays_inside_its_buffers(gpu, batch, with_rgb):
+    """maua_pack_const_conv_f32 + maua_const_styledconv_f32 (conv1 on the constant input as y = T s): T at exactly Cout * 16 * Cin floats."""
+    lib = _lib.load()
+    cin, cout = 64, 96
+    m, r = _layer(cin, cout, False, 1234 + batch, gpu)
+    g = Guard(gpu)
+    f = lambda *shape: torch.from_numpy(r.standard_normal(shape).astype(np.float32))  # noqa: E731
+    c_, s_, d_ = f(cin, 4, 4), 1 + 0.3 * f(batch, 128), 0.5 + torch.rand(batch, cout)
+    bias_, nz_, rgb_w_, rgb_s_ = 0.3 * f(cout), f(batch, 1, 4, 4), f(3, cout), 1 + 0.3 * f(batch, 128)
+    w_in, c_in = g.inp(m.weight.reshape(cout, cin, 3, 3), "w"), g.inp(c_, "const")
+    T = g.out((cout * 16 * cin,), "T")
+    assert lib.maua_pack_const_conv_f32(w_in.data_ptr(), c_in.data_ptr(), T.data_ptr(), cout, cin, 4, 4, _lib.stream_ptr(gpu)) == 0
+    g.check(written=("T",))
+    s, d, bias, nz, nw = g.inp(s_, "s"), g.inp(d_, "d"), g.inp(bias_, "bias"), g.inp(nz_, "noise"), g.inp(torch.tensor([0.2]), "noise_w")
+    rgb_w, rgb_s = g.inp(rgb_w_, "rgb_w"), g.inp(rgb_s_, "rgb_s")
+    y = g.out((batch, cout, 4, 4), "y")
+    part = g.out((batch, 3 * (cout // 32), 4, 4), "rgb_partial") if with_rgb else None
+    rc = lib.maua_const_styledconv_f32(T.data_ptr(), s.data_ptr(), 128, d.data_ptr(), y.data_ptr(), nz.data_ptr(), 16, nw.data_ptr(), bias.data_ptr(),
+                                       rgb_w.data_ptr() if with_rgb else None, rgb_s.data_ptr() if with_rgb else None, 0.1, _lib.ptr(part), None, 0,
+                                       batch, cin, cout, 4, 4, float(m.scale), _lib.stream_ptr(gpu))
+    assert rc == 0, rc
+    g.check(written=("y",) + (("rgb_partial",) if with_rgb else ()))
+    x_ = c_[None].expand(batch, -1, -1, -1)
+    t = _direct_conv(x_, s_[:, :cin], d_, m.weight.cpu(), False) + 0.2 * nz_ + bias_[None, :, None, None]
+    feat = torch.where(t > 0, t, 0.2 * t) * 2 ** 0.5
+    assert float((y.cpu() - feat).abs().max()) <= 3e-4 * float(feat.abs().max())
+    if with_rgb:
+        want = torch.einsum("co,bo,bohw->bchw", 0.1 * rgb_w_, rgb_s_[:, :cout], feat)
+        got = part.cpu().view(batch, cout // 32, 3, 4, 4).sum(1)
+        assert float((got - want).abs().max()) <= 3e-4 * max(1.0, float(want.abs().max()))
+    assert lib.maua_const_conv_ok(cin, cout, 4, 8) == 0 and lib.maua_const_conv_ok(60, cout, 4, 4) == 0

@@ -407,7 +407,8 @@ def _lowres_setup(gpu, cin, cout, h, w, b, up, seed):
 
 
 @pytest.mark.parametrize("cin,cout,h,w,b,noise_b,post", [(512, 512, 4, 4, 8, 8, False), (512, 512, 8, 8, 8, 1, False), (512, 512, 16, 16, 3, 3, True),
-                                                           (24, 40, 5, 7, 2, 2, True), (64, 32, 16, 8, 1, 1, False), (32, 64, 1, 1, 2, 2, False)])
+                                                           (24, 40, 5, 7, 2, 2, True), (64, 32, 16, 8, 1, 1, False), (32, 64, 1, 1, 2, 2, False),
+                                                           (512, 512, 16, 16, 8, 8, False), (64, 32, 16, 16, 1, 1, True), (72, 96, 16, 16, 2, 1, False)])
 def test_upconv_blur_lowres_equals_three_launches_and_oracle(gpu, cin, cout, h, w, b, noise_b, post):
     """The low-resolution entry of an up-sampling StyledConv (polyphase convolution -> split-K slabs, then slab sum + demodulation + blur +
     noise + bias + leaky ReLU in one launch) against the three-launch path it replaces — BIT-identical: the slab sum keeps reduce_tail_kernel's
@@ -419,9 +420,10 @@ def test_upconv_blur_lowres_equals_three_launches_and_oracle(gpu, cin, cout, h, 
     nz = torch.from_numpy(r.standard_normal((noise_b, 1, 2 * h, 2 * w)).astype(np.float32))
     post_s = torch.from_numpy(r.standard_normal((b, cin + cout)).astype(np.float32)).to(gpu) if post else None
     full = styles if not post else torch.cat([styles, post_s], 1).contiguous()  # (post_off indexes the same table: a second block of styles)
+    ok6 = _lib.load().maua_lowres_ok(cin, cout, h, w, 6) == 1  # 16-wide inputs: the F(2,2)^2 kernel on 16 x 16-position tiles, K split
     outs = {}
-    for fused in (True, False):
-        conv.lowres_fusion = fused
+    for name, fused, up2d in (("pair", False, False), ("low1", True, False)) + ((("low6", True, True),) if ok6 else ()):
+        conv.lowres_fusion, conv.lowres_up2d = fused, up2d
         held = {}
 
         def bufs(name, shape):
@@ -430,11 +432,16 @@ def test_upconv_blur_lowres_equals_three_launches_and_oracle(gpu, cin, cout, h, 
 
         y = conv.run(x.to(gpu), full, 0, demod.view(b, cout), nz.to(gpu), bufs, "u", post_off=(cin + cout) if post else None)
         assert conv.last_path == ("lowres" if fused else "pair") and conv.posted == post
-        outs[fused] = y.cpu().numpy()
+        if fused:
+            assert ("up2d" in _lib.last_modconv_instance()) == up2d
+        outs[name] = y.cpu().numpy()
     if _lib.load().maua_modconv_ws_floats(b, cin, cout, h, w, 1) > 0:  # K is split: the same slabs, the same association
-        assert np.array_equal(outs[True], outs[False])
+        assert np.array_equal(outs["low1"], outs["pair"])
     else:                                                              # (wscale * d as one factor in the pair, as two here)
-        np.testing.assert_allclose(outs[True], outs[False], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(outs["low1"], outs["pair"], atol=1e-5, rtol=1e-5)
+    outs[True] = outs["low6"] if ok6 else outs["low1"]
+    if ok6:
+        np.testing.assert_allclose(outs["low6"], outs["pair"], atol=2e-4 * max(1.0, float(np.abs(outs["pair"]).max()) / 8), rtol=2e-4)
     want = so.styled_conv(sd, "C", x, s1, nz.expand(b, -1, -1, -1) if noise_b == 1 else nz, True).numpy()
     if post:
         want = want * post_s[:, :cout].cpu().numpy()[:, :, None, None]
