@@ -880,6 +880,8 @@ def main():
                     those redundant products keep the matrix cores busy but are not throughput — they are reported beside, never inside, `frac`."""
                     if "constant input" in row_name:  # conv1 as y = T s (csrc/constconv.hip): fp32 VALU, 1/9 of the direct form's multiplies
                         return (0.0, "y = T s on the vector units: no matrix-core products")
+                    if "up2d" in (INSTANCES.get(row_name) or ""):  # (the low-resolution entry runs the 16-wide layer on the F(2,2)^2 kernel)
+                        return EXECUTED[6]
                     return EXECUTED.get(mode_of(row_name), (1.0, "direct form"))
 
                 conv_rows = [r for r in rows if r[1].startswith("modconv")]
