@@ -602,6 +602,8 @@ def main():
                     help="A/B switch: every convolution multiplies its input by its styles itself (round 5's form) instead of reading a map its producer pre-multiplied")
     ap.add_argument("--no-lowres-fusion", action="store_true",
                     help="A/B switch: the 4^2 .. 32^2 layers as convolution, reduce + tail, blur / ToRGB (separate launches) instead of the low-resolution entries")
+    ap.add_argument("--no-small-winograd", action="store_true",
+                    help="A/B switch: the 8^2 / 16^2 plain layers on the direct kernel instead of Winograd F(2,3) along x")
     ap.add_argument("--no-partial-rgb", action="store_true", help="A/B switch: ToRGB of the >= 128-channel layers as a separate pass over the feature map")
     ap.add_argument("--wino2d-min-cout", type=int, default=None,
                     help="A/B switch: override ModulatedConv2d.winograd2d_min_cout (smallest layer that runs the 2-D Winograd kernel)")
@@ -651,6 +653,8 @@ def main():
         StyledConv.partial_rgb_fusion = False
     if args.no_lowres_fusion:
         StyledConv.lowres_fusion = False
+    if args.no_small_winograd:
+        ModulatedConv2d.winograd_small_min_cout = 1 << 30
     if args.no_style_fold:
         from maua_stylegan2_amd.models.stylegan2 import Generator
 

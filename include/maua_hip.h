@@ -253,8 +253,9 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
  * polyphase form (csrc/modconv_up2d.hip on 16 x 16-position tiles, K split over workgroups; wp = maua_pack_weight_up2d_f32): 16-wide
  * inputs, 25 instead of 36 products per 2 x 2 positions and that kernel's operand pipeline (the 16^2 -> 32^2 layer: 129 -> ?? us).
  * maua_lowres_ok: up == 1: 2H * 2W <= 1024;  up == 6: W == 16, H % 16 == 0, Cin % 8 == 0, Cout % 32 == 0, 2H * 2W <= 1024;
- * up == 0: Cout % 32 == 0, H * W % 16 == 0, H * W <= 1024.  MAUA_ENOSYS otherwise.
- * `wp` of the plain entry = maua_pack_weight_f32 (the direct tap-major form); s must not be NULL (no pre-scaled instances here). */
+ * up == 0 / 2 / 3 (the plain entry's `mode`: direct, Winograd F(2,3) / F(4,3) along x — 2 needs an even W, 3 W % 4 == 0): Cout % 32 == 0,
+ * H * W % 16 == 0, H * W <= 1024.  MAUA_ENOSYS otherwise.  `wp` of the plain entry = the pack of its mode (maua_pack_weight_f32 /
+ * maua_pack_weight_wino_f32 / maua_pack_weight_wino43_f32); s must not be NULL (no pre-scaled instances here). */
 int maua_lowres_ok(int cin, int cout, int h, int w, int up);
 int64_t maua_lowres_ws_floats(int batch, int cin, int cout, int h, int w, int up);
 int maua_upconv_blur_lowres_f32(const float* x, const float* wp, const float* s, int s_stride, const float* d, float* y, float* ws,
@@ -265,7 +266,7 @@ int maua_styledconv_rgbpart_lowres_f32(const float* x, const float* wp, const fl
                                        const float* noise, int64_t noise_batch_stride, const float* noise_w, const float* bias,
                                        const float* rgb_w, const float* rgb_s, float rgb_wscale, float* rgb_partial,
                                        const maua_frame_source_t* src, int noise_slot, int batch, int cin, int cout, int h, int w,
-                                       float wscale, void* stream);
+                                       int mode, float wscale, void* stream);
 
 /* conv1 on a ConstantInput (models/stylegan2.py:269-278, :547-549; csrc/constconv.hip).  The input of a generator's first StyledConv is
  * the learned 4 x 4 constant, the same for every frame and scaled per (frame, channel) by the styles, so

@@ -70,7 +70,7 @@ _SIGNATURES = {
     "maua_lowres_ws_floats": (c_int64, [c_int] * 6),
     "maua_upconv_blur_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int] + [c_int] * 6 + [c_float, _P, _P]),
     "maua_styledconv_rgbpart_lowres_f32": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, _P, c_int]
-                                           + [c_int] * 5 + [c_float, _P]),
+                                           + [c_int] * 6 + [c_float, _P]),
     "maua_const_conv_ok": (c_int, [c_int] * 4),
     "maua_pack_const_conv_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "maua_const_styledconv_f32": (c_int, [_P, _P, c_int, _P, _P, _P, c_int64, _P, _P, _P, _P, c_float, _P, _P, c_int] + [c_int] * 5 + [c_float, _P]),

@@ -1575,10 +1575,10 @@ int modconv_impl(const float* x, const float* wp, const float* s, int s_stride, 
                  int cin, int cout, int h, int w, int up, float wscale, int fuse_act, const float* noise,
                  int64_t noise_batch_stride, const float* noise_w, const float* bias, float* ws, const RgbArgs* rgb,
                  const maua_frame_source_t* src, int noise_slot, const float* post_s, void* stream, int* partial_splits = nullptr) {
-    // partial_splits != NULL (modes 0 and 1, the low-resolution entries): the convolution leaves its split-K slabs (one slab when K is not
+    // partial_splits != NULL (modes 0 .. 3, the low-resolution entries): the convolution leaves its split-K slabs (one slab when K is not
     // split) in ws and the caller reduces them; *partial_splits receives the slab count
     if (!x || !wp || !y || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return MAUA_EINVAL;
-    if (partial_splits && (up > 1 || rgb || !ws)) return MAUA_EINVAL;
+    if (partial_splits && (up > 3 || rgb || !ws)) return MAUA_EINVAL;
     // the style fold (include/maua_hip.h): s == NULL = x arrives multiplied by this layer's styles — the 2-D Winograd and the F(2,2)^2
     // transposed kernels have instances without the multiply; post_s = the consumer's styles, applied to the stored map by the
     // 2-D Winograd kernels' epilogue
@@ -1686,9 +1686,10 @@ extern "C" int maua_modconv3x3_f32(const float* x, const float* wp, const float*
 
 // ---- low-resolution entries: convolution (modes 0 / 1) + the fused reducers above
 extern "C" int maua_lowres_ok(int cin, int cout, int h, int w, int up) {
-    if (cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (up != 0 && up != 1 && up != 6)) return 0;
+    if (cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (up != 0 && up != 1 && up != 2 && up != 3 && up != 6)) return 0;
     if (up == 6) return 4 * h * w <= 1024 && maua_up2d16_ok(cin, cout, h, w);  // the F(2,2)^2 kernel's 16-column tiles (modconv_up2d.hip)
-    if (up) return 4 * h * w <= 1024;                                   // reduce_blur_tail_kernel: at most four outputs per thread
+    if (up == 1) return 4 * h * w <= 1024;                              // reduce_blur_tail_kernel: at most four outputs per thread
+    if ((up == 2 && (w & 1)) || (up == 3 && (w & 3))) return 0;         // plain layer through Winograd F(2,3) / F(4,3) along x
     return cout % 32 == 0 && (h * w) % 16 == 0 && h * w <= 1024;        // reduce_tail_rgbpart_kernel: 32-channel groups, 16 / 32-pixel tiles
 }
 
@@ -1696,7 +1697,7 @@ extern "C" int64_t maua_lowres_ws_floats(int batch, int cin, int cout, int h, in
     if (batch <= 0 || !maua_lowres_ok(cin, cout, h, w, up)) return 0;
     if (up == 6)  // slabs + the exported last input column
         return (int64_t)maua_up2d16_splits(batch, cin, cout, h, w) * batch * cout * (2 * h + 1) * (2 * w + 1) + maua_up2d_ws_floats(batch, cin, h);
-    Plan pl = make_plan(batch, cin, cout, h, w, up ? 1 : 0);
+    Plan pl = make_plan(batch, cin, cout, h, w, up);
     return pl.g.ws_slab * pl.g.splits;
 }
 
@@ -1728,13 +1729,13 @@ extern "C" int maua_styledconv_rgbpart_lowres_f32(const float* x, const float* w
                                                   float* ws, const float* noise, int64_t noise_batch_stride, const float* noise_w,
                                                   const float* bias, const float* rgb_w, const float* rgb_s, float rgb_wscale,
                                                   float* rgb_partial, const maua_frame_source_t* src, int noise_slot, int batch, int cin,
-                                                  int cout, int h, int w, float wscale, void* stream) {
-    if (!x || !wp || !s || !y || !ws || !rgb_w || !rgb_s || !rgb_partial || batch <= 0) return MAUA_EINVAL;
-    if (!maua_lowres_ok(cin, cout, h, w, 0)) return MAUA_ENOSYS;
+                                                  int cout, int h, int w, int mode, float wscale, void* stream) {
+    if (!x || !wp || !s || !y || !ws || !rgb_w || !rgb_s || !rgb_partial || batch <= 0 || (mode != 0 && mode != 2 && mode != 3)) return MAUA_EINVAL;
+    if (!maua_lowres_ok(cin, cout, h, w, mode)) return MAUA_ENOSYS;
     if ((noise || src) && !noise_w) return MAUA_EINVAL;
     if (src && (noise_slot < 0 || noise_slot >= MAUA_MAX_NOISE_SLOTS)) return MAUA_EINVAL;
     int splits = 0;
-    if (int rc = modconv_impl(x, wp, s, s_stride, nullptr, y, batch, cin, cout, h, w, 0, wscale, 0, nullptr, 0, nullptr, nullptr, ws, nullptr,
+    if (int rc = modconv_impl(x, wp, s, s_stride, nullptr, y, batch, cin, cout, h, w, mode, wscale, 0, nullptr, 0, nullptr, nullptr, ws, nullptr,
                               nullptr, 0, nullptr, stream, &splits))
         return rc;
     const int64_t slab = (int64_t)batch * cout * h * w;

@@ -168,6 +168,8 @@ class ModulatedConv2d(nn.Module):
     # plain 3x3 layers with at least this many output channels run through Winograd F(2,3) (MFMA-bound layers);
     # a huge value turns it off
     winograd_min_cout = 32
+    # ... on the maps below 32 x 32 from this many output channels (a huge value turns it off there)
+    winograd_small_min_cout = 128
     # ... and from this many output channels, on maps at least this wide, through F(4,3) (6 products per 4 outputs)
     winograd43_min_cout = 32
     winograd43_min_width = 32
@@ -219,6 +221,10 @@ class ModulatedConv2d(nn.Module):
                 and h * (w // 4) >= 128):
             return 3
         if self.out_channel >= self.winograd_min_cout and w % 2 == 0 and w >= 32 and h * (w // 2) >= 128:
+            return 2
+        # the 8^2 / 16^2 layers of a generator (128 and more channels: the 128 x 64 Winograd tile, several images per tile at 8^2): F(2,3) as well —
+        # 50 -> 41 us at 8^2, 103 -> 75 us at 16^2 for 512 channels at batch 8 (tools/plain_mode_probe.py, round 6)
+        if self.out_channel >= self.winograd_small_min_cout and w % 2 == 0 and 8 <= w < 32 and h >= 8:
             return 2
         return 0
 
@@ -488,8 +494,9 @@ class StyledConv(nn.Module):
         n_ws = lib.maua_modconv_ws_floats(b, cin, conv.out_channel, h, w, conv.conv_mode(h, w))
         # one split-K workspace PER LAYER: a shared name would be re-allocated whenever the size changes, and a captured
         # hipGraph keeps writing through the pointer of the buffer that was freed
-        low = (self.lowres_fusion and not prescaled and conv.conv_mode(h, w) == (1 if conv.upsample else 0)
-               and lib.maua_lowres_ok(cin, conv.out_channel, h, w, int(conv.upsample)))
+        low_mode = conv.conv_mode(h, w)
+        low = (self.lowres_fusion and not prescaled and low_mode in ((1,) if conv.upsample else (0, 2, 3))
+               and lib.maua_lowres_ok(cin, conv.out_channel, h, w, low_mode))
         # (up-sampling layers: 6 = the F(2,2)^2 kernel on 16-wide inputs where the shape allows it, else 1 = the polyphase kernel)
         low_up = 6 if (low and conv.upsample and self.lowres_up2d and lib.maua_lowres_ok(cin, conv.out_channel, h, w, 6)) else 1
         ws = bufs(tag + ".ws", (n_ws,)) if (n_ws and not low) else None
@@ -561,14 +568,15 @@ class StyledConv(nn.Module):
                 if skip is None or (tuple(t.upsample.kernel.shape) == (4, 4) and t.upsample.factor == 2
                                     and skip.shape[2] * 2 == h and skip.shape[3] * 2 == w):
                     groups = conv.out_channel // 32
-                    lws = bufs(tag + ".lws", (lib.maua_lowres_ws_floats(b, cin, conv.out_channel, h, w, 0),))
+                    lws = bufs(tag + ".lws", (lib.maua_lowres_ws_floats(b, cin, conv.out_channel, h, w, low_mode),))
                     part = bufs(tag + ".rgb_partial", (b, 3 * groups, h, w))
                     nstride = 0 if noise is None or noise.shape[0] == 1 else noise.shape[-1] * noise.shape[-2]
+                    wpk = conv.packed_wino(low_mode) if low_mode >= 2 else conv.packed()[0]
                     _lib.check(lib.maua_styledconv_rgbpart_lowres_f32(
-                        x.data_ptr(), conv.packed()[0].data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(), lws.data_ptr(),
+                        x.data_ptr(), wpk.data_ptr(), s_ptr, s.shape[1], _lib.ptr(d), out.data_ptr(), lws.data_ptr(),
                         _lib.ptr(noise), nstride, self.noise.weight.data_ptr(), self.activate.bias.data_ptr(), t.conv.weight.data_ptr(),
                         s.data_ptr() + 4 * rgb["s_off"], float(t.conv.scale), part.data_ptr(), src, slot, b, cin, conv.out_channel, h, w,
-                        float(conv.scale), _lib.stream_ptr(x.device)), "maua_styledconv_rgbpart_lowres_f32")
+                        low_mode, float(conv.scale), _lib.stream_ptr(x.device)), "maua_styledconv_rgbpart_lowres_f32")
                     _lib.check(lib.maua_torgb_f32(part.data_ptr(), None, None, 0, t.bias.data_ptr(), _lib.ptr(skip),
                                                   _lib.ptr(t.upsample.kernel) if skip is not None else None, rgb["out"].data_ptr(), b,
                                                   3 * groups, h, w, 1.0, _lib.stream_ptr(x.device)), "maua_torgb_f32")

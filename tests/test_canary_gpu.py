@@ -108,6 +108,7 @@ PLAIN = [  # (mode, cin, cout, h, w, batch)
     (0, 512, 512, 8, 8, 8),      # the generator's 8^2 layer at the bench batch
     (2, 64, 64, 16, 34, 1),      # Winograd F(2,3): W even, not a multiple of the tile
     (2, 512, 512, 16, 16, 2),
+    (2, 512, 512, 8, 8, 8),      # ... several images per tile (the generator's 8^2 layer at the bench batch, round 6)
     (3, 64, 96, 8, 36, 2),       # Winograd F(4,3): W % 4 == 0
     (3, 512, 512, 32, 32, 1),
     (5, 4, 32, 16, 32, 1),       # 2-D Winograd, minimum: one K step, wave-complete kernel
@@ -378,16 +379,17 @@ def test_lowres_upsampling_entry_stays_inside_its_buffers(gpu, up, cin, cout, h,
     assert lib.maua_lowres_ok(cin, cout, 32, 32, up) == 0 and lib.maua_lowres_ok(cin, cout, 16, 32, 6) == 0
 
 
-LOWRES_PLAIN = [(512, 512, 4, 4, 8, True), (40, 96, 4, 8, 3, True), (512, 512, 16, 16, 2, False), (64, 32, 8, 8, 1, True)]  # (cin, cout, h, w, batch, noise)
+LOWRES_PLAIN = [(0, 512, 512, 4, 4, 8, True), (0, 40, 96, 4, 8, 3, True), (0, 512, 512, 16, 16, 2, False), (0, 64, 32, 8, 8, 1, True),
+                (2, 512, 512, 8, 8, 8, True), (2, 512, 512, 16, 16, 2, True), (3, 128, 128, 16, 16, 1, False)]  # (mode, cin, cout, h, w, batch, noise)
 
 
-@pytest.mark.parametrize("cin,cout,h,w,batch,with_noise", LOWRES_PLAIN)
-def test_lowres_plain_entry_and_plane_sum_stay_inside_their_buffers(gpu, cin, cout, h, w, batch, with_noise):
+@pytest.mark.parametrize("mode,cin,cout,h,w,batch,with_noise", LOWRES_PLAIN)
+def test_lowres_plain_entry_and_plane_sum_stay_inside_their_buffers(gpu, mode, cin, cout, h, w, batch, with_noise):
     """maua_styledconv_rgbpart_lowres_f32 (direct convolution -> slabs; slab sum + tail + per-group partial ToRGB sums) and maua_torgb_f32's
     plane-sum form over its planes (+ bias + up-sampled skip)."""
     lib = _lib.load()
     m, r = _layer(cin, cout, False, cin + cout + h + w, gpu)
-    assert lib.maua_lowres_ok(cin, cout, h, w, 0) == 1
+    assert lib.maua_lowres_ok(cin, cout, h, w, mode) == 1
     g = Guard(gpu)
     f = lambda *shape: torch.from_numpy(r.standard_normal(shape).astype(np.float32))  # noqa: E731
     stride = max(cin, cout)
@@ -399,13 +401,13 @@ def test_lowres_plain_entry_and_plane_sum_stay_inside_their_buffers(gpu, cin, co
     rgb_w, rgb_s, rgb_b = g.inp(rgb_w_, "rgb_w"), g.inp(rgb_s_, "rgb_s"), g.inp(rgb_b_, "rgb_bias")
     skip_ = f(batch, 3, h // 2, w // 2)
     skip, k4 = g.inp(skip_, "skip"), g.inp(torch.from_numpy(seeding.fir_kernel_2d((1, 3, 3, 1), 4.0)), "k4")
-    wp = _packed(m, 0, g)
+    wp = _packed(m, mode, g)
     groups = cout // 32
     y, part, img = g.out((batch, cout, h, w), "y"), g.out((batch, 3 * groups, h, w), "rgb_partial"), g.out((batch, 3, h, w), "rgb")
-    ws = g.out((lib.maua_lowres_ws_floats(batch, cin, cout, h, w, 0),), "ws")
+    ws = g.out((lib.maua_lowres_ws_floats(batch, cin, cout, h, w, mode),), "ws")
     rc = lib.maua_styledconv_rgbpart_lowres_f32(x.data_ptr(), wp.data_ptr(), s.data_ptr(), stride, d.data_ptr(), y.data_ptr(), ws.data_ptr(),
                                                 _lib.ptr(nz), h * w, nw.data_ptr(), bias.data_ptr(), rgb_w.data_ptr(), rgb_s.data_ptr(), 0.1,
-                                                part.data_ptr(), None, 0, batch, cin, cout, h, w, float(m.scale), _lib.stream_ptr(gpu))
+                                                part.data_ptr(), None, 0, batch, cin, cout, h, w, mode, float(m.scale), _lib.stream_ptr(gpu))
     assert rc == 0, rc
     rc = lib.maua_torgb_f32(part.data_ptr(), None, None, 0, rgb_b.data_ptr(), skip.data_ptr(), k4.data_ptr(), img.data_ptr(), batch, 3 * groups, h, w,
                             1.0, _lib.stream_ptr(gpu))

@@ -448,9 +448,11 @@ def test_upconv_blur_lowres_equals_three_launches_and_oracle(gpu, cin, cout, h, 
     np.testing.assert_allclose(outs[True], want, atol=5e-4 * max(1.0, float(np.abs(want).max()) / 8), rtol=2e-4)
 
 
+@pytest.mark.parametrize("small_wino", [False, True])
 @pytest.mark.parametrize("cin,cout,h,w,b,with_skip", [(512, 512, 4, 4, 8, False), (512, 512, 8, 8, 8, True), (512, 512, 16, 16, 2, True),
-                                                        (40, 96, 4, 8, 3, True), (64, 32, 16, 16, 1, False), (32, 64, 4, 4, 2, False)])
-def test_styledconv_rgbpart_lowres_equals_separate_launches_and_oracle(gpu, cin, cout, h, w, b, with_skip):
+                                                        (40, 96, 4, 8, 3, True), (64, 32, 16, 16, 1, False), (32, 64, 4, 4, 2, False),
+                                                        (128, 256, 8, 16, 3, True)])
+def test_styledconv_rgbpart_lowres_equals_separate_launches_and_oracle(gpu, cin, cout, h, w, b, with_skip, small_wino):
     """The low-resolution entry of a plain StyledConv + ToRGB (direct convolution -> split-K slabs; slab sum + tail + per-group partial ToRGB sums;
     plane sum) against convolution, reduce + tail, ToRGB as separate launches: the feature map BIT-identical, the image within rounding of the
     re-associated channel sum; and against the oracle."""
@@ -458,7 +460,12 @@ def test_styledconv_rgbpart_lowres_equals_separate_launches_and_oracle(gpu, cin,
 
     conv, rgb, sd, styles, demod, x, s1, s2, r = _lowres_setup(gpu, cin, cout, h, w, b, False, 3 * cin + cout + h + w)
     conv.conv.winograd_min_cout = conv.conv.winograd43_min_cout = conv.conv.winograd2d_min_cout = 1 << 30
-    assert conv.conv.conv_mode(h, w) == 0 and _lib.load().maua_lowres_ok(cin, cout, h, w, 0) == 1
+    # small_wino: the 8^2 / 16^2 layers of 128 and more channels through Winograd F(2,3) along x (the generator's default), else the direct form
+    conv.conv.winograd_small_min_cout = 128 if small_wino else 1 << 30
+    want_mode = 2 if (small_wino and cout >= 128 and 8 <= w < 32 and h >= 8) else 0
+    if small_wino and want_mode == 0:
+        pytest.skip("the shape stays on the direct form either way")
+    assert conv.conv.conv_mode(h, w) == want_mode and _lib.load().maua_lowres_ok(cin, cout, h, w, want_mode) == 1
     nz = torch.from_numpy(r.standard_normal((b, 1, h, w)).astype(np.float32))
     skip = torch.from_numpy(r.standard_normal((b, 3, h // 2, w // 2)).astype(np.float32)) if with_skip else None
     feat_want = so.styled_conv(sd, "C", x, s1, nz, False)
@@ -479,7 +486,7 @@ def test_styledconv_rgbpart_lowres_equals_separate_launches_and_oracle(gpu, cin,
         if not fused:
             rgb.run(y, styles, cin, skip.to(gpu) if with_skip else None, img)
         got[fused] = (y.cpu().numpy(), img.cpu().numpy())
-    if _lib.load().maua_modconv_ws_floats(b, cin, cout, h, w, 0) > 0:
+    if _lib.load().maua_modconv_ws_floats(b, cin, cout, h, w, want_mode) > 0:
         assert np.array_equal(got[True][0], got[False][0])
     else:
         np.testing.assert_allclose(got[True][0], got[False][0], atol=1e-5, rtol=1e-5)
