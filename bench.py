@@ -170,7 +170,7 @@ def layer_breakdown(g, batch, noise_batch, stream):
             rows.append((f"convs.{2*n}.upconv+blur+noise+act (one kernel)", "modconv_up_fused", t_all, 2 * cin * cout * 9 * h * h * batch,
                          4 * batch * (cin * h * h + cout * (2 * h) ** 2)))
             # (maua_upconv_blur_f32's kernel instance; the seam pass is up2d_seam_kernel)
-            INSTANCES[rows[-1][0]] = f"modconv_up2d_kernel<8, 2, {'true' if pre_up else 'false'}>"
+            INSTANCES[rows[-1][0]] = f"modconv_up2d_kernel<8, 2, {'true' if pre_up else 'false'}, 32>"
             # workgroups = images x vertical segments x tile columns x 32-channel tiles; the segment count from the seam workspace the library
             # asks for ((segments - 1) x 6 rows of 2W floats per image and channel + 4)
             n_seg = (_lib.load().maua_upconv_blur_ws_floats(batch, cin, cout, h, h) - 4) // (batch * cout * 12 * h) + 1

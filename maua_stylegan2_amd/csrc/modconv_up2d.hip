@@ -992,7 +992,7 @@ extern "C" int maua_upconv_blur_f32(const float* x, const float* wq, const float
     static unsigned long long lds_ok = 0, lds_ok_pre = 0;
     if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 2, false>), &lds_ok, 160 * 1024)) return rc;
     if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 2, true>), &lds_ok_pre, 160 * 1024)) return rc;
-    snprintf(g_up2d_instance, sizeof(g_up2d_instance), s ? "modconv_up2d_kernel<8, 2, false>" : "modconv_up2d_kernel<8, 2, true>");
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), s ? "modconv_up2d_kernel<8, 2, false, 32>" : "modconv_up2d_kernel<8, 2, true, 32>");
     hipStream_t st = (hipStream_t)stream;
 #ifdef MAUA_EXPERIMENTS
     if (getenv("MAUA_FUSE_DEBUG")) {
@@ -1106,7 +1106,7 @@ int maua_up2d_launch(const float* x, const float* wq, const float* s, int s_stri
     if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 0, false>), &lds_ok[1], 160 * 1024)) return rc;
     if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<4, 0, true>), &lds_ok[2], 160 * 1024)) return rc;
     if (int rc = maua_allow_full_lds(reinterpret_cast<const void*>(modconv_up2d_kernel<8, 0, true>), &lds_ok[3], 160 * 1024)) return rc;
-    snprintf(g_up2d_instance, sizeof(g_up2d_instance), s ? "modconv_up2d_kernel<%d, 0, false>" : "modconv_up2d_kernel<%d, 0, true>", cc);
+    snprintf(g_up2d_instance, sizeof(g_up2d_instance), s ? "modconv_up2d_kernel<%d, 0, false, 32>" : "modconv_up2d_kernel<%d, 0, true, 32>", cc);
     if (cc == 8 && s) hipLaunchKernelGGL((modconv_up2d_kernel<8, 0, false>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     else if (cc == 8) hipLaunchKernelGGL((modconv_up2d_kernel<8, 0, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     else if (s) hipLaunchKernelGGL((modconv_up2d_kernel<4, 0, false>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);

@@ -335,6 +335,8 @@ LOWRES_UP = [  # (up, cin, cout, h, w, batch, noise_batch)
     (6, 8, 32, 16, 16, 1, 1),      # F(2,2)^2 on 16 x 16-position tiles, minimum: one K step, one slab; exported column + edge lines
     (6, 72, 96, 16, 16, 3, 0),     # nine K steps, three output-channel tiles, no noise
     (6, 512, 512, 16, 16, 8, 8),   # the generator's 16^2 -> 32^2 layer at the bench batch: K split four-fold
+    (6, 64, 32, 16, 16, 2, 2),     # one output-channel tile, two images, K split in two (the sanitizer driver's case)
+    (6, 64, 64, 32, 16, 1, 1),     # two tiles per image along y? (H = 32: outside 2H * 2W <= 1024 -> rejected; kept as the boundary of the entry)
 ]
 
 
@@ -346,6 +348,9 @@ def test_lowres_upsampling_entry_stays_inside_its_buffers(gpu, up, cin, cout, h,
 
     lib = _lib.load()
     m, r = _layer(cin, cout, True, cin + cout + h + w + up, gpu)
+    if 4 * h * w > 1024:
+        assert lib.maua_lowres_ok(cin, cout, h, w, up) == 0
+        return
     assert lib.maua_lowres_ok(cin, cout, h, w, up) == 1
     g = Guard(gpu)
     stride = max(cin, cout)

@@ -193,6 +193,51 @@ static void upconv_blur_case(int batch, int cin, int cout, int h, int w) {
     compare(name, dgot.download(), dref.download(), 2e-5f);
 }
 
+static void lowres_up_case(int batch, int cin, int cout, int h, int w, int up) {
+    // The low-resolution entry of an up-sampling layer (maua_upconv_blur_lowres_f32: convolution -> split-K slabs [up = 6: the F(2,2)^2 kernel on
+    // 16 x 16-position tiles + exported column + edge lines], slab sum + blur + tail in one launch) against polyphase convolution + reduce + blur tail.
+    if (!maua_lowres_ok(cin, cout, h, w, up)) {
+        printf("  lowres up %d->%d @%dx%d up=%d: shape not accepted, skipped\n", cin, cout, h, w, up);
+        return;
+    }
+    const size_t plane_in = (size_t)h * w, plane_raw = (size_t)(2 * h + 1) * (2 * w + 1), plane_out = (size_t)4 * h * w;
+    std::vector<float> x(batch * cin * plane_in), wt((size_t)cout * cin * 9), s((size_t)batch * cin), d((size_t)batch * cout), noise(batch * plane_out), bias(cout),
+        taps(16);
+    for (auto& v : x) v = rnd();
+    for (auto& v : wt) v = rnd();
+    for (auto& v : s) v = rnd();
+    for (auto& v : d) v = 0.75f + 0.25f * rnd();
+    for (auto& v : noise) v = rnd();
+    for (auto& v : bias) v = rnd();
+    const float t1[4] = {0.5f, 1.5f, 1.5f, 0.5f};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) taps[i * 4 + j] = t1[i] * t1[j] / 4.f;
+    const int cpad = (cout + 31) / 32 * 32;
+    DevBuf<float> dx(x.size()), dwt(wt.size()), dwp((size_t)9 * cin * cpad), dsq((size_t)cout * cin),
+        dwq(up == 6 ? (size_t)maua_pack_weight_up2d_floats(cout, cin) : 4), ds(s.size()), dd(d.size()), dn(noise.size()), db(cout), dk(16), dnw(1),
+        draw(batch * cout * plane_raw), dref(batch * cout * plane_out), dgot(batch * cout * plane_out),
+        dws((size_t)maua_modconv_ws_floats(batch, cin, cout, h, w, 1) + 4), dlws((size_t)maua_lowres_ws_floats(batch, cin, cout, h, w, up) + 4);
+    dx.upload(x), dwt.upload(wt), ds.upload(s), dd.upload(d), dn.upload(noise), db.upload(bias), dk.upload(taps), dnw.upload(std::vector<float>{0.3f});
+    const float wscale = 1.f / std::sqrt((float)cin * 9.f);
+    int rc_pack = maua_pack_weight_f32(dwt.p, dwp.p, dsq.p, cout, cin, 9, nullptr);
+    if (up == 6) rc_pack |= maua_pack_weight_up2d_f32(dwt.p, dwq.p, cout, cin, nullptr);
+    const int rc_conv = maua_modconv3x3_f32(dx.p, dwp.p, ds.p, cin, dd.p, draw.p, batch, cin, cout, h, w, 1, wscale, 0, nullptr, 0, nullptr, nullptr, dws.p, nullptr, 0, nullptr);
+    const int rc_tail = maua_blur_noise_act_f32(draw.p, dk.p, dref.p, batch, cout, 2 * h + 1, 2 * w + 1, 4, 4, 1, 1, nullptr, dn.p, (int64_t)plane_out, dnw.p, db.p, nullptr, 0,
+                                                nullptr, 0, nullptr);
+    const int rc_low = maua_upconv_blur_lowres_f32(dx.p, up == 6 ? dwq.p : dwp.p, ds.p, cin, dd.p, dgot.p, dlws.p, dk.p, dn.p, (int64_t)plane_out, dnw.p, db.p, nullptr, 0,
+                                                   batch, cin, cout, h, w, up, wscale, nullptr, nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    char name[128];
+    const int rc = rc_pack | rc_conv | rc_tail | rc_low;
+    snprintf(name, sizeof(name), "lowres up=%d vs three launches %d->%d @%dx%d B=%d rc=%d/%d/%d/%d", up, cin, cout, h, w, batch, rc_pack, rc_conv, rc_tail, rc_low);
+    if (rc) ++failures;
+    if (rc_conv || rc_low) {
+        printf("  %-58s launch refused (hipError %d / %d)\n", name, rc_conv, rc_low);
+        return;
+    }
+    compare(name, dgot.download(), dref.download(), up == 6 ? 2e-4f : 2e-5f);
+}
+
 int main() {
     setvbuf(stdout, nullptr, _IOLBF, 0);  // (the log is a pipe: keep every finished case even if the process dies later)
     int cu = 0, lds = 0;
@@ -234,6 +279,9 @@ int main() {
     blur_tail_case(2, 5, 33, 17);
     upconv_blur_case(2, 64, 32, 32, 32);   // three vertical segments: seam rows through the second launch
     upconv_blur_case(1, 128, 64, 24, 96);  // two m-tiles, four x tiles, tile counts that are not powers of two
+    lowres_up_case(2, 64, 64, 4, 4, 1);    // low-resolution entries (round 6): polyphase slabs -> reduce + blur + tail
+    lowres_up_case(3, 24, 40, 5, 7, 1);    // ... ragged, K not split
+    lowres_up_case(2, 64, 32, 16, 16, 6);  // ... the F(2,2)^2 kernel on 16 x 16-position tiles, K split, exported column + edge lines
     HIP_OK(hipDeviceSynchronize());
     printf("asan_driver: %s\n", failures ? "FAILED" : "all cases ok");
     fflush(stdout);

@@ -96,7 +96,7 @@ The serial run is the one whose per-kernel averages are comparable with the live
 individual durations stretch while the step time drops.  Each trace also contains bench.py's per-layer breakdown pass (eager
 launches), which is why calls != steps x layers.  Template arguments of modconv_mfma_kernel: <BM, BN, WM, MODE, MULTI, FAST, MAXP>,
 MODE 0 direct, 1 transposed (polyphase), 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed with F(2,2) on the even x-phase;
-modconv_w2d_kernel<TM, TN, MINB, PRE> = 2-D Winograd F(2x4,3x3) (mode 5), modconv_w2dw_kernel<PRE> = its wave-complete form for 32 output channels; modconv_up2d_kernel<CC, FUSE, PRE> = transposed with F(2,2) on both axes (mode 6; FUSE = 2: + blur + noise + bias + act in the same kernel),
+modconv_w2d_kernel<TM, TN, MINB, PRE> = 2-D Winograd F(2x4,3x3) (mode 5), modconv_w2dw_kernel<PRE> = its wave-complete form for 32 output channels; modconv_up2d_kernel<CC, FUSE, PRE, TW> = transposed with F(2,2) on both axes (mode 6; FUSE = 2: + blur + noise + bias + act in the same kernel; TW = 16: the 16 x 16-position tiles of the low-resolution entry, K split into slabs),
 up2d_edge_kernel = its two edge lines.  PRE = true: the instance for an input map that arrives multiplied by the layer's styles (the style fold, round 6): no style multiplies in its K loop.  (These short runs time one cold step: the frames/s quoted here are not the headline.)
 
 ## Copies per batch
@@ -121,7 +121,7 @@ SQ_WAVE_CYCLES --kernel-trace -- python bench.py --steps 1 --warmup 1 --batches-
 SQ_INSTS_VALU SQ_WAIT_ANY` (counters only, with --kernel-trace; no sys/hip/hsa trace domains).  Averages over every dispatch of the template instance in the run (batch 8, 1024^2 generator).
 MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); clock = (GRBM_GUI_ACTIVE / 8) / duration.
 Template arguments: <BM, BN, WM, MODE (0 direct, 1 transposed, 2 Winograd F(2,3), 3 Winograd F(4,3), 4 transposed + F(2,2)),
-MULTI, FAST, MAXP>; modconv_w2d_kernel<TM, TN, MINB, PRE> / modconv_w2dw_kernel<PRE> = mode 5, modconv_up2d_kernel<CC, FUSE, PRE> = mode 6 (PRE: pre-scaled input, the style fold).  "executed TFLOP/s" = MFMA_MOPS_F32 x 512 flop /
+MULTI, FAST, MAXP>; modconv_w2d_kernel<TM, TN, MINB, PRE> / modconv_w2dw_kernel<PRE> = mode 5, modconv_up2d_kernel<CC, FUSE, PRE, TW> = mode 6 (PRE: pre-scaled input, the style fold; TW: position columns of a tile).  "executed TFLOP/s" = MFMA_MOPS_F32 x 512 flop /
 duration; "non-MFMA VALU per MFMA" = (SQ_INSTS_VALU - MOPS / 4) / (MOPS / 4).
 
 | kernel instance | dispatches | avg us | clock GHz | MFMA busy % | executed TFLOP/s | non-MFMA VALU per MFMA | wave cycles waiting on an instruction % | waiting on a counter / barrier % | LDS bank conflicts % of LDS active |
