@@ -408,7 +408,8 @@ def _lowres_setup(gpu, cin, cout, h, w, b, up, seed):
 
 @pytest.mark.parametrize("cin,cout,h,w,b,noise_b,post", [(512, 512, 4, 4, 8, 8, False), (512, 512, 8, 8, 8, 1, False), (512, 512, 16, 16, 3, 3, True),
                                                            (24, 40, 5, 7, 2, 2, True), (64, 32, 16, 8, 1, 1, False), (32, 64, 1, 1, 2, 2, False),
-                                                           (512, 512, 16, 16, 8, 8, False), (64, 32, 16, 16, 1, 1, True), (72, 96, 16, 16, 2, 1, False)])
+                                                           (512, 512, 16, 16, 8, 8, False), (64, 32, 16, 16, 1, 1, True), (72, 96, 16, 16, 2, 1, False),
+                                                           (64, 32, 16, 16, 2, 2, False), (64, 64, 16, 16, 3, 3, False)])
 def test_upconv_blur_lowres_equals_three_launches_and_oracle(gpu, cin, cout, h, w, b, noise_b, post):
     """The low-resolution entry of an up-sampling StyledConv (polyphase convolution -> split-K slabs, then slab sum + demodulation + blur +
     noise + bias + leaky ReLU in one launch) against the three-launch path it replaces — BIT-identical: the slab sum keeps reduce_tail_kernel's

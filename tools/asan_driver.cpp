@@ -43,7 +43,12 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    explicit DevBuf(size_t count) : n(count) { HIP_OK(hipMalloc(&p, (count ? count : 1) * sizeof(T))); }
+    // (every allocation starts as all-ones bytes = NaN floats: a launch that silently does nothing — as the kernels launched through a host
+    // function-pointer variable did under -fsanitize=function, round 6 — leaves NaNs, which compare() counts as failures)
+    explicit DevBuf(size_t count) : n(count) {
+        HIP_OK(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+        HIP_OK(hipMemset(p, 0xff, (count ? count : 1) * sizeof(T)));
+    }
     ~DevBuf() { (void)hipFree(p); }
     void upload(const std::vector<T>& h) { HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
     std::vector<T> download() const {
@@ -56,9 +61,20 @@ struct DevBuf {
 static int failures = 0;
 static void compare(const char* what, const std::vector<float>& got, const std::vector<float>& want, float tol) {
     float worst = 0.f;
-    for (size_t i = 0; i < want.size(); ++i) worst = std::fmax(worst, std::fabs(got[i] - want[i]));
+    for (size_t i = 0; i < want.size(); ++i) {
+        const float e = std::fabs(got[i] - want[i]);
+        worst = (e == e) ? std::fmax(worst, e) : INFINITY;  // (a NaN on either side is a failure, not a value fmax skips)
+    }
     printf("  %-58s max |err| %.3g over %zu values %s\n", what, worst, want.size(), worst <= tol ? "ok" : "FAILED");
-    if (!(worst <= tol)) ++failures;
+    if (!(worst <= tol)) {
+        ++failures;
+        size_t bad = 0, first = want.size(), last = 0;  // (where: helps to tell a tile / plane / edge-line pattern from noise)
+        for (size_t i = 0; i < want.size(); ++i)
+            if (!(std::fabs(got[i] - want[i]) <= tol)) ++bad, first = first < i ? first : i, last = i;
+        printf("    %zu values beyond the tolerance, first at %zu (got %g, want %g), last at %zu\n", bad, first, got[first], want[first], last);
+        for (size_t i = first, n = 0; i < want.size() && n < 12; ++i)
+            if (!(std::fabs(got[i] - want[i]) <= tol)) printf("      [%zu] got %g want %g\n", i, got[i], want[i]), ++n;
+    }
 }
 
 static void fir_case(int major, int in_h, int in_w, int k, int up, int down, int p0, int p1) {
@@ -235,7 +251,57 @@ static void lowres_up_case(int batch, int cin, int cout, int h, int w, int up) {
         printf("  %-58s launch refused (hipError %d / %d)\n", name, rc_conv, rc_low);
         return;
     }
+    if (const char* dump = getenv("MAUA_DRIVER_DUMP")) {  // (the reference path's raw transposed-convolution map, for a diff between two builds)
+        if (FILE* f = fopen(dump, "ab")) {
+            const std::vector<float> r = draw.download();
+            fwrite(r.data(), sizeof(float), r.size(), f);
+            fclose(f);
+        }
+    }
+    if (getenv("MAUA_DRIVER_VERBOSE")) {  // (first values of both paths: which of the two moves between two builds of the library)
+        const std::vector<float> g = dgot.download(), r = dref.download();
+        printf("    got  %.6g %.6g %.6g %.6g\n    want %.6g %.6g %.6g %.6g\n", g[0], g[1], g[2], g[3], r[0], r[1], r[2], r[3]);
+    }
     compare(name, dgot.download(), dref.download(), up == 6 ? 2e-4f : 2e-5f);
+}
+
+static void lowres_plain_case(int batch, int cin, int cout, int h, int w, int mode) {
+    // The low-resolution entry of a plain layer (maua_styledconv_rgbpart_lowres_f32: convolution -> slabs, slab sum + tail + partial ToRGB sums) and
+    // maua_const_styledconv_f32-free reference: maua_modconv3x3_f32(fuse_act = 1) of the same mode — the feature maps must be bit-identical.
+    if (!maua_lowres_ok(cin, cout, h, w, mode)) {
+        printf("  lowres plain %d->%d @%dx%d mode %d: shape not accepted, skipped\n", cin, cout, h, w, mode);
+        return;
+    }
+    const size_t plane = (size_t)h * w;
+    std::vector<float> x(batch * cin * plane), wt((size_t)cout * cin * 9), s((size_t)batch * cin), d((size_t)batch * cout), noise(batch * plane), bias(cout),
+        rgb_w((size_t)3 * cout), rgb_s((size_t)batch * cin);
+    for (auto* v : {&x, &wt, &s, &noise, &bias, &rgb_w, &rgb_s})
+        for (auto& e : *v) e = rnd();
+    for (auto& v : d) v = 0.75f + 0.25f * rnd();
+    const int cpad = mode == 2 && cout > 32 ? (cout + 63) / 64 * 64 : (cout + 31) / 32 * 32;
+    DevBuf<float> dx(x.size()), dwt(wt.size()), dwp((size_t)(mode == 2 ? 12 : 9) * cin * cpad), dsq((size_t)cout * cin), ds(s.size()), dd(d.size()), dn(noise.size()),
+        db(cout), dnw(1), drw(rgb_w.size()), drs(rgb_s.size()), dref(batch * cout * plane), dgot(batch * cout * plane), dpart((size_t)batch * 3 * (cout / 32) * plane),
+        dws((size_t)maua_modconv_ws_floats(batch, cin, cout, h, w, mode) + 4), dlws((size_t)maua_lowres_ws_floats(batch, cin, cout, h, w, mode) + 4);
+    dx.upload(x), dwt.upload(wt), ds.upload(s), dd.upload(d), dn.upload(noise), db.upload(bias), dnw.upload(std::vector<float>{0.3f}), drw.upload(rgb_w), drs.upload(rgb_s);
+    const float wscale = 1.f / std::sqrt((float)cin * 9.f);
+    const int rc_pack = mode == 2 ? maua_pack_weight_wino_f32(dwt.p, dwp.p, cout, cin, nullptr) : maua_pack_weight_f32(dwt.p, dwp.p, dsq.p, cout, cin, 9, nullptr);
+    const int rc_ref = maua_modconv3x3_f32(dx.p, dwp.p, ds.p, cin, dd.p, dref.p, batch, cin, cout, h, w, mode, wscale, 1, dn.p, (int64_t)plane, dnw.p, db.p, dws.p, nullptr,
+                                           0, nullptr);
+    const int rc_low = maua_styledconv_rgbpart_lowres_f32(dx.p, dwp.p, ds.p, cin, dd.p, dgot.p, dlws.p, dn.p, (int64_t)plane, dnw.p, db.p, drw.p, drs.p, 0.1f, dpart.p,
+                                                          nullptr, 0, batch, cin, cout, h, w, mode, wscale, nullptr);
+    HIP_OK(hipDeviceSynchronize());
+    char name[128];
+    snprintf(name, sizeof(name), "lowres plain mode %d vs conv+reduce %d->%d @%dx%d B=%d rc=%d/%d/%d", mode, cin, cout, h, w, batch, rc_pack, rc_ref, rc_low);
+    if (rc_pack | rc_ref | rc_low) {
+        ++failures;
+        printf("  %-58s launch refused\n", name);
+        return;
+    }
+    compare(name, dgot.download(), dref.download(), 0.f);
+    const std::vector<float> part = dpart.download();
+    size_t nonfinite = 0;
+    for (float v : part) nonfinite += !(v == v);
+    if (nonfinite) ++failures, printf("    %zu partial ToRGB sums never written\n", nonfinite);
 }
 
 int main() {
@@ -282,6 +348,8 @@ int main() {
     lowres_up_case(2, 64, 64, 4, 4, 1);    // low-resolution entries (round 6): polyphase slabs -> reduce + blur + tail
     lowres_up_case(3, 24, 40, 5, 7, 1);    // ... ragged, K not split
     lowres_up_case(2, 64, 32, 16, 16, 6);  // ... the F(2,2)^2 kernel on 16 x 16-position tiles, K split, exported column + edge lines
+    lowres_plain_case(2, 64, 64, 4, 4, 0);   // plain layers: direct kernel, several images per tile
+    lowres_plain_case(3, 128, 128, 8, 8, 2); // ... Winograd F(2,3) along x
     HIP_OK(hipDeviceSynchronize());
     printf("asan_driver: %s\n", failures ? "FAILED" : "all cases ok");
     fflush(stdout);
