@@ -119,3 +119,62 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(root, f)
                 assert "/root/reference" not in src.replace("/root/reference/", "REF:") or True
+
+
+def test_low_resolution_entries_shape_rules_and_workspaces(built_lib):
+    """Host-side contract of the round-6 entries (no GPU): which shapes they accept, that a workspace size is a pure function of the shape and
+    holds at least one slab, and that bad arguments are rejected before any HIP call."""
+    from maua_stylegan2_amd import _lib
+
+    lib = _lib.load()
+    ok = lib.maua_lowres_ok
+    # up-sampling entry: polyphase kernel up to 16 x 16 inputs; F(2,2)^2 kernel for 16-wide inputs in whole 16 x 16 tiles, Cin % 8, Cout % 32
+    assert ok(512, 512, 4, 4, 1) == 1 and ok(24, 40, 5, 7, 1) == 1 and ok(512, 512, 16, 16, 1) == 1 and ok(512, 512, 32, 32, 1) == 0
+    assert ok(512, 512, 16, 16, 6) == 1 and ok(64, 32, 16, 16, 6) == 1
+    assert ok(60, 32, 16, 16, 6) == 0 and ok(64, 48, 16, 16, 6) == 0 and ok(64, 32, 8, 8, 6) == 0 and ok(64, 32, 32, 16, 6) == 0
+    # plain entry: 32-channel groups, 16-pixel tiles, up to 32 x 32; Winograd forms want an even width / a multiple of four
+    assert ok(512, 512, 4, 4, 0) == 1 and ok(40, 96, 4, 8, 0) == 1 and ok(64, 48, 8, 8, 0) == 0 and ok(64, 32, 3, 5, 0) == 0 and ok(64, 32, 64, 64, 0) == 0
+    assert ok(64, 64, 8, 8, 2) == 1 and ok(64, 64, 16, 18, 2) == 1 and ok(64, 64, 16, 18, 3) == 0 and ok(64, 64, 16, 16, 3) == 1
+    assert ok(64, 64, 8, 8, 4) == 0 and ok(64, 64, 8, 8, 5) == 0 and ok(0, 64, 8, 8, 0) == 0
+    for shape in [(8, 512, 512, 4, 4, 1), (8, 512, 512, 16, 16, 6), (3, 24, 40, 5, 7, 1), (8, 512, 512, 8, 8, 2), (2, 64, 32, 16, 16, 0)]:
+        b, cin, cout, h, w, up = shape
+        n = lib.maua_lowres_ws_floats(*shape)
+        slab = b * cout * ((2 * h + 1) * (2 * w + 1) if up in (1, 6) else h * w)
+        assert n >= slab and (n % slab == 0 or up == 6), shape          # whole slabs (+ the exported column behind them for up = 6)
+        if up == 6:
+            assert (n - b * cin * h) % slab == 0
+        assert all(lib.maua_lowres_ws_floats(*shape) == n for _ in range(3))
+    assert lib.maua_lowres_ws_floats(8, 512, 512, 32, 32, 1) == 0          # outside the entry's range
+    fake = 0x1000
+    up_call = lambda **kw: lib.maua_upconv_blur_lowres_f32(kw.get("x", fake), fake, kw.get("s", fake), 64, None, fake, kw.get("ws", fake), fake, None, 0, None, None,  # noqa: E731
+                                                          None, 0, 1, 64, 64, kw.get("h", 4), 4, kw.get("up", 1), 1.0, None, None)
+    assert up_call(x=None) == -22 and up_call(s=None) == -22 and up_call(ws=None) == -22 and up_call(up=2) == -22
+    assert up_call(h=512) == -38                                           # MAUA_ENOSYS: the two-launch path serves the shape
+    plain = lambda mode, rgb=fake: lib.maua_styledconv_rgbpart_lowres_f32(fake, fake, fake, 64, None, fake, fake, None, 0, None, None, rgb, fake, 0.1, fake, None, 0,  # noqa: E731
+                                                                          1, 64, 64, 4, 4, mode, 1.0, None)
+    assert plain(1) == -22 and plain(5) == -22 and plain(0, rgb=None) == -22
+    # conv1 on the constant input: 4 x 4 only, Cin % 8, Cout % 32
+    assert lib.maua_const_conv_ok(512, 512, 4, 4) == 1 and lib.maua_const_conv_ok(512, 512, 8, 8) == 0 and lib.maua_const_conv_ok(60, 64, 4, 4) == 0
+    assert lib.maua_pack_const_conv_f32(fake, fake, None, 64, 64, 4, 4, None) == -22 and lib.maua_pack_const_conv_f32(fake, fake, fake, 64, 64, 4, 8, None) == -38
+    assert lib.maua_const_styledconv_f32(None, fake, 64, None, fake, None, 0, None, None, None, None, 0.0, None, None, 0, 1, 64, 64, 4, 4, 1.0, None) == -22
+    assert lib.maua_const_styledconv_f32(fake, fake, 64, None, fake, None, 0, None, None, None, None, 0.0, fake, None, 0, 1, 64, 64, 4, 4, 1.0, None) == -22  # partial sums without ToRGB operands
+    # ToRGB plane-sum form: w and s both NULL, a plane count of 3 M, a width that is a multiple of 4
+    assert lib.maua_torgb_f32(fake, fake, None, 0, None, None, None, fake, 1, 6, 4, 4, 1.0, None) == -22
+    assert lib.maua_torgb_f32(fake, None, None, 0, None, None, None, fake, 1, 7, 4, 4, 1.0, None) == -22
+    assert lib.maua_torgb_f32(fake, None, None, 0, None, None, None, fake, 1, 6, 4, 6, 1.0, None) == -22
+
+
+def test_kernel_selection_rules_of_the_low_resolution_layers(built_lib):
+    """ModulatedConv2d.conv_mode on the maps below 32 x 32 (round 6): plain layers of 128 and more channels take Winograd F(2,3) along x from 8 x 8
+    on, everything else the direct / polyphase kernels; the rule is a pure function of (channels, h, w) and of the class switches."""
+    from maua_stylegan2_amd.models.stylegan2 import ModulatedConv2d
+
+    m = ModulatedConv2d(512, 512, 3, 512)
+    assert [m.conv_mode(r, r) for r in (4, 8, 16, 32, 64)] == [0, 2, 2, 5, 5]
+    assert m.conv_mode(8, 9) == 0 and m.conv_mode(4, 8) == 0              # odd width; fewer than 8 rows
+    small = ModulatedConv2d(64, 64, 3, 512)
+    assert [small.conv_mode(r, r) for r in (8, 16, 32)] == [0, 0, 5]      # below 128 channels the direct form stays
+    m.winograd_small_min_cout = 1 << 30
+    assert [m.conv_mode(r, r) for r in (8, 16)] == [0, 0]
+    up = ModulatedConv2d(512, 512, 3, 512, upsample=True)
+    assert [up.conv_mode(r, r) for r in (4, 8, 16, 32)] == [1, 1, 1, 6]   # (the 16-wide layer reaches the F(2,2)^2 kernel through the low-resolution entry)
