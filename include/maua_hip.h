@@ -251,7 +251,7 @@ int maua_styledconv_torgb_f32(const float* x, const float* wp, const float* s, i
  *       which maua_torgb_f32's plane-sum form (w = s = NULL) turns into the image.
  * `up` of the up-sampling entry picks the convolution: 1 = the polyphase kernel (wp = maua_pack_weight_f32), 6 = F(2,2) on both axes of the
  * polyphase form (csrc/modconv_up2d.hip on 16 x 16-position tiles, K split over workgroups; wp = maua_pack_weight_up2d_f32): 16-wide
- * inputs, 25 instead of 36 products per 2 x 2 positions and that kernel's operand pipeline (the 16^2 -> 32^2 layer: 129 -> ?? us).
+ * inputs, 25 instead of 36 products per 2 x 2 positions and that kernel's operand pipeline (the 16^2 -> 32^2 layer at batch 8: 129 -> 77 us).
  * maua_lowres_ok: up == 1: 2H * 2W <= 1024;  up == 6: W == 16, H % 16 == 0, Cin % 8 == 0, Cout % 32 == 0, 2H * 2W <= 1024;
  * up == 0 / 2 / 3 (the plain entry's `mode`: direct, Winograd F(2,3) / F(4,3) along x — 2 needs an even W, 3 W % 4 == 0): Cout % 32 == 0,
  * H * W % 16 == 0, H * W <= 1024.  MAUA_ENOSYS otherwise.  `wp` of the plain entry = the pack of its mode (maua_pack_weight_f32 /
